@@ -1,25 +1,36 @@
 """bench.py -- throughput of the Mean-Teacher training step on MI355X (BASELINE.json metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload unet2d|unet3d]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload unet3d|unet2d|vnet|swin|cross|...]
 
-A "step" is one full Mean-Teacher iteration (noise, student fwd on labeled+unlabeled, EMA-teacher
-fwd, fused CE+Dice+consistency loss tail, student bwd, [RCCL all-reduce], fused SGD+EMA, schedule
-advance) on one resident synthetic batch.  Default workload = BASELINE.json configs[1]: Mean-Teacher
-2D UNet, ACDC-like 256x256, 4 classes, 24 labeled + 24 unlabeled per GPU.  ``--workload unet3d`` is
-configs[2] (the north-star target): unet_3D, BraTS-like 96^3, 2 classes, 4+4 per GPU.
-Pure data parallel: every rank owns its own 24+24 (4+4) shard -> weak scaling; value = samples of
-all ranks / max-over-ranks time.
+``--gpus N`` with N > 1 is self-launching: when the process was not started by ``torch.distributed.run``
+(no ``WORLD_SIZE`` in the environment) it re-executes itself as
+``python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py ...``
+-- one rank per GPU over RCCL -- and forwards the single JSON line of rank 0.  Started by ``torch.distributed.run``
+directly it reads RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment.
+
+A "step" is one full Mean-Teacher iteration (noise, student fwd on labeled+unlabeled, EMA-teacher fwd, fused
+CE+Dice+consistency loss tail, student bwd, [RCCL all-reduce of the flat gradient bucket, issued per bucket while
+the backward is still running], fused SGD+EMA, schedule advance) on one resident synthetic batch.
+
+Default workload = BASELINE.json configs[2], the north-star target: Mean-Teacher ``unet_3D``, BraTS-like 96^3,
+2 classes, 4 labeled + 4 unlabeled volumes per GPU.  Pure data parallel: every rank owns its own 4+4 shard -> weak
+scaling; value = samples of all ranks / max-over-ranks time.
 
 Prints ONE JSON line (rank 0) with the contract fields plus
-  roofline     live HIP-event timing of the dominant kernel family (the MFMA conv kernel) over the
-               timed region: achieved = algorithmic FLOPs of its launches / their summed duration
-  cpu_baseline the CPU oracle (a port of the reference arithmetic on stock torch CPU ops) timed on
-               this host's cores on a bounded sample of the same workload (rank 0, N=1 only)
+  roofline     live HIP-event timing of the dominant kernel (the MFMA conv kernel) over the timed region:
+               achieved = algorithmic FLOPs of its launches / their summed duration; ``step_flop_frac`` = the
+               algorithmic FLOPs of the WHOLE step / step time / peak
+  others       (N=1) the other single-GPU configurations of BASELINE.json -- configs[1] 2-D UNet, configs[3]
+               SwinUnet, configs[4] per-GPU cross teaching, and V-Net -- each with value, ms_per_step, step-level
+               flop_frac and dominant-kernel fraction
+  cpu_baseline the CPU oracle (a port of the reference arithmetic on stock torch CPU ops) timed on this host's
+               cores: thread count swept, best reported, 2 warm-up + 5 timed steps (rank 0, N=1 only)
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -28,57 +39,245 @@ for p in (os.path.join(ROOT, "cv-ssl-mis_amd"), ROOT):
     if p not in sys.path:
         sys.path.insert(0, p)
 
-import torch  # noqa: E402
-
 PEAK_FP32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_*_f32 dense peak
 
+# step_gflop: algorithmic FLOP of one step, SURVEY.md s.8d: F_fwd * (3*(L+U) + U) (student fwd+dgrad+wgrad, teacher
+# fwd); cross teaching: both students train on the whole batch.
 WORKLOADS = {
-    "unet2d": dict(config="Mean-Teacher 2D UNet, synthetic ACDC 256x256 4-class, bs=24+24 (BASELINE configs[1])",
-                   shape=(48, 1, 256, 256), labeled=24, classes=4, cons_start=1000, label_dtype=torch.uint8,
-                   cpu_sample=(8, 4)),
     "unet3d": dict(config="Mean-Teacher 3D UNet (unet_3D), synthetic BraTS 96x96x96 2-class, bs=4+4 "
-                          "(BASELINE configs[2])",
-                   shape=(8, 1, 96, 96, 96), labeled=4, classes=2, cons_start=0, label_dtype=torch.int64,
-                   cpu_sample=(2, 1)),
+                          "(BASELINE configs[2], the north-star target)",
+                   shape=(8, 1, 96, 96, 96), labeled=4, classes=2, cons_start=0, label="int64",
+                   cpu_sample=(2, 1), step_gflop=121.98 * 28),
+    "unet2d": dict(config="Mean-Teacher 2D UNet, synthetic ACDC 256x256 4-class, bs=24+24 (BASELINE configs[1])",
+                   shape=(48, 1, 256, 256), labeled=24, classes=4, cons_start=1000, label="uint8",
+                   cpu_sample=(8, 4), step_gflop=5.90 * 168),
     "vnet": dict(config="Mean-Teacher 3D V-Net (--model vnet), synthetic BraTS 96x96x96 2-class, bs=4+4 "
                         "(BASELINE configs[2] geometry with the reference's other 3-D backbone)",
-                 shape=(8, 1, 96, 96, 96), labeled=4, classes=2, cons_start=0, label_dtype=torch.int64,
-                 cpu_sample=(2, 1)),
+                 shape=(8, 1, 96, 96, 96), labeled=4, classes=2, cons_start=0, label="int64",
+                 cpu_sample=(2, 1), step_gflop=70.72 * 28),
     "uamt3d": dict(config="UA-MT 3D UNet (unet_3D), synthetic BraTS 96x96x96 2-class, bs=4+4, T=8 MC-dropout teacher "
                           "passes (SURVEY s.8 row n1; BASELINE configs[2] geometry)",
-                   shape=(8, 1, 96, 96, 96), labeled=4, classes=2, cons_start=0, label_dtype=torch.int64,
-                   cpu_sample=None),
+                   shape=(8, 1, 96, 96, 96), labeled=4, classes=2, cons_start=0, label="int64",
+                   cpu_sample=None, step_gflop=121.98 * (28 + 32)),
     "swin": dict(config="Mean-Teacher ViT (SwinUNet 2D), synthetic ACDC 224x224 4-class, bs=24+24 "
                         "(BASELINE configs[3])",
-                 shape=(48, 1, 224, 224), labeled=24, classes=4, cons_start=1000, label_dtype=torch.uint8,
-                 cpu_sample=(4, 2)),
+                 shape=(48, 1, 224, 224), labeled=24, classes=4, cons_start=1000, label="uint8",
+                 cpu_sample=(4, 2), step_gflop=12.17 * 168),
     "cross": dict(config="Cross-teaching CNN+ViT 2D (UNet + SwinUNet), synthetic ACDC 224x224 4-class, bs=16+16 "
                          "per GPU (BASELINE configs[4]; 224 because SwinUnet window 7 cannot run 256, as in the "
                          "reference)",
-                  shape=(32, 1, 224, 224), labeled=16, classes=4, cons_start=0, label_dtype=torch.uint8,
-                  cpu_sample=None),
+                  shape=(32, 1, 224, 224), labeled=16, classes=4, cons_start=0, label="uint8",
+                  cpu_sample=None, step_gflop=(4.52 + 12.17) * 96),
     "cnnvit": dict(config="CNN + ViT students with an EMA ViT teacher (train_cnn_meet_vit_2D: UNet + 2x SwinUNet), "
                           "synthetic ACDC 224x224 4-class, bs=8+8 per GPU (the script's defaults; SURVEY s.8 row n2)",
-                   shape=(16, 1, 224, 224), labeled=8, classes=4, cons_start=1000, label_dtype=torch.uint8,
-                   cpu_sample=None),
+                   shape=(16, 1, 224, 224), labeled=8, classes=4, cons_start=1000, label="uint8",
+                   cpu_sample=None, step_gflop=(4.52 + 12.17) * 48 + 12.17 * 8),
 }
+OTHERS = ("unet2d", "swin", "cross", "vnet")     # reported under "others" beside the default workload (N=1)
+UNIT = {"unet3d": "volumes/s", "vnet": "volumes/s", "uamt3d": "volumes/s"}
 
 
-def make_models(kind, classes):
-    if kind == "swin":
+# ------------------------------------------------------------------------------------------------ launcher
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def self_launch(argv, gpus):
+    """Re-execute this script under torch.distributed.run with one rank per GPU; forward rank 0's output."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")    # dmabuf IPC: RCCL across processes needs it on this host
+    env.setdefault("OMP_NUM_THREADS", "8")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + argv
+    return subprocess.call(cmd, env=env)
+
+
+# ------------------------------------------------------------------------------------------------ workloads
+def build_trainer(name, wl, world, stub=False):
+    import torch
+    if stub:
+        return _StubTrainer(wl)
+    from mis_hip.step import MeanTeacherTrainer
+    C, L = wl["classes"], wl["labeled"]
+    vit_teacher = None
+    if name in ("cross", "cnnvit"):
+        from mis_hip.step import CnnMeetVitTrainer, CrossTeachingTrainer
         from networks.net_factory import net_factory
-        return net_factory("ViT_Seg", 1, classes), net_factory("ViT_Seg", 1, classes)
-    if kind == "unet2d":
+        model, ema = net_factory("unet", 1, C), net_factory("ViT_Seg", 1, C)
+        if name == "cnnvit":      # here `ema` is the Transformer STUDENT, vit_teacher its EMA
+            vit_teacher = net_factory("ViT_Seg", 1, C)
+            vit_teacher.load_state_dict(ema.state_dict())
+    elif name in ("swin", "unet2d"):
         from networks.net_factory import net_factory
-        return net_factory("unet", 1, classes), net_factory("unet", 1, classes)
-    from networks.net_factory_3d import net_factory_3d
-    key = "vnet" if kind == "vnet" else "unet_3D"
-    return net_factory_3d(key, 1, classes), net_factory_3d(key, 1, classes)
+        key = "ViT_Seg" if name == "swin" else "unet"
+        model, ema = net_factory(key, 1, C), net_factory(key, 1, C)
+        ema.load_state_dict(model.state_dict())
+    else:
+        from networks.net_factory_3d import net_factory_3d
+        key = "vnet" if name == "vnet" else "unet_3D"
+        model, ema = net_factory_3d(key, 1, C), net_factory_3d(key, 1, C)
+        ema.load_state_dict(model.state_dict())
+    if world > 1:   # identical initial weights on every rank
+        for m in (model, ema, vit_teacher):
+            if m is not None:
+                torch.distributed.broadcast(m.flat_param, 0)
+    if name == "cross":
+        return CrossTeachingTrainer(model, ema, labeled_bs=L, num_classes=C, seed=1337, iter_num=1000)
+    if name == "cnnvit":
+        return CnnMeetVitTrainer(model, ema, vit_teacher, labeled_bs=L, num_classes=C, seed=1337, iter_num=1000)
+    if name == "uamt3d":
+        from mis_hip.step import UAMTTrainer
+        return UAMTTrainer(model, ema, labeled_bs=L, num_classes=C, seed=1337, iter_num=1000)
+    return MeanTeacherTrainer(model, ema, labeled_bs=L, num_classes=C, cons_start_iter=wl["cons_start"], seed=1337,
+                              iter_num=1000)
 
 
-def cpu_baseline(kind, wl, steps=2):
-    """The oracle step (reference arithmetic on stock torch CPU ops, dropout + noise active) on this
-    host's cores, on a reduced batch of the same geometry.  Returns samples/s."""
+class _StubTrainer:
+    """CPU/gloo stand-in for the step (``--stub``): exercises the launcher, the rendezvous, the barrier + max-over-ranks
+    timing and the JSON contract without a GPU (tests/test_bench_cpu.py).  Never used for a measurement."""
+
+    def __init__(self, wl):
+        import torch
+        self.w = torch.zeros(1 << 14)
+        self.g = torch.zeros(1 << 14)
+
+    def step(self, vol, lab):
+        from mis_hip import dist
+        self.g.copy_(vol.reshape(-1)[:self.g.numel()])
+        scale = dist.sync_gradients(self.g)
+        self.w.add_(self.g, alpha=-0.01 * scale)
+
+    def losses(self):
+        return dict(loss=float(self.w.abs().mean()))
+
+
+def run_workload(name, args, rank, world, kernel_events=True):
+    """Warm-up, then EXACTLY args.steps timed steps between barrier + device sync; returns (rank 0) the result dict."""
+    import torch
+    import torch.distributed as tdist
+    stub = args.stub
+    dev = "cpu" if stub else "cuda"
+    wl = WORKLOADS[name]
+    torch.manual_seed(1337 + rank)
+    tr = build_trainer(name, wl, world, stub)
+    g = torch.Generator(device=dev).manual_seed(1337 + rank)
+    shape = (4, 1, 64, 64) if stub else wl["shape"]
+    vol = torch.rand(shape, generator=g, device=dev)
+    lab = torch.randint(0, wl["classes"], (shape[0],) + shape[2:], generator=g,
+                        device=dev).to(getattr(torch, wl["label"]))
+
+    def sync():
+        if not stub:
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        tr.step(vol, lab)
+    prof = None
+    if not stub:
+        from mis_hip import ops
+        prof = [] if kernel_events else None
+        ops.PROFILE = prof
+    sync()
+    if world > 1:
+        tdist.barrier()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        tr.step(vol, lab)
+    sync()
+    if world > 1:
+        tdist.barrier()
+    sync()
+    dt_local = time.perf_counter() - t0
+    if not stub:
+        ops.PROFILE = None
+    dt, per_rank = dt_local, [dt_local]
+    if world > 1:
+        t = torch.tensor([dt_local], device=dev, dtype=torch.float64)
+        allt = [torch.zeros_like(t) for _ in range(world)]
+        tdist.all_gather(allt, t)
+        per_rank = [float(x.item()) for x in allt]
+        dt = max(per_rank)                         # MAX over ranks
+    losses = tr.losses()
+    assert all(map(lambda v: v == v and abs(v) < 1e6, losses.values())), f"non-finite losses {losses}"
+
+    roofline = None
+    if prof:
+        per = {}
+        for kname, flops, e0, e1 in prof:
+            d = per.setdefault(kname, [0.0, 0.0, 0])
+            d[0] += flops
+            d[1] += e0.elapsed_time(e1) * 1e-3
+            d[2] += 1
+        fam_flops = sum(d[0] for d in per.values())
+        fam_time = sum(d[1] for d in per.values())
+        dom = max(per, key=lambda k: per[k][1])
+        achieved = per[dom][0] / per[dom][1] / 1e12
+        # HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this same
+        # command (FETCH_SIZE / WRITE_SIZE in separate runs, scripts/pmc_traffic.py); null if not collected
+        traffic, traffic_src = None, None
+        for rnd in ("r02", "r01"):
+            tfile = os.path.join(ROOT, "profiles", f"{rnd}_{name}_pmc_traffic.json")
+            if os.path.exists(tfile):
+                with open(tfile) as f:
+                    ent = json.load(f)["kernels"].get(dom)
+                if ent:
+                    traffic, traffic_src = ent["hbm_bytes_per_launch"], os.path.relpath(tfile, ROOT)
+                    break
+        roofline = dict(bound="mfma", kernel=dom, achieved=round(achieved, 3), peak=PEAK_FP32_MFMA_TFLOPS,
+                        unit="TFLOP/s", frac=round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), traffic=traffic,
+                        traffic_unit="HBM bytes per launch (PMC)", traffic_source=traffic_src,
+                        launches=per[dom][2], avg_launch_ms=round(per[dom][1] / per[dom][2] * 1e3, 4),
+                        flops_per_launch_avg=per[dom][0] / per[dom][2],
+                        family=dict(kernel="all event-timed MFMA launches (conv_fwd_kernel<*> forward + data-gradient; "
+                                           "gemm_nt_kernel<*> / gemm_tn_kernel<*> for SwinUnet)",
+                                    achieved=round(fam_flops / fam_time / 1e12, 3),
+                                    frac=round(fam_flops / fam_time / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
+                                    share_of_step_time=round(fam_time / dt_local, 4)))
+    step_s = dt / args.steps
+    step_frac = wl["step_gflop"] * 1e9 / step_s / (PEAK_FP32_MFMA_TFLOPS * 1e12)
+    if roofline is not None:
+        roofline["step_flops"] = wl["step_gflop"] * 1e9
+        roofline["step_flop_frac"] = round(step_frac, 4)
+    res = dict(value=round(shape[0] * world * args.steps / dt, 3), unit=UNIT.get(name, "images/s"),
+               ms_per_step=round(step_s * 1e3, 3), step_flop_frac=round(step_frac, 4), roofline=roofline,
+               losses={k: round(v, 6) for k, v in losses.items()},
+               per_rank_ms_per_step=[round(t / args.steps * 1e3, 3) for t in per_rank])
+    del tr
+    if not stub:
+        torch.cuda.empty_cache()
+    return res
+
+
+# ------------------------------------------------------------------------------------------------ CPU baseline
+def _physical_cores():
+    try:
+        seen = set()
+        with open("/proc/cpuinfo") as f:
+            phys = core = None
+            for line in f:
+                if line.startswith("physical id"):
+                    phys = line.split(":")[1].strip()
+                elif line.startswith("core id"):
+                    core = line.split(":")[1].strip()
+                elif not line.strip():
+                    if phys is not None and core is not None:
+                        seen.add((phys, core))
+                    phys = core = None
+        if seen:
+            return len(seen)
+    except OSError:
+        pass
+    return os.cpu_count() or 1
+
+
+def cpu_baseline(kind, wl, timed=5, warm=2, budget_s=150.0):
+    """The oracle step (reference arithmetic on stock torch CPU ops, dropout + noise active) on this host's cores,
+    on a reduced batch of the same geometry.  ``torch.set_num_threads`` is swept over {8,16,32,64,physical cores}
+    (1 warm-up + 1 timed step each), then the best count is timed with ``warm`` + ``timed`` steps (median)."""
+    import torch
     from oracle.nets import OracleUNet2D, OracleUNet3D, OracleVNet
     from oracle.step import mean_teacher_step
     B, L = wl["cpu_sample"]
@@ -101,163 +300,131 @@ def cpu_baseline(kind, wl, steps=2):
                 t.fill_(1.0)
     teacher = {k: v.clone() for k, v in student.items()}
     vol = torch.rand(shape, generator=g)
-    lab = torch.randint(0, C, (B,) + shape[2:], generator=g).to(wl["label_dtype"])
+    lab = torch.randint(0, C, (B,) + shape[2:], generator=g).to(getattr(torch, wl["label"]))
     mom = {}
-    cores = torch.get_num_threads()
-    times = []
-    for i in range(steps + 1):
+    it = [1000]
+
+    def one():
         noise = torch.clamp(torch.randn((B - L,) + shape[1:], generator=g) * 0.1, -0.2, 0.2)
         t0 = time.perf_counter()
-        mean_teacher_step(onet, student, teacher, mom, vol, lab, noise, 1000 + i, labeled_bs=L, num_classes=C,
+        mean_teacher_step(onet, student, teacher, mom, vol, lab, noise, it[0], labeled_bs=L, num_classes=C,
                           cons_start_iter=wl["cons_start"])
-        times.append(time.perf_counter() - t0)
-    t = sorted(times[1:])[len(times[1:]) // 2]   # median of the timed steps (first one is warm-up)
-    return dict(value=B / t, unit="samples/s", cores=cores, kind="port",
+        it[0] += 1
+        return time.perf_counter() - t0
+
+    logical, physical = os.cpu_count() or 1, _physical_cores()
+    default_threads = torch.get_num_threads()
+    cands = sorted({n for n in (8, 16, 32, 64, physical) if 1 <= n <= logical})
+    sweep, t_start = {}, time.perf_counter()
+    for n in cands:
+        torch.set_num_threads(n)
+        one()
+        sweep[n] = one()
+        if time.perf_counter() - t_start > budget_s * 0.5:
+            break
+    best = min(sweep, key=sweep.get)
+    torch.set_num_threads(best)
+    for _ in range(warm):
+        one()
+    times = sorted(one() for _ in range(timed))
+    t = times[len(times) // 2]
+    torch.set_num_threads(default_threads)
+    return dict(value=B / t, unit="samples/s", cores=best, kind="port",
+                host=dict(logical_cpus=logical, physical_cores=physical),
+                thread_sweep_s_per_step={str(k): round(v, 3) for k, v in sweep.items()},
                 sample=f"oracle.step.mean_teacher_step, batch {L}+{B - L} of {'x'.join(map(str, shape[2:]))}, "
-                       f"1 warm-up + {steps} timed steps, median {t:.3f} s/step, torch {torch.__version__} CPU")
+                       f"torch.set_num_threads swept over {sorted(sweep)} -> best {best}; {warm} warm-up + {timed} "
+                       f"timed steps, median {t:.3f} s/step, torch {torch.__version__} CPU")
 
 
+# ------------------------------------------------------------------------------------------------ main
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="unet2d", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default="unet3d", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-others", action="store_true", help="skip the 'others' block (the other single-GPU configs)")
     ap.add_argument("--no-kernel-events", action="store_true", help="skip the per-launch HIP events")
     ap.add_argument("--overlap-teacher", action="store_true",
                     help="run the teacher forward on a side stream, concurrently with the student forward "
                          "(MeanTeacherTrainer, MIS_TWO_STREAM=1): higher throughput, but per-launch durations then "
                          "include time shared with the other stream's kernels, so the roofline object understates "
                          "the kernels -- off by default to keep it meaningful")
+    ap.add_argument("--stub", action="store_true", help=argparse.SUPPRESS)   # CPU/gloo launcher test only
     args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(self_launch(sys.argv[1:], args.gpus))
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run "
-                         f"--nproc-per-node {args.gpus}")
-    torch.cuda.set_device(local_rank)
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher's --nproc-per-node must equal --gpus")
+
+    import torch
+    backend = None
+    if not args.stub:
+        torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.stub:
+            backend = "gloo"
+            torch.distributed.init_process_group("gloo")
+        else:
+            backend = "nccl (RCCL)"
+            torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
-    from mis_hip import ops, step as _step
-    from mis_hip.step import MeanTeacherTrainer
-    if args.overlap_teacher:
-        _step.TWO_STREAM = True
+    two_stream = False
+    if not args.stub:
+        from mis_hip import step as _step
+        if args.overlap_teacher:
+            _step.TWO_STREAM = True
+        two_stream = _step.TWO_STREAM
 
     wl = WORKLOADS[args.workload]
-    torch.manual_seed(1337 + rank)
-    vit_teacher = None
-    if args.workload in ("cross", "cnnvit"):
-        from mis_hip.step import CnnMeetVitTrainer, CrossTeachingTrainer
-        from networks.net_factory import net_factory
-        model, ema = net_factory("unet", 1, wl["classes"]), net_factory("ViT_Seg", 1, wl["classes"])
-        if args.workload == "cnnvit":      # here `ema` is the Transformer STUDENT, vit_teacher its EMA
-            vit_teacher = net_factory("ViT_Seg", 1, wl["classes"])
-            vit_teacher.load_state_dict(ema.state_dict())
-    else:
-        model, ema = make_models(args.workload, wl["classes"])
-        ema.load_state_dict(model.state_dict())
-    if world > 1:   # identical initial weights on every rank
-        torch.distributed.broadcast(model.flat_param, 0)
-        torch.distributed.broadcast(ema.flat_param, 0)
-    if args.workload == "cross":
-        tr = CrossTeachingTrainer(model, ema, labeled_bs=wl["labeled"], num_classes=wl["classes"], seed=1337,
-                                  iter_num=1000)
-    elif args.workload == "cnnvit":
-        if world > 1:
-            torch.distributed.broadcast(vit_teacher.flat_param, 0)
-        tr = CnnMeetVitTrainer(model, ema, vit_teacher, labeled_bs=wl["labeled"], num_classes=wl["classes"],
-                               seed=1337, iter_num=1000)
-    elif args.workload == "uamt3d":
-        from mis_hip.step import UAMTTrainer
-        tr = UAMTTrainer(model, ema, labeled_bs=wl["labeled"], num_classes=wl["classes"], seed=1337, iter_num=1000)
-    else:
-        tr = MeanTeacherTrainer(model, ema, labeled_bs=wl["labeled"], num_classes=wl["classes"],
-                                cons_start_iter=wl["cons_start"], seed=1337, iter_num=1000)
-    g = torch.Generator(device="cuda").manual_seed(1337 + rank)
-    vol = torch.rand(wl["shape"], generator=g, device="cuda")
-    lab = torch.randint(0, wl["classes"], (wl["shape"][0],) + wl["shape"][2:], generator=g,
-                        device="cuda").to(wl["label_dtype"])
-
-    for _ in range(args.warmup):
-        tr.step(vol, lab)
-    prof = None if args.no_kernel_events else []
-    ops.PROFILE = prof
-    if world > 1:
-        torch.distributed.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        tr.step(vol, lab)
-    torch.cuda.synchronize()
-    if world > 1:
-        torch.distributed.barrier()
-    dt = time.perf_counter() - t0
-    ops.PROFILE = None
-    if world > 1:
-        tmax = torch.tensor([dt], device="cuda", dtype=torch.float64)
-        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
-        dt = float(tmax.item())
-    losses = tr.losses()
-    assert all(map(lambda v: v == v and abs(v) < 1e6, losses.values())), f"non-finite losses {losses}"
-
-    roofline = None
-    if prof:
-        per = {}
-        for name, flops, e0, e1 in prof:
-            d = per.setdefault(name, [0.0, 0.0, 0])
-            d[0] += flops
-            d[1] += e0.elapsed_time(e1) * 1e-3
-            d[2] += 1
-        fam_flops = sum(d[0] for d in per.values())
-        fam_time = sum(d[1] for d in per.values())
-        dom = max(per, key=lambda k: per[k][1])
-        achieved = per[dom][0] / per[dom][1] / 1e12
-        # HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this same
-        # command (FETCH_SIZE / WRITE_SIZE in separate runs, scripts/pmc_traffic.py); null if not collected
-        traffic, traffic_src = None, None
-        tfile = os.path.join(ROOT, "profiles", f"r01_{args.workload}_pmc_traffic.json")
-        if os.path.exists(tfile):
-            with open(tfile) as f:
-                ent = json.load(f)["kernels"].get(dom)
-            if ent:
-                traffic, traffic_src = ent["hbm_bytes_per_launch"], os.path.relpath(tfile, ROOT)
-        roofline = dict(bound="mfma", kernel=dom, achieved=round(achieved, 3), peak=PEAK_FP32_MFMA_TFLOPS,
-                        unit="TFLOP/s", frac=round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), traffic=traffic,
-                        traffic_unit="HBM bytes per launch (PMC)", traffic_source=traffic_src,
-                        launches=per[dom][2], avg_launch_ms=round(per[dom][1] / per[dom][2] * 1e3, 4),
-                        flops_per_launch_avg=per[dom][0] / per[dom][2],
-                        family=dict(kernel="all event-timed MFMA launches (conv_fwd_kernel<*> forward + data-gradient; "
-                                           "gemm_nt_kernel<*> / gemm_tn_kernel<*> for SwinUnet)",
-                                    achieved=round(fam_flops / fam_time / 1e12, 3),
-                                    frac=round(fam_flops / fam_time / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
-                                    share_of_step_time=round(fam_time / dt, 4)))
+    res = run_workload(args.workload, args, rank, world, kernel_events=not args.no_kernel_events)
 
     if rank == 0:
-        samples = wl["shape"][0] * world * args.steps
         out = {
             "metric": "training images-or-volumes/sec/node (Mean-Teacher step)",
-            "value": round(samples / dt, 3),
-            "unit": "volumes/s" if args.workload in ("unet3d", "vnet", "uamt3d") else "images/s",
+            "value": res["value"], "unit": res["unit"],
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(dt / args.steps * 1e3, 3),
+            "ms_per_step": res["ms_per_step"],
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic (U[0,1) images, uniform labels, random-init weights, resident in HBM)",
             "config": {"workload": wl["config"], "per_gpu_batch": f"{wl['labeled']}+{wl['shape'][0] - wl['labeled']}",
                        "global_batch": wl["shape"][0] * world, "parallelism": f"dp{world}",
                        "dropout": "on (Philox)", "teacher_noise": "on", "iter_num_start": 1000,
-                       "teacher_forward": "side stream (overlapped)" if _step.TWO_STREAM else "same stream"},
-            "losses_last_step": {k: round(v, 6) for k, v in losses.items()},
-            "roofline": roofline,
+                       "teacher_forward": "side stream (overlapped)" if two_stream else "same stream"},
+            "distributed": {"world_size_seen": torch.distributed.get_world_size() if world > 1 else 1,
+                            "backend": backend, "per_rank_ms_per_step": res["per_rank_ms_per_step"],
+                            "max_ms_per_step": res["ms_per_step"]},
+            "losses_last_step": res["losses"],
+            "roofline": res["roofline"],
         }
-        if world == 1 and not args.no_cpu_baseline and wl["cpu_sample"] is not None:
+        if args.stub:
+            out["data"] = "stub (CPU/gloo launcher test, not a measurement)"
+    if world == 1 and not args.stub and not args.no_others and args.workload == "unet3d":
+        # the other single-GPU configurations of BASELINE.json, shorter runs of the same protocol
+        import copy
+        oargs = copy.copy(args)
+        oargs.steps, oargs.warmup = max(5, args.steps // 2), min(args.warmup, 2)
+        others = {}
+        for name in OTHERS:
+            r = run_workload(name, oargs, rank, world, kernel_events=not args.no_kernel_events)
+            rf = r["roofline"] or {}
+            others[name] = dict(workload=WORKLOADS[name]["config"], value=r["value"], unit=r["unit"],
+                                ms_per_step=r["ms_per_step"], steps=oargs.steps, flop_frac=r["step_flop_frac"],
+                                dominant_kernel=rf.get("kernel"), dominant_kernel_frac=rf.get("frac"))
+        out["others"] = others
+    if rank == 0:
+        if world == 1 and not args.stub and not args.no_cpu_baseline and wl["cpu_sample"] is not None:
             out["cpu_baseline"] = cpu_baseline(args.workload, wl)
             out["gpu_over_cpu"] = round(out["value"] / out["cpu_baseline"]["value"], 2)
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()
 

@@ -23,6 +23,22 @@ static inline int mis_launch_status() {
 
 static inline long long mis_cdiv(long long a, long long b) { return (a + b - 1) / b; }
 
+// Opt-in for > 64 KiB of dynamic LDS: a per-function, per-device attribute.  `done` is one bit per device ordinal
+// (function-local static of the calling template instantiation); atomic, so any host thread and any device of
+// the process may launch first.  Idempotent, never changes results.
+#include <atomic>
+static inline int mis_set_lds_attr(const void* fn, int lds_bytes, std::atomic<unsigned long long>& done) {
+    if (lds_bytes <= 64 * 1024) return MIS_OK;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return MIS_ERR_LAUNCH;
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (done.load(std::memory_order_acquire) & bit) return MIS_OK;
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) != hipSuccess)
+        return MIS_ERR_LAUNCH;
+    done.fetch_or(bit, std::memory_order_release);
+    return MIS_OK;
+}
+
 // XCD-aware block remap (workgroup b is observed to run on XCD b % 8; each XCD
 // has a private L2).  Gives every XCD a contiguous run of logical tiles so
 // neighbouring tiles (shared halos / shared weights) hit the same L2.  The

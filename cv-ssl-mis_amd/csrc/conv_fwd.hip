@@ -440,14 +440,8 @@ int launch_cfg(ConvFwdArgs a, hipStream_t stream) {
     if (nb <= 0 || nb > 0x7fffffffLL) return MIS_ERR_ARG;
     a.n_blocks = (unsigned)nb;
     a.n_blocks_padded = (unsigned)(mis_cdiv(nb, MIS_NUM_XCD) * MIS_NUM_XCD);
-    static bool attr_set = false;   // per instantiation; > 64 KiB of LDS needs the opt-in
-    if (!attr_set) {
-        if (C::LDS_BYTES > 64 * 1024 &&
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_fwd_kernel<C>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES) != hipSuccess)
-            return MIS_ERR_LAUNCH;
-        attr_set = true;
-    }
+    static std::atomic<unsigned long long> attr_done{0};   // per instantiation, one bit per device
+    if (mis_set_lds_attr(reinterpret_cast<const void*>(&conv_fwd_kernel<C>), C::LDS_BYTES, attr_done) != MIS_OK) return MIS_ERR_LAUNCH;
     hipLaunchKernelGGL(conv_fwd_kernel<C>, dim3(a.n_blocks_padded), dim3(256), C::LDS_BYTES, stream, a);
     return mis_launch_status();
 }

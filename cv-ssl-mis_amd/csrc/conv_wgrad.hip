@@ -338,14 +338,8 @@ void fill_tiles(WgradArgs& a) {
 
 template <class C>
 int launch_wgrad(WgradArgs a, float* dw, int accumulate, hipStream_t stream) {
-    static bool attr_set = false;   // per instantiation; > 64 KiB of LDS needs the opt-in
-    if (!attr_set) {
-        if (C::LDS_BYTES > 64 * 1024 &&
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_kernel<C>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES) != hipSuccess)
-            return MIS_ERR_LAUNCH;
-        attr_set = true;
-    }
+    static std::atomic<unsigned long long> attr_done{0};   // per instantiation, one bit per device
+    if (mis_set_lds_attr(reinterpret_cast<const void*>(&conv_wgrad_kernel<C>), C::LDS_BYTES, attr_done) != MIS_OK) return MIS_ERR_LAUNCH;
     a.n_blocks_padded = (unsigned)(mis_cdiv((long long)a.pairs * a.KS, MIS_NUM_XCD) * MIS_NUM_XCD);
     hipLaunchKernelGGL(conv_wgrad_kernel<C>, dim3(a.n_blocks_padded), dim3(256), C::LDS_BYTES, stream, a);
     int st = mis_launch_status();

@@ -410,14 +410,8 @@ bool a16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
 template <int BN>
 int launch_nt(const GemmArgs& a, hipStream_t stream) {
-    static bool attr_set = false;   // per instantiation; > 64 KiB of LDS needs the opt-in
-    if (!attr_set) {
-        if (NtCfg<BN>::LDS_BYTES > 64 * 1024 &&
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_kernel<BN>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, NtCfg<BN>::LDS_BYTES) != hipSuccess)
-            return MIS_ERR_LAUNCH;
-        attr_set = true;
-    }
+    static std::atomic<unsigned long long> attr_done{0};   // per instantiation, one bit per device
+    if (mis_set_lds_attr(reinterpret_cast<const void*>(&gemm_nt_kernel<BN>), NtCfg<BN>::LDS_BYTES, attr_done) != MIS_OK) return MIS_ERR_LAUNCH;
     hipLaunchKernelGGL(gemm_nt_kernel<BN>, dim3(a.n_blocks_padded), dim3(256), NtCfg<BN>::LDS_BYTES, stream, a);
     return mis_launch_status();
 }

@@ -1,0 +1,44 @@
+"""bench.py's self-launching path (``python bench.py --gpus N`` without an external torchrun) on CPU:
+world 2 over gloo on a stub step -- the rendezvous, barrier + max-over-ranks timing and the JSON contract."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(extra, env_extra=None):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(env_extra or {})
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--stub", "--steps", "3", "--warmup", "1"] + extra,
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout       # exactly ONE JSON line, from rank 0
+    return json.loads(lines[0])
+
+
+@pytest.mark.timeout(900)
+def test_self_launch_world2_gloo():
+    out = _run(["--gpus", "2"])
+    assert out["n_gpus"] == 2 and out["steps"] == 3 and out["warmup"] == 1
+    assert out["distributed"]["world_size_seen"] == 2 and out["distributed"]["backend"] == "gloo"
+    per = out["distributed"]["per_rank_ms_per_step"]
+    assert len(per) == 2 and abs(max(per) - out["ms_per_step"]) < 1e-6      # MAX over ranks
+    assert out["scaling"] == "weak" and out["higher_is_better"] is True
+    assert out["config"]["global_batch"] == 2 * 8 and out["config"]["parallelism"] == "dp2"
+    assert "configs[2]" in out["config"]["workload"]                        # default = the north-star workload
+
+
+@pytest.mark.timeout(600)
+def test_single_process_default_and_world_mismatch():
+    out = _run([])
+    assert out["n_gpus"] == 1 and out["distributed"]["world_size_seen"] == 1
+    env = {k: v for k, v in os.environ.items()}
+    env.update(WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--stub", "--gpus", "4"], capture_output=True,
+                       text=True, timeout=300, env=env)
+    assert p.returncode != 0 and "must equal --gpus" in p.stderr
