@@ -28,6 +28,7 @@ struct Geo {
     int P;            // splits of one (group, chunk)
     int nchunks;      // chunks per group: N (batch norm) or 1 (instance norm)
     int G;            // groups
+    int cg;           // per_sample only: channels sharing one (mean, rstd): 1 = InstanceNorm, C/16 = GroupNorm(16)
 };
 
 __host__ __device__ inline int pick_P(long long S) {
@@ -37,9 +38,9 @@ __host__ __device__ inline int pick_P(long long S) {
     return (int)p;
 }
 
-Geo make_geo(int N, int C, long long S, long long x_bs, int per_sample) {
+Geo make_geo(int N, int C, long long S, long long x_bs, int per_sample, int cg = 1) {
     Geo g;
-    g.N = N; g.C = C; g.S = S; g.x_bs = x_bs; g.per_sample = per_sample;
+    g.N = N; g.C = C; g.S = S; g.x_bs = x_bs; g.per_sample = per_sample; g.cg = cg;
     g.P = pick_P(S);
     g.nchunks = per_sample ? 1 : N;
     g.G = per_sample ? N * C : C;
@@ -183,7 +184,7 @@ __global__ __launch_bounds__(256) void apply_fwd_kernel(const float* __restrict_
                                                         const float* __restrict__ beta, float slope, DropCfg d,
                                                         float* __restrict__ y, long long y_bs) {
     const int c = blockIdx.y, n = blockIdx.z;
-    const int grp = g.per_sample ? n * g.C + c : c;
+    const int grp = g.per_sample ? (n * g.C + c) / g.cg : c;
     const float sc = (gamma ? gamma[c] : 1.f) * rstd[grp];
     const float sh = (beta ? beta[c] : 0.f) - mean[grp] * sc;
     const float* __restrict__ xb = x + (long long)n * g.x_bs + (long long)c * g.S;
@@ -223,7 +224,8 @@ __global__ __launch_bounds__(256) void bwd_partial_kernel(const float* __restric
     const int p = blockIdx.x, k = blockIdx.y, grp = blockIdx.z;
     const int n = g.per_sample ? grp / g.C : k;
     const int c = g.per_sample ? grp % g.C : grp;
-    const float m = mean[grp], rs = rstd[grp];
+    const int sg = g.per_sample ? grp / g.cg : grp;   // statistics group of this (n, c)
+    const float m = mean[sg], rs = rstd[sg];
     const float ga = gamma ? gamma[c] : 1.f, be = beta ? beta[c] : 0.f;
     const float* __restrict__ xb = x + (long long)n * g.x_bs + (long long)c * g.S;
     const float* __restrict__ db = da + (long long)n * da_bs + (long long)c * g.S;
@@ -280,6 +282,52 @@ __global__ __launch_bounds__(256) void bwd_final_kernel(const float2* __restrict
     }
 }
 
+// GroupNorm backward, second stage.  part[(n*C + c)*P + p] = (sum dz, sum dz*xhat) of one channel of one sample
+// (dz = gradient at the affine output).  With dxhat = gamma_c * dz:
+//   sums[n*G + grp] = (sum_{c in grp} gamma_c * a_nc, sum gamma_c * b_nc) / (cg * S)      one wave per (n, grp)
+__global__ __launch_bounds__(256) void gn_bwd_group_kernel(const float2* __restrict__ part, Geo g,
+                                                           const float* __restrict__ gamma,
+                                                           float2* __restrict__ sums) {
+    const int G = g.C / g.cg;
+    const int sg = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (sg >= g.N * G) return;
+    const int n = sg / G, c0 = (sg - n * G) * g.cg;
+    const int np = g.cg * g.P;
+    const float2* __restrict__ pg = part + ((long long)n * g.C + c0) * g.P;
+    double s1 = 0.0, s2 = 0.0;
+    for (int i = lane; i < np; i += 64) {
+        const float ga = gamma ? gamma[c0 + i / g.P] : 1.f;
+        const float2 q = pg[i];
+        s1 += (double)ga * q.x; s2 += (double)ga * q.y;
+    }
+    s1 = mis_wave_sum_d(s1); s2 = mis_wave_sum_d(s2);
+    if (lane == 0) {
+        const double E = (double)g.cg * (double)g.S;
+        sums[sg] = make_float2((float)(s1 / E), (float)(s2 / E));
+    }
+}
+
+//   dgamma[c] = sum_n b_nc, dbeta[c] = sum_n a_nc                                          one wave per channel
+__global__ __launch_bounds__(256) void gn_bwd_affine_kernel(const float2* __restrict__ part, Geo g, float* dgamma,
+                                                            float* dbeta, int accumulate) {
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (c >= g.C) return;
+    double s1 = 0.0, s2 = 0.0;
+    for (int i = lane; i < g.N * g.P; i += 64) {
+        const int n = i / g.P, p = i - n * g.P;
+        const float2 q = part[((long long)n * g.C + c) * g.P + p];
+        s1 += q.x; s2 += q.y;
+    }
+    s1 = mis_wave_sum_d(s1); s2 = mis_wave_sum_d(s2);
+    if (lane == 0) {
+        dgamma[c] = accumulate ? dgamma[c] + (float)s2 : (float)s2;
+        dbeta[c] = accumulate ? dbeta[c] + (float)s1 : (float)s1;
+    }
+}
+
+// kind 0: BatchNorm / InstanceNorm (sums = means of dz, dz*xhat; gamma is constant over the group and factors out)
+// kind 1: GroupNorm (sums = means of gamma*dz, gamma*dz*xhat over the channel group)
+// kind 2: no normalisation (mean = 0, rstd = 1, gamma = null): dx = dz
 __global__ __launch_bounds__(256) void apply_bwd_kernel(const float* __restrict__ x, Geo g,
                                                         const float* __restrict__ da, long long da_bs,
                                                         const float* __restrict__ mean,
@@ -287,12 +335,12 @@ __global__ __launch_bounds__(256) void apply_bwd_kernel(const float* __restrict_
                                                         const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, float slope, DropCfg d,
                                                         const float2* __restrict__ sums, float* __restrict__ dx,
-                                                        long long dx_bs) {
+                                                        long long dx_bs, int kind) {
     const int c = blockIdx.y, n = blockIdx.z;
-    const int grp = g.per_sample ? n * g.C + c : c;
+    const int grp = g.per_sample ? (n * g.C + c) / g.cg : c;
     const float m = mean[grp], rs = rstd[grp];
     const float ga = gamma ? gamma[c] : 1.f, be = beta ? beta[c] : 0.f;
-    const float2 sm = sums[grp];
+    const float2 sm = kind == 2 ? make_float2(0.f, 0.f) : sums[grp];
     const float k = ga * rs;
     const float* __restrict__ xb = x + (long long)n * g.x_bs + (long long)c * g.S;
     const float* __restrict__ db = da + (long long)n * da_bs + (long long)c * g.S;
@@ -320,7 +368,7 @@ __global__ __launch_bounds__(256) void apply_bwd_kernel(const float* __restrict_
             const float xh = (xs[j] - m) * rs;
             const float z = xh * ga + be;
             const float dz = z > 0.f ? gs[j] : gs[j] * slope;
-            o[j] = k * (dz - sm.x - xh * sm.y);
+            o[j] = kind == 1 ? rs * (ga * dz - sm.x - xh * sm.y) : k * (dz - sm.x - xh * sm.y);
         }
         *reinterpret_cast<float4*>(ob + u * 4) = make_float4(o[0], o[1], o[2], o[3]);
     }
@@ -402,22 +450,81 @@ extern "C" int mis_norm_stats_from_running(const float* running_mean, const floa
     return mis_launch_status();
 }
 
-extern "C" int mis_norm_act_fwd(const float* x, long long x_bs, float* y, long long y_bs, int N, int C,
-                                long long S, int per_sample, const float* mean, const float* rstd,
-                                const float* gamma, const float* beta, float slope, float drop_p,
-                                unsigned drop_salt, const MisStepState* state, const float* drop_mask,
-                                hipStream_t stream) {
+// Generalised form: ``cg`` channels share one (mean, rstd) when per_sample != 0 (mean / rstd hold N * C/cg entries):
+// cg = 1 is InstanceNorm, cg = C/16 is nn.GroupNorm(16, C) (reference code/networks/vnet.py:19-20) with its per-channel
+// affine in gamma / beta.  Statistics of a GroupNorm come from mis_norm_stats on the same memory viewed as
+// [N, C/cg, cg*S] with per_sample = 1 (the channels of a group are contiguous in NCDHW), or from the conv epilogue's
+// per-(n, c, tile) partials through mis_norm_stats_finalize(part, N, C/cg, cg*S, cg*tiles, 1, ...).
+extern "C" int mis_norm_act_fwd_g(const float* x, long long x_bs, float* y, long long y_bs, int N, int C,
+                                  long long S, int per_sample, int cg, const float* mean, const float* rstd,
+                                  const float* gamma, const float* beta, float slope, float drop_p,
+                                  unsigned drop_salt, const MisStepState* state, const float* drop_mask,
+                                  hipStream_t stream) {
     int st = check_geo(x, N, C, S, x_bs);
     if (st) return st;
+    if (cg < 1 || C % cg != 0 || (cg > 1 && !per_sample)) return MIS_ERR_ARG;
     if (!y || !mean || !rstd || y_bs % 4 != 0 || !aligned16(y) || y_bs < (long long)C * S) return MIS_ERR_ARG;
     if (drop_p < 0.f || drop_p >= 1.f) return MIS_ERR_ARG;
     if (drop_p > 0.f && !state && !drop_mask) return MIS_ERR_ARG;
-    const Geo g = make_geo(N, C, S, x_bs, per_sample);
+    const Geo g = make_geo(N, C, S, x_bs, per_sample, cg);
     DropCfg d{drop_p, drop_salt, state, drop_mask};
     const long long units = S >> 2;
     const unsigned gx = (unsigned)mis_cdiv(units, 256 * APPLY_U);
     hipLaunchKernelGGL(apply_fwd_kernel, dim3(gx, C, N), dim3(256), 0, stream, x, g, mean, rstd, gamma, beta,
                        slope, d, y, y_bs);
+    return mis_launch_status();
+}
+
+extern "C" int mis_norm_act_fwd(const float* x, long long x_bs, float* y, long long y_bs, int N, int C,
+                                long long S, int per_sample, const float* mean, const float* rstd,
+                                const float* gamma, const float* beta, float slope, float drop_p,
+                                unsigned drop_salt, const MisStepState* state, const float* drop_mask,
+                                hipStream_t stream) {
+    return mis_norm_act_fwd_g(x, x_bs, y, y_bs, N, C, S, per_sample, 1, mean, rstd, gamma, beta, slope, drop_p,
+                              drop_salt, state, drop_mask, stream);
+}
+
+// Backward of mis_norm_act_fwd_g.  ``no_norm`` != 0: the layer is activation (+ dropout) only -- the reference's
+// normalization='none' blocks -- mean must hold zeros, rstd ones, gamma / beta null; no reduction runs.
+// Workspace: mis_norm_workspace_bytes(N, C, S, per_sample) (covers every cg).
+extern "C" int mis_norm_act_bwd_g(const float* x, long long x_bs, const float* da, long long da_bs, float* dx,
+                                  long long dx_bs, int N, int C, long long S, int per_sample, int cg, int no_norm,
+                                  const float* mean, const float* rstd, const float* gamma, const float* beta,
+                                  float slope, float drop_p, unsigned drop_salt, const MisStepState* state,
+                                  const float* drop_mask, float* dgamma, float* dbeta, int accumulate_affine,
+                                  void* workspace, long long workspace_bytes, hipStream_t stream) {
+    int st = check_geo(x, N, C, S, x_bs);
+    if (st) return st;
+    if (cg < 1 || C % cg != 0 || (cg > 1 && !per_sample) || (no_norm && (gamma || beta))) return MIS_ERR_ARG;
+    if (!da || !dx || !mean || !rstd || !workspace) return MIS_ERR_ARG;
+    if (da_bs % 4 != 0 || dx_bs % 4 != 0 || !aligned16(da) || !aligned16(dx)) return MIS_ERR_UNSUPPORTED;
+    if (da_bs < (long long)C * S || dx_bs < (long long)C * S) return MIS_ERR_ARG;
+    if (drop_p < 0.f || drop_p >= 1.f) return MIS_ERR_ARG;
+    if (drop_p > 0.f && !state && !drop_mask) return MIS_ERR_ARG;
+    if (workspace_bytes < mis_norm_workspace_bytes(N, C, S, per_sample)) return MIS_ERR_WORKSPACE;
+    const Geo g = make_geo(N, C, S, x_bs, per_sample, cg);
+    DropCfg d{drop_p, drop_salt, state, drop_mask};
+    float2* part = reinterpret_cast<float2*>(workspace);
+    float2* sums = part + (long long)g.G * g.nchunks * g.P;
+    const bool gn = per_sample && (cg > 1 || gamma);    // per-channel affine inside a per-sample group
+    if (!no_norm) {
+        hipLaunchKernelGGL(bwd_partial_kernel, dim3(g.P, g.nchunks, g.G), dim3(256), 0, stream, x, g, da, da_bs, mean,
+                           rstd, gamma, beta, slope, d, part);
+        if (gn) {
+            hipLaunchKernelGGL(gn_bwd_group_kernel, dim3((N * (C / cg) + 3) / 4), dim3(256), 0, stream, part, g, gamma,
+                               sums);
+            if (dgamma && dbeta)
+                hipLaunchKernelGGL(gn_bwd_affine_kernel, dim3((C + 3) / 4), dim3(256), 0, stream, part, g, dgamma,
+                                   dbeta, accumulate_affine);
+        } else {
+            hipLaunchKernelGGL(bwd_final_kernel, dim3((g.G + 3) / 4), dim3(256), 0, stream, part, g, sums, dgamma,
+                               dbeta, accumulate_affine);
+        }
+    }
+    const long long units = S >> 2;
+    const unsigned gx = (unsigned)mis_cdiv(units, 256 * APPLY_U);
+    hipLaunchKernelGGL(apply_bwd_kernel, dim3(gx, C, N), dim3(256), 0, stream, x, g, da, da_bs, mean, rstd, gamma,
+                       beta, slope, d, sums, dx, dx_bs, no_norm ? 2 : (gn ? 1 : 0));
     return mis_launch_status();
 }
 
@@ -427,25 +534,7 @@ extern "C" int mis_norm_act_bwd(const float* x, long long x_bs, const float* da,
                                 float drop_p, unsigned drop_salt, const MisStepState* state,
                                 const float* drop_mask, float* dgamma, float* dbeta, int accumulate_affine,
                                 void* workspace, long long workspace_bytes, hipStream_t stream) {
-    int st = check_geo(x, N, C, S, x_bs);
-    if (st) return st;
-    if (!da || !dx || !mean || !rstd || !workspace) return MIS_ERR_ARG;
-    if (da_bs % 4 != 0 || dx_bs % 4 != 0 || !aligned16(da) || !aligned16(dx)) return MIS_ERR_UNSUPPORTED;
-    if (da_bs < (long long)C * S || dx_bs < (long long)C * S) return MIS_ERR_ARG;
-    if (drop_p < 0.f || drop_p >= 1.f) return MIS_ERR_ARG;
-    if (drop_p > 0.f && !state && !drop_mask) return MIS_ERR_ARG;
-    if (workspace_bytes < mis_norm_workspace_bytes(N, C, S, per_sample)) return MIS_ERR_WORKSPACE;
-    const Geo g = make_geo(N, C, S, x_bs, per_sample);
-    DropCfg d{drop_p, drop_salt, state, drop_mask};
-    float2* part = reinterpret_cast<float2*>(workspace);
-    float2* sums = part + (long long)g.G * g.nchunks * g.P;
-    hipLaunchKernelGGL(bwd_partial_kernel, dim3(g.P, g.nchunks, g.G), dim3(256), 0, stream, x, g, da, da_bs, mean,
-                       rstd, gamma, beta, slope, d, part);
-    hipLaunchKernelGGL(bwd_final_kernel, dim3((g.G + 3) / 4), dim3(256), 0, stream, part, g, sums, dgamma, dbeta,
-                       accumulate_affine);
-    const long long units = S >> 2;
-    const unsigned gx = (unsigned)mis_cdiv(units, 256 * APPLY_U);
-    hipLaunchKernelGGL(apply_bwd_kernel, dim3(gx, C, N), dim3(256), 0, stream, x, g, da, da_bs, mean, rstd, gamma,
-                       beta, slope, d, sums, dx, dx_bs);
-    return mis_launch_status();
+    return mis_norm_act_bwd_g(x, x_bs, da, da_bs, dx, dx_bs, N, C, S, per_sample, 1, 0, mean, rstd, gamma, beta,
+                              slope, drop_p, drop_salt, state, drop_mask, dgamma, dbeta, accumulate_affine, workspace,
+                              workspace_bytes, stream);
 }

@@ -29,6 +29,70 @@ def sync_gradients(flat_grad, group=None):
     return 1.0 / w
 
 
+class GradBucketer:
+    """Overlap of the gradient exchange with the backward pass.
+
+    The flat gradient buffer is laid out in parameter (= forward) order and the backward pass finishes it from the
+    END towards the start, so the finished part is always a suffix.  ``advance(lo)`` -- called by ``Plan.backward``
+    after every op with the start of the finished suffix -- issues an asynchronous all-reduce (sum) for every bucket
+    that now lies completely inside it; RCCL runs it on the process group's own stream while the remaining backward
+    kernels keep the compute stream busy.  ``finish()`` issues what is left and makes the current stream wait for all
+    of them (no host synchronisation).  The reduction is element-wise, so the result is identical to one all-reduce
+    of the whole buffer; every rank cuts the same buckets (a pure function of the buffer size).
+
+    Bucket size: xGMI is point-to-point (7 links x ~153 GB/s per GPU), a ring all-reduce is per-link bound and needs
+    messages of several MB to reach its bandwidth; 8 MiB buckets give 3 (unet_3D, 23.5 MB) to 13 (SwinUnet, 108.7 MB)
+    collectives per step instead of ~240 per-tensor ones."""
+
+    def __init__(self, flat_grad, group=None, bucket_bytes=8 << 20):
+        self.flat, self.group = flat_grad, group
+        n, per = flat_grad.numel(), max(1, bucket_bytes // flat_grad.element_size())
+        # cut from the end (the part that finishes first); the first bucket takes the remainder
+        cuts = list(range(n, 0, -per)) + [0]
+        self.buckets = [(cuts[i + 1], cuts[i]) for i in range(len(cuts) - 1)]     # (lo, hi), descending
+        self._next, self._works = 0, []
+
+    def begin(self):
+        self._next, self._works = 0, []
+
+    def advance(self, lo):
+        """All gradient elements at offsets >= ``lo`` are final."""
+        while self._next < len(self.buckets) and self.buckets[self._next][0] >= lo:
+            b_lo, b_hi = self.buckets[self._next]
+            self._works.append(dist.all_reduce(self.flat[b_lo:b_hi], op=dist.ReduceOp.SUM, group=self.group,
+                                               async_op=True))
+            self._next += 1
+
+    def finish(self):
+        self.advance(0)
+        for w in self._works:
+            w.wait()
+        self._works = []
+        return 1.0 / world_size(self.group)
+
+
+def param_progress(ops, flat_grad):
+    """For a plan's op list (forward order): ``done[i]`` = start of the finished suffix of ``flat_grad`` once the
+    backward pass has executed ops ``i, i+1, ...`` (it runs them in reverse), i.e. the highest end offset of any
+    parameter gradient written by the ops still to run (``0`` when none is left).  An op writes the gradients of the
+    parameter references it holds as attributes (objects with ``.grad`` views into ``flat_grad``)."""
+    base, esz, total = flat_grad.data_ptr(), flat_grad.element_size(), flat_grad.numel()
+    ends = []
+    for op in ops:
+        hi = 0
+        for v in vars(op).values():
+            g = getattr(v, "grad", None)
+            if isinstance(g, torch.Tensor) and hasattr(v, "data") and g.numel() and \
+                    base <= g.data_ptr() < base + total * esz:
+                hi = max(hi, (g.data_ptr() - base) // esz + g.numel())
+        ends.append(hi)
+    done, run = [], 0
+    for hi in ends:              # prefix maximum over the ops BEFORE i
+        done.append(run)
+        run = max(run, hi)
+    return done
+
+
 def broadcast_state(flat_tensors, src=0, group=None):
     """Make every rank start from rank ``src``'s parameters / buffers."""
     if world_size(group) > 1:

@@ -213,28 +213,41 @@ def norm_stats_from_running(running_mean, running_var, eps, mean, rstd):
 
 
 def norm_act_fwd(x, y, per_sample, mean, rstd, gamma, beta, slope, drop_p=0.0, drop_salt=0, state=None,
-                 drop_mask=None):
+                 drop_mask=None, cg=1):
+    """``cg``: channels per statistics group of a per-sample norm (1 InstanceNorm, C/16 GroupNorm(16))."""
     L = _l.load()
     N, C, D, H, W, S, xbs = _geom(x)
     _, _, _, _, _, _, ybs = _geom(y)
-    _l.check(L.mis_norm_act_fwd(_l.ptr(x), xbs, _l.ptr(y), ybs, N, C, S, int(per_sample), _l.ptr(mean),
-                                _l.ptr(rstd), _l.ptr(gamma), _l.ptr(beta), slope, drop_p, drop_salt,
-                                _l.ptr(state), _l.ptr(drop_mask), _l.stream_ptr()), "mis_norm_act_fwd")
+    _l.check(L.mis_norm_act_fwd_g(_l.ptr(x), xbs, _l.ptr(y), ybs, N, C, S, int(per_sample), int(cg), _l.ptr(mean),
+                                  _l.ptr(rstd), _l.ptr(gamma), _l.ptr(beta), slope, drop_p, drop_salt,
+                                  _l.ptr(state), _l.ptr(drop_mask), _l.stream_ptr()), "mis_norm_act_fwd_g")
 
 
 def norm_act_bwd(x, da, dx, per_sample, mean, rstd, gamma, beta, slope, drop_p=0.0, drop_salt=0, state=None,
-                 drop_mask=None, dgamma=None, dbeta=None, accumulate_affine=False):
+                 drop_mask=None, dgamma=None, dbeta=None, accumulate_affine=False, cg=1, no_norm=False):
     L = _l.load()
     N, C, D, H, W, S, xbs = _geom(x)
     _, _, _, _, _, _, dabs = _geom(da)
     _, _, _, _, _, _, dxbs = _geom(dx)
     nb = L.mis_norm_workspace_bytes(N, C, S, int(per_sample))
     ws = scratch(nb, "norm")
-    _l.check(L.mis_norm_act_bwd(_l.ptr(x), xbs, _l.ptr(da), dabs, _l.ptr(dx), dxbs, N, C, S, int(per_sample),
-                                _l.ptr(mean), _l.ptr(rstd), _l.ptr(gamma), _l.ptr(beta), slope, drop_p,
-                                drop_salt, _l.ptr(state), _l.ptr(drop_mask), _l.ptr(dgamma), _l.ptr(dbeta),
-                                int(accumulate_affine), _l.ptr(ws), ws.numel(), _l.stream_ptr()),
-             "mis_norm_act_bwd")
+    _l.check(L.mis_norm_act_bwd_g(_l.ptr(x), xbs, _l.ptr(da), dabs, _l.ptr(dx), dxbs, N, C, S, int(per_sample),
+                                  int(cg), int(no_norm), _l.ptr(mean), _l.ptr(rstd), _l.ptr(gamma), _l.ptr(beta),
+                                  slope, drop_p, drop_salt, _l.ptr(state), _l.ptr(drop_mask), _l.ptr(dgamma),
+                                  _l.ptr(dbeta), int(accumulate_affine), _l.ptr(ws), ws.numel(), _l.stream_ptr()),
+             "mis_norm_act_bwd_g")
+
+
+def group_norm_stats(x, cg, eps, mean, rstd):
+    """(mean, rstd) per (n, group of ``cg`` consecutive channels): the groups are contiguous in NCDHW, so this is the
+    InstanceNorm statistics kernel on the [N, C/cg, cg*S] view of the same memory."""
+    L = _l.load()
+    N, C, D, H, W, S, xbs = _geom(x)
+    G = C // cg
+    nb = L.mis_norm_workspace_bytes(N, G, cg * S, 1)
+    ws = scratch(nb, "norm")
+    _l.check(L.mis_norm_stats(_l.ptr(x), xbs, N, G, cg * S, 1, eps, _l.ptr(mean), _l.ptr(rstd), None, None, None,
+                              0.0, _l.ptr(ws), ws.numel(), _l.stream_ptr()), "mis_norm_stats")
 
 
 # ------------------------------------------------------------ pool / upsample

@@ -121,32 +121,40 @@ class ConvOp:
 
 
 class NormActOp:
-    """BatchNorm(train/eval) or InstanceNorm, then (Leaky)ReLU, then inverted dropout."""
+    """BatchNorm(train/eval), InstanceNorm or GroupNorm (``per_sample`` with ``cg`` channels per group and a per-channel
+    affine), or no normalisation at all (``no_norm``), then (Leaky)ReLU, then inverted dropout."""
 
-    def __init__(self, x, y, per_sample, gamma, beta, running, slope, drop_p, site, eps=1e-5, momentum=0.1):
+    def __init__(self, x, y, per_sample, gamma, beta, running, slope, drop_p, site, eps=1e-5, momentum=0.1, cg=1,
+                 no_norm=False):
         self.x, self.y, self.per_sample = x, y, per_sample
+        self.cg, self.no_norm = cg, no_norm
         self.gamma, self.beta, self.running = gamma, beta, running  # running = (mean, var, nbt) or None
         self.slope, self.drop_p, self.site, self.eps, self.momentum = slope, drop_p, site, eps, momentum
         self.salt = 0
         self.fused = None        # (partials, tiles): statistics come from the producing ConvOp's epilogue
         self.drop3d = False      # True: nn.Dropout3d semantics (whole feature maps)
         N, C = x.shape[0], x.shape[1]
-        G = N * C if per_sample else C
-        self.mean = torch.empty(G, dtype=torch.float32, device="cuda")
-        self.rstd = torch.empty(G, dtype=torch.float32, device="cuda")
+        G = N * C // cg if per_sample else C
+        self.mean = torch.zeros(G, dtype=torch.float32, device="cuda")     # no_norm: stays (0, 1)
+        self.rstd = torch.ones(G, dtype=torch.float32, device="cuda")
         self._p = 0.0
         self._mask = None
 
     def fwd(self, ctx):
-        if not self.per_sample and not ctx.training:
+        if self.no_norm:
+            pass
+        elif not self.per_sample and not ctx.training:
             ops.norm_stats_from_running(self.running[0], self.running[1], self.eps, self.mean, self.rstd)
         else:
             rm, rv, nbt = self.running if (self.running is not None and ctx.training) else (None, None, None)
             if self.fused is not None:       # the producing conv already left per-tile (sum, sumsq) partials
                 N, C = self.x.shape[0], self.x.shape[1]
                 S = self.x.shape[2] * self.x.shape[3] * self.x.shape[4]
-                ops.norm_stats_finalize(self.fused[0], N, C, S, self.fused[1], self.per_sample, self.eps, self.mean,
-                                        self.rstd, rm, rv, nbt, self.momentum)
+                # a group of cg channels of one sample = cg * tiles consecutive partials
+                ops.norm_stats_finalize(self.fused[0], N, C // self.cg, S * self.cg, self.fused[1] * self.cg,
+                                        self.per_sample, self.eps, self.mean, self.rstd, rm, rv, nbt, self.momentum)
+            elif self.cg > 1:
+                ops.group_norm_stats(self.x.t, self.cg, self.eps, self.mean, self.rstd)
             else:
                 ops.norm_stats(self.x.t, self.per_sample, self.eps, self.mean, self.rstd, rm, rv, nbt, self.momentum)
         self._p = self.drop_p if (ctx.training and ctx.dropout) else 0.0
@@ -159,7 +167,7 @@ class NormActOp:
         ops.norm_act_fwd(self.x.t, self.y.t, self.per_sample, self.mean, self.rstd,
                          None if self.gamma is None else self.gamma.data,
                          None if self.beta is None else self.beta.data, self.slope, self._p, self.salt,
-                         self._state, self._mask)
+                         self._state, self._mask, cg=self.cg)
 
     def bwd(self, ctx):
         assert not self.x.written
@@ -168,7 +176,7 @@ class NormActOp:
                          None if self.beta is None else self.beta.data, self.slope, self._p, self.salt,
                          self._state, self._mask,
                          None if self.gamma is None else self.gamma.grad,
-                         None if self.beta is None else self.beta.grad)
+                         None if self.beta is None else self.beta.grad, cg=self.cg, no_norm=self.no_norm)
         self.x.mark_written()
 
 
@@ -200,8 +208,8 @@ class UpsampleOp:
 class DownConvOp:
     """nn.Conv3d(Cin, Cout, 2, stride=2) (reference vnet.py:73) = space_to_depth + 1x1x1 MFMA conv."""
 
-    def __init__(self, x, y, w, b):
-        self.x, self.y, self.w, self.b = x, y, w, b
+    def __init__(self, x, y, w, b, bias_grad=False):
+        self.x, self.y, self.w, self.b, self.bias_grad = x, y, w, b, bias_grad
         N, Cin, D, H, W = x.shape
         self.cin8, self.cout = 8 * Cin, w.data.shape[0]
         self.xs = torch.empty((N, self.cin8, D // 2, H // 2, W // 2), dtype=torch.float32, device="cuda")
@@ -216,7 +224,9 @@ class DownConvOp:
     def bwd(self, ctx):
         dy = self.y.grad()
         ops.conv_wgrad(self.xs, dy, self.w.grad, (1, 1, 1))      # [Cout][8Cin] == [Cout][Cin][2][2][2] in memory
-        # bias gradient exactly 0: the conv feeds a BatchNorm (see ConvOp)
+        # bias gradient exactly 0 when the conv feeds a normalisation (see ConvOp)
+        if self.bias_grad:
+            ops.channel_sum(dy, self.b.grad)
         if self.dxs is None:
             self.dxs = torch.empty_like(self.xs)
         self.wpd = ops.conv_pack_raw(self.w.data, self.cout, self.cin8, 1, 1, out=self.wpd)
@@ -229,8 +239,8 @@ class UpConvOp:
     """nn.ConvTranspose3d(Cin, Cout, 2, stride=2) (reference vnet.py:100) = 1x1x1 MFMA conv to 8*Cout
     channels (weight stored input-major [Cin][Cout*8]) + depth_to_space (+ bias)."""
 
-    def __init__(self, x, y, w, b):
-        self.x, self.y, self.w, self.b = x, y, w, b
+    def __init__(self, x, y, w, b, bias_grad=False):
+        self.x, self.y, self.w, self.b, self.bias_grad = x, y, w, b, bias_grad
         N, Cin, d, h, wd = x.shape
         self.cin, self.cout8 = Cin, 8 * w.data.shape[1]
         self.y8 = torch.empty((N, self.cout8, d, h, wd), dtype=torch.float32, device="cuda")
@@ -248,6 +258,8 @@ class UpConvOp:
         if self.dy8 is None:
             self.dy8 = torch.empty_like(self.y8)
             self.dw8 = torch.empty((self.cout8, self.cin), dtype=torch.float32, device="cuda")
+        if self.bias_grad:
+            ops.channel_sum(self.y.grad(), self.b.grad)
         ops.space_to_depth2(self.y.grad(), self.dy8, self.y.shape, True)
         ops.conv_wgrad(self.x.t, self.dy8, self.dw8, (1, 1, 1))                  # [8Cout][Cin]
         tops.transpose(self.dw8, self.w.grad.view(self.cin, self.cout8))         # parameter is [Cin][8Cout]
@@ -289,6 +301,8 @@ class Plan:
         self._salt = itertools.count(0)
         self.out = None
         self._packs = None
+        self.generation = 0      # forwards run on this plan (its buffers hold the activations of the LAST one)
+        self._progress = None    # dist.param_progress(self.ops, net.flat_grad), built on the first overlapped backward
 
     # ---- builders used by the networks ----
     def new(self, C, spatial, N=None):
@@ -305,12 +319,13 @@ class Plan:
         self.ops.append(ConvOp(x, y, w, b, ksize, need_dx, bias_grad))
         return y
 
-    def norm_act(self, x, y, per_sample, gamma=None, beta=None, running=None, slope=0.0, drop_p=0.0, drop3d=False):
-        op = NormActOp(x, y, per_sample, gamma, beta, running, slope, drop_p, next(self._salt))
+    def norm_act(self, x, y, per_sample, gamma=None, beta=None, running=None, slope=0.0, drop_p=0.0, drop3d=False,
+                 cg=1, no_norm=False):
+        op = NormActOp(x, y, per_sample, gamma, beta, running, slope, drop_p, next(self._salt), cg=cg, no_norm=no_norm)
         op.drop3d = drop3d
         # conv -> norm: let the conv epilogue produce the statistics (no separate pass over the conv output)
         prev = self.ops[-1] if self.ops else None
-        if FUSE_CONV_STATS and type(prev) is ConvOp and prev.y is x:
+        if FUSE_CONV_STATS and not no_norm and type(prev) is ConvOp and prev.y is x:
             N, C, D, H, W = x.shape
             T = ops.conv_stat_tiles(N, prev.cin, prev.cout, D, H, W, prev.ksize)
             if T > 0:
@@ -321,12 +336,12 @@ class Plan:
         self.ops.append(op)
         return y
 
-    def down_conv(self, x, y, w, b):
-        self.ops.append(DownConvOp(x, y, w, b))
+    def down_conv(self, x, y, w, b, bias_grad=False):
+        self.ops.append(DownConvOp(x, y, w, b, bias_grad))
         return y
 
-    def up_conv(self, x, y, w, b):
-        self.ops.append(UpConvOp(x, y, w, b))
+    def up_conv(self, x, y, w, b, bias_grad=False):
+        self.ops.append(UpConvOp(x, y, w, b, bias_grad))
         return y
 
     def add(self, a, b, out):
@@ -365,20 +380,32 @@ class Plan:
 
     def forward(self, x5, ctx):
         assert tuple(x5.shape) == self.in_shape, (tuple(x5.shape), self.in_shape)
+        self.generation += 1
         self.inp.t = x5
         self._pack(0)
         for op in self.ops:
             op.fwd(ctx)
         return self.out.t
 
-    def backward(self, dlogits5, ctx):
+    def backward(self, dlogits5, ctx, on_progress=None):
+        """``on_progress(lo)``: called after every op with the start of the finished suffix of the flat gradient
+        buffer (data-parallel runs issue the finished gradient buckets while the backward continues, mis_hip.dist)."""
         for a in self.acts:
             a.reset()
         if dlogits5 is not None:
             self.out.g = dlogits5
         self._pack(1)
-        for op in reversed(self.ops):
-            op.bwd(ctx)
+        if on_progress is None:
+            for op in reversed(self.ops):
+                op.bwd(ctx)
+            return
+        if self._progress is None:
+            from .dist import param_progress
+            self._progress = param_progress(self.ops, self.net.flat_grad)
+        for i in range(len(self.ops) - 1, -1, -1):
+            self.ops[i].bwd(ctx)
+            if i == 0 or self._progress[i] != self._progress[i - 1] or i == len(self.ops) - 1:
+                on_progress(self._progress[i])
 
     def drop_sites(self):
         """Site ids (keys of ``net.drop_masks``) of the active dropout layers, in forward order."""
@@ -514,9 +541,12 @@ class HipNet(nn.Module):
         self._last = (plan, ctx)
         return out
 
-    def backward_raw(self, dlogits5=None):
+    def backward_raw(self, dlogits5=None, on_progress=None):
         plan, ctx = self._last
-        plan.backward(dlogits5, ctx)
+        if on_progress is None:
+            plan.backward(dlogits5, ctx)
+        else:
+            plan.backward(dlogits5, ctx, on_progress)
 
     def logits_grad_buffer(self):
         return self._last[0].out.grad()
@@ -537,11 +567,22 @@ class _NetFn(torch.autograd.Function):
         out = net.forward_raw(x)
         ctx.net = net
         ctx.plan_ctx = net._last
+        ctx.generation = net._last[0].generation
         return net._from5(out).clone()
 
     @staticmethod
     def backward(ctx, dout):
         net = ctx.net
+        plan = ctx.plan_ctx[0]
+        if plan.generation != ctx.generation:
+            # one static plan (activation buffers, dropout masks) per input shape: a later same-shape forward --
+            # a pseudo-label pass under no_grad, a validation pass, a second grad-enabled call -- has overwritten
+            # what this backward needs.  torch autograd would keep both graphs; here it must fail loudly.
+            raise RuntimeError(
+                "backward() of a HIP network whose activations were overwritten: forward was called again with the "
+                f"same input shape {plan.in_shape} before this loss.backward() "
+                f"(forward #{ctx.generation}, now #{plan.generation}).  Call backward before the next same-shape "
+                "forward, or use a second network instance.")
         net._last = ctx.plan_ctx
         net.backward_raw(net._as5(dout.contiguous()))
         grads = tuple(net._refs[n].grad.clone() for n, _, k, _ in net._specs if k == "param")

@@ -21,6 +21,24 @@ import torch
 from . import dist, ops
 
 TWO_STREAM = os.environ.get("MIS_TWO_STREAM", "0") == "1"   # teacher forward on a side stream (see _run)
+# data parallel: issue the all-reduce of finished gradient buckets while the backward is still running
+# (dist.GradBucketer); MIS_GRAD_OVERLAP=0 falls back to one blocking all-reduce after the backward
+GRAD_OVERLAP = os.environ.get("MIS_GRAD_OVERLAP", "1") != "0"
+
+
+def backward_and_sync(model, pg, bucketer=None):
+    """Student backward + the step's only exchange: the all-reduce (sum) of the flat gradient bucket.  Returns the
+    1/world scale the optimizer kernel folds in.  With a bucketer the finished buckets travel during the backward."""
+    if bucketer is None:
+        model.backward_raw()
+        return dist.sync_gradients(model.flat_grad, pg)
+    bucketer.begin()
+    model.backward_raw(on_progress=bucketer.advance)
+    return bucketer.finish()
+
+
+def make_bucketer(model, pg):
+    return dist.GradBucketer(model.flat_grad, pg) if (GRAD_OVERLAP and dist.world_size(pg) > 1) else None
 
 
 class MeanTeacherTrainer:
@@ -47,11 +65,13 @@ class MeanTeacherTrainer:
         self.momentum_buf = torch.zeros_like(model.flat_param)
         self.out = torch.zeros(16, dtype=torch.float32, device="cuda")
         self.iter_num = iter_num
-        self.use_graph = use_graph
+        # a captured replay of a step that contains an RCCL collective is not verified on hardware: single-GPU only
+        self.use_graph = bool(use_graph) and self.world == 1
         self._graph = None
         self._static = None
         self._ema_in = None
         self._side = None
+        self._bucketer = make_bucketer(model, process_group)
 
     # ---- the step (eager form; also what gets captured) ----
     def _run(self, volume, label, noise):
@@ -79,8 +99,7 @@ class MeanTeacherTrainer:
             t_logits = self.ema_model.forward_raw(self._ema_in)
         ops.loss_tail(s_logits, t_logits, label[:L].contiguous(), L, self.out,
                       dlogits=self.model.logits_grad_buffer(), state=self.state)
-        self.model.backward_raw()
-        grad_scale = dist.sync_gradients(self.model.flat_grad, self.pg)   # the step's only collective
+        grad_scale = backward_and_sync(self.model, self.pg, self._bucketer)   # the step's only exchange
         ops.sgd_ema_step(self.model.flat_param, self.model.flat_grad, self.momentum_buf,
                          self.ema_model.flat_param, momentum=self.momentum, weight_decay=self.weight_decay,
                          grad_scale=grad_scale, state=self.state)
@@ -169,8 +188,7 @@ class UAMTTrainer(MeanTeacherTrainer):
         self.ema_model.rng_stream = 2
         ops.uamt_tail(s_logits, t_logits, self._mean_probs, label[:L].contiguous(), L, self.out,
                       self.hyper["max_iterations"], dlogits=self.model.logits_grad_buffer(), state=self.state)
-        self.model.backward_raw()
-        grad_scale = dist.sync_gradients(self.model.flat_grad, self.pg)
+        grad_scale = backward_and_sync(self.model, self.pg, self._bucketer)
         ops.sgd_ema_step(self.model.flat_param, self.model.flat_grad, self.momentum_buf,
                          self.ema_model.flat_param, momentum=self.momentum, weight_decay=self.weight_decay,
                          grad_scale=grad_scale, state=self.state)
@@ -226,6 +244,7 @@ class CrossTeachingTrainer:
         self.out2 = torch.zeros(16, dtype=torch.float32, device="cuda")
         self.iter_num = iter_num
         self._side = None
+        self._bucketers = (make_bucketer(model1, process_group), make_bucketer(model2, process_group))
 
     def step(self, volume_batch, label_batch):
         if not (self.model1.training and self.model2.training):
@@ -255,11 +274,21 @@ class CrossTeachingTrainer:
                 self.model2.backward_raw()
             self.model1.backward_raw()
             main.wait_stream(self._side)
+            scales = [dist.sync_gradients(m.flat_grad, self.pg) for m in (self.model1, self.model2)]
+        elif self._bucketers[0] is not None:
+            # both students' buckets are in flight while the other student's backward runs; one wait at the end
+            b1, b2 = self._bucketers
+            b1.begin()
+            self.model1.backward_raw(on_progress=b1.advance)
+            b1.advance(0)
+            b2.begin()
+            self.model2.backward_raw(on_progress=b2.advance)
+            scales = [b1.finish(), b2.finish()]
         else:
             self.model1.backward_raw()
             self.model2.backward_raw()
-        for m, mom in ((self.model1, self.mom1), (self.model2, self.mom2)):
-            scale = dist.sync_gradients(m.flat_grad, self.pg)
+            scales = [dist.sync_gradients(m.flat_grad, self.pg) for m in (self.model1, self.model2)]
+        for m, mom, scale in ((self.model1, self.mom1, scales[0]), (self.model2, self.mom2, scales[1])):
             ops.sgd_ema_step(m.flat_param, m.flat_grad, mom, None, momentum=self.momentum,
                              weight_decay=self.weight_decay, grad_scale=scale, state=self.state)
         h = self.hyper
@@ -318,6 +347,7 @@ class CnnMeetVitTrainer:
         self.out2 = torch.zeros(16, dtype=torch.float32, device="cuda")
         self.iter_num = iter_num
         self._ema_in = None
+        self._bucketers = (make_bucketer(model1, process_group), make_bucketer(model2, process_group))
 
     def weights(self):
         """(pseudo-supervision weight, mean-teacher weight) of the current iteration"""
@@ -345,10 +375,10 @@ class CnnMeetVitTrainer:
                                 cons_weight=w_cps, teacher=t, mt_weight=w_mt)
         ops.cross_teaching_tail(o2, o1, lab, L, self.out2, dlogits=self.model2.logits_grad_buffer(),
                                 cons_weight=w_cps, teacher=t, mt_weight=w_mt)
-        self.model1.backward_raw()
-        self.model2.backward_raw()
-        for m, mom, ema in ((self.model1, self.mom1, None), (self.model2, self.mom2, self.ema_model.flat_param)):
-            scale = dist.sync_gradients(m.flat_grad, self.pg)
+        scales = [backward_and_sync(self.model1, self.pg, self._bucketers[0]),
+                  backward_and_sync(self.model2, self.pg, self._bucketers[1])]
+        for m, mom, ema, scale in ((self.model1, self.mom1, None, scales[0]),
+                                   (self.model2, self.mom2, self.ema_model.flat_param, scales[1])):
             ops.sgd_ema_step(m.flat_param, m.flat_grad, mom, ema, momentum=self.momentum,
                              weight_decay=self.weight_decay, grad_scale=scale, state=self.state)
         h = self.hyper

@@ -229,6 +229,8 @@ class SwinPlan:
         self.inp_t = None
         self._site = itertools.count(0)
         self.out = None
+        self.generation = 0      # forwards run on this plan (see mis_hip.plan.Plan / _NetFn.backward)
+        self._progress = None
 
     def new(self, rows, C):
         a = TAct(rows, C)
@@ -249,19 +251,29 @@ class SwinPlan:
 
     def forward(self, x5, ctx):
         assert tuple(x5.shape) == self.in_shape, (tuple(x5.shape), self.in_shape)
+        self.generation += 1
         self.inp_t = x5[:, :, 0]             # [N, 1, H, W]
         for op in self.ops:
             op.fwd(ctx)
         return self.out.t
 
-    def backward(self, dlogits5, ctx):
+    def backward(self, dlogits5, ctx, on_progress=None):
         for a in self.acts:
             a.reset()
         self.out.reset()
         if dlogits5 is not None:
             self.out.g = dlogits5
-        for op in reversed(self.ops):
-            op.bwd(ctx)
+        if on_progress is None:
+            for op in reversed(self.ops):
+                op.bwd(ctx)
+            return
+        if self._progress is None:
+            from .dist import param_progress
+            self._progress = param_progress(self.ops, self.net.flat_grad)
+        for i in range(len(self.ops) - 1, -1, -1):      # see mis_hip.plan.Plan.backward
+            self.ops[i].bwd(ctx)
+            if i == 0 or self._progress[i] != self._progress[i - 1] or i == len(self.ops) - 1:
+                on_progress(self._progress[i])
 
     def drop_sites(self):
         return [op.site for op in self.ops if isinstance(op, ResidualOp) and op.drop_p > 0]

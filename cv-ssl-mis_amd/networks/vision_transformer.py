@@ -12,6 +12,7 @@ mlp x4, qkv bias, drop_path linspace(0, 0.2, 8), patch-expand decoder, 1x1 outpu
 Single-channel inputs are repeated to 3 channels (vision_transformer.py:49-50) inside the im2col kernel.
 """
 import math
+import re
 
 import torch
 
@@ -143,20 +144,42 @@ class SwinUnet(HipNet):
         if path is None:
             print("none pretrain")
             return
+        print("pretrained_path:{}".format(path))
         sd = torch.load(path, map_location="cuda")
-        sd = sd.get("model", sd)
         own = self.state_dict()
-        full = {}
+        if "model" not in sd:
+            # :60-68: a checkpoint of a whole wrapped SwinUnet -- the reference strips a 17-character prefix
+            # ("module.swin_unet.") and drops the segmentation head ("output")
+            print("---start load pretrained modle by splitting---")
+            full = {}
+            for k, v in sd.items():
+                k = k[17:]
+                if "output" in k:
+                    print("delete key:{}".format(k))
+                    continue
+                if "swin_unet." + k in own:
+                    full["swin_unet." + k] = v
+            self.load_state_dict(full, strict=False)
+            return
+        # :69-87: an ImageNet Swin encoder checkpoint {"model": {...}}; encoder stage weights are mirrored into the
+        # decoder stages (layers.N -> layers_up.(3-N)); shape mismatches are dropped
+        print("---start load pretrained modle of swin encoder---")
+        sd = sd["model"]
+        full = dict(sd)
         for k, v in sd.items():
-            k2 = k if k.startswith("swin_unet.") else "swin_unet." + k
-            if k2 in own and own[k2].shape == v.shape:
-                full[k2] = v
-            if "layers." in k:          # mirror encoder weights into the decoder, as the reference does (:74-80)
-                num = 3 - int(k[7:8])
-                k3 = "swin_unet.layers_up." + str(num) + k[8:]
-                if k3 in own and own[k3].shape == v.shape:
-                    full[k3] = v
-        self.load_state_dict(full, strict=False)
+            if "layers." in k:
+                m = re.match(r"layers\.(\d)(.*)", k)      # the reference indexes k[7:8]: keys start with "layers.N"
+                if m:
+                    full["layers_up." + str(3 - int(m.group(1))) + m.group(2)] = v
+        keep = {}
+        for k, v in full.items():
+            k2 = "swin_unet." + k
+            if k2 in own:
+                if own[k2].shape != v.shape:
+                    print("delete:{};shape pretrain:{};shape model:{}".format(k, v.shape, own[k2].shape))
+                    continue
+                keep[k2] = v
+        self.load_state_dict(keep, strict=False)
 
     # ---- layer graph ----
     def _new_plan(self, key):

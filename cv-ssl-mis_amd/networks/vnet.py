@@ -1,15 +1,20 @@
 """V-Net (``--model vnet``) on hand-written gfx950 kernels.
 
-Drop-in for the reference's ``networks.vnet.VNet`` (code/networks/vnet.py:145-239) as ``net_factory_3d`` builds
-it (``normalization='batchnorm', has_dropout=True``, net_factory_3d.py:18-20): same constructor, same
+Drop-in for the reference's ``networks.vnet.VNet`` (code/networks/vnet.py:145-239): same constructor, same
 ``forward(x[N,C,D,H,W])``, same state_dict keys (``block_one.conv.{0,1}.*``, ``block_one_dw.conv.{0,1}.*``,
-``block_two.conv.{0,1,3,4}.*`` ... ``block_five_up.conv.{0,1}.*`` ... ``out_conv.*``).
+``block_two.conv.{0,1,3,4}.*`` ... ``block_five_up.conv.{0,1}.*`` ... ``out_conv.*``).  ``net_factory_3d`` builds it
+with ``normalization='batchnorm', has_dropout=True`` (net_factory_3d.py:18-20).
 
-Layers: 3x3x3 conv + BatchNorm3d + ReLU stages (1/2/3/3/3 encoder, 3/3/2/1 decoder), kernel-2 stride-2
-down convolutions and transposed convolutions (executed as space/depth re-layout + the 1x1x1 MFMA conv),
-additive skips, ``Dropout3d(0.5)`` after block_five and block_nine, 1x1x1 output conv.
-The GroupNorm / InstanceNorm / 'none' variants of the reference class are not instantiated by the factory
-and are not built here.
+Layers: 3x3x3 conv + norm + ReLU stages (1/2/3/3/3 encoder, 3/3/2/1 decoder), kernel-2 stride-2 down convolutions and
+transposed convolutions (executed as space/depth re-layout + the 1x1x1 MFMA conv), additive skips, ``Dropout3d(0.5)``
+after block_five and block_nine, 1x1x1 output conv.
+
+``normalization`` selects the block of vnet.py:15-22 (and :73-84, :100-110):
+  'batchnorm'     conv + BatchNorm3d + ReLU (keys ``conv.{3s}``, ``conv.{3s+1}.{weight,bias,running_*}``)
+  'groupnorm'     conv + GroupNorm(16) + ReLU -- the conv+GN+ReLU block; per-(sample, group) statistics, per-channel
+                  affine (keys ``conv.{3s+1}.{weight,bias}``); statistics come from the conv epilogue
+  'instancenorm'  conv + InstanceNorm3d (no affine, no running statistics: no keys) + ReLU
+  'none'          conv + ReLU (ConvBlock keys ``conv.{2s}``); here the conv biases get their real gradient
 """
 import math
 
@@ -32,8 +37,11 @@ class VNet(HipNet):
 
     def __init__(self, n_channels=3, n_classes=2, n_filters=16, normalization='none', has_dropout=False):
         super().__init__()
-        if normalization != 'batchnorm':
-            raise NotImplementedError("only normalization='batchnorm' (what net_factory_3d builds) is on the HIP path")
+        if normalization not in ('batchnorm', 'groupnorm', 'instancenorm', 'none'):
+            raise AssertionError(f"normalization={normalization!r}")          # `assert False` in vnet.py:24
+        if normalization == 'groupnorm' and n_filters % 16:
+            raise ValueError("num_channels must be divisible by num_groups")  # nn.GroupNorm(16, n_filters)
+        self.normalization = normalization
         self.n_channels, self.n_classes, self.nf, self.has_dropout = n_channels, n_classes, n_filters, has_dropout
         f = n_filters
         # (name, kind, stages, cin, cout) in the reference's registration order
@@ -58,26 +66,41 @@ class VNet(HipNet):
                 else:
                     shape = (ci, cout, 2, 2, 2)            # ConvTranspose3d weight layout
                 w, bound = _default_init(shape)
-                p = f"{name}.conv.{3 * s}"
+                p, bn = self._keys(name, s)
                 self._declare(p + ".weight", w)
                 self._declare(p + ".bias", torch.empty(cout).uniform_(-bound, bound))
-                bn = f"{name}.conv.{3 * s + 1}"
-                self._declare(bn + ".weight", torch.ones(cout))
-                self._declare(bn + ".bias", torch.zeros(cout))
-                self._declare(bn + ".running_mean", torch.zeros(cout), "buffer")
-                self._declare(bn + ".running_var", torch.ones(cout), "buffer")
-                self._declare(bn + ".num_batches_tracked", torch.zeros((), dtype=torch.long), "buffer")
+                if normalization in ('batchnorm', 'groupnorm'):
+                    self._declare(bn + ".weight", torch.ones(cout))
+                    self._declare(bn + ".bias", torch.zeros(cout))
+                if normalization == 'batchnorm':
+                    self._declare(bn + ".running_mean", torch.zeros(cout), "buffer")
+                    self._declare(bn + ".running_var", torch.ones(cout), "buffer")
+                    self._declare(bn + ".num_batches_tracked", torch.zeros((), dtype=torch.long), "buffer")
         w, bound = _default_init((n_classes, f, 1, 1, 1))
         self._declare("out_conv.weight", w)
         self._declare("out_conv.bias", torch.empty(n_classes).uniform_(-bound, bound))
         self._materialize()
+        # nn.ConvTranspose3d weights (not touched by the reference's kaiming / xavier re-initialisation helpers)
+        self.transposed_convs = {f"{name}.conv.0.weight" for name, kind, *_ in self.layout if kind == "up"}
+
+    def _keys(self, name, s):
+        """(conv key, norm key) of stage s: nn.Sequential indices, 3 modules per stage (2 without a norm)."""
+        k = 2 if self.normalization == 'none' else 3
+        return f"{name}.conv.{k * s}", f"{name}.conv.{k * s + 1}"
 
     def _bn_relu(self, plan, prefix, t, y, drop_p=0.0):
         P, B = self.P, self.B
-        return plan.norm_act(t, y, per_sample=False, gamma=P(prefix + ".weight"), beta=P(prefix + ".bias"),
-                             running=(B(prefix + ".running_mean"), B(prefix + ".running_var"),
-                                      B(prefix + ".num_batches_tracked")),
-                             slope=0.0, drop_p=drop_p, drop3d=True)
+        if self.normalization == 'batchnorm':
+            return plan.norm_act(t, y, per_sample=False, gamma=P(prefix + ".weight"), beta=P(prefix + ".bias"),
+                                 running=(B(prefix + ".running_mean"), B(prefix + ".running_var"),
+                                          B(prefix + ".num_batches_tracked")),
+                                 slope=0.0, drop_p=drop_p, drop3d=True)
+        if self.normalization == 'groupnorm':     # nn.GroupNorm(16, C): C/16 consecutive channels per group
+            return plan.norm_act(t, y, per_sample=True, gamma=P(prefix + ".weight"), beta=P(prefix + ".bias"),
+                                 slope=0.0, drop_p=drop_p, drop3d=True, cg=t.shape[1] // 16)
+        if self.normalization == 'instancenorm':
+            return plan.norm_act(t, y, per_sample=True, slope=0.0, drop_p=drop_p, drop3d=True)
+        return plan.norm_act(t, y, per_sample=False, slope=0.0, drop_p=drop_p, drop3d=True, no_norm=True)
 
     def _build(self, plan):
         N, C, D, H, W = plan.in_shape
@@ -89,6 +112,11 @@ class VNet(HipNet):
         x = plan.inp
         feats = {}
         drop = 0.5 if self.has_dropout else 0.0
+        # a conv bias has a real gradient unless the normalisation group lies inside one channel (BatchNorm,
+        # InstanceNorm, GroupNorm with one channel per group): a GroupNorm group of cg > 1 channels is NOT invariant
+        # to a per-channel shift
+        def bias_grad(cout):
+            return self.normalization == 'none' or (self.normalization == 'groupnorm' and cout // 16 > 1)
         for name, kind, stages, cin, cout in self.layout:
             if kind == "conv":
                 if name in ("block_six", "block_seven", "block_eight", "block_nine"):
@@ -97,21 +125,22 @@ class VNet(HipNet):
                     x = plan.add(x, feats[skip], plan.new(cout, sp))       # x_up + skip (vnet.py:210-222)
                 for s in range(stages):
                     t = plan.new(cout, sp)
-                    plan.conv(x, t, P(f"{name}.conv.{3 * s}.weight"), P(f"{name}.conv.{3 * s}.bias"), (3, 3, 3),
-                              need_dx=not (name == "block_one" and s == 0), bias_grad=False)
+                    ck, nk = self._keys(name, s)
+                    plan.conv(x, t, P(ck + ".weight"), P(ck + ".bias"), (3, 3, 3),
+                              need_dx=not (name == "block_one" and s == 0), bias_grad=bias_grad(cout))
                     last = s == stages - 1
                     dp = drop if (last and name in ("block_five", "block_nine")) else 0.0   # Dropout3d :176-177,224-225
-                    x = self._bn_relu(plan, f"{name}.conv.{3 * s + 1}", t, plan.new(cout, sp), dp)
+                    x = self._bn_relu(plan, nk, t, plan.new(cout, sp), dp)
                 feats[name] = x
             elif kind == "down":
                 sp = tuple(v // 2 for v in sp)
                 t = plan.new(cout, sp)
-                plan.down_conv(x, t, P(f"{name}.conv.0.weight"), P(f"{name}.conv.0.bias"))
+                plan.down_conv(x, t, P(f"{name}.conv.0.weight"), P(f"{name}.conv.0.bias"), bias_grad=bias_grad(cout))
                 x = self._bn_relu(plan, f"{name}.conv.1", t, plan.new(cout, sp))
             else:
                 sp = tuple(v * 2 for v in sp)
                 t = plan.new(cout, sp)
-                plan.up_conv(x, t, P(f"{name}.conv.0.weight"), P(f"{name}.conv.0.bias"))
+                plan.up_conv(x, t, P(f"{name}.conv.0.weight"), P(f"{name}.conv.0.bias"), bias_grad=bias_grad(cout))
                 x = self._bn_relu(plan, f"{name}.conv.1", t, plan.new(cout, sp))
         plan.out = plan.new(self.n_classes, sp)
         plan.conv(x, plan.out, P("out_conv.weight"), P("out_conv.bias"), (1, 1, 1), bias_grad=True)

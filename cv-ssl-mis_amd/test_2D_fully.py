@@ -40,6 +40,12 @@ def Inference(FLAGS):
     with open(os.path.join(FLAGS.root_path, 'test.list')) as f:
         image_list = sorted(item.replace('\n', '').split(".")[0] for item in f.readlines())
     snapshot_path = "../model/{}_{}/{}".format(FLAGS.exp, FLAGS.labeled_num, FLAGS.model)
+    if not os.path.isdir(snapshot_path):
+        # the directory the Mean-Teacher / UA-MT 2-D training scripts write (train_mean_teacher_2D.py:328); the
+        # reference keeps this spelling as the commented alternative at test_2D_fully.py:90
+        labeled = "../model/{}_{}_labeled/{}".format(FLAGS.exp, FLAGS.labeled_num, FLAGS.model)
+        if os.path.isdir(labeled):
+            snapshot_path = labeled
     test_save_path = "../model/{}_{}/{}_predictions/".format(FLAGS.exp, FLAGS.labeled_num, FLAGS.model)
     if os.path.exists(test_save_path):
         shutil.rmtree(test_save_path)

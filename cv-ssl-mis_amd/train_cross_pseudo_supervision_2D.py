@@ -22,7 +22,9 @@ def main(argv=None):
             raise SystemExit(f"unknown --model {args.model}")
         return net
 
-    return run_cross_teaching(args, make_model, make_model, label_dtype=torch.uint8, pseudo_ce=True)
+    from mis_hip.train_common import kaiming_normal_init_weight, xavier_normal_init_weight
+    return run_cross_teaching(args, make_model, make_model, label_dtype=torch.uint8, pseudo_ce=True,
+                              init_fns=(kaiming_normal_init_weight, xavier_normal_init_weight))
 
 
 if __name__ == "__main__":

@@ -3,8 +3,8 @@
 Command-line drop-in for the reference's code/train_cross_pseudo_supervision_3D.py (same flags and defaults,
 :31-64): two students of the same architecture, each supervised on the labeled half and by the OTHER network's
 arg-max pseudo labels (cross-entropy) on the unlabeled half (:149-185).  Runs as
-mis_hip.step.CrossTeachingTrainer(pseudo_ce=True); the two students start from different random weights (the
-reference uses kaiming / xavier initialisation for model1 / model2, :124-125).
+mis_hip.step.CrossTeachingTrainer(pseudo_ce=True); model1 is re-initialised with
+``kaiming_normal_init_weight`` and model2 with ``xavier_normal_init_weight`` as in the reference (:79-96, :108-109).
 """
 import torch
 
@@ -25,7 +25,9 @@ def main(argv=None):
             raise SystemExit(f"unknown --model {args.model}")
         return net
 
-    return run_cross_teaching(args, make_model, make_model, label_dtype=torch.int64, pseudo_ce=True)
+    from mis_hip.train_common import kaiming_normal_init_weight, xavier_normal_init_weight
+    return run_cross_teaching(args, make_model, make_model, label_dtype=torch.int64, pseudo_ce=True,
+                              init_fns=(kaiming_normal_init_weight, xavier_normal_init_weight))   # :108-109
 
 
 if __name__ == "__main__":

@@ -42,7 +42,8 @@ def main(argv=None):
             raise SystemExit(f"unknown --model {args.model}")
         return net
 
-    return run_training(args, make_model, label_dtype=torch.int64, cons_start_iter=0, save_ema=False)
+    return run_training(args, make_model, label_dtype=torch.int64, cons_start_iter=0, save_ema=False,
+                        snapshot_fmt="../model/{}_{}/{}")     # train_mean_teacher_3D.py:252
 
 
 if __name__ == "__main__":

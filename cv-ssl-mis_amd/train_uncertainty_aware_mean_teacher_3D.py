@@ -42,7 +42,7 @@ def main(argv=None):
         return net
 
     return run_training(args, make_model, label_dtype=torch.int64, cons_start_iter=0, save_ema=False,
-                        trainer_cls=UAMTTrainer)
+                        trainer_cls=UAMTTrainer, snapshot_fmt="../model/{}_{}/{}")
 
 
 if __name__ == "__main__":

@@ -118,6 +118,23 @@ int mis_norm_act_bwd(const float* x, long long x_bs, const float* da, long long 
                      const float* gamma, const float* beta, float slope, float drop_p, unsigned drop_salt,
                      const MisStepState* state, const float* drop_mask, float* dgamma, float* dbeta,
                      int accumulate_affine, void* workspace, long long workspace_bytes, mis_stream_t stream);
+/* Group-wise form: with per_sample != 0, `cg` consecutive channels share one (mean, rstd) (mean / rstd hold
+ * N*C/cg floats): cg = 1 is InstanceNorm, cg = C/16 is nn.GroupNorm(16, C) -- the conv+GN+ReLU block of
+ * reference code/networks/vnet.py:19-20,48,76,103 -- with the per-channel affine in gamma / beta.  Statistics of a
+ * GroupNorm: mis_norm_stats on the same memory viewed as [N, C/cg, cg*S] with per_sample = 1, or
+ * mis_norm_stats_finalize(part, N, C/cg, cg*S, cg*tiles, 1, ...) on the conv epilogue's partials.
+ * no_norm != 0 (backward): activation + dropout only (normalization='none' blocks, vnet.py:22,84,110); mean must
+ * hold zeros and rstd ones, gamma / beta NULL.  Workspace: mis_norm_workspace_bytes(N, C, S, per_sample). */
+int mis_norm_act_fwd_g(const float* x, long long x_bs, float* y, long long y_bs, int N, int C, long long S,
+                       int per_sample, int cg, const float* mean, const float* rstd, const float* gamma,
+                       const float* beta, float slope, float drop_p, unsigned drop_salt, const MisStepState* state,
+                       const float* drop_mask, mis_stream_t stream);
+int mis_norm_act_bwd_g(const float* x, long long x_bs, const float* da, long long da_bs, float* dx, long long dx_bs,
+                       int N, int C, long long S, int per_sample, int cg, int no_norm, const float* mean,
+                       const float* rstd, const float* gamma, const float* beta, float slope, float drop_p,
+                       unsigned drop_salt, const MisStepState* state, const float* drop_mask, float* dgamma,
+                       float* dbeta, int accumulate_affine, void* workspace, long long workspace_bytes,
+                       mis_stream_t stream);
 
 /* ---- 2x max-pool / 2x linear up-sampling ----------------------------------------------------------
  * reference: nn.MaxPool2d(2) unet.py:56; nn.MaxPool3d(2) unet_3D.py:35-47;

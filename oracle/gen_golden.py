@@ -114,9 +114,10 @@ def build_reference(kind, in_chns, num_classes):
                                   PATCH_NORM=True)),
                  TRAIN=NS(USE_CHECKPOINT=False))
         return SwinUnet(cfg, img_size=224, num_classes=num_classes)
-    if kind == "vnet":
+    if kind.startswith("vnet"):       # "vnet" = batchnorm (the factory's), "vnet_groupnorm", "vnet_instancenorm", ...
         from networks.vnet import VNet
-        return VNet(n_channels=in_chns, n_classes=num_classes, normalization='batchnorm', has_dropout=True)
+        norm = kind.split("_", 1)[1] if "_" in kind else "batchnorm"
+        return VNet(n_channels=in_chns, n_classes=num_classes, normalization=norm, has_dropout=True)
     from networks.unet_3D import unet_3D
     return unet_3D(n_classes=num_classes, in_channels=in_chns)
 
@@ -150,7 +151,7 @@ def set_reference_dropout(model, kind, drop, sites):
             blk.conv_conv[3] = torch.nn.Identity() if drop == "off" else MaskDrop(drop[site])
         for up in (model.decoder.up1, model.decoder.up2, model.decoder.up3, model.decoder.up4):
             assert up.conv.conv_conv[3].p == 0.0
-    elif kind == "vnet":
+    elif kind.startswith("vnet"):
         assert isinstance(model.dropout, (torch.nn.Dropout3d, torch.nn.Identity, SeqMask))
         model.dropout = torch.nn.Identity() if drop == "off" else SeqMask([drop[0], drop[1]])
     else:
@@ -236,9 +237,9 @@ def run_case(name, kind, cfg, iters, drop_mode, eval_logits=False):
     if kind == "swin":
         from oracle.swin import OracleSwinUnet
         onet = OracleSwinUnet(C)
-    elif kind == "vnet":
+    elif kind.startswith("vnet"):
         from oracle.nets import OracleVNet
-        onet = OracleVNet(C, 1)
+        onet = OracleVNet(C, 1, normalization=kind.split("_", 1)[1] if "_" in kind else "batchnorm")
     else:
         onet = OracleUNet2D(1, C) if kind == "unet2d" else OracleUNet3D(C, 1)
     model = build_reference(kind, 1, C)
@@ -830,6 +831,16 @@ def main():
          True),
         ("vnet_64_masks", "vnet", dict(CFG3D, batch_size=4, labeled_bs=2, spatial=[64, 64, 64]), [450], "masks",
          False),
+        # the other blocks of vnet.py:15-22: conv + GroupNorm(16) + ReLU (the north-star's conv+GN+ReLU block),
+        # conv + InstanceNorm3d + ReLU, conv + ReLU
+        ("vnet_gn_64_dropoff", "vnet_groupnorm", dict(CFG3D, batch_size=2, labeled_bs=1, spatial=[64, 64, 64]), [0, 7],
+         "off", True),
+        ("vnet_gn_64_masks", "vnet_groupnorm", dict(CFG3D, batch_size=2, labeled_bs=1, spatial=[64, 64, 64]), [450],
+         "masks", False),
+        ("vnet_in_64_dropoff", "vnet_instancenorm", dict(CFG3D, batch_size=2, labeled_bs=1, spatial=[64, 64, 64]), [7],
+         "off", False),
+        ("vnet_none_64_masks", "vnet_none", dict(CFG3D, batch_size=2, labeled_bs=1, spatial=[64, 64, 64]), [450],
+         "masks", False),
         # BASELINE shapes: config 1 (2D 256^2, 4+4) and config 3 geometry at batch 1+1 (96^3)
         ("unet2d_256_cfg1", "unet2d", dict(CFG2D, batch_size=8, labeled_bs=4, spatial=[256, 256]), [1000], "off",
          False),

@@ -169,10 +169,12 @@ class OracleUNet3D:
 
 
 class OracleVNet:
-    """reference code/networks/vnet.py:145-239 as built by net_factory_3d.py:18-20
-    (normalization='batchnorm', has_dropout=True)."""
+    """reference code/networks/vnet.py:145-239 (has_dropout=True); ``normalization`` as in vnet.py:15-22:
+    'batchnorm' (what net_factory_3d.py:18-20 builds), 'groupnorm' (GroupNorm(16)), 'instancenorm', 'none'."""
 
-    def __init__(self, n_classes=2, n_channels=1, n_filters=16):
+    def __init__(self, n_classes=2, n_channels=1, n_filters=16, normalization='batchnorm'):
+        assert normalization in ('batchnorm', 'groupnorm', 'instancenorm', 'none')
+        self.normalization = normalization
         self.n_classes, self.n_channels, self.nf = n_classes, n_channels, n_filters
         f = n_filters
         # (module name, kind, n_stages, cin, cout) in registration order, vnet.py:150-175
@@ -194,27 +196,38 @@ class OracleVNet:
             for s in range(stages):
                 ci = cin if s == 0 else cout
                 wshape = {"conv": (cout, ci, 3, 3, 3), "down": (cout, ci, 2, 2, 2), "up": (ci, cout, 2, 2, 2)}[kind]
-                c, bn = f"{name}.conv.{3 * s}", f"{name}.conv.{3 * s + 1}"
-                keys += [(c + ".weight", wshape), (c + ".bias", (cout,)),
-                         (bn + ".weight", (cout,)), (bn + ".bias", (cout,)), (bn + ".running_mean", (cout,)),
-                         (bn + ".running_var", (cout,)), (bn + ".num_batches_tracked", ())]
+                c, bn = self._keys(name, s)
+                keys += [(c + ".weight", wshape), (c + ".bias", (cout,))]
+                if self.normalization in ('batchnorm', 'groupnorm'):
+                    keys += [(bn + ".weight", (cout,)), (bn + ".bias", (cout,))]
+                if self.normalization == 'batchnorm':
+                    keys += [(bn + ".running_mean", (cout,)), (bn + ".running_var", (cout,)),
+                             (bn + ".num_batches_tracked", ())]
         keys += [("out_conv.weight", (self.n_classes, self.nf, 1, 1, 1)), ("out_conv.bias", (self.n_classes,))]
         return keys
 
     new_state = OracleUNet2D.new_state
     is_param = staticmethod(OracleUNet2D.is_param)
 
-    @staticmethod
-    def _bn_relu(sd, bn, x, training):
-        if training:
-            sd[bn + ".num_batches_tracked"] += 1
-        x = F.batch_norm(x, sd[bn + ".running_mean"], sd[bn + ".running_var"], sd[bn + ".weight"],
-                         sd[bn + ".bias"], training, 0.1, 1e-5)
+    def _keys(self, name, s):
+        k = 2 if self.normalization == 'none' else 3      # modules per stage of the nn.Sequential
+        return f"{name}.conv.{k * s}", f"{name}.conv.{k * s + 1}"
+
+    def _bn_relu(self, sd, bn, x, training):
+        if self.normalization == 'batchnorm':
+            if training:
+                sd[bn + ".num_batches_tracked"] += 1
+            x = F.batch_norm(x, sd[bn + ".running_mean"], sd[bn + ".running_var"], sd[bn + ".weight"],
+                             sd[bn + ".bias"], training, 0.1, 1e-5)
+        elif self.normalization == 'groupnorm':                                       # vnet.py:19-20
+            x = F.group_norm(x, 16, sd[bn + ".weight"], sd[bn + ".bias"], 1e-5)
+        elif self.normalization == 'instancenorm':                                    # vnet.py:21-22
+            x = F.instance_norm(x, eps=1e-5)
         return F.relu(x)
 
     def _block(self, sd, name, kind, stages, x, training):
         for s in range(stages):
-            c, bn = f"{name}.conv.{3 * s}", f"{name}.conv.{3 * s + 1}"
+            c, bn = self._keys(name, s)
             if kind == "conv":                                                        # ConvBlock, vnet.py:5-31
                 x = F.conv3d(x, sd[c + ".weight"], sd[c + ".bias"], padding=1)
             elif kind == "down":                                                      # DownsamplingConvBlock :67-91

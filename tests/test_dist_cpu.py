@@ -125,3 +125,75 @@ def test_shard_indices_are_disjoint_and_cover():
         seen_u += b
     assert sorted(seen_l) == lab and sorted(seen_u) == unl
     assert world_size() == 1
+
+
+class _FakeOp:
+    """Stands in for a plan op: holds parameter references (``.data`` / ``.grad`` views into the flat buffers) and
+    writes their gradients in ``bwd`` -- what mis_hip.plan ops do on the device."""
+
+    def __init__(self, refs, src):
+        for i, r in enumerate(refs):
+            setattr(self, f"p{i}", r)
+        self.refs, self.src = refs, src
+        self.activation = torch.zeros(3)         # non-parameter attributes must be ignored by param_progress
+
+    def bwd(self):
+        for r in self.refs:
+            r.grad.copy_(r.true_grad)
+
+
+class _Ref:
+    def __init__(self, data, grad, true_grad):
+        self.data, self.grad, self.true_grad = data, grad, true_grad
+
+
+def _bucket_worker(rank, world, port, out_dir):
+    for p in (os.path.join(ROOT, "cv-ssl-mis_amd"), ROOT):
+        sys.path.insert(0, p)
+    import torch.distributed as dist
+    from mis_hip import dist as mdist
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    g = torch.Generator().manual_seed(100 + rank)
+    sizes = [300, 7, 4096, 33, 9000, 2, 512, 12000, 64]          # parameter tensors in forward order
+    total = sum((n + 3) // 4 * 4 for n in sizes)
+    flat_p, flat_g = torch.zeros(total), torch.zeros(total)
+    true = torch.randn(total, generator=g)
+    refs, off = [], 0
+    for n in sizes:
+        refs.append(_Ref(flat_p[off:off + n], flat_g[off:off + n], true[off:off + n]))
+        off += (n + 3) // 4 * 4
+    # ops in forward order; op 1 has no parameters, op 3 owns two tensors
+    ops = [_FakeOp(refs[0:2], flat_g), _FakeOp([], flat_g), _FakeOp(refs[2:3], flat_g), _FakeOp(refs[3:5], flat_g),
+           _FakeOp(refs[5:7], flat_g), _FakeOp(refs[7:9], flat_g)]
+    done = mdist.param_progress(ops, flat_g)
+    assert done[0] == 0 and done == sorted(done) and done[-1] == refs[6].grad.data_ptr() // 4 - flat_g.data_ptr() // 4 + 512
+    b = mdist.GradBucketer(flat_g, bucket_bytes=16384)           # 4096-float buckets -> several collectives
+    assert b.buckets[0][1] == total and b.buckets[-1][0] == 0 and len(b.buckets) >= 5
+    assert all(b.buckets[i][0] == b.buckets[i + 1][1] for i in range(len(b.buckets) - 1))
+    issued = []
+    b.begin()
+    for i in range(len(ops) - 1, -1, -1):                        # Plan.backward(on_progress=b.advance)
+        ops[i].bwd()
+        b.advance(done[i])
+        issued.append(b._next)
+    scale = b.finish()
+    assert scale == 1.0 / world and b._next == len(b.buckets)
+    assert issued[0] > 0 and issued == sorted(issued)            # buckets left while the "backward" was still running
+    ref = true.clone()
+    pad = torch.ones(total, dtype=torch.bool)
+    for r in refs:
+        o = r.grad.data_ptr() // 4 - flat_g.data_ptr() // 4
+        pad[o:o + r.grad.numel()] = False
+    ref[pad] = 0
+    dist.all_reduce(ref)                                         # the single blocking all-reduce it replaces
+    assert torch.equal(flat_g, ref)
+    torch.save(flat_g, os.path.join(out_dir, f"g{rank}.pt"))
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_bucketed_overlapped_allreduce_equals_single_allreduce(tmp_path):
+    world = 2
+    mp.spawn(_bucket_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    a, b = (torch.load(os.path.join(tmp_path, f"g{r}.pt")) for r in range(world))
+    assert torch.equal(a, b)

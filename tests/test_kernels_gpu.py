@@ -195,6 +195,55 @@ def test_norm_act_fwd_bwd(per_sample, slope, shape):
         _close(db, beta.grad, rtol=5e-4, atol=1e-4)
 
 
+@pytest.mark.parametrize("shape,cg", [((2, 32, 4, 8, 8), 2), ((2, 64, 2, 8, 8), 4), ((3, 16, 4, 4, 8), 1)])
+def test_group_norm_act_fwd_bwd(shape, cg):
+    """nn.GroupNorm(16, C) + ReLU (reference code/networks/vnet.py:19-20) against torch CPU: statistics per
+    (sample, group of cg = C/16 channels), per-channel affine, dx / dgamma / dbeta."""
+    ops = _ops()
+    N, C = shape[0], shape[1]
+    assert C // cg == 16
+    x = _rand(*shape, seed=21, scale=2.0) + 0.3
+    x.requires_grad_(True)
+    gamma = (1 + 0.3 * _rand(C, seed=22)).requires_grad_(True)
+    beta = (0.2 * _rand(C, seed=23)).requires_grad_(True)
+    a_ref = F.relu(F.group_norm(x, 16, gamma, beta, 1e-5))
+    da = _rand(*shape, seed=24)
+    a_ref.backward(da)
+    xd = x.detach().cuda()
+    mean = torch.empty(N * 16, device="cuda")
+    rstd = torch.empty(N * 16, device="cuda")
+    ops.group_norm_stats(xd, cg, 1e-5, mean, rstd)
+    xg = x.detach().reshape(N, 16, -1)
+    _close(mean, xg.mean(2).flatten(), atol=1e-5)
+    _close(rstd, (xg.var(2, unbiased=False) + 1e-5).rsqrt().flatten(), rtol=1e-4)
+    a = torch.empty(*shape, device="cuda")
+    g, bt = gamma.detach().cuda(), beta.detach().cuda()
+    ops.norm_act_fwd(xd, a, True, mean, rstd, g, bt, 0.0, cg=cg)
+    _close(a, a_ref)
+    dx = torch.empty(*shape, device="cuda")
+    dg, db = torch.empty(C, device="cuda"), torch.empty(C, device="cuda")
+    ops.norm_act_bwd(xd, da.cuda(), dx, True, mean, rstd, g, bt, 0.0, dgamma=dg, dbeta=db, cg=cg)
+    _close(dx, x.grad, rtol=5e-4, atol=1e-5)
+    _close(dg, gamma.grad, rtol=5e-4, atol=1e-4)
+    _close(db, beta.grad, rtol=5e-4, atol=1e-4)
+
+
+def test_act_only_fwd_bwd():
+    """normalization='none' blocks (reference vnet.py:22,84): ReLU (+ dropout) without statistics."""
+    ops = _ops()
+    shape = (2, 8, 4, 8, 8)
+    x = _rand(*shape, seed=31)
+    da = _rand(*shape, seed=32)
+    xd = x.cuda()
+    mean, rstd = torch.zeros(8, device="cuda"), torch.ones(8, device="cuda")
+    a = torch.empty(*shape, device="cuda")
+    ops.norm_act_fwd(xd, a, False, mean, rstd, None, None, 0.0)
+    assert torch.equal(a.cpu(), F.relu(x))
+    dx = torch.empty(*shape, device="cuda")
+    ops.norm_act_bwd(xd, da.cuda(), dx, False, mean, rstd, None, None, 0.0, no_norm=True)
+    assert torch.equal(dx.cpu(), da * (x > 0).float())
+
+
 def test_norm_act_dropout_mask_injected_and_philox():
     ops = _ops()
     shape = (2, 16, 1, 32, 32)

@@ -24,7 +24,7 @@ def _sample_idx(numel):
 
 
 @pytest.mark.parametrize("name", ["unet2d_64_dropoff", "unet2d_64_masks", "unet3d_64_dropoff", "unet3d_64_masks",
-                                  "vnet_64_masks"])
+                                  "vnet_64_masks", "vnet_gn_64_masks"])
 def test_oracle_reproduces_reference_goldens(name):
     """oracle.step on the fixture inputs == numbers the real reference produced (gen_golden.py)."""
     from oracle import filler
@@ -34,7 +34,8 @@ def test_oracle_reproduces_reference_goldens(name):
     kind, cfg, iters, mode = meta["kind"], meta["cfg"], meta["iters"], meta["drop_mode"]
     C, L = cfg["num_classes"], cfg["labeled_bs"]
     onet = {"unet2d": lambda: OracleUNet2D(1, C), "unet3d": lambda: OracleUNet3D(C, 1),
-            "vnet": lambda: OracleVNet(C, 1)}[kind]()
+            "vnet": lambda: OracleVNet(C, 1),
+            "vnet_groupnorm": lambda: OracleVNet(C, 1, normalization="groupnorm")}[kind]()
     sd0 = filler.fill_state_dict(onet.new_state())
     tsd0 = filler.fill_state_dict({"t." + k: v.clone() for k, v in onet.new_state().items()})
     tsd0 = {k[2:]: v for k, v in tsd0.items()}

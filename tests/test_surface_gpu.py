@@ -192,3 +192,27 @@ def test_train_cli_on_resident_dataset(tmp_path):
         assert r.returncode == 0, r.stderr[-2000:]
         assert "Training Finished!" in r.stdout and "iteration 5 : loss :" in r.stdout
         assert note in r.stdout and "resident in HBM" in r.stdout
+
+
+def test_backward_after_same_shape_forward_fails_loudly():
+    """One static plan per input shape: a second same-shape forward overwrites the activations the first
+    loss.backward() needs; torch autograd would keep both graphs, so this must raise, never silently use the wrong
+    activations.  A different-shape forward in between is harmless."""
+    from networks.net_factory import net_factory
+    model = net_factory("unet", 1, 4)
+    model.train()
+    model.dropout_enabled = False
+    x = torch.rand(2, 1, 32, 32, device="cuda")
+    y = model(x)
+    with torch.no_grad():
+        model(torch.rand(1, 1, 32, 32, device="cuda"))     # other shape: other plan
+    y.mean().backward()                                    # still valid
+    g0 = model.flat_grad.clone()
+    y = model(x)
+    with torch.no_grad():
+        model(torch.rand(2, 1, 32, 32, device="cuda"))     # same shape: pseudo-label / validation style pass
+    with pytest.raises(RuntimeError, match="activations were overwritten"):
+        y.mean().backward()
+    y = model(x)
+    y.mean().backward()
+    assert torch.equal(model.flat_grad, g0)
