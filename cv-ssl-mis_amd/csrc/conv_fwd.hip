@@ -35,6 +35,7 @@
 // contiguous bytes per channel per 16 lanes.
 #include "common.h"
 #include <stdio.h>
+#include <stdlib.h>
 
 namespace {
 
@@ -48,6 +49,7 @@ struct ConvFwdArgs {
     unsigned n_blocks, n_blocks_padded;
     int st2;  // 1: output rows may be stored as aligned float2 (W even, 8-byte aligned rows)
     float2* stat; long long stat_sc, stat_sn;   // optional per-tile (sum, sumsq) of the output, see mis_conv_fwd_stats
+    int stagger, stagger_mod;                   // experiment: de-phase the first round of workgroups
 };
 
 using namespace mis_dma;   // LDS-DMA helpers (common.h)
@@ -89,6 +91,10 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvFwdArgs a) {
 
     const unsigned L = mis_xcd_remap(blockIdx.x, a.n_blocks_padded);
     if (L >= a.n_blocks) return;
+    if (a.stagger > 0 && blockIdx.x < 1024) {
+        const int k = (blockIdx.x >> 8) % a.stagger_mod;
+        for (int i = 0; i < k * a.stagger; ++i) __builtin_amdgcn_s_sleep(16);   // 1024 clocks per unit
+    }
     unsigned t = L;
     const int cob = t % a.co_blocks; t /= a.co_blocks;
     const int tx = t % a.tiles_x;    t /= a.tiles_x;
@@ -440,6 +446,9 @@ int launch_cfg(ConvFwdArgs a, hipStream_t stream) {
     if (nb <= 0 || nb > 0x7fffffffLL) return MIS_ERR_ARG;
     a.n_blocks = (unsigned)nb;
     a.n_blocks_padded = (unsigned)(mis_cdiv(nb, MIS_NUM_XCD) * MIS_NUM_XCD);
+    static const int stagger = getenv("MIS_CF_STAGGER") ? atoi(getenv("MIS_CF_STAGGER")) : 0;
+    static const int stagger_mod = getenv("MIS_CF_STAGGER_MOD") ? atoi(getenv("MIS_CF_STAGGER_MOD")) : 4;
+    a.stagger = stagger; a.stagger_mod = stagger_mod;
     static std::atomic<unsigned long long> attr_done{0};   // per instantiation, one bit per device
     if (mis_set_lds_attr(reinterpret_cast<const void*>(&conv_fwd_kernel<C>), C::LDS_BYTES, attr_done) != MIS_OK) return MIS_ERR_LAUNCH;
     hipLaunchKernelGGL(conv_fwd_kernel<C>, dim3(a.n_blocks_padded), dim3(256), C::LDS_BYTES, stream, a);

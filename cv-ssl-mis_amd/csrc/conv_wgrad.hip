@@ -22,6 +22,7 @@
 // (61 floats per lane per tile), and halo / channel padding is the descriptor's range check.
 // With NBUF = 2 the DMA of the next tile overlaps the MFMAs of the current one.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -35,6 +36,8 @@ struct WgradArgs {
     int tiles_z, tiles_y, tiles_x, tiles_total;
     int ci_tiles, pairs, KS;
     unsigned n_blocks_padded;
+    int stagger_shift;
+    int stagger;   // s_sleep units (64 clocks each) by which every second resident workgroup of a CU starts late
 };
 
 template <int KD_, int KH_, int KW_, int TZ_, int TY_, int TX_, int NBUF_>
@@ -259,6 +262,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
             }
         }
     } else {
+        // Two workgroups share a CU and each alternates "DMA a tile" / "MFMA over it".  Started together they stay in
+        // phase: both copy (matrix pipe idle), then both compute (sharing the pipe) -- measured 70 % MFMA-busy.  Starting
+        // the second resident workgroup of a CU (dispatch order: b and b + 256 land on the same CU) half a period late
+        // lets one workgroup's copy run under the other's MFMAs.  Timing only, never results.
+        if (a.stagger > 0 && ((blockIdx.x >> a.stagger_shift) & 1)) {
+            for (int i = 0; i < a.stagger; i += 127) __builtin_amdgcn_s_sleep(127);
+        }
         for (int tile = ks; tile < a.tiles_total; tile += a.KS) {
             __syncthreads();   // previous tile fully consumed
             issue(tile, 0);
@@ -341,6 +351,10 @@ int launch_wgrad(WgradArgs a, float* dw, int accumulate, hipStream_t stream) {
     static std::atomic<unsigned long long> attr_done{0};   // per instantiation, one bit per device
     if (mis_set_lds_attr(reinterpret_cast<const void*>(&conv_wgrad_kernel<C>), C::LDS_BYTES, attr_done) != MIS_OK) return MIS_ERR_LAUNCH;
     a.n_blocks_padded = (unsigned)(mis_cdiv((long long)a.pairs * a.KS, MIS_NUM_XCD) * MIS_NUM_XCD);
+    static const int stagger = getenv("MIS_WG_STAGGER") ? atoi(getenv("MIS_WG_STAGGER")) : 0;
+    a.stagger = stagger;
+    static const int stagger_shift = getenv("MIS_WG_STAGGER_SHIFT") ? atoi(getenv("MIS_WG_STAGGER_SHIFT")) : 8;
+    a.stagger_shift = stagger_shift;
     hipLaunchKernelGGL(conv_wgrad_kernel<C>, dim3(a.n_blocks_padded), dim3(256), C::LDS_BYTES, stream, a);
     int st = mis_launch_status();
     if (st) return st;

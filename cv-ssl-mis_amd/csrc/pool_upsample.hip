@@ -16,6 +16,7 @@
 // Launch shape: grid = (plane chunks, depth slice, n*C + c); all index math is 32-bit (a flat
 // 64-bit index decoded with 64-bit divisions costs more than the memory traffic of these kernels).
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -393,6 +394,111 @@ __global__ __launch_bounds__(256) void upsample_tri2_bwd_kernel(const UpBwdArgs 
     }
 }
 
+// LDS-tiled form of the same backward (the one the dispatcher picks when rows are float4-aligned).  The gather above
+// reads dy with a lane stride of four floats (every load instruction touches 4x the bytes it uses) and was measured
+// at 1.5 TB/s on the 96^3 level of unet_3D.  Here a workgroup owns a 4 x 8 x 32 tile of dx: the
+// (2*4+2) x (2*8+2) x (2*32+8) region of dy it gathers from is brought into LDS once with coalesced float4 loads
+// (z / y indices clamped to the volume = the clamped-neighbour form of the border weights; x handled per lane),
+// then every thread reduces an x-pair of cells for two consecutive z from LDS: per (plane, row) one 16-byte read of
+// dy[4j .. 4j+3] plus the two neighbours dy[4j-1], dy[4j+4].
+//   dx[i] = 0.25 dy[2i-1] + 0.75 dy[2i] + 0.75 dy[2i+1] + 0.25 dy[2i+2]   with dy[-1] := dy[0], dy[2n] := dy[2n-1]
+// along each axis (separable).  Gather form, fixed order: deterministic.
+template <int ZPT>       // z cells per thread (2: 4 x 8 x 32 tile, 47.5 KB of LDS; 1: 2 x 8 x 32 tile, 28.5 KB)
+struct Tri2 {
+    static constexpr int TZ = 2 * ZPT, TY = 8, TX = 32;
+    static constexpr int RZ = 2 * TZ + 2, RY = 2 * TY + 2, RQ = (2 * TX + 8) / 4, PITCH = RQ * 4;   // 10 x 18 x 72
+    static constexpr int LDS_FLOATS = RZ * RY * PITCH;
+};
+
+template <int ZPT>
+__global__ __launch_bounds__(256) void upsample_tri2_bwd_lds_kernel(const UpBwdArgs a, int tiles_x, int tiles_y,
+                                                                    int tiles_z, unsigned n_blocks,
+                                                                    unsigned n_blocks_padded) {
+    constexpr int TZ = Tri2<ZPT>::TZ, TY = Tri2<ZPT>::TY, TX = Tri2<ZPT>::TX, RZ = Tri2<ZPT>::RZ, RY = Tri2<ZPT>::RY,
+                  RQ = Tri2<ZPT>::RQ, PITCH = Tri2<ZPT>::PITCH;
+    extern __shared__ __attribute__((aligned(16))) float tri2_lds[];
+    // XCD-aware order: neighbouring tiles of one (n, c) volume (shared halo rows, the two x-tiles of a cache line)
+    // run on the same XCD, i.e. behind the same L2 -- with the plain 3-D grid every halo line was fetched from HBM
+    // once per XCD (measured 2.4 TB/s of useful traffic at ~2.5x that in fetched bytes)
+    unsigned t = mis_xcd_remap(blockIdx.x, n_blocks_padded);
+    if (t >= n_blocks) return;
+    const int tx = t % tiles_x; t /= tiles_x;
+    const int ty = t % tiles_y; t /= tiles_y;
+    const int tz = t % tiles_z; t /= tiles_z;
+    const int nc = (int)t;
+    const int n = nc / a.C, c = nc - n * a.C;
+    const int z0 = tz * TZ, y0 = ty * TY, x0 = tx * TX;
+    const int S = a.D * a.H * a.W;
+    const long long So = (long long)a.Do * a.Ho * a.Wo;
+    const float* __restrict__ db = a.dy + (long long)n * a.dy_bs + (long long)c * So;
+    // ---- stage the dy region: planes 2z0-1 .. 2z0+8, rows 2y0-1 .. 2y0+16 (clamped), floats 2x0-4 .. 2x0+67 ----
+    // all loads of a thread are issued before the first LDS write (a load -> store loop serialises on the memory
+    // latency).  The kernel is VALU-issue bound (a wave64 instruction takes 4 cycles on the 16-lane SIMDs), so the
+    // staging index arithmetic is kept minimal: thread -> (float4 column q, row rr) once, 14 rows further per step.
+    constexpr int RPS = 256 / RQ;                               // rows per staging step (14 of 18-float4 rows)
+    constexpr int NLD = (RZ * RY + RPS - 1) / RPS;
+    const int sq = threadIdx.x % RQ, srr = threadIdx.x / RQ;
+    const int sox = 2 * x0 - 4 + 4 * sq;
+    const bool scol = threadIdx.x < RPS * RQ && sox >= 0 && sox < a.Wo;
+    float4 v[NLD];
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+        const int r = srr + i * RPS;
+        const int rz = (r * 57) >> 10, ry = r - rz * RY;        // r / 18 for r < 1024 / 18... (r < 182 here)
+        static_assert(RY == 18, "the r / 18 shortcut");
+        int oz = 2 * z0 - 1 + rz, oy = 2 * y0 - 1 + ry;
+        oz = min(max(oz, 0), a.Do - 1);
+        oy = min(max(oy, 0), a.Ho - 1);
+        v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (scol && r < RZ * RY) v[i] = *reinterpret_cast<const float4*>(db + (unsigned)((oz * a.Ho + oy) * a.Wo + sox));
+    }
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+        const int r = srr + i * RPS;
+        if (threadIdx.x < RPS * RQ && r < RZ * RY) *reinterpret_cast<float4*>(&tri2_lds[r * PITCH + 4 * sq]) = v[i];
+    }
+    __syncthreads();
+    const int xl = threadIdx.x & 15, yl = (threadIdx.x >> 4) & 7, zh = threadIdx.x >> 7;
+    const int x = x0 + 2 * xl, y = y0 + yl, zb = z0 + ZPT * zh;
+    if (x >= a.W || y >= a.H || zb >= a.D) return;
+    const bool left_edge = x == 0, right_edge = 2 * x + 4 >= a.Wo;
+    // un-normalised weights (1, 3, 3, 1) per axis, one scale by 4^-3 at the end (exact: powers of two)
+    float g[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
+#pragma unroll
+    for (int j = 0; j < 2 * ZPT + 2; ++j) {             // dy planes 2zb-1 .. = region planes 2*ZPT*zh + j
+        float p0 = 0.f, p1 = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {                   // dy rows 2y-1 .. 2y+2 = region rows 2yl + k
+            const float* __restrict__ row = &tri2_lds[((2 * ZPT * zh + j) * RY + 2 * yl + k) * PITCH + 4 + 4 * xl];
+            const float4 q = *reinterpret_cast<const float4*>(row);
+            const float lf = left_edge ? q.x : row[-1];
+            const float rt = right_edge ? q.w : row[4];
+            const float r0 = fmaf(3.f, q.x + q.y, lf + q.z);
+            const float r1 = fmaf(3.f, q.z + q.w, q.y + rt);
+            if (k == 0 || k == 3) { p0 += r0; p1 += r1; } else { p0 = fmaf(3.f, r0, p0); p1 = fmaf(3.f, r1, p1); }
+        }
+        if (j < 4) {
+            if (j == 0 || j == 3) { g[0][0] += p0; g[0][1] += p1; }
+            else { g[0][0] = fmaf(3.f, p0, g[0][0]); g[0][1] = fmaf(3.f, p1, g[0][1]); }
+        }
+        if (ZPT == 2 && j >= 2) {
+            if (j == 2 || j == 5) { g[1][0] += p0; g[1][1] += p1; }
+            else { g[1][0] = fmaf(3.f, p0, g[1][0]); g[1][1] = fmaf(3.f, p1, g[1][1]); }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) { g[i][0] *= 0.015625f; g[i][1] *= 0.015625f; }
+    float* __restrict__ dxb = a.dx + (long long)n * a.dx_bs + (long long)c * S;
+#pragma unroll
+    for (int i = 0; i < ZPT; ++i) {
+        if (zb + i >= a.D) break;
+        float2* p = reinterpret_cast<float2*>(dxb + ((long long)(zb + i) * a.H + y) * a.W + x);
+        float2 o = make_float2(g[i][0], g[i][1]);
+        if (a.accumulate) { const float2 old = *p; o.x += old.x; o.y += old.y; }
+        *p = o;
+    }
+}
+
 // Backward of the 2-D bilinear x2 up-sampling with align_corners=True (UNet's decoder, reference unet.py:74-75):
 // input index i is read by outputs 2i-2 .. 2i+3 (covers every ratio (in-1)/(2in-1)).  A workgroup owns a 16 x 32
 // tile of dx: the (2*16+4) x (2*32+4) region of dy it gathers from is loaded once, coalesced, into LDS (the
@@ -518,6 +624,21 @@ extern "C" int mis_upsample2_bwd(const float* dy, long long dy_bs, float* dx, lo
                            dim3(256), 0, stream, a);
     } else if (a.align) {
         hipLaunchKernelGGL(upsample_bwd_kernel<6>, grid, dim3(256), 0, stream, a);
+    } else if (D > 1 && So < (1LL << 31) && W % 2 == 0 && W >= 4 && !(dy_bs & 3) && !((uintptr_t)dy & 15) &&
+               !(dx_bs & 1) && !((uintptr_t)dx & 7)) {
+        // float4-aligned dy rows (Wo = 2W is a multiple of 4, So a multiple of 8) and float2-aligned dx rows
+        static const int zpt = getenv("MIS_TRI2_ZPT") ? atoi(getenv("MIS_TRI2_ZPT")) : 2;
+        const int tiles_x = (int)mis_cdiv(W, 32), tiles_y = (int)mis_cdiv(H, 8);
+        const int tiles_z = (int)mis_cdiv(D, 2 * zpt);
+        const long long nb = (long long)tiles_x * tiles_y * tiles_z * N * C;
+        if (nb > 0x7fffffffLL) return MIS_ERR_UNSUPPORTED;
+        const unsigned nbp = (unsigned)(mis_cdiv(nb, MIS_NUM_XCD) * MIS_NUM_XCD);
+        if (zpt == 1)
+            hipLaunchKernelGGL(upsample_tri2_bwd_lds_kernel<1>, dim3(nbp), dim3(256), Tri2<1>::LDS_FLOATS * 4, stream, a,
+                               tiles_x, tiles_y, tiles_z, (unsigned)nb, nbp);
+        else
+            hipLaunchKernelGGL(upsample_tri2_bwd_lds_kernel<2>, dim3(nbp), dim3(256), Tri2<2>::LDS_FLOATS * 4, stream, a,
+                               tiles_x, tiles_y, tiles_z, (unsigned)nb, nbp);
     } else if (D > 1 && So < (1LL << 31)) {
         constexpr int ZR = 4;
         hipLaunchKernelGGL(upsample_tri2_bwd_kernel<ZR>, dim3((H * ((W + 1) / 2) + 255) / 256, (D + ZR - 1) / ZR, N * C),
