@@ -63,11 +63,16 @@ WORKLOADS = {
                         "(BASELINE configs[3])",
                  shape=(48, 1, 224, 224), labeled=24, classes=4, cons_start=1000, label="uint8",
                  cpu_sample=(4, 2), step_gflop=12.17 * 168),
-    "cross": dict(config="Cross-teaching CNN+ViT 2D (UNet + SwinUNet), synthetic ACDC 224x224 4-class, bs=16+16 "
-                         "per GPU (BASELINE configs[4]; 224 because SwinUnet window 7 cannot run 256, as in the "
-                         "reference)",
-                  shape=(32, 1, 224, 224), labeled=16, classes=4, cons_start=0, label="uint8",
-                  cpu_sample=None, step_gflop=(4.52 + 12.17) * 96),
+    # SwinUnet at 256^2 = DATA.IMG_SIZE 256 + MODEL.SWIN.WINDOW_SIZE 8 (reference config.py:194-195): 4096 tokens per
+    # image instead of 3136 (Linear layers x1.306), 64-token windows (attention core x1.306 x 64/49)
+    "cross": dict(config="Cross-teaching CNN+ViT 2D (UNet + SwinUNet window 8), synthetic ACDC 256x256 4-class, "
+                         "bs=16+16 per GPU (BASELINE configs[4])",
+                  shape=(32, 1, 256, 256), labeled=16, classes=4, cons_start=0, label="uint8", swin=(256, 8),
+                  cpu_sample=None, step_gflop=(5.90 + 11.74 * 1.306 + 0.43 * 1.306 * 64 / 49) * 96),
+    "cross224": dict(config="Cross-teaching CNN+ViT 2D (UNet + SwinUNet window 7), synthetic ACDC 224x224 4-class, "
+                            "bs=16+16 per GPU (BASELINE configs[4] at the reference yaml's 224)",
+                     shape=(32, 1, 224, 224), labeled=16, classes=4, cons_start=0, label="uint8",
+                     cpu_sample=None, step_gflop=(4.52 + 12.17) * 96),
     "cnnvit": dict(config="CNN + ViT students with an EMA ViT teacher (train_cnn_meet_vit_2D: UNet + 2x SwinUNet), "
                           "synthetic ACDC 224x224 4-class, bs=8+8 per GPU (the script's defaults; SURVEY s.8 row n2)",
                    shape=(16, 1, 224, 224), labeled=8, classes=4, cons_start=1000, label="uint8",
@@ -102,10 +107,17 @@ def build_trainer(name, wl, world, stub=False):
     from mis_hip.step import MeanTeacherTrainer
     C, L = wl["classes"], wl["labeled"]
     vit_teacher = None
-    if name in ("cross", "cnnvit"):
+    if name in ("cross", "cross224", "cnnvit"):
         from mis_hip.step import CnnMeetVitTrainer, CrossTeachingTrainer
         from networks.net_factory import net_factory
-        model, ema = net_factory("unet", 1, C), net_factory("ViT_Seg", 1, C)
+        if "swin" in wl:           # SwinUnet at another image size: the reference's --opts overrides
+            from config import lite_config
+            from networks.vision_transformer import SwinUnet
+            cfg = lite_config()
+            cfg.DATA.IMG_SIZE, cfg.MODEL.SWIN.WINDOW_SIZE = wl["swin"]
+            model, ema = net_factory("unet", 1, C), SwinUnet(cfg, img_size=wl["swin"][0], num_classes=C)
+        else:
+            model, ema = net_factory("unet", 1, C), net_factory("ViT_Seg", 1, C)
         if name == "cnnvit":      # here `ema` is the Transformer STUDENT, vit_teacher its EMA
             vit_teacher = net_factory("ViT_Seg", 1, C)
             vit_teacher.load_state_dict(ema.state_dict())
@@ -123,7 +135,7 @@ def build_trainer(name, wl, world, stub=False):
         for m in (model, ema, vit_teacher):
             if m is not None:
                 torch.distributed.broadcast(m.flat_param, 0)
-    if name == "cross":
+    if name in ("cross", "cross224"):
         return CrossTeachingTrainer(model, ema, labeled_bs=L, num_classes=C, seed=1337, iter_num=1000)
     if name == "cnnvit":
         return CnnMeetVitTrainer(model, ema, vit_teacher, labeled_bs=L, num_classes=C, seed=1337, iter_num=1000)

@@ -18,810 +18,69 @@
 // and runs all five matrix products on v_mfma_f32_16x16x4_f32 (measured at 48 images: forward 132 -> 79 us,
 // backward 784 -> 432 us at 56^2; 335 -> 75 us at 7^2).
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
-constexpr int WS = 7, NTOK = 49, HD = 32;
+#define MIS_ATTN_WS 7
+#define MIS_ATTN_NS ws7
+#include "attention_impl.inc"
+#undef MIS_ATTN_WS
+#undef MIS_ATTN_NS
 
-struct AttnArgs {
-    const float* qkv; long long ldq;      // [B*H*W][3*C] natural token order
-    float* out; long long ldo;            // [B*H*W][C]
-    const float* table;                   // relative_position_bias_table [169][nH]
-    int B, H, W, nH, shift;
-    float scale;
-};
-
-// region id of the reference's img_mask slices (0,-ws), (-ws,-shift), (-shift,None)  (:219-224)
-__device__ __forceinline__ int region(int s, int n, int shift) { return s < n - WS ? 0 : (s < n - shift ? 1 : 2); }
-
-// unit decode shared by forward and backward
-struct Unit {
-    int b, wy, wx, h, tok, iy, ix, rid;
-    bool active;
-};
-
-__device__ __forceinline__ Unit decode(long long u, int lane, int B, int H, int W, int nH, int shift) {
-    Unit r;
-    const int nWx = W / WS, nWy = H / WS;
-    r.h = (int)(u % nH); u /= nH;
-    r.wx = (int)(u % nWx); u /= nWx;
-    r.wy = (int)(u % nWy);
-    r.b = (int)(u / nWy);
-    r.active = lane < NTOK;
-    const int i = r.active ? lane : 0;
-    r.iy = i / WS; r.ix = i - r.iy * WS;
-    const int sy = r.wy * WS + r.iy, sx = r.wx * WS + r.ix;     // coordinates in the shifted image
-    r.rid = shift > 0 ? region(sy, H, shift) * 3 + region(sx, W, shift) : 0;
-    const int y = (sy + shift) % H, x = (sx + shift) % W;       // natural coordinates
-    r.tok = (r.b * H + y) * W + x;
-    return r;
-}
-
-// 4 waves per workgroup, one unit each.  LDS per wave: K[49][32], V[49][32], bias[169], rid[49]
-constexpr int LDS_PER_WAVE = 2 * NTOK * HD + 176 + 64;
-
-__global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs a, long long units) {
-    __shared__ __attribute__((aligned(16))) float smem[4 * LDS_PER_WAVE];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const long long u = blockIdx.x * 4LL + wave;
-    if (u >= units) return;
-    float* sk = smem + wave * LDS_PER_WAVE;
-    float* sv = sk + NTOK * HD;
-    float* sb = sv + NTOK * HD;
-    int* srid = reinterpret_cast<int*>(sb + 176);
-    const Unit t = decode(u, lane, a.B, a.H, a.W, a.nH, a.shift);
-    const int C = a.nH * HD;
-    const float* __restrict__ row = a.qkv + (long long)t.tok * a.ldq + t.h * HD;
-    float q[HD];
-    if (t.active) {
-#pragma unroll
-        for (int e = 0; e < HD; e += 4) {
-            const float4 vq = *reinterpret_cast<const float4*>(row + e);
-            q[e] = vq.x * a.scale; q[e + 1] = vq.y * a.scale; q[e + 2] = vq.z * a.scale; q[e + 3] = vq.w * a.scale;
-            *reinterpret_cast<float4*>(sk + lane * HD + e) = *reinterpret_cast<const float4*>(row + C + e);
-            *reinterpret_cast<float4*>(sv + lane * HD + e) = *reinterpret_cast<const float4*>(row + 2 * C + e);
-        }
-        srid[lane] = t.rid;
-    }
-    for (int i = lane; i < 169; i += 64) sb[i] = a.table[i * a.nH + t.h];
-    __builtin_amdgcn_s_waitcnt(0);   // LDS writes of this wave complete (single wave: no barrier needed)
-    __builtin_amdgcn_wave_barrier();
-    if (!t.active) return;
-
-    float s[NTOK];
-    float mx = -INFINITY;
-#pragma unroll
-    for (int j = 0; j < NTOK; ++j) {
-        float acc = 0.f;
-#pragma unroll
-        for (int e = 0; e < HD; e += 4) {
-            const float4 kk = *reinterpret_cast<const float4*>(sk + j * HD + e);
-            acc += (q[e] * kk.x + q[e + 1] * kk.y) + (q[e + 2] * kk.z + q[e + 3] * kk.w);
-        }
-        const int jy = j / WS, jx = j - jy * WS;
-        acc += sb[(t.iy - jy + WS - 1) * (2 * WS - 1) + (t.ix - jx + WS - 1)];
-        if (a.shift > 0 && srid[j] != t.rid) acc += -100.f;
-        s[j] = acc;
-        mx = fmaxf(mx, acc);
-    }
-    float sum = 0.f;
-#pragma unroll
-    for (int j = 0; j < NTOK; ++j) { s[j] = expf(s[j] - mx); sum += s[j]; }
-    const float inv = 1.f / sum;
-    float o[HD];
-#pragma unroll
-    for (int e = 0; e < HD; ++e) o[e] = 0.f;
-#pragma unroll
-    for (int j = 0; j < NTOK; ++j) {
-        const float p = s[j] * inv;
-#pragma unroll
-        for (int e = 0; e < HD; e += 4) {
-            const float4 vv = *reinterpret_cast<const float4*>(sv + j * HD + e);
-            o[e] += p * vv.x; o[e + 1] += p * vv.y; o[e + 2] += p * vv.z; o[e + 3] += p * vv.w;
-        }
-    }
-    float* __restrict__ orow = a.out + (long long)t.tok * a.ldo + t.h * HD;
-#pragma unroll
-    for (int e = 0; e < HD; e += 4) *reinterpret_cast<float4*>(orow + e) = make_float4(o[e], o[e + 1], o[e + 2], o[e + 3]);
-}
-
-// ---------------------------------------------------------------------------------------------------
-// MFMA form (v_mfma_f32_16x16x4_f32, exact fp32): the 49-token window is padded to 64 = 4 tiles of 16.
-// One wave per (sample, window, head), NO LDS for the operands: every operand is loaded from global memory
-// straight into the register layout the matrix instruction wants --
-//   "L1" rows-on-lanes   X1[t][s]     = X[16t + lane%16][8*(lane/16) + s]        (two float4 loads per tile)
-//        A or B operand of a product that contracts over the 32 head dims: step s of lane group g supplies
-//        dim 8g+s (the contraction index may be permuted freely as long as A and B agree);
-//   "L2" rows-on-groups  X2[t][i][nt] = X[16t + 4*(lane/16) + i][16nt + lane%16]  (64-byte row segments)
-//        B operand of a product that contracts over tokens, matching the accumulator layout
-//        D[4*(lane/16) + i][lane%16] of the previous product used as its A operand (A = D^T).
-// Forward: S^T = K Q^T (keys on accumulator rows) -> + bias/mask, softmax over the accumulator rows (in-lane over
-// 16 values, then two cross-group shuffles) -> O = P V with A = (S^T)^T straight from the accumulators.
-// ---------------------------------------------------------------------------------------------------
-struct WinGeo {
-    int b, wy, wx, h;
-};
-
-__device__ __forceinline__ WinGeo decode_window(long long u, int H, int W, int nH) {
-    WinGeo r;
-    const int nWx = W / WS, nWy = H / WS;
-    r.h = (int)(u % nH); u /= nH;
-    r.wx = (int)(u % nWx); u /= nWx;
-    r.wy = (int)(u % nWy);
-    r.b = (int)(u / nWy);
-    return r;
-}
-
-// Per-wave LDS row table (64 entries, rows >= 49 alias row 0 and are masked by the callers):
-//   srow[r]  = natural token offset of window row r inside its image ((y*W + x), cyclic shift folded in)
-//   smeta[r] = (iy*13 + ix) | mask-region id << 8   (relative-position index arithmetic / shift mask :216-238)
-__device__ __forceinline__ void fill_row_table(int wy, int wx, int lane, int H, int W, int shift, int* srow, int* smeta) {
-    const int r = lane < NTOK ? lane : 0;
-    const int iy = r / WS, ix = r - iy * WS;
-    const int sy = wy * WS + iy, sx = wx * WS + ix;
-    const int rid = shift > 0 ? region(sy, H, shift) * 3 + region(sx, W, shift) : 0;
-    srow[lane] = ((sy + shift) % H) * W + (sx + shift) % W;
-    smeta[lane] = (iy * (2 * WS - 1) + ix) | (rid << 8);
-}
-
-// L1 load: rows 16t + lane%16 (zero for rows >= 49), dims 8*(lane/16) .. +7, optionally scaled.
-// Element offsets are 32-bit (the host checks that the buffers are < 2^31 bytes).
-__device__ __forceinline__ void load_l1(const float* __restrict__ base, int tb, const int* srow, int ld, int col0,
-                                        int lane, float scale, float (*dst)[8]) {
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
-        const int r = 16 * t + (lane & 15);
-        if (r < NTOK) {
-            const float* p = base + ((tb + srow[r]) * ld + col0 + 8 * (lane >> 4));
-            a = *reinterpret_cast<const float4*>(p);
-            b = *reinterpret_cast<const float4*>(p + 4);
-        }
-        dst[t][0] = a.x * scale; dst[t][1] = a.y * scale; dst[t][2] = a.z * scale; dst[t][3] = a.w * scale;
-        dst[t][4] = b.x * scale; dst[t][5] = b.y * scale; dst[t][6] = b.z * scale; dst[t][7] = b.w * scale;
-    }
-}
-
-// L2 load: rows 16t + 4*(lane/16) + i (zero for rows >= 49), dims 16nt + lane%16
-__device__ __forceinline__ void load_l2(const float* __restrict__ base, int tb, const int* srow, int ld, int col0,
-                                        int lane, float scale, float (*dst)[4][2]) {
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int r = 16 * t + 4 * (lane >> 4) + i;
-            const int e = (tb + srow[r]) * ld + col0 + (lane & 15);
-#pragma unroll
-            for (int nt = 0; nt < 2; ++nt) dst[t][i][nt] = r < NTOK ? base[e + 16 * nt] * scale : 0.f;
-        }
-}
-
-// store an accumulator tile set D[t][nt] (rows 16t + 4*(lane/16) + i, dims 16nt + lane%16) to token rows
-__device__ __forceinline__ void store_l2(float* __restrict__ base, int tb, const int* srow, int ld, int col0, int lane,
-                                         float scale, const f32x4 (*acc)[2]) {
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int r = 16 * t + 4 * (lane >> 4) + i;
-            if (r < NTOK) {
-                const int e = (tb + srow[r]) * ld + col0 + (lane & 15);
-#pragma unroll
-                for (int nt = 0; nt < 2; ++nt) base[e + 16 * nt] = acc[t][nt][i] * scale;
-            }
-        }
-}
-
-// reductions over the 16 lanes of a DPP row (all lanes end up with the result): quad swaps, then the two mirrors --
-// vector-pipe data movement instead of ds_bpermute round trips through the LDS crossbar
-template <int CTRL>
-__device__ __forceinline__ float dpp_mov(float v) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
-}
-__device__ __forceinline__ float row16_sum(float v) {
-    v += dpp_mov<0xB1>(v);     // quad_perm [1,0,3,2]
-    v += dpp_mov<0x4E>(v);     // quad_perm [2,3,0,1]
-    v += dpp_mov<0x141>(v);    // row_half_mirror
-    v += dpp_mov<0x140>(v);    // row_mirror
-    return v;
-}
-__device__ __forceinline__ float row16_max(float v) {
-    v = fmaxf(v, dpp_mov<0xB1>(v));
-    v = fmaxf(v, dpp_mov<0x4E>(v));
-    v = fmaxf(v, dpp_mov<0x141>(v));
-    v = fmaxf(v, dpp_mov<0x140>(v));
-    return v;
-}
-
-constexpr int BIAS_OFF = (WS - 1) * (2 * WS - 1) + (WS - 1);     // 84
-
-// 4 waves per workgroup, one unit each; LDS per wave: the head's 169 biases + the row table
-__global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(const AttnArgs a, long long units) {
-    __shared__ float sbias[4][176];
-    __shared__ int stab[4][128];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, lj = lane & 15, g = lane >> 4;
-    const long long u = blockIdx.x * 4LL + wave;
-    if (u >= units) return;
-    const WinGeo w = decode_window(u, a.H, a.W, a.nH);
-    float* sb = sbias[wave];
-    int* srow = stab[wave];
-    int* smeta = srow + 64;
-    for (int i = lane; i < 169; i += 64) sb[i] = a.table[i * a.nH + w.h];
-    fill_row_table(w.wy, w.wx, lane, a.H, a.W, a.shift, srow, smeta);
-    __builtin_amdgcn_wave_barrier();
-    const int C = a.nH * HD, col = w.h * HD, ldq = (int)a.ldq;
-    const int tb = w.b * a.H * a.W;
-    // S^T[key = 16mt + 4g + i][query = 16qt + lj]
-    f32x4 st[4][4];
-    {
-        float q1[4][8], k1[4][8];
-        load_l1(a.qkv, tb, srow, ldq, col, lane, a.scale, q1);
-        load_l1(a.qkv, tb, srow, ldq, C + col, lane, 1.f, k1);
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-            for (int qt = 0; qt < 4; ++qt) st[mt][qt] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int s = 0; s < 8; ++s)
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-                for (int qt = 0; qt < 4; ++qt)
-                    st[mt][qt] = __builtin_amdgcn_mfma_f32_16x16x4f32(k1[mt][s], q1[qt][s], st[mt][qt], 0, 0, 0);
-    }
-    float v2[4][4][2];
-    load_l2(a.qkv, tb, srow, ldq, 2 * C + col, lane, 1.f, v2);     // in flight during the softmax
-    int mk[16];
-#pragma unroll
-    for (int e = 0; e < 16; ++e) mk[e] = smeta[16 * (e >> 2) + 4 * g + (e & 3)];
-    // bias + mask, softmax over keys (accumulator rows) per query column
-#pragma unroll
-    for (int qt = 0; qt < 4; ++qt) {
-        const int mq = smeta[16 * qt + lj];
-        float mx = -INFINITY;
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                float v = -INFINITY;
-                if (16 * mt + 4 * g + i < NTOK) {
-                    v = st[mt][qt][i] + sb[(mq & 255) - (mk[4 * mt + i] & 255) + BIAS_OFF];
-                    if (a.shift > 0 && (mk[4 * mt + i] >> 8) != (mq >> 8)) v += -100.f;
-                }
-                st[mt][qt][i] = v;
-                mx = fmaxf(mx, v);
-            }
-        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        float sum = 0.f;
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const float e = expf(st[mt][qt][i] - mx);
-                st[mt][qt][i] = e;
-                sum += e;
-            }
-        sum += __shfl_xor(sum, 16, 64);
-        sum += __shfl_xor(sum, 32, 64);
-        const float inv = 1.f / sum;
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) st[mt][qt][i] *= inv;
-    }
-    // O[query = 16qt + 4g + i'][dim = 16nt + lj] = sum_key P[query][key] V[key][dim]
-    f32x4 o[4][2];
-#pragma unroll
-    for (int qt = 0; qt < 4; ++qt)
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt) o[qt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int qt = 0; qt < 4; ++qt)
-#pragma unroll
-                for (int nt = 0; nt < 2; ++nt)
-                    o[qt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(st[mt][qt][i], v2[mt][i][nt], o[qt][nt], 0, 0, 0);
-    store_l2(a.out, tb, srow, (int)a.ldo, col, lane, 1.f, o);
-}
-
-struct AttnBwdArgs {
-    const float* qkv; long long ldq;
-    const float* dout; long long ldo;     // gradient of the attention output [B*H*W][C]
-    float* dqkv; long long lddq;          // [B*H*W][3*C]
-    const float* table;
-    float* dS_part;                       // [chunks][nWy*nWx][nH][49*49] partial sums of dS over a batch chunk
-    int B, H, W, nH, shift, chunk;        // chunk = samples per workgroup
-    float scale;
-};
-
-// one wave per (batch chunk, window, head): loops over the samples of the chunk, accumulating dS for
-// the relative-position-bias gradient.  LDS per wave: K,V,dO [49][32] each + one [49][49] matrix; the scaled Q rows
-// (needed row-wise only by the last phase) are written over V once V is dead: 29 KiB -> 5 waves per CU instead of 4.
-constexpr int BWD_LDS = 3 * NTOK * HD + NTOK * NTOK + 176 + 64;
-
-__global__ __launch_bounds__(64) void attn_bwd_kernel(const AttnBwdArgs a) {
-    __shared__ __attribute__((aligned(16))) float smem[BWD_LDS];
-    const int lane = threadIdx.x;
-    float* sk = smem;
-    float* sv = sk + NTOK * HD;
-    float* sq = sv;                       // aliases V: filled after phase 1b (V's last use)
-    float* sdo = sv + NTOK * HD;
-    float* sm = sdo + NTOK * HD;          // [49][49]: first P, then dS
-    float* sb = sm + NTOK * NTOK;
-    int* srid = reinterpret_cast<int*>(sb + 176);
-    const int nWx = a.W / WS, nWy = a.H / WS;
-    int u = blockIdx.x;
-    const int h = u % a.nH; u /= a.nH;
-    const int w = u % (nWx * nWy);
-    const int ck = u / (nWx * nWy);
-    const int C = a.nH * HD;
-    for (int i = lane; i < 169; i += 64) sb[i] = a.table[i * a.nH + h];
-    float dsacc[NTOK];
-#pragma unroll
-    for (int j = 0; j < NTOK; ++j) dsacc[j] = 0.f;
-
-    const int b0 = ck * a.chunk;
-    const int b1 = b0 + a.chunk < a.B ? b0 + a.chunk : a.B;
-    for (int b = b0; b < b1; ++b) {
-        const long long unit = ((long long)b * nWy * nWx + w) * a.nH + h;
-        const Unit t = decode(unit, lane, a.B, a.H, a.W, a.nH, a.shift);
-        __builtin_amdgcn_wave_barrier();
-        const float* __restrict__ row = a.qkv + (long long)t.tok * a.ldq + h * HD;
-        const float* __restrict__ drow = a.dout + (long long)t.tok * a.ldo + h * HD;
-        float q[HD], dOi[HD];
-        if (t.active) {
-#pragma unroll
-            for (int e = 0; e < HD; e += 4) {
-                const float4 vq = *reinterpret_cast<const float4*>(row + e);
-                q[e] = vq.x * a.scale; q[e + 1] = vq.y * a.scale; q[e + 2] = vq.z * a.scale; q[e + 3] = vq.w * a.scale;
-                *reinterpret_cast<float4*>(sk + lane * HD + e) = *reinterpret_cast<const float4*>(row + C + e);
-                *reinterpret_cast<float4*>(sv + lane * HD + e) = *reinterpret_cast<const float4*>(row + 2 * C + e);
-                const float4 vd = *reinterpret_cast<const float4*>(drow + e);
-                dOi[e] = vd.x; dOi[e + 1] = vd.y; dOi[e + 2] = vd.z; dOi[e + 3] = vd.w;
-                *reinterpret_cast<float4*>(sdo + lane * HD + e) = vd;
-            }
-            srid[lane] = t.rid;
-        }
-        __builtin_amdgcn_s_waitcnt(0);
-        __builtin_amdgcn_wave_barrier();
-
-        // ---- phase 1 (lane = query row i): P row, dP row, dS row, dq ----
-        float p[NTOK];
-        if (t.active) {
-            float mx = -INFINITY;
-#pragma unroll
-            for (int j = 0; j < NTOK; ++j) {
-                float acc = 0.f;
-#pragma unroll
-                for (int e = 0; e < HD; e += 4) {
-                    const float4 kk = *reinterpret_cast<const float4*>(sk + j * HD + e);
-                    acc += (q[e] * kk.x + q[e + 1] * kk.y) + (q[e + 2] * kk.z + q[e + 3] * kk.w);
-                }
-                const int jy = j / WS, jx = j - jy * WS;
-                acc += sb[(t.iy - jy + WS - 1) * (2 * WS - 1) + (t.ix - jx + WS - 1)];
-                if (a.shift > 0 && srid[j] != t.rid) acc += -100.f;
-                p[j] = acc;
-                mx = fmaxf(mx, acc);
-            }
-            float sum = 0.f;
-#pragma unroll
-            for (int j = 0; j < NTOK; ++j) { p[j] = expf(p[j] - mx); sum += p[j]; }
-            const float inv = 1.f / sum;
-#pragma unroll
-            for (int j = 0; j < NTOK; ++j) { p[j] *= inv; sm[lane * NTOK + j] = p[j]; }
-        }
-        __builtin_amdgcn_s_waitcnt(0);
-        __builtin_amdgcn_wave_barrier();
-        // ---- phase 2a (lane = key row j): dV_j = sum_i P[i][j] dO_i ----
-        float* __restrict__ dqrow = a.dqkv + (long long)t.tok * a.lddq + h * HD;
-        if (t.active) {
-            float dv[HD];
-#pragma unroll
-            for (int e = 0; e < HD; ++e) dv[e] = 0.f;
-            for (int i = 0; i < NTOK; ++i) {
-                const float pij = sm[i * NTOK + lane];
-#pragma unroll
-                for (int e = 0; e < HD; e += 4) {
-                    const float4 d = *reinterpret_cast<const float4*>(sdo + i * HD + e);
-                    dv[e] += pij * d.x; dv[e + 1] += pij * d.y; dv[e + 2] += pij * d.z; dv[e + 3] += pij * d.w;
-                }
-            }
-#pragma unroll
-            for (int e = 0; e < HD; e += 4)
-                *reinterpret_cast<float4*>(dqrow + 2 * C + e) = make_float4(dv[e], dv[e + 1], dv[e + 2], dv[e + 3]);
-        }
-        __builtin_amdgcn_wave_barrier();
-        // ---- phase 1b: dS row (overwrites P in LDS), dq ----
-        if (t.active) {
-            float dot = 0.f;
-            float dp[NTOK];
-#pragma unroll
-            for (int j = 0; j < NTOK; ++j) {
-                float acc = 0.f;
-#pragma unroll
-                for (int e = 0; e < HD; e += 4) {
-                    const float4 vv = *reinterpret_cast<const float4*>(sv + j * HD + e);
-                    acc += (dOi[e] * vv.x + dOi[e + 1] * vv.y) + (dOi[e + 2] * vv.z + dOi[e + 3] * vv.w);
-                }
-                dp[j] = acc;
-                dot += acc * p[j];
-            }
-            float dq[HD];
-#pragma unroll
-            for (int e = 0; e < HD; ++e) dq[e] = 0.f;
-#pragma unroll
-            for (int j = 0; j < NTOK; ++j) {
-                const float ds = p[j] * (dp[j] - dot);
-                sm[lane * NTOK + j] = ds;
-                dsacc[j] += ds;
-#pragma unroll
-                for (int e = 0; e < HD; e += 4) {
-                    const float4 kk = *reinterpret_cast<const float4*>(sk + j * HD + e);
-                    dq[e] += ds * kk.x; dq[e + 1] += ds * kk.y; dq[e + 2] += ds * kk.z; dq[e + 3] += ds * kk.w;
-                }
-            }
-#pragma unroll
-            for (int e = 0; e < HD; e += 4)
-                *reinterpret_cast<float4*>(dqrow + e) = make_float4(dq[e] * a.scale, dq[e + 1] * a.scale,
-                                                                   dq[e + 2] * a.scale, dq[e + 3] * a.scale);
-        }
-        __builtin_amdgcn_s_waitcnt(0);
-        __builtin_amdgcn_wave_barrier();       // every lane is done reading V
-        if (t.active) {
-#pragma unroll
-            for (int e = 0; e < HD; e += 4)
-                *reinterpret_cast<float4*>(sq + lane * HD + e) = make_float4(q[e], q[e + 1], q[e + 2], q[e + 3]);
-        }
-        __builtin_amdgcn_s_waitcnt(0);
-        __builtin_amdgcn_wave_barrier();
-        // ---- phase 2b (lane = key row j): dK_j = sum_i dS[i][j] * (scale*q_i) ----
-        if (t.active) {
-            float dk[HD];
-#pragma unroll
-            for (int e = 0; e < HD; ++e) dk[e] = 0.f;
-            for (int i = 0; i < NTOK; ++i) {
-                const float ds = sm[i * NTOK + lane];
-#pragma unroll
-                for (int e = 0; e < HD; e += 4) {
-                    const float4 qq = *reinterpret_cast<const float4*>(sq + i * HD + e);
-                    dk[e] += ds * qq.x; dk[e + 1] += ds * qq.y; dk[e + 2] += ds * qq.z; dk[e + 3] += ds * qq.w;
-                }
-            }
-#pragma unroll
-            for (int e = 0; e < HD; e += 4)
-                *reinterpret_cast<float4*>(dqrow + C + e) = make_float4(dk[e], dk[e + 1], dk[e + 2], dk[e + 3]);
-        }
-    }
-    // partial of dS summed over this chunk's samples: [ck][w][h][i][j]
-    if (lane < NTOK) {
-        float* __restrict__ o = a.dS_part + (((long long)ck * nWy * nWx + w) * a.nH + h) * (NTOK * NTOK) + lane * NTOK;
-#pragma unroll
-        for (int j = 0; j < NTOK; ++j) o[j] = dsacc[j];
-    }
-}
-
-// MFMA backward (layouts: see attn_fwd_mfma_kernel).  Queries sit on the accumulator rows here:
-//   S = Q K^T, dP = dO V^T                    (contract over head dims, L1 operands)
-//   P = softmax(S + bias + mask), dS = P o (dP - rowsum(P o dP))   (row reductions = 16-lane shuffles)
-//   dV = P^T dO, dK = dS^T (scale Q)          (contract over queries: A = accumulators transposed, B = L2 operands)
-//   dQ = scale * dS K                         (contracts over keys = the accumulators' lane axis: dS goes through a
-//                                              [64][68] LDS tile once and comes back as a rows-on-lanes A operand)
-// One wave per (sample, window, head) (the host passes chunk == 1): dS also goes out as this unit's partial of the
-// bias-table gradient.  Summing dS over several samples in accumulators (first version) cost 64 registers and with
-// them the second wave per SIMD; per-unit partials + the coalesced attn_ds_reduce_kernel are faster (stage-1
-// backward 300 -> 262 us) although they move 88 MB more.
-constexpr int DS_LD = 68;
-
-__global__ __launch_bounds__(64, 2) void attn_bwd_mfma_kernel(const AttnBwdArgs a) {
-    __shared__ float sb[176];
-    __shared__ int srow[64], smeta[64];
-    __shared__ __attribute__((aligned(16))) float sds[64 * DS_LD];
-    const int lane = threadIdx.x, lj = lane & 15, g = lane >> 4;
-    const int nWx = a.W / WS, nWy = a.H / WS;
-    int u = blockIdx.x;
-    const int h = u % a.nH; u /= a.nH;
-    const int wdw = u % (nWx * nWy);
-    const int ck = u / (nWx * nWy);
-    const int C = a.nH * HD, col = h * HD;
-    const int ldq = (int)a.ldq, ldo = (int)a.ldo, lddq = (int)a.lddq;
-    for (int i = lane; i < 169; i += 64) sb[i] = a.table[i * a.nH + h];
-    fill_row_table(wdw / nWx, wdw % nWx, lane, a.H, a.W, a.shift, srow, smeta);
-    __builtin_amdgcn_wave_barrier();
-    // this unit's dS partial: [ck][w][h][query][key]
-    float* __restrict__ opart = a.dS_part + (((long long)ck * nWy * nWx + wdw) * a.nH + h) * (NTOK * NTOK);
-
-    const int b0 = ck * a.chunk;
-    const int b1 = b0 + a.chunk < a.B ? b0 + a.chunk : a.B;
-    for (int b = b0; b < b1; ++b) {
-        const int tb = b * a.H * a.W;
-        f32x4 p[4][4], ds[4][4];
-        {
-            float q1[4][8], k1[4][8];
-            load_l1(a.qkv, tb, srow, ldq, col, lane, a.scale, q1);
-            load_l1(a.qkv, tb, srow, ldq, C + col, lane, 1.f, k1);
-#pragma unroll
-            for (int qt = 0; qt < 4; ++qt)
-#pragma unroll
-                for (int kt = 0; kt < 4; ++kt) p[qt][kt] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int s = 0; s < 8; ++s)
-#pragma unroll
-                for (int qt = 0; qt < 4; ++qt)
-#pragma unroll
-                    for (int kt = 0; kt < 4; ++kt)
-                        p[qt][kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(q1[qt][s], k1[kt][s], p[qt][kt], 0, 0, 0);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        {
-            float do1[4][8], v1[4][8];
-            load_l1(a.dout, tb, srow, ldo, col, lane, 1.f, do1);
-            load_l1(a.qkv, tb, srow, ldq, 2 * C + col, lane, 1.f, v1);
-#pragma unroll
-            for (int qt = 0; qt < 4; ++qt)
-#pragma unroll
-                for (int kt = 0; kt < 4; ++kt) ds[qt][kt] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int s = 0; s < 8; ++s)
-#pragma unroll
-                for (int qt = 0; qt < 4; ++qt)
-#pragma unroll
-                    for (int kt = 0; kt < 4; ++kt)
-                        ds[qt][kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(do1[qt][s], v1[kt][s], ds[qt][kt], 0, 0, 0);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        // softmax rows (query = 16qt + 4g + i; keys = 16kt + lj across the 16 lanes of a group), dS
-        int mk[4];
-#pragma unroll
-        for (int kt = 0; kt < 4; ++kt) mk[kt] = smeta[16 * kt + lj];
-#pragma unroll
-        for (int qt = 0; qt < 4; ++qt)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int mq = smeta[16 * qt + 4 * g + i];
-                float mx = -INFINITY;
-#pragma unroll
-                for (int kt = 0; kt < 4; ++kt) {
-                    float v = -INFINITY;
-                    if (16 * kt + lj < NTOK) {
-                        v = p[qt][kt][i] + sb[(mq & 255) - (mk[kt] & 255) + BIAS_OFF];
-                        if (a.shift > 0 && (mk[kt] >> 8) != (mq >> 8)) v += -100.f;
-                    }
-                    p[qt][kt][i] = v;
-                    mx = fmaxf(mx, v);
-                }
-                mx = row16_max(mx);
-                float sum = 0.f;
-#pragma unroll
-                for (int kt = 0; kt < 4; ++kt) {
-                    const float e = expf(p[qt][kt][i] - mx);
-                    p[qt][kt][i] = e;
-                    sum += e;
-                }
-                sum = row16_sum(sum);
-                const float inv = 1.f / sum;
-                float dot = 0.f;
-#pragma unroll
-                for (int kt = 0; kt < 4; ++kt) {
-                    p[qt][kt][i] *= inv;
-                    dot += p[qt][kt][i] * ds[qt][kt][i];
-                }
-                dot = row16_sum(dot);
-#pragma unroll
-                for (int kt = 0; kt < 4; ++kt) {
-                    const float d = p[qt][kt][i] * (ds[qt][kt][i] - dot);
-                    ds[qt][kt][i] = d;
-                    if (16 * qt + 4 * g + i < NTOK && 16 * kt + lj < NTOK)
-                        opart[(16 * qt + 4 * g + i) * NTOK + 16 * kt + lj] = d;
-                    sds[(16 * qt + 4 * g + i) * DS_LD + 16 * kt + lj] = d;
-                }
-            }
-        __builtin_amdgcn_sched_barrier(0);
-        // dV[key = 16kt + 4g + i'][dim] = sum_query P[query][key] dO[query][dim]
-        {
-            float x2[4][4][2];
-            load_l2(a.dout, tb, srow, ldo, col, lane, 1.f, x2);
-            f32x4 acc[4][2];
-#pragma unroll
-            for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-                for (int nt = 0; nt < 2; ++nt) acc[kt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int qt = 0; qt < 4; ++qt)
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-                        for (int nt = 0; nt < 2; ++nt)
-                            acc[kt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(p[qt][kt][i], x2[qt][i][nt], acc[kt][nt], 0, 0, 0);
-            store_l2(a.dqkv, tb, srow, lddq, 2 * C + col, lane, 1.f, acc);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        // dK[key][dim] = sum_query dS[query][key] (scale * Q[query][dim])
-        {
-            float x2[4][4][2];
-            load_l2(a.qkv, tb, srow, ldq, col, lane, a.scale, x2);
-            f32x4 acc[4][2];
-#pragma unroll
-            for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-                for (int nt = 0; nt < 2; ++nt) acc[kt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int qt = 0; qt < 4; ++qt)
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-                        for (int nt = 0; nt < 2; ++nt)
-                            acc[kt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ds[qt][kt][i], x2[qt][i][nt], acc[kt][nt], 0, 0, 0);
-            store_l2(a.dqkv, tb, srow, lddq, C + col, lane, 1.f, acc);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        // dQ[query = 16qt + 4g + i'][dim] = scale * sum_key dS[query][key] K[key][dim]; A rows from the LDS tile
-        __builtin_amdgcn_wave_barrier();
-        {
-            f32x4 acc[4][2];
-#pragma unroll
-            for (int qt = 0; qt < 4; ++qt)
-#pragma unroll
-                for (int nt = 0; nt < 2; ++nt) acc[qt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int st = 0; st < 13; ++st) {
-                float kb[2];
-                const int r = 4 * st + g;
-                const int e = (tb + srow[r]) * ldq + C + col + lj;
-#pragma unroll
-                for (int nt = 0; nt < 2; ++nt) kb[nt] = r < NTOK ? a.qkv[e + 16 * nt] : 0.f;
-#pragma unroll
-                for (int qt = 0; qt < 4; ++qt) {
-                    const float av = sds[(16 * qt + lj) * DS_LD + 4 * st + g];
-#pragma unroll
-                    for (int nt = 0; nt < 2; ++nt)
-                        acc[qt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, kb[nt], acc[qt][nt], 0, 0, 0);
-                }
-            }
-            store_l2(a.dqkv, tb, srow, lddq, col, lane, a.scale, acc);
-        }
-        __builtin_amdgcn_wave_barrier();
-    }
-}
-
-// Bias-table gradient, stage 1: dsum[h][e] = sum over the partial blocks of part[p][h][e], e < 49*49.
-// grid = (ceil(2401/64), nH); block = 64 consecutive e (coalesced 256-byte rows) x 16 partial lanes, double
-// accumulators, fixed-order tree over the lanes.
-__global__ __launch_bounds__(1024) void attn_ds_reduce_kernel(const float* __restrict__ part, int nparts, int nH,
-                                                              float* __restrict__ dsum) {
-    __shared__ double red[1024];
-    const int el = threadIdx.x & 63, pl = threadIdx.x >> 6;
-    const int e = blockIdx.x * 64 + el, h = blockIdx.y;
-    const long long stride = (long long)nH * (NTOK * NTOK);
-    double s = 0.0;
-    if (e < NTOK * NTOK) {
-        const float* __restrict__ m = part + (long long)h * (NTOK * NTOK) + e;
-        int p = pl;
-        for (; p + 48 < nparts; p += 64) {
-            const float v0 = m[p * stride], v1 = m[(p + 16) * stride], v2 = m[(p + 32) * stride], v3 = m[(p + 48) * stride];
-            s += v0; s += v1; s += v2; s += v3;
-        }
-        for (; p < nparts; p += 16) s += m[p * stride];
-    }
-    red[threadIdx.x] = s;
-    __syncthreads();
-    if (pl == 0 && e < NTOK * NTOK) {
-#pragma unroll
-        for (int j = 1; j < 16; ++j) s += red[j * 64 + el];
-        dsum[(long long)h * (NTOK * NTOK) + e] = (float)s;
-    }
-}
-
-// stage 2: dtable[idx][h] (+)= sum of dsum[h][(i, j)] over the <= 49 pairs with relative-position index idx
-__global__ __launch_bounds__(256) void attn_dtable_kernel(const float* __restrict__ dsum, int nH,
-                                                          float* __restrict__ dtable, int accumulate) {
-    const int o = blockIdx.x * 256 + threadIdx.x;              // idx*nH + h
-    if (o >= 169 * nH) return;
-    const int idx = o / nH, h = o - idx * nH;
-    const int dy = idx / (2 * WS - 1) - (WS - 1), dx = idx % (2 * WS - 1) - (WS - 1);
-    const float* __restrict__ m = dsum + (long long)h * (NTOK * NTOK);
-    double s = 0.0;
-    for (int jy = 0; jy < WS; ++jy) {
-        const int iy = jy + dy;
-        if (iy < 0 || iy >= WS) continue;
-        for (int jx = 0; jx < WS; ++jx) {
-            const int ix = jx + dx;
-            if (ix < 0 || ix >= WS) continue;
-            s += m[(iy * WS + ix) * NTOK + jy * WS + jx];
-        }
-    }
-    dtable[o] = accumulate ? dtable[o] + (float)s : (float)s;
-}
-
-int geometry_ok(int B, int H, int W, int nH, int shift) {
-    if (B <= 0 || H <= 0 || W <= 0 || nH <= 0) return MIS_ERR_ARG;
-    if (H % WS || W % WS || shift < 0 || shift >= WS) return MIS_ERR_UNSUPPORTED;
-    return MIS_OK;
-}
-
-// samples per backward wave (its dS partial is accumulated over them): the count in 1..8 that needs the fewest
-// rounds of the 1024 resident waves (one per SIMD) times samples per round -- e.g. 48 images at 56^2: 3 (3072 waves =
-// exactly three rounds) instead of 4 (2304 waves: the third round would run a quarter full); ties go to the larger
-// count (fewer partials for the bias-gradient reduction)
-bool use_valu();
-
-int bwd_chunk(int B, int H, int W, int nH) {
-    if (!use_valu()) return 1;      // the MFMA kernel writes one dS partial per unit (see its header)
-    const long long per_sample = (long long)(H / WS) * (W / WS) * nH;
-    int best = 1;
-    long long best_cost = -1;
-    for (int c = 1; c <= 8 && c <= B; ++c) {
-        const long long waves = mis_cdiv(B, c) * per_sample;
-        const long long cost = mis_cdiv(waves, 1024) * c;
-        if (best_cost < 0 || cost <= best_cost) { best = c; best_cost = cost; }
-    }
-    return best;
-}
-
-// MIS_ATTN_VALU=1 selects the first-generation vector-pipe kernels (kept for A/B measurements)
-bool use_valu() {
-    static const bool v = getenv("MIS_ATTN_VALU") != nullptr;
-    return v;
-}
+// window 8 (64 tokens: no padded rows): the reference's IMG_SIZE 256 / WINDOW_SIZE 8 configuration
+// (code/config.py:194-195), which lets SwinUnet run the 256 x 256 inputs of BASELINE config 5
+#define MIS_ATTN_WS 8
+#define MIS_ATTN_NS ws8
+#include "attention_impl.inc"
+#undef MIS_ATTN_WS
+#undef MIS_ATTN_NS
 
 }  // namespace
 
-// head_dim is fixed to 32 and the window to 7x7 (SwinUnet tiny: heads 3/6/12/24 at C = 96..768)
+// head_dim is fixed to 32; window 7 (SwinUnet tiny: heads 3/6/12/24 at C = 96..768) or 8
+extern "C" int mis_window_attention_fwd_ws(const float* qkv, long long ldq, float* out, long long ldo,
+                                           const float* bias_table, int B, int H, int W, int nH, int shift, float scale,
+                                           int window, hipStream_t stream) {
+    if (window == 7) return ws7::window_attention_fwd(qkv, ldq, out, ldo, bias_table, B, H, W, nH, shift, scale, stream);
+    if (window == 8) return ws8::window_attention_fwd(qkv, ldq, out, ldo, bias_table, B, H, W, nH, shift, scale, stream);
+    return MIS_ERR_UNSUPPORTED;
+}
+
+extern "C" long long mis_window_attention_workspace_bytes_ws(int B, int H, int W, int nH, int window) {
+    if (window == 7) return ws7::window_attention_workspace_bytes(B, H, W, nH);
+    if (window == 8) return ws8::window_attention_workspace_bytes(B, H, W, nH);
+    return MIS_ERR_UNSUPPORTED;
+}
+
+extern "C" int mis_window_attention_bwd_ws(const float* qkv, long long ldq, const float* dout, long long ldo,
+                                           float* dqkv, long long lddq, const float* bias_table, float* dbias_table,
+                                           int accumulate_table, int B, int H, int W, int nH, int shift, float scale,
+                                           int window, void* workspace, long long workspace_bytes, hipStream_t stream) {
+    if (window == 7)
+        return ws7::window_attention_bwd(qkv, ldq, dout, ldo, dqkv, lddq, bias_table, dbias_table, accumulate_table, B, H,
+                                         W, nH, shift, scale, workspace, workspace_bytes, stream);
+    if (window == 8)
+        return ws8::window_attention_bwd(qkv, ldq, dout, ldo, dqkv, lddq, bias_table, dbias_table, accumulate_table, B, H,
+                                         W, nH, shift, scale, workspace, workspace_bytes, stream);
+    return MIS_ERR_UNSUPPORTED;
+}
+
+// the window-7 entry points of ABI version 1
 extern "C" int mis_window_attention_fwd(const float* qkv, long long ldq, float* out, long long ldo,
                                         const float* bias_table, int B, int H, int W, int nH, int shift, float scale,
                                         hipStream_t stream) {
-    int st = geometry_ok(B, H, W, nH, shift);
-    if (st) return st;
-    if (!qkv || !out || !bias_table) return MIS_ERR_ARG;
-    if (ldq % 4 || ldo % 4 || ((uintptr_t)qkv & 15) || ((uintptr_t)out & 15)) return MIS_ERR_UNSUPPORTED;
-    AttnArgs a{qkv, ldq, out, ldo, bias_table, B, H, W, nH, shift, scale};
-    const long long units = (long long)B * (H / WS) * (W / WS) * nH;
-    // the MFMA kernels index with 32-bit element offsets
-    const bool small = (long long)B * H * W * (ldq > ldo ? ldq : ldo) * 4 < (1LL << 31);
-    if (use_valu() || !small)
-        hipLaunchKernelGGL(attn_fwd_kernel, dim3((unsigned)mis_cdiv(units, 4)), dim3(256), 0, stream, a, units);
-    else
-        hipLaunchKernelGGL(attn_fwd_mfma_kernel, dim3((unsigned)mis_cdiv(units, 4)), dim3(256), 0, stream, a, units);
-    return mis_launch_status();
+    return mis_window_attention_fwd_ws(qkv, ldq, out, ldo, bias_table, B, H, W, nH, shift, scale, 7, stream);
 }
 
 extern "C" long long mis_window_attention_workspace_bytes(int B, int H, int W, int nH) {
-    if (B <= 0 || H <= 0 || W <= 0 || nH <= 0 || H % WS || W % WS) return MIS_ERR_ARG;
-    // dS partials [chunks * windows][nH][49*49] + their sum over the partials [nH][49*49]
-    return (mis_cdiv(B, bwd_chunk(B, H, W, nH)) * (H / WS) * (W / WS) + 1) * nH * (long long)(NTOK * NTOK) * 4;
+    return mis_window_attention_workspace_bytes_ws(B, H, W, nH, 7);
 }
 
 extern "C" int mis_window_attention_bwd(const float* qkv, long long ldq, const float* dout, long long ldo,
                                         float* dqkv, long long lddq, const float* bias_table, float* dbias_table,
                                         int accumulate_table, int B, int H, int W, int nH, int shift, float scale,
                                         void* workspace, long long workspace_bytes, hipStream_t stream) {
-    int st = geometry_ok(B, H, W, nH, shift);
-    if (st) return st;
-    if (!qkv || !dout || !dqkv || !bias_table || !dbias_table || !workspace) return MIS_ERR_ARG;
-    if (ldq % 4 || ldo % 4 || lddq % 4) return MIS_ERR_UNSUPPORTED;
-    if (workspace_bytes < mis_window_attention_workspace_bytes(B, H, W, nH)) return MIS_ERR_WORKSPACE;
-    AttnBwdArgs a{qkv, ldq, dout, ldo, dqkv, lddq, bias_table, reinterpret_cast<float*>(workspace),
-                  B, H, W, nH, shift, bwd_chunk(B, H, W, nH), scale};
-    const int chunks = (int)mis_cdiv(B, a.chunk);
-    const int nW = (H / WS) * (W / WS);
-    long long ldmax = ldq > ldo ? ldq : ldo;
-    if (lddq > ldmax) ldmax = lddq;
-    const bool small = (long long)B * H * W * ldmax * 4 < (1LL << 31);
-    if (use_valu() || !small)
-        hipLaunchKernelGGL(attn_bwd_kernel, dim3(chunks * nW * nH), dim3(64), 0, stream, a);
-    else
-        hipLaunchKernelGGL(attn_bwd_mfma_kernel, dim3(chunks * nW * nH), dim3(64), 0, stream, a);
-    float* dsum = a.dS_part + (long long)chunks * nW * nH * (NTOK * NTOK);
-    hipLaunchKernelGGL(attn_ds_reduce_kernel, dim3((NTOK * NTOK + 63) / 64, nH), dim3(1024), 0, stream, a.dS_part,
-                       chunks * nW, nH, dsum);
-    hipLaunchKernelGGL(attn_dtable_kernel, dim3((169 * nH + 255) / 256), dim3(256), 0, stream, dsum, nH, dbias_table,
-                       accumulate_table);
-    return mis_launch_status();
+    return mis_window_attention_bwd_ws(qkv, ldq, dout, ldo, dqkv, lddq, bias_table, dbias_table, accumulate_table, B, H, W,
+                                       nH, shift, scale, 7, workspace, workspace_bytes, stream);
 }

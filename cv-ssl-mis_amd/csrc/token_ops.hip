@@ -447,10 +447,11 @@ __global__ __launch_bounds__(256) void rearrange_kernel(const RearrArgs a) {
     }
 }
 
-// PatchEmbed im2col with the 1->3 channel repeat: out[b*Hp*Wp + ph*Wp + pw][c*16 + ky*4 + kx] = x[b][0][4ph+ky][4pw+kx]
+// PatchEmbed im2col: out[b*Hp*Wp + ph*Wp + pw][c*16 + ky*4 + kx] = x[b][c][4ph+ky][4pw+kx]; src_chans == 1: the
+// single input channel feeds every c (the 1 -> 3 channel repeat of vision_transformer.py:49-50)
 __global__ __launch_bounds__(256) void patch_im2col_kernel(const float* __restrict__ x, long long x_bs,
                                                            float* __restrict__ out, int B, int H, int W,
-                                                           int in_chans) {
+                                                           int in_chans, int src_chans) {
     const int Hp = H >> 2, Wp = W >> 2;
     const long long total = (long long)B * Hp * Wp * 4;   // one thread per (patch, ky): 4 floats
     for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
@@ -459,9 +460,13 @@ __global__ __launch_bounds__(256) void patch_im2col_kernel(const float* __restri
         const int pw = (int)(t % Wp); t /= Wp;
         const int ph = (int)(t % Hp);
         const int b = (int)(t / Hp);
-        const float4 v = *reinterpret_cast<const float4*>(x + (long long)b * x_bs + (long long)(4 * ph + ky) * W + 4 * pw);
+        const float* __restrict__ px = x + (long long)b * x_bs + (long long)(4 * ph + ky) * W + 4 * pw;
+        float4 v = *reinterpret_cast<const float4*>(px);
         float* o = out + (((long long)b * Hp + ph) * Wp + pw) * (in_chans * 16) + ky * 4;
-        for (int c = 0; c < in_chans; ++c) *reinterpret_cast<float4*>(o + c * 16) = v;
+        for (int c = 0; c < in_chans; ++c) {
+            if (src_chans > 1 && c > 0) v = *reinterpret_cast<const float4*>(px + (long long)c * H * W);
+            *reinterpret_cast<float4*>(o + c * 16) = v;
+        }
     }
 }
 
@@ -720,13 +725,20 @@ extern "C" int mis_token_rearrange(const float* src, long long lds, float* dst, 
     return mis_launch_status();
 }
 
+extern "C" int mis_patch_im2col_c(const float* x, long long x_bs, float* out, int B, int H, int W, int in_chans,
+                                  int src_chans, hipStream_t stream) {
+    if (!x || !out || B <= 0 || H <= 0 || W <= 0 || in_chans <= 0) return MIS_ERR_ARG;
+    if (src_chans != 1 && src_chans != in_chans) return MIS_ERR_ARG;
+    if ((H | W) & 3 || x_bs % 4 || !a16(x) || !a16(out)) return MIS_ERR_UNSUPPORTED;
+    if (x_bs < (long long)src_chans * H * W) return MIS_ERR_ARG;
+    hipLaunchKernelGGL(patch_im2col_kernel, dim3(sgrid((long long)B * (H / 4) * (W / 4) * 4)), dim3(256), 0, stream, x,
+                       x_bs, out, B, H, W, in_chans, src_chans);
+    return mis_launch_status();
+}
+
 extern "C" int mis_patch_im2col(const float* x, long long x_bs, float* out, int B, int H, int W, int in_chans,
                                 hipStream_t stream) {
-    if (!x || !out || B <= 0 || H <= 0 || W <= 0 || in_chans <= 0) return MIS_ERR_ARG;
-    if ((H | W) & 3 || x_bs % 4 || !a16(x) || !a16(out)) return MIS_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(patch_im2col_kernel, dim3(sgrid((long long)B * (H / 4) * (W / 4) * 4)), dim3(256), 0, stream, x,
-                       x_bs, out, B, H, W, in_chans);
-    return mis_launch_status();
+    return mis_patch_im2col_c(x, x_bs, out, B, H, W, in_chans, 1, stream);
 }
 
 extern "C" int mis_head_fwd(const float* x, long long ldx, const float* w, float* logits, long long y_bs, int B,

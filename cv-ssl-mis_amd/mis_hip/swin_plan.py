@@ -116,18 +116,19 @@ class GeluOp:
 
 
 class AttnOp:
-    def __init__(self, qkv, out, table, B, H, W, nH, shift):
+    def __init__(self, qkv, out, table, B, H, W, nH, shift, window=7):
         self.qkv, self.out, self.table = qkv, out, table
         self.geo = (B, H, W, nH, shift)
         self.scale = 32 ** -0.5
+        self.window = window
 
     def fwd(self, ctx):
-        tops.window_attention_fwd(self.qkv.t, self.out.t, self.table.data, *self.geo, self.scale)
+        tops.window_attention_fwd(self.qkv.t, self.out.t, self.table.data, *self.geo, self.scale, window=self.window)
 
     def bwd(self, ctx):
         assert not self.qkv.written
         tops.window_attention_bwd(self.qkv.t, self.out.grad(), self.qkv.grad(), self.table.data, self.table.grad,
-                                  *self.geo, self.scale)
+                                  *self.geo, self.scale, window=self.window)
         self.qkv.mark_written()
 
 
@@ -252,7 +253,7 @@ class SwinPlan:
     def forward(self, x5, ctx):
         assert tuple(x5.shape) == self.in_shape, (tuple(x5.shape), self.in_shape)
         self.generation += 1
-        self.inp_t = x5[:, :, 0]             # [N, 1, H, W]
+        self.inp_t = x5[:, :, 0]             # [N, 1 | 3, H, W]
         for op in self.ops:
             op.fwd(ctx)
         return self.out.t

@@ -146,12 +146,12 @@ def token_rearrange(src, dst, B, H, W, C, P, mode, inverse=False):
 
 
 def patch_im2col(x4, out, in_chans):
-    """x4 [B,1,H,W] (dense H,W) -> out [B*H/4*W/4, in_chans*16]."""
+    """x4 [B,1|in_chans,H,W] (dense C,H,W) -> out [B*H/4*W/4, in_chans*16]; a single channel is repeated."""
     L = _l.load()
-    B, _, H, W = x4.shape
-    assert x4.stride(3) == 1 and x4.stride(2) == W
-    _l.check(L.mis_patch_im2col(_l.ptr(x4), x4.stride(0), _l.ptr(out), B, H, W, in_chans, _l.stream_ptr()),
-             "mis_patch_im2col")
+    B, Cs, H, W = x4.shape
+    assert x4.stride(3) == 1 and x4.stride(2) == W and (Cs == 1 or x4.stride(1) == H * W)
+    _l.check(L.mis_patch_im2col_c(_l.ptr(x4), x4.stride(0), _l.ptr(out), B, H, W, in_chans, Cs, _l.stream_ptr()),
+             "mis_patch_im2col_c")
 
 
 def head_fwd(x, w, logits5):
@@ -176,20 +176,23 @@ def head_bwd(x, w, dlogits5, dx, dw, accumulate_dw=False):
              "mis_head_bwd")
 
 
-def window_attention_fwd(qkv, out, table, B, H, W, nH, shift, scale):
+def window_attention_fwd(qkv, out, table, B, H, W, nH, shift, scale, window=7):
     L = _l.load()
     _, _, ldq = _mat(qkv)
     _, _, ldo = _mat(out)
-    _l.check(L.mis_window_attention_fwd(_l.ptr(qkv), ldq, _l.ptr(out), ldo, _l.ptr(table), B, H, W, nH, shift,
-                                        scale, _l.stream_ptr()), "mis_window_attention_fwd")
+    _l.check(L.mis_window_attention_fwd_ws(_l.ptr(qkv), ldq, _l.ptr(out), ldo, _l.ptr(table), B, H, W, nH, shift,
+                                           scale, window, _l.stream_ptr()), "mis_window_attention_fwd_ws")
 
 
-def window_attention_bwd(qkv, dout, dqkv, table, dtable, B, H, W, nH, shift, scale, accumulate_table=False):
+def window_attention_bwd(qkv, dout, dqkv, table, dtable, B, H, W, nH, shift, scale, accumulate_table=False, window=7):
     L = _l.load()
     _, _, ldq = _mat(qkv)
     _, _, ldo = _mat(dout)
     _, _, lddq = _mat(dqkv)
-    ws = scratch(L.mis_window_attention_workspace_bytes(B, H, W, nH), "attn")
-    _l.check(L.mis_window_attention_bwd(_l.ptr(qkv), ldq, _l.ptr(dout), ldo, _l.ptr(dqkv), lddq, _l.ptr(table),
-                                        _l.ptr(dtable), int(accumulate_table), B, H, W, nH, shift, scale,
-                                        _l.ptr(ws), ws.numel(), _l.stream_ptr()), "mis_window_attention_bwd")
+    nb = L.mis_window_attention_workspace_bytes_ws(B, H, W, nH, window)
+    if nb < 0:
+        _l.check(nb, "mis_window_attention_workspace_bytes_ws")
+    ws = scratch(nb, "attn")
+    _l.check(L.mis_window_attention_bwd_ws(_l.ptr(qkv), ldq, _l.ptr(dout), ldo, _l.ptr(dqkv), lddq, _l.ptr(table),
+                                           _l.ptr(dtable), int(accumulate_table), B, H, W, nH, shift, scale, window,
+                                           _l.ptr(ws), ws.numel(), _l.stream_ptr()), "mis_window_attention_bwd_ws")

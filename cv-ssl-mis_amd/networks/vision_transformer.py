@@ -9,7 +9,10 @@ buffers) so checkpoints interchange.
 Architecture as instantiated by the reference yaml (swin_tiny_patch4_window7_224_lite.yaml): embed 96,
 depths [2,2,2,2] for encoder AND decoder (``DECODER_DEPTHS`` is never read), heads [3,6,12,24], window 7,
 mlp x4, qkv bias, drop_path linspace(0, 0.2, 8), patch-expand decoder, 1x1 output conv without bias.
-Single-channel inputs are repeated to 3 channels (vision_transformer.py:49-50) inside the im2col kernel.
+Single-channel inputs are repeated to 3 channels (vision_transformer.py:49-50) inside the im2col kernel; 3-channel
+inputs are taken as they are (the other branch of :48-50).  ``MODEL.SWIN.WINDOW_SIZE`` 7 (``DATA.IMG_SIZE`` a
+multiple of 224) or 8 (a multiple of 256: ``--opts DATA.IMG_SIZE 256 MODEL.SWIN.WINDOW_SIZE 8``, config.py:194-195 --
+the way the reference runs SwinUnet on the 256 x 256 inputs of the cross-teaching configuration).
 """
 import math
 import re
@@ -19,16 +22,13 @@ import torch
 from mis_hip.plan import HipNet
 from mis_hip import swin_plan as sp
 
-WS = 7
-
-
 def _trunc_normal(*shape, std=0.02):
     t = torch.empty(*shape)
     torch.nn.init.trunc_normal_(t, std=std)
     return t
 
 
-def _rel_pos_index():
+def _rel_pos_index(WS):
     coords = torch.stack(torch.meshgrid([torch.arange(WS), torch.arange(WS)], indexing="ij")).flatten(1)
     rel = (coords[:, :, None] - coords[:, None, :]).permute(1, 2, 0).contiguous()
     rel[:, :, 0] += WS - 1
@@ -37,7 +37,7 @@ def _rel_pos_index():
     return rel.sum(-1)
 
 
-def _attn_mask(H, W, shift):
+def _attn_mask(H, W, shift, WS):
     """The reference's attn_mask buffer (swin...sys.py:216-238); kept for state_dict parity only --
     the attention kernel derives the mask from the token coordinates."""
     img = torch.zeros((1, H, W, 1))
@@ -61,13 +61,15 @@ class SwinUnet(HipNet):
         self.img = config.DATA.IMG_SIZE       # the reference ignores the img_size argument too (:31)
         self.embed, self.depths, self.heads = sw.EMBED_DIM, list(sw.DEPTHS), list(sw.NUM_HEADS)
         self.in_chans, self.mlp_ratio = sw.IN_CHANS, sw.MLP_RATIO
-        if sw.PATCH_SIZE != 4 or sw.WINDOW_SIZE != WS or sw.APE or not sw.PATCH_NORM or not sw.QKV_BIAS or \
+        self.ws = WS = int(sw.WINDOW_SIZE)
+        if sw.PATCH_SIZE != 4 or WS not in (7, 8) or sw.APE or not sw.PATCH_NORM or not sw.QKV_BIAS or \
                 sw.QK_SCALE is not None or config.MODEL.DROP_RATE != 0.0 or self.embed // self.heads[0] != 32:
-            raise NotImplementedError("HIP SwinUnet covers the configuration the reference yaml instantiates "
-                                      "(patch 4, window 7, head_dim 32, no APE, patch norm, drop_rate 0)")
+            raise NotImplementedError("HIP SwinUnet covers the configurations the reference instantiates "
+                                      "(patch 4, window 7 or 8, head_dim 32, no APE, patch norm, drop_rate 0)")
         if self.img % (4 * WS * 2 ** (len(self.depths) - 1)):
             # same failure point as the reference: window_partition cannot view e.g. 256 with window 7
-            raise RuntimeError(f"img_size {self.img} is not divisible by patch*window*2^stages (use 224)")
+            raise RuntimeError(f"img_size {self.img} is not divisible by patch*window*2^stages "
+                               f"(224 with window 7, 256 with window 8)")
         self.dpr = [x.item() for x in torch.linspace(0, config.MODEL.DROP_PATH_RATE, sum(self.depths))]
         self._declare_all()
         self._materialize()
@@ -83,11 +85,12 @@ class SwinUnet(HipNet):
         self._declare(name + ".bias", torch.zeros(C))
 
     def _declare_block(self, p, dim, res, heads, shift):
+        WS = self.ws
         if shift > 0:
-            self._declare(p + ".attn_mask", _attn_mask(res, res, shift), "buffer")
+            self._declare(p + ".attn_mask", _attn_mask(res, res, shift, WS), "buffer")
         self._declare_ln(p + ".norm1", dim)
         self._declare(p + ".attn.relative_position_bias_table", _trunc_normal((2 * WS - 1) ** 2, heads))
-        self._declare(p + ".attn.relative_position_index", _rel_pos_index(), "buffer")
+        self._declare(p + ".attn.relative_position_index", _rel_pos_index(WS), "buffer")
         self._declare_linear(p + ".attn.qkv", 3 * dim, dim)
         self._declare_linear(p + ".attn.proj", dim, dim)
         self._declare_ln(p + ".norm2", dim)
@@ -95,7 +98,7 @@ class SwinUnet(HipNet):
         self._declare_linear(p + ".mlp.fc2", dim, int(dim * self.mlp_ratio))
 
     def _shift(self, res, blk):
-        return 0 if (blk % 2 == 0 or res <= WS) else WS // 2
+        return 0 if (blk % 2 == 0 or res <= self.ws) else self.ws // 2
 
     def _declare_all(self):
         E, nl = self.embed, len(self.depths)
@@ -193,7 +196,8 @@ class SwinUnet(HipNet):
         qkv = plan.new(rows, 3 * dim)
         plan.add(sp.LinearOp(n1, qkv, P(p + ".attn.qkv.weight"), P(p + ".attn.qkv.bias")))
         att = plan.new(rows, dim)
-        plan.add(sp.AttnOp(qkv, att, P(p + ".attn.relative_position_bias_table"), B, res, res, heads, shift))
+        plan.add(sp.AttnOp(qkv, att, P(p + ".attn.relative_position_bias_table"), B, res, res, heads, shift,
+                           window=self.ws))
         pr = plan.new(rows, dim)
         plan.add(sp.LinearOp(att, pr, P(p + ".attn.proj.weight"), P(p + ".attn.proj.bias")))
         x1 = plan.new(rows, dim)
@@ -228,9 +232,9 @@ class SwinUnet(HipNet):
         # the reference asserts this in PatchEmbed.forward (swin...sys.py:583-584)
         assert D == 1 and H == self.img and W == self.img, \
             f"Input image size ({H}*{W}) doesn't match model ({self.img}*{self.img})."
-        if C != 1:
-            raise RuntimeError(f"single-channel input expected (the 1 -> 3 repeat of vision_transformer.py:49-50 is "
-                               f"folded into the patch embedding), got {C} channels")
+        if C != 1 and C != self.in_chans:
+            raise RuntimeError(f"input must have 1 channel (repeated to {self.in_chans} inside the patch embedding, "
+                               f"vision_transformer.py:49-50) or {self.in_chans}; got {C}")
         E, nl, B = self.embed, len(self.depths), N
         pr = self.img // 4
         Pn = self.P

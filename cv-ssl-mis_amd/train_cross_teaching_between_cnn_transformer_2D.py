@@ -3,7 +3,8 @@
 Command-line drop-in for the reference's code/train_cross_teaching_between_cnn_transformer_2D.py (same flags and
 defaults, :46-105: ``--exp ACDC/Cross_Teaching_Between_CNN_Transformer --batch_size 16 --labeled_bs 8``):
 model1 = ``net_factory(args.model)`` (UNet), model2 = ``ViT_seg(config, ...)`` + ``load_from`` (:169-172), both at
-``--patch_size`` 224x224.  The loop body (:216-263) runs as the fused HIP cross-teaching step; under ``torchrun``
+``--patch_size`` 224x224 -- or at 256x256 with ``--patch_size 256 256 --opts DATA.IMG_SIZE 256 MODEL.SWIN.WINDOW_SIZE 8``
+(the reference's own override mechanism, config.py:194-195; BASELINE config 5's literal image size).  The loop body (:216-263) runs as the fused HIP cross-teaching step; under ``torchrun``
 each rank owns its 16+16 shard and the only exchange is one RCCL all-reduce per model's flat gradient bucket.
 """
 import os
@@ -23,8 +24,9 @@ def main(argv=None):
     if config.MODEL.PRETRAIN_CKPT is not None and not os.path.exists(config.MODEL.PRETRAIN_CKPT):
         config.MODEL.PRETRAIN_CKPT = None
     if list(args.patch_size) != [config.DATA.IMG_SIZE] * 2:
-        raise SystemExit(f"--patch_size {args.patch_size} != DATA.IMG_SIZE {config.DATA.IMG_SIZE}: the reference runs "
-                         "both networks at 224 (SwinUnet with window 7 cannot run 256)")
+        raise SystemExit(f"--patch_size {args.patch_size} != DATA.IMG_SIZE {config.DATA.IMG_SIZE}: both networks run at "
+                         "the SwinUnet's image size (224 with window 7; 256 needs --opts DATA.IMG_SIZE 256 "
+                         "MODEL.SWIN.WINDOW_SIZE 8)")
 
     def make_model1():
         return net_factory(net_type=args.model, in_chns=1, class_num=args.num_classes)

@@ -297,6 +297,10 @@ int mis_token_rearrange(const float* src, long long lds, float* dst, long long l
  * repeat of vision_transformer.py:49-50 folded in (:573-588) */
 int mis_patch_im2col(const float* x, long long x_bs, float* out, int B, int H, int W, int in_chans,
                      mis_stream_t stream);
+/* same with an explicit source channel count: src_chans == in_chans reads x[b][c] (3-channel inputs, the other branch
+ * of vision_transformer.py:48-50), src_chans == 1 repeats the single channel */
+int mis_patch_im2col_c(const float* x, long long x_bs, float* out, int B, int H, int W, int in_chans, int src_chans,
+                       mis_stream_t stream);
 /* up_x4 tail (:775-786): token-major [B*S][K] -> NCHW logits[B][NC][S] through the bias-free 1x1 conv */
 int mis_head_fwd(const float* x, long long ldx, const float* w, float* logits, long long y_bs, int B, long long S,
                  int K, int NC, mis_stream_t stream);
@@ -314,6 +318,16 @@ int mis_window_attention_bwd(const float* qkv, long long ldq, const float* dout,
                              long long lddq, const float* bias_table, float* dbias_table, int accumulate_table,
                              int B, int H, int W, int nH, int shift, float scale, void* workspace,
                              long long workspace_bytes, mis_stream_t stream);
+/* the same three with the window size as an argument: window 7 (bias_table [169][nH], shift in {0,3}) or window 8
+ * (bias_table [225][nH], shift in {0,4}) -- MODEL.SWIN.WINDOW_SIZE = 8 with DATA.IMG_SIZE = 256 is how the
+ * reference runs SwinUnet on 256 x 256 inputs (code/config.py:194-195, swin_transformer_unet_...sys.py:198-201) */
+int mis_window_attention_fwd_ws(const float* qkv, long long ldq, float* out, long long ldo, const float* bias_table,
+                                int B, int H, int W, int nH, int shift, float scale, int window, mis_stream_t stream);
+long long mis_window_attention_workspace_bytes_ws(int B, int H, int W, int nH, int window);
+int mis_window_attention_bwd_ws(const float* qkv, long long ldq, const float* dout, long long ldo, float* dqkv,
+                                long long lddq, const float* bias_table, float* dbias_table, int accumulate_table,
+                                int B, int H, int W, int nH, int shift, float scale, int window, void* workspace,
+                                long long workspace_bytes, mis_stream_t stream);
 
 /* ---- input pipeline on the device (SURVEY s.8 row n4): the training set is resident in HBM as one float pool
  * (images) and one byte pool (labels); a batch is one gather launch that applies the reference's per-sample

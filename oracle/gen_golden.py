@@ -103,17 +103,19 @@ def build_reference(kind, in_chns, num_classes):
     if kind == "unet2d":
         from networks.unet import UNet
         return UNet(in_chns=in_chns, class_num=num_classes)
-    if kind == "swin":
+    if kind in ("swin", "swin_w8"):
         _install_timm_shim()
         from types import SimpleNamespace as NS
         from networks.vision_transformer import SwinUnet
-        cfg = NS(DATA=NS(IMG_SIZE=224),
+        # "swin_w8": DATA.IMG_SIZE 256 + MODEL.SWIN.WINDOW_SIZE 8 (the --opts overrides of code/config.py:194-195)
+        img, win = (256, 8) if kind == "swin_w8" else (224, 7)
+        cfg = NS(DATA=NS(IMG_SIZE=img),
                  MODEL=NS(DROP_RATE=0.0, DROP_PATH_RATE=0.2, PRETRAIN_CKPT=None,
                           SWIN=NS(PATCH_SIZE=4, IN_CHANS=3, EMBED_DIM=96, DEPTHS=[2, 2, 2, 2], NUM_HEADS=[3, 6, 12, 24],
-                                  WINDOW_SIZE=7, MLP_RATIO=4., QKV_BIAS=True, QK_SCALE=None, APE=False,
+                                  WINDOW_SIZE=win, MLP_RATIO=4., QKV_BIAS=True, QK_SCALE=None, APE=False,
                                   PATCH_NORM=True)),
                  TRAIN=NS(USE_CHECKPOINT=False))
-        return SwinUnet(cfg, img_size=224, num_classes=num_classes)
+        return SwinUnet(cfg, img_size=img, num_classes=num_classes)
     if kind.startswith("vnet"):       # "vnet" = batchnorm (the factory's), "vnet_groupnorm", "vnet_instancenorm", ...
         from networks.vnet import VNet
         norm = kind.split("_", 1)[1] if "_" in kind else "batchnorm"
@@ -137,7 +139,7 @@ class SeqMask(torch.nn.Module):
 
 def set_reference_dropout(model, kind, drop, sites):
     """drop == 'off': p := 0; dict: inject masks in forward-site order."""
-    if kind == "swin":
+    if kind in ("swin", "swin_w8"):
         for bi, blk in enumerate(_swin_blocks(model)):
             if drop == "off" or (2 * bi) not in drop:
                 blk.drop_path = torch.nn.Identity()
@@ -224,10 +226,10 @@ def rel_close(a, b, tol, what):
 def make_inputs(kind, cfg):
     B = cfg["batch_size"]
     sp = tuple(cfg["spatial"])
-    volume = filler.image((B, 1) + sp, "volume")
-    ldt = torch.uint8 if kind in ("unet2d", "swin") else torch.int64
+    volume = filler.image((B, cfg.get("in_channels", 1)) + sp, "volume")
+    ldt = torch.uint8 if kind in ("unet2d", "swin", "swin_w8") else torch.int64
     label = filler.labels((B,) + sp, cfg["num_classes"], ldt)
-    noise = filler.noise((B - cfg["labeled_bs"], 1) + sp, "noise")
+    noise = filler.noise((B - cfg["labeled_bs"], cfg.get("in_channels", 1)) + sp, "noise")
     return volume, label, noise
 
 
@@ -237,6 +239,9 @@ def run_case(name, kind, cfg, iters, drop_mode, eval_logits=False):
     if kind == "swin":
         from oracle.swin import OracleSwinUnet
         onet = OracleSwinUnet(C)
+    elif kind == "swin_w8":
+        from oracle.swin import OracleSwinUnet
+        onet = OracleSwinUnet(C, img_size=256, window=8)
     elif kind.startswith("vnet"):
         from oracle.nets import OracleVNet
         onet = OracleVNet(C, 1, normalization=kind.split("_", 1)[1] if "_" in kind else "batchnorm")
@@ -850,6 +855,11 @@ def main():
         ("swin_224_dropoff", "swin", dict(CFG2D, batch_size=2, labeled_bs=1, spatial=[224, 224]), [1000], "off", True),
         ("swin_224_masks", "swin", dict(CFG2D, batch_size=2, labeled_bs=1, spatial=[224, 224]), [1200], "masks",
          False),
+        # SwinUnet input variants: 3-channel input (vision_transformer.py:48-50 passes it through un-repeated) and
+        # the IMG_SIZE 256 / WINDOW_SIZE 8 configuration (config.py:194-195) that runs BASELINE config 5's 256 x 256
+        ("swin_224_rgb", "swin", dict(CFG2D, batch_size=2, labeled_bs=1, spatial=[224, 224], in_channels=3), [1200],
+         "off", False),
+        ("swin_256_w8", "swin_w8", dict(CFG2D, batch_size=2, labeled_bs=1, spatial=[256, 256]), [1200], "off", True),
     ]
     for name, kind, cfg, iters, mode, ev in cases:
         if not only or name in only:

@@ -13,10 +13,7 @@ import torch
 import torch.nn.functional as F
 from einops import rearrange
 
-WS = 7
-
-
-def _rel_pos_index():
+def _rel_pos_index(WS):
     coords = torch.stack(torch.meshgrid([torch.arange(WS), torch.arange(WS)], indexing="ij")).flatten(1)
     rel = (coords[:, :, None] - coords[:, None, :]).permute(1, 2, 0).contiguous()
     rel[:, :, 0] += WS - 1
@@ -25,44 +22,47 @@ def _rel_pos_index():
     return rel.sum(-1)
 
 
-def _window_partition(x):                                   # swin...sys.py:28-41
+def _window_partition(x, WS):                                   # swin...sys.py:28-41
     B, H, W, C = x.shape
     x = x.view(B, H // WS, WS, W // WS, WS, C)
     return x.permute(0, 1, 3, 2, 4, 5).contiguous().view(-1, WS, WS, C)
 
 
-def _window_reverse(windows, H, W):                         # :44-60
+def _window_reverse(windows, H, W, WS):                         # :44-60
     B = int(windows.shape[0] / (H * W / WS / WS))
     x = windows.view(B, H // WS, W // WS, WS, WS, -1)
     return x.permute(0, 1, 3, 2, 4, 5).contiguous().view(B, H, W, -1)
 
 
-def _attn_mask(H, W, shift):                                # :216-238
+def _attn_mask(H, W, shift, WS):                                # :216-238
     img = torch.zeros((1, H, W, 1))
     cnt = 0
     for hs in (slice(0, -WS), slice(-WS, -shift), slice(-shift, None)):
         for ws_ in (slice(0, -WS), slice(-WS, -shift), slice(-shift, None)):
             img[:, hs, ws_, :] = cnt
             cnt += 1
-    mw = _window_partition(img).view(-1, WS * WS)
+    mw = _window_partition(img, WS).view(-1, WS * WS)
     am = mw.unsqueeze(1) - mw.unsqueeze(2)
     return am.masked_fill(am != 0, float(-100.0)).masked_fill(am == 0, float(0.0))
 
 
 class OracleSwinUnet:
     def __init__(self, num_classes=4, img_size=224, embed_dim=96, depths=(2, 2, 2, 2), num_heads=(3, 6, 12, 24),
-                 in_chans=3, mlp_ratio=4.0, drop_path_rate=0.2):
+                 in_chans=3, mlp_ratio=4.0, drop_path_rate=0.2, window=7):
+        # window 7 / img 224 (the reference yaml) or window 8 / img 256 (config.py:194-195 overrides)
+        assert img_size % (32 * window) == 0
+        self.ws = window
         self.nc, self.img, self.E = num_classes, img_size, embed_dim
         self.depths, self.heads, self.in_chans, self.mlp = list(depths), list(num_heads), in_chans, mlp_ratio
         self.dpr = [x.item() for x in torch.linspace(0, drop_path_rate, sum(depths))]
         self.pr = img_size // 4
 
     def _shift(self, res, b):
-        return 0 if (b % 2 == 0 or res <= WS) else WS // 2
+        return 0 if (b % 2 == 0 or res <= self.ws) else self.ws // 2
 
     # ---- state ----
     def spec(self):
-        E, nl, keys = self.E, len(self.depths), []
+        E, nl, keys, WS = self.E, len(self.depths), [], self.ws
 
         def lin(n, o, i, bias=True):
             keys.append((n + ".weight", (o, i), "p"))
@@ -75,10 +75,10 @@ class OracleSwinUnet:
 
         def block(p, dim, res, heads, shift):
             if shift > 0:
-                keys.append((p + ".attn_mask", ((res // WS) ** 2, 49, 49), "mask"))
+                keys.append((p + ".attn_mask", ((res // WS) ** 2, WS * WS, WS * WS), "mask"))
             ln(p + ".norm1", dim)
-            keys.append((p + ".attn.relative_position_bias_table", (169, heads), "p"))
-            keys.append((p + ".attn.relative_position_index", (49, 49), "index"))
+            keys.append((p + ".attn.relative_position_bias_table", ((2 * WS - 1) ** 2, heads), "p"))
+            keys.append((p + ".attn.relative_position_index", (WS * WS, WS * WS), "index"))
             lin(p + ".attn.qkv", 3 * dim, dim)
             lin(p + ".attn.proj", dim, dim)
             ln(p + ".norm2", dim)
@@ -119,12 +119,13 @@ class OracleSwinUnet:
 
     def new_state(self):
         sd = OrderedDict()
+        WS = self.ws
         for name, shape, kind in self.spec():
             if kind == "index":
-                sd[name] = _rel_pos_index()
+                sd[name] = _rel_pos_index(WS)
             elif kind == "mask":
                 res = int(round((shape[0]) ** 0.5)) * WS
-                sd[name] = _attn_mask(res, res, WS // 2)
+                sd[name] = _attn_mask(res, res, WS // 2, WS)
             else:
                 sd[name] = torch.ones(shape) if (name.endswith("norm.weight") or ".norm1.weight" in name or
                                                  ".norm2.weight" in name or name.endswith("norm_up.weight")) \
@@ -147,11 +148,12 @@ class OracleSwinUnet:
 
     def _block(self, sd, p, x, res, dim, heads, shift, dp, training, drop, sites):
         B, L, C = x.shape
+        WS = self.ws
         shortcut = x
         x = F.layer_norm(x, (C,), sd[p + ".norm1.weight"], sd[p + ".norm1.bias"], 1e-5).view(B, res, res, C)
         if shift > 0:
             x = torch.roll(x, shifts=(-shift, -shift), dims=(1, 2))
-        xw = _window_partition(x).view(-1, WS * WS, C)
+        xw = _window_partition(x, WS).view(-1, WS * WS, C)
         B_, N, _ = xw.shape
         qkv = F.linear(xw, sd[p + ".attn.qkv.weight"], sd[p + ".attn.qkv.bias"])
         qkv = qkv.reshape(B_, N, 3, heads, C // heads).permute(2, 0, 3, 1, 4)
@@ -167,7 +169,7 @@ class OracleSwinUnet:
         attn = attn.softmax(dim=-1)
         xw = (attn @ v).transpose(1, 2).reshape(B_, N, C)
         xw = F.linear(xw, sd[p + ".attn.proj.weight"], sd[p + ".attn.proj.bias"])
-        x = _window_reverse(xw.view(-1, WS, WS, C), res, res)
+        x = _window_reverse(xw.view(-1, WS, WS, C), res, res, WS)
         if shift > 0:
             x = torch.roll(x, shifts=(shift, shift), dims=(1, 2))
         x = x.view(B, res * res, C)

@@ -60,5 +60,27 @@ def main():
             timeit(lambda: ops.norm_act_bwd(x, da, dx, True, mean, rstd, None, None, 0.0)), 3 * x.numel() * 4)
 
 
-if __name__ == "__main__":
+if __name__ == "__main__" and len(sys.argv) == 1:
     main()
+
+
+def chunked():
+    """Infinity-cache experiment: InstanceNorm backward run per sample (x + da of one sample = 113 MB at 16 x 96^3), so
+    that the apply pass re-reads what the partial-sum pass just streamed."""
+    N, C, D = 8, 16, 96
+    x = torch.randn(N, C, D, D, D, device="cuda")
+    da = torch.randn_like(x)
+    dx = torch.empty_like(x)
+    mean = torch.zeros(N * C, device="cuda")
+    rstd = torch.ones(N * C, device="cuda")
+    whole = timeit(lambda: ops.norm_act_bwd(x, da, dx, True, mean, rstd, None, None, 0.0))
+    for step in (1, 2, 4):
+        def run():
+            for n in range(0, N, step):
+                ops.norm_act_bwd(x[n:n + step], da[n:n + step], dx[n:n + step], True, mean[n * C:(n + step) * C],
+                                 rstd[n * C:(n + step) * C], None, None, 0.0)
+        print(f"norm bwd 16x96^3: whole batch {whole * 1e3:.1f} us; {step} sample(s) per call {timeit(run) * 1e3:.1f} us")
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "chunked":
+    chunked()

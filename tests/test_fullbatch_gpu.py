@@ -1,0 +1,162 @@
+"""Step-level parity at the FULL per-GPU batch of every BASELINE.json configuration.
+
+The golden fixtures are small-batch (they are produced by the reference on the CPU of the build container); the
+kernels, however, pick their instantiation from the problem size -- conv tile shapes (conv_fwd.hip dispatch: 16x32 vs
+16x16 2-D tiles, 8x8x8 vs 4x8x8 for 24^3 volumes by workgroup count, 16- vs 32-channel blocks), split-K factors of the
+weight-gradient and NT GEMM kernels, samples-per-wave of the attention backward.  These tests run
+
+    config 2  Mean-Teacher 2-D UNet      24+24 @ 256^2      config 4  Mean-Teacher SwinUnet   24+24 @ 224^2
+    config 3  Mean-Teacher unet_3D        4+4  @ 96^3       config 5  cross teaching CNN+ViT  16+16 @ 224^2
+
+with every dropout / DropPath at p = 0 and injected teacher noise, and compare the student and teacher logits, the loss
+scalars, the gradients (coarse bound: these are dispatch checks, the tight gradient gates are the fixture-size tests in
+test_parity_gpu.py) and the updated parameters against oracle.step evaluated here on the host CPU on the same inputs,
+and assert that the full-batch kernel instantiations were the ones dispatched."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+TOL_LOGIT, TOL_LOSS = 1e-3, 2e-4          # the north-star bar on logits; scalar losses tighter
+GRAD_REL, GRAD_ABS = 0.25, 2e-3           # per tensor: |dg|_max <= GRAD_REL * |g|_max + GRAD_ABS * (largest |g| of the net)
+
+
+def _states(onet, tag=""):
+    from oracle import filler
+    sd = filler.fill_state_dict({tag + k: v for k, v in onet.new_state().items()})
+    return {k[len(tag):]: v for k, v in sd.items()}
+
+
+def _record_kernels(fn):
+    """Run ``fn`` with the conv-launch hook armed; returns the set of conv_fwd instantiation names it dispatched."""
+    from mis_hip import ops
+    ops.PROFILE = []
+    try:
+        fn()
+        torch.cuda.synchronize()
+        return {name for name, *_ in ops.PROFILE}
+    finally:
+        ops.PROFILE = None
+
+
+def _check_grads_and_params(model, grads, student_after, lr, what):
+    gscale = max(float(g.abs().max()) for g in grads.values())
+    for n, g in model.named_flat(model.flat_grad):
+        ref = grads[n]
+        err = (g.cpu() - ref).abs().max().item()
+        tol = GRAD_REL * float(ref.abs().max()) + GRAD_ABS * gscale
+        assert err <= tol, (what, n, err, tol)
+    for n, v in model.named_flat(model.flat_param):
+        err = (v.cpu() - student_after[n]).abs().max().item()
+        assert err <= 1e-6 + lr * (GRAD_REL + GRAD_ABS) * gscale, (what, n, err)
+
+
+MT_CASES = {
+    # name: (kind, shape, labeled, classes, label dtype, iter_num, cons_start_iter, conv instantiations that only the
+    #        full batch reaches)
+    "config2_unet2d_24+24_256": ("unet2d", (48, 1, 256, 256), 24, 4, torch.uint8, 1200, 1000,
+                                 ["Cfg<1, 3, 3, 1, 16, 32, 16, 8, 8>", "Cfg<1, 3, 3, 1, 16, 32, 32, 8, 8>",
+                                  "Cfg<1, 3, 3, 1, 16, 16, 32, 8, 4>"]),
+    "config3_unet3d_4+4_96": ("unet3d", (8, 1, 96, 96, 96), 4, 2, torch.int64, 1200, 0,
+                              ["Cfg<3, 3, 3, 4, 8, 16, 16, 4, 8>", "Cfg<3, 3, 3, 4, 8, 16, 32, 4, 8>",
+                               "Cfg<3, 3, 3, 8, 8, 8, 32, 4, 8>",      # 24^3, student batch 8: enough workgroups
+                               "Cfg<3, 3, 3, 4, 8, 8, 32, 4, 4>"]),    # 24^3, teacher batch 4: smaller tiles
+    "config4_swin_24+24_224": ("swin", (48, 1, 224, 224), 24, 4, torch.uint8, 1200, 1000, []),
+}
+
+
+@pytest.mark.parametrize("name", list(MT_CASES))
+@pytest.mark.timeout(1500)
+def test_mean_teacher_step_at_full_batch(name):
+    from mis_hip.step import MeanTeacherTrainer
+    from oracle import filler
+    from oracle.step import mean_teacher_step
+    from test_parity_gpu import _build
+    kind, shape, L, C, ldt, it, cons_start, expect = MT_CASES[name]
+    onet, make = _build(kind, C)
+    sd0, tsd0 = _states(onet), _states(onet, "t.")
+    volume = filler.image(shape, "volume")
+    label = filler.labels((shape[0],) + shape[2:], C, ldt)
+    noise = filler.noise((shape[0] - L,) + shape[1:], "noise")
+    model, ema = make(), make()
+    model.train(); ema.train()
+    model.dropout_enabled = ema.dropout_enabled = False
+    model.load_state_dict(sd0)
+    ema.load_state_dict(tsd0)
+    tr = MeanTeacherTrainer(model, ema, labeled_bs=L, num_classes=C, cons_start_iter=cons_start, iter_num=it)
+    mom = {}
+    for n, v in model.named_flat(tr.momentum_buf):
+        m = filler.uniform(v.shape, "mom." + n, -0.01, 0.01)
+        v.copy_(m)
+        mom[n] = m.clone()
+    vol_d, lab_d, noise_d = volume.cuda(), label.cuda(), noise.cuda()
+    names = _record_kernels(lambda: tr.step(vol_d, lab_d, noise=noise_d))
+    for e in expect:
+        assert f"conv_fwd_kernel<{e}>" in names, (e, sorted(names))
+    got = tr.losses()
+    s_logits = model._last[0].out.t.cpu()
+    t_logits = ema._last[0].out.t.cpu()
+    # ---- the same step on the host CPU ----
+    student = {k: v.clone() for k, v in sd0.items()}
+    teacher = {k: v.clone() for k, v in tsd0.items()}
+    orc = mean_teacher_step(onet, student, teacher, mom, volume, label, noise, it, labeled_bs=L, num_classes=C,
+                            cons_start_iter=cons_start, drop_student="off", drop_teacher="off")
+    assert (s_logits.reshape(orc["logits"].shape) - orc["logits"]).abs().max().item() <= TOL_LOGIT
+    assert (t_logits.reshape(orc["teacher_logits"].shape) - orc["teacher_logits"]).abs().max().item() <= TOL_LOGIT
+    for k in ("loss", "loss_ce", "loss_dice", "consistency_loss"):
+        assert abs(got[k] - orc[k]) <= TOL_LOSS, (k, got[k], orc[k])
+    assert abs(got["consistency_weight"] - orc["consistency_weight"]) <= 1e-6
+    _check_grads_and_params(model, orc["grads"], student, orc["lr"], name)
+    alpha = orc["ema_alpha"]
+    gscale = max(float(g.abs().max()) for g in orc["grads"].values())
+    for n, v in ema.named_flat(ema.flat_param):
+        assert (v.cpu() - teacher[n]).abs().max().item() <= 1e-6 + (1 - alpha) * orc["lr"] * gscale, n
+
+
+@pytest.mark.timeout(1500)
+def test_cross_teaching_step_at_full_batch():
+    """config 5 per GPU: UNet <-> SwinUnet, 16 labeled + 16 unlabeled images of 224^2."""
+    from config import lite_config
+    from mis_hip.step import CrossTeachingTrainer
+    from networks.net_factory import net_factory
+    from networks.vision_transformer import SwinUnet
+    from oracle import filler
+    from oracle.nets import OracleUNet2D
+    from oracle.step import cross_teaching_step
+    from oracle.swin import OracleSwinUnet
+    C, L, B, it = 4, 16, 32, 1300
+    nets = [OracleUNet2D(1, C), OracleSwinUnet(C)]
+    sds = [_states(nets[0], "m0."), _states(nets[1], "m1.")]
+    volume = filler.image((B, 1, 224, 224), "volume")
+    label = filler.labels((B, 224, 224), C, torch.uint8)
+    models = [net_factory("unet", 1, C), SwinUnet(lite_config(), img_size=224, num_classes=C)]
+    for m in range(2):
+        models[m].load_state_dict(sds[m])
+        models[m].train()
+        models[m].dropout_enabled = False
+    tr = CrossTeachingTrainer(models[0], models[1], labeled_bs=L, num_classes=C, iter_num=it)
+    moms = []
+    for m, buf in enumerate((tr.mom1, tr.mom2)):
+        mm = {}
+        for n, v in models[m].named_flat(buf):
+            t = filler.uniform(v.shape, f"mom{m}." + n, -0.01, 0.01)
+            v.copy_(t)
+            mm[n] = t.clone()
+        moms.append(mm)
+    vol_d, lab_d = volume.cuda(), label.cuda()
+    names = _record_kernels(lambda: tr.step(vol_d, lab_d))
+    assert "conv_fwd_kernel<Cfg<1, 3, 3, 1, 16, 32, 16, 8, 8>>" in names, sorted(names)
+    got = tr.losses()
+    osd = [{k: v.clone() for k, v in sd.items()} for sd in sds]
+    r = cross_teaching_step(nets[0], nets[1], osd[0], osd[1], moms[0], moms[1], volume, label, it, labeled_bs=L,
+                            num_classes=C, drop1="off", drop2="off")
+    assert abs(got["model1_loss"] - r["model1_loss"]) <= TOL_LOSS
+    assert abs(got["model2_loss"] - r["model2_loss"]) <= TOL_LOSS
+    for m in range(2):
+        ce, dl, ps = r["parts"][m]
+        assert abs(got[f"loss{m + 1}_ce"] - ce) <= TOL_LOSS and abs(got[f"loss{m + 1}_dice"] - dl) <= TOL_LOSS
+        assert abs(got[f"pseudo_supervision{m + 1}"] - ps) <= TOL_LOSS
+        lg = models[m]._last[0].out.t.cpu().reshape(r[f"logits{m + 1}"].shape)
+        assert (lg - r[f"logits{m + 1}"]).abs().max().item() <= TOL_LOGIT
+        _check_grads_and_params(models[m], r["grads"][m], osd[m], r["lr"], f"model{m + 1}")

@@ -34,6 +34,13 @@ def _build(kind, C):
         from networks.vision_transformer import SwinUnet
         from oracle.swin import OracleSwinUnet
         return OracleSwinUnet(C), (lambda: SwinUnet(lite_config(), img_size=224, num_classes=C))
+    if kind == "swin_w8":          # DATA.IMG_SIZE 256 + MODEL.SWIN.WINDOW_SIZE 8 (reference config.py:194-195)
+        from config import lite_config
+        from networks.vision_transformer import SwinUnet
+        from oracle.swin import OracleSwinUnet
+        cfg = lite_config()
+        cfg.DATA.IMG_SIZE, cfg.MODEL.SWIN.WINDOW_SIZE = 256, 8
+        return OracleSwinUnet(C, img_size=256, window=8), (lambda: SwinUnet(cfg, img_size=256, num_classes=C))
     if kind == "unet2d":
         from networks.net_factory import net_factory
         return OracleUNet2D(1, C), (lambda: net_factory("unet", 1, C))
@@ -61,9 +68,11 @@ def _fixture_states(onet):
 def _inputs(kind, cfg):
     from oracle import filler
     B, sp = cfg["batch_size"], tuple(cfg["spatial"])
-    volume = filler.image((B, 1) + sp, "volume")
-    label = filler.labels((B,) + sp, cfg["num_classes"], torch.uint8 if kind in ("unet2d", "swin") else torch.int64)
-    noise = filler.noise((B - cfg["labeled_bs"], 1) + sp, "noise")
+    ch = cfg.get("in_channels", 1)
+    volume = filler.image((B, ch) + sp, "volume")
+    label = filler.labels((B,) + sp, cfg["num_classes"],
+                          torch.uint8 if kind in ("unet2d", "swin", "swin_w8") else torch.int64)
+    noise = filler.noise((B - cfg["labeled_bs"], ch) + sp, "noise")
     return volume, label, noise
 
 
@@ -79,7 +88,8 @@ def _check_summary(t, z, prefix, tol):
 
 CASES = ["unet2d_64_dropoff", "unet2d_64_masks", "unet3d_64_dropoff", "unet3d_64_masks", "unet2d_256_cfg1",
          "unet3d_96_cfg3_b2", "swin_224_dropoff", "swin_224_masks", "vnet_64_dropoff", "vnet_64_masks",
-         "vnet_gn_64_dropoff", "vnet_gn_64_masks", "vnet_in_64_dropoff", "vnet_none_64_masks"]
+         "vnet_gn_64_dropoff", "vnet_gn_64_masks", "vnet_in_64_dropoff", "vnet_none_64_masks",
+         "swin_224_rgb", "swin_256_w8"]
 
 
 @pytest.mark.parametrize("name", CASES)

@@ -158,6 +158,12 @@ def test_rearrange_and_im2col():
     y = torch.empty(2 * 4 * 6, 96, device="cuda")
     tops.gemm(cols, w.view(96, 48).cuda(), y)
     _close(y, ref)
+    # 3-channel input (the other branch of vision_transformer.py:48-50): every channel from its own plane
+    img3 = _rand(2, 3, 16, 24, seed=19)
+    ref3 = F.conv2d(img3, w, stride=4).flatten(2).transpose(1, 2).reshape(-1, 96)
+    tops.patch_im2col(img3.cuda(), cols, 3)
+    tops.gemm(cols, w.view(96, 48).cuda(), y)
+    _close(y, ref3)
 
 
 def test_output_head():
@@ -177,59 +183,63 @@ def test_output_head():
     _close(dw, w.grad, rtol=3e-4)
 
 
-def _ref_window_attention(qkv, table, B, H, W, nH, shift, scale):
+def _ref_window_attention(qkv, table, B, H, W, nH, shift, scale, ws=7):
     """torch restatement of WindowAttention.forward + the roll/partition plumbing (natural token order in/out)."""
-    C = nH * 32
+    C, n = nH * 32, ws * ws
     x = qkv.view(B, H, W, 3 * C)
     if shift:
         x = torch.roll(x, shifts=(-shift, -shift), dims=(1, 2))
-    xw = x.view(B, H // 7, 7, W // 7, 7, 3 * C).permute(0, 1, 3, 2, 4, 5).reshape(-1, 49, 3, nH, 32).permute(2, 0, 3, 1, 4)
+    xw = x.view(B, H // ws, ws, W // ws, ws, 3 * C).permute(0, 1, 3, 2, 4, 5).reshape(-1, n, 3, nH, 32).permute(2, 0, 3, 1, 4)
     q, k, v = xw[0] * scale, xw[1], xw[2]
     attn = q @ k.transpose(-2, -1)
-    coords = torch.stack(torch.meshgrid([torch.arange(7), torch.arange(7)], indexing="ij")).flatten(1)
-    rel = (coords[:, :, None] - coords[:, None, :]).permute(1, 2, 0) + 6
-    idx = rel[:, :, 0] * 13 + rel[:, :, 1]
-    attn = attn + table[idx.view(-1)].view(49, 49, nH).permute(2, 0, 1).unsqueeze(0)
+    coords = torch.stack(torch.meshgrid([torch.arange(ws), torch.arange(ws)], indexing="ij")).flatten(1)
+    rel = (coords[:, :, None] - coords[:, None, :]).permute(1, 2, 0) + ws - 1
+    idx = rel[:, :, 0] * (2 * ws - 1) + rel[:, :, 1]
+    attn = attn + table[idx.view(-1)].view(n, n, nH).permute(2, 0, 1).unsqueeze(0)
     if shift:
         img = torch.zeros(1, H, W, 1)
         cnt = 0
-        for hs in (slice(0, -7), slice(-7, -shift), slice(-shift, None)):
-            for ws_ in (slice(0, -7), slice(-7, -shift), slice(-shift, None)):
+        for hs in (slice(0, -ws), slice(-ws, -shift), slice(-shift, None)):
+            for ws_ in (slice(0, -ws), slice(-ws, -shift), slice(-shift, None)):
                 img[:, hs, ws_, :] = cnt
                 cnt += 1
-        mw = img.view(1, H // 7, 7, W // 7, 7, 1).permute(0, 1, 3, 2, 4, 5).reshape(-1, 49)
+        mw = img.view(1, H // ws, ws, W // ws, ws, 1).permute(0, 1, 3, 2, 4, 5).reshape(-1, n)
         am = mw.unsqueeze(1) - mw.unsqueeze(2)
         am = am.masked_fill(am != 0, -100.0).masked_fill(am == 0, 0.0).to(attn.dtype)
         nW = am.shape[0]
-        attn = (attn.view(B, nW, nH, 49, 49) + am.unsqueeze(1).unsqueeze(0)).view(-1, nH, 49, 49)
+        attn = (attn.view(B, nW, nH, n, n) + am.unsqueeze(1).unsqueeze(0)).view(-1, nH, n, n)
     attn = attn.softmax(-1)
-    o = (attn @ v).transpose(1, 2).reshape(-1, 7, 7, C)
-    o = o.view(B, H // 7, W // 7, 7, 7, C).permute(0, 1, 3, 2, 4, 5).reshape(B, H, W, C)
+    o = (attn @ v).transpose(1, 2).reshape(-1, ws, ws, C)
+    o = o.view(B, H // ws, W // ws, ws, ws, C).permute(0, 1, 3, 2, 4, 5).reshape(B, H, W, C)
     if shift:
         o = torch.roll(o, shifts=(shift, shift), dims=(1, 2))
     return o.reshape(B * H * W, C)
 
 
-@pytest.mark.parametrize("B,H,W,nH,shift", [(2, 14, 14, 3, 0), (3, 14, 21, 2, 3), (2, 7, 7, 6, 0), (9, 28, 28, 3, 3),
-                                             # enough (sample, window, head) units that the backward sums dS over 4
-                                             # samples per wave, with a ragged last chunk (18 = 4*4 + 2)
-                                             (18, 56, 56, 3, 3)])
-def test_window_attention(B, H, W, nH, shift):
+@pytest.mark.parametrize("B,H,W,nH,shift,ws", [(2, 14, 14, 3, 0, 7), (3, 14, 21, 2, 3, 7), (2, 7, 7, 6, 0, 7),
+                                                (9, 28, 28, 3, 3, 7),
+                                                # enough (sample, window, head) units that the backward sums dS over 4
+                                                # samples per wave, with a ragged last chunk (18 = 4*4 + 2)
+                                                (18, 56, 56, 3, 3, 7),
+                                                # window 8 (64 tokens: IMG_SIZE 256 / WINDOW_SIZE 8), shift 4
+                                                (2, 16, 16, 3, 0, 8), (3, 16, 24, 2, 4, 8), (2, 8, 8, 6, 0, 8),
+                                                (5, 64, 64, 3, 4, 8)])
+def test_window_attention(B, H, W, nH, shift, ws):
     tops = _t()
     C = nH * 32
     qkv = _rand(B * H * W, 3 * C, seed=22, scale=1.5).double().requires_grad_(True)
-    table = (_rand(169, nH, seed=23, scale=0.5)).double().requires_grad_(True)
+    table = (_rand((2 * ws - 1) ** 2, nH, seed=23, scale=0.5)).double().requires_grad_(True)
     scale = 32 ** -0.5
-    ref = _ref_window_attention(qkv, table, B, H, W, nH, shift, scale)
+    ref = _ref_window_attention(qkv, table, B, H, W, nH, shift, scale, ws)
     dout = _rand(B * H * W, C, seed=24).double()
     ref.backward(dout)
     qd, td = qkv.detach().float().cuda(), table.detach().float().cuda()
     out = torch.empty(B * H * W, C, device="cuda")
-    tops.window_attention_fwd(qd, out, td, B, H, W, nH, shift, scale)
+    tops.window_attention_fwd(qd, out, td, B, H, W, nH, shift, scale, window=ws)
     _close(out, ref, rtol=1e-4, atol=1e-5)
     dqkv = torch.empty(B * H * W, 3 * C, device="cuda")
-    dt = torch.empty(169, nH, device="cuda")
-    tops.window_attention_bwd(qd, dout.float().cuda(), dqkv, td, dt, B, H, W, nH, shift, scale)
+    dt = torch.empty((2 * ws - 1) ** 2, nH, device="cuda")
+    tops.window_attention_bwd(qd, dout.float().cuda(), dqkv, td, dt, B, H, W, nH, shift, scale, window=ws)
     _close(dqkv, qkv.grad, rtol=2e-4, atol=1e-5)
     _close(dt, table.grad, rtol=2e-4, atol=1e-4)
 
