@@ -47,7 +47,24 @@ struct GemmArgs {
     // NT only, optional: store C through the PatchExpand pixel shuffle 'b h w (p1 p2 c) -> b (h p1) (w p2) c'
     // (row m = (b, h, w) of an ex_H x ex_W token grid, column n = (p1, p2, c)); ex_P == 0: plain row-major C
     int ex_P, ex_H, ex_W, ex_c;
+    int vec4;   // NT: C / bias (/ E1 / C2) are 16-byte aligned with row strides and N multiples of 4: LDS-staged float4 epilogue
+    // NT only, optional fused epilogue (mis_gemm_ex): EP_GELU_FWD  C = v, C2 = gelu(v)          (v = acc + bias)
+    //                                                 EP_GELU_BWD  C = v * gelu'(E1)             (E1 = pre-activation)
+    //                                                 EP_RESIDUAL  C = E1 + rowscale[m / rps] * v (E1 = shortcut)
+    int ep;
+    const float* E1; long long lde1;
+    float* C2; long long ldc2;
+    const float* rowscale; long long rps;
 };
+
+enum { EP_NONE = 0, EP_GELU_FWD = 1, EP_GELU_BWD = 2, EP_RESIDUAL = 3 };
+
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_grad_f(float x) {      // same expressions as token_ops.hip::gelu_kernel
+    const float cdf = 0.5f * (1.f + erff(x * 0.70710678118654752f));
+    const float pdf = 0.3989422804014327f * expf(-0.5f * x * x);
+    return cdf + x * pdf;
+}
 
 extern __shared__ __attribute__((aligned(16))) float mis_gemm_lds[];
 
@@ -57,12 +74,20 @@ struct NtCfg {
     static constexpr int NJ = BN / 32;                    // 16-column MFMA tiles per wave (wave = 64 x BN/2)
     static constexpr int A_FLOATS = BM * BK, B_FLOATS = BN * BK;
     static constexpr int STAGE = A_FLOATS + B_FLOATS;
-    static constexpr int LDS_BYTES = 2 * STAGE * 4;       // double buffered
+    // epilogue: the accumulator tile goes through LDS (row stride BN + 4: the four 4-row lane groups land 16 banks
+    // apart) so that C -- and the operands of the fused epilogues -- move as float4 rows instead of 64-byte dword pieces
+    static constexpr int LDC_T = BN + 4;
+    static constexpr int CT_FLOATS = BM * LDC_T;
+    static constexpr int LDS_FLOATS = 2 * STAGE > CT_FLOATS ? 2 * STAGE : CT_FLOATS;
+    static constexpr int LDS_BYTES = LDS_FLOATS * 4;      // double-buffered operand stage, re-used by the epilogue
     static constexpr int PB = BN / 8;                     // 8-row DMA pieces of the B tile (A: 16)
     static_assert(BN % 32 == 0 && PB % 4 == 0, "pieces split evenly over 4 waves");
 };
 
-template <int BN>
+// EP: compile-time epilogue (EP_NONE / EP_GELU_FWD / EP_GELU_BWD / EP_RESIDUAL).  The fused epilogues are separate
+// instantiations: compiled into the plain kernel they cost it 41 registers and one resident workgroup per CU
+// (measured: every Linear of the step slowed down, 38.5 -> 41.7 ms).
+template <int BN, int EP>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs a) {
     using G = NtCfg<BN>;
     float* const lds = mis_gemm_lds;
@@ -215,27 +240,52 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs a) {
         }
         return;
     }
-    if (a.N % 16 == 0 && (long long)a.M * a.ldc * 4 < (1LL << 31)) {
-        const unsigned c_bytes = (unsigned)((long long)(a.M - 1) * a.ldc + a.N) * 4u;
-        const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc((void*)a.C, 0, (int)c_bytes, 0x00020000);
-        const unsigned ldc4 = (unsigned)a.ldc * 4u;
-        const unsigned v0 = (unsigned)(m0 + wm + lk * 4) * ldc4 + (unsigned)(n0 + wn + lj) * 4u;
+    if (a.vec4) {
+        // Fast path (C, bias, E1, C2 float4-addressable; checked by the host): accumulators -> LDS tile -> float4 rows.
+        // The main loop ended with a barrier, so the stage buffers are free.  D row = lk*4 + r -> m, col = lj -> n.
+        float* const ct = lds;
 #pragma unroll
-        for (int j = 0; j < G::NJ; ++j) {
-            if (n0 + wn + j * 16 >= a.N) break;   // uniform
-            const float bv = a.bias ? a.bias[n0 + wn + j * 16 + lj] : 0.f;
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int j = 0; j < G::NJ; ++j)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const unsigned off = v0 + (unsigned)(i * 16 + r) * ldc4 + (unsigned)(j * 16) * 4u;
-                    float v = acc[i][j][r] + bv;
-                    if (a.accumulate) v += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rc, (int)off, 0, 0));
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rc, (int)off, 0, 0);
+                for (int r = 0; r < 4; ++r)
+                    ct[(wm + i * 16 + lk * 4 + r) * G::LDC_T + wn + j * 16 + lj] = acc[i][j][r];
+        __syncthreads();
+        constexpr int Q = BN / 4;
+#pragma unroll 4
+        for (int it = 0; it < BM * Q / 256; ++it) {
+            const int e = tid + it * 256;
+            const int row = e / Q, q = e - row * Q;
+            const int m = m0 + row, n = n0 + q * 4;
+            if (m >= a.M || n >= a.N) continue;
+            float4 v = *reinterpret_cast<const float4*>(&ct[row * G::LDC_T + q * 4]);
+            if (a.bias) {
+                const float4 b = *reinterpret_cast<const float4*>(a.bias + n);
+                v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+            }
+            float* const cp = a.C + (long long)m * a.ldc + n;
+            if constexpr (EP == EP_GELU_FWD) {
+                *reinterpret_cast<float4*>(a.C2 + (long long)m * a.ldc2 + n) =
+                    make_float4(gelu_f(v.x), gelu_f(v.y), gelu_f(v.z), gelu_f(v.w));
+            } else if constexpr (EP == EP_GELU_BWD) {
+                const float4 h = *reinterpret_cast<const float4*>(a.E1 + (long long)m * a.lde1 + n);
+                v.x *= gelu_grad_f(h.x); v.y *= gelu_grad_f(h.y); v.z *= gelu_grad_f(h.z); v.w *= gelu_grad_f(h.w);
+            } else if constexpr (EP == EP_RESIDUAL) {
+                const float4 sc = *reinterpret_cast<const float4*>(a.E1 + (long long)m * a.lde1 + n);
+                const float rs = a.rowscale ? a.rowscale[m / a.rps] : 1.f;
+                v.x = sc.x + rs * v.x; v.y = sc.y + rs * v.y; v.z = sc.z + rs * v.z; v.w = sc.w + rs * v.w;
+            } else {
+                if (a.accumulate) {
+                    const float4 o = *reinterpret_cast<const float4*>(cp);
+                    v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
                 }
+            }
+            *reinterpret_cast<float4*>(cp) = v;
         }
         return;
     }
+    if constexpr (EP != EP_NONE) return;   // the host only launches a fused instantiation on the float4 path
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -375,6 +425,13 @@ __global__ __launch_bounds__(256) void gemm_reduce_kernel(const GemmArgs a) {
         const int m = (int)(e / a.N), n = (int)(e - (long long)m * a.N);
         if (a.bias) s += a.bias[n];
         float* p = a.C + (long long)m * a.ldc + n;
+        if (a.ep == EP_GELU_FWD) {
+            a.C2[(long long)m * a.ldc2 + n] = gelu_f(s);
+        } else if (a.ep == EP_GELU_BWD) {
+            s *= gelu_grad_f(a.E1[(long long)m * a.lde1 + n]);
+        } else if (a.ep == EP_RESIDUAL) {
+            s = a.E1[(long long)m * a.lde1 + n] + (a.rowscale ? a.rowscale[m / a.rps] : 1.f) * s;
+        }
         *p = a.accumulate ? *p + s : s;
     }
 }
@@ -408,12 +465,22 @@ int pick_ks(int M, int N, int K, int trans) {
 
 bool a16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
+template <int BN, int EP>
+int launch_nt_ep(const GemmArgs& a, hipStream_t stream) {
+    static std::atomic<unsigned long long> attr_done{0};   // per instantiation, one bit per device
+    if (mis_set_lds_attr(reinterpret_cast<const void*>(&gemm_nt_kernel<BN, EP>), NtCfg<BN>::LDS_BYTES, attr_done) != MIS_OK)
+        return MIS_ERR_LAUNCH;
+    hipLaunchKernelGGL((gemm_nt_kernel<BN, EP>), dim3(a.n_blocks_padded), dim3(256), NtCfg<BN>::LDS_BYTES, stream, a);
+    return mis_launch_status();
+}
+
+// split-K slices write raw partials (the epilogue runs in gemm_reduce_kernel): always the plain instantiation
 template <int BN>
 int launch_nt(const GemmArgs& a, hipStream_t stream) {
-    static std::atomic<unsigned long long> attr_done{0};   // per instantiation, one bit per device
-    if (mis_set_lds_attr(reinterpret_cast<const void*>(&gemm_nt_kernel<BN>), NtCfg<BN>::LDS_BYTES, attr_done) != MIS_OK) return MIS_ERR_LAUNCH;
-    hipLaunchKernelGGL(gemm_nt_kernel<BN>, dim3(a.n_blocks_padded), dim3(256), NtCfg<BN>::LDS_BYTES, stream, a);
-    return mis_launch_status();
+    if (a.KS > 1 || a.ep == EP_NONE) return launch_nt_ep<BN, EP_NONE>(a, stream);
+    if (a.ep == EP_GELU_FWD) return launch_nt_ep<BN, EP_GELU_FWD>(a, stream);
+    if (a.ep == EP_GELU_BWD) return launch_nt_ep<BN, EP_GELU_BWD>(a, stream);
+    return launch_nt_ep<BN, EP_RESIDUAL>(a, stream);
 }
 
 }  // namespace
@@ -422,6 +489,50 @@ extern "C" long long mis_gemm_workspace_bytes(int M, int N, int K, int trans) {
     if (M <= 0 || N <= 0 || K <= 0) return MIS_ERR_ARG;
     const int ks = pick_ks(M, N, K, trans);
     return ks > 1 ? (long long)ks * M * N * 4 : 0;
+}
+
+// mis_gemm (NT form only) with a fused epilogue, v = A.B^T + bias:
+//   epilogue 1  C = v, C2 = gelu(v)                      Mlp.fc1 + GELU (reference ...sys.py:14-15,20-21): the
+//                                                        pre-activation stays for the backward, the GELU pass is gone
+//   epilogue 2  C = v * gelu'(E1)                        dX of Mlp.fc2 straight into the gradient of fc1's output
+//   epilogue 3  C = E1 + rowscale[m / rows_per_scale] * v  proj / fc2 + DropPath + residual add (:276, :281);
+//                                                        rowscale NULL = 1
+// E1 / C2 are [M][N] views with their own row strides.  accumulate is not supported here.
+extern "C" int mis_gemm_ex(const float* A, long long lda, const float* B, long long ldb, float* C, long long ldc,
+                           const float* bias, int M, int N, int K, int epilogue, const float* E1, long long lde1,
+                           float* C2, long long ldc2, const float* rowscale, long long rows_per_scale,
+                           float* workspace, long long workspace_bytes, hipStream_t stream) {
+    if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0) return MIS_ERR_ARG;
+    if (epilogue < EP_GELU_FWD || epilogue > EP_RESIDUAL) return MIS_ERR_ARG;
+    if (epilogue == EP_GELU_FWD ? (!C2 || ldc2 < N) : (!E1 || lde1 < N)) return MIS_ERR_ARG;
+    if (epilogue == EP_RESIDUAL && rowscale && rows_per_scale <= 0) return MIS_ERR_ARG;
+    if (!a16(A) || !a16(B) || lda % 4 || ldb % 4 || K % 4) return MIS_ERR_UNSUPPORTED;
+    // the fused epilogues live in the float4 (LDS-staged) epilogue
+    if (N % 4 || ldc % 4 || !a16(C) || (bias && !a16(bias))) return MIS_ERR_UNSUPPORTED;
+    if (epilogue == EP_GELU_FWD ? (ldc2 % 4 || !a16(C2)) : (lde1 % 4 || !a16(E1))) return MIS_ERR_UNSUPPORTED;
+    if ((long long)M * lda * 4 >= (1LL << 31) || (long long)N * ldb * 4 >= (1LL << 31)) return MIS_ERR_UNSUPPORTED;
+    GemmArgs a{A, lda, B, ldb, C, ldc, bias, workspace, M, N, K, 1, K, 0};
+    a.ex_P = 0;
+    a.ep = epilogue; a.E1 = E1; a.lde1 = lde1; a.C2 = C2; a.ldc2 = ldc2; a.rowscale = rowscale; a.rps = rows_per_scale;
+    a.vec4 = 1;
+    a.KS = pick_ks(M, N, K, 0);
+    if (a.KS > 1) {
+        if (!workspace || workspace_bytes < (long long)a.KS * M * N * 4) return MIS_ERR_WORKSPACE;
+        a.kchunk = (int)(mis_cdiv(mis_cdiv(K, a.KS), BK) * BK);
+        a.KS = (int)mis_cdiv(K, a.kchunk);
+    }
+    const int bn = nt_tile_n(N);
+    a.tiles_n = (int)mis_cdiv(N, bn);
+    a.tiles_m = (int)mis_cdiv(M, BM);
+    const long long nb = (long long)a.tiles_n * a.tiles_m * a.KS;
+    if (nb > 0x7fffffffLL) return MIS_ERR_UNSUPPORTED;
+    a.n_blocks = (unsigned)nb;
+    a.n_blocks_padded = (unsigned)(mis_cdiv(nb, MIS_NUM_XCD) * MIS_NUM_XCD);
+    int st = bn == 96 ? launch_nt<96>(a, stream) : launch_nt<128>(a, stream);
+    if (st) return st;
+    if (a.KS > 1)
+        hipLaunchKernelGGL(gemm_reduce_kernel, dim3((unsigned)mis_cdiv((long long)M * N, 32)), dim3(256), 0, stream, a);
+    return mis_launch_status();
 }
 
 extern "C" int mis_gemm(const float* A, long long lda, const float* B, long long ldb, float* C, long long ldc,
@@ -436,6 +547,8 @@ extern "C" int mis_gemm(const float* A, long long lda, const float* B, long long
     if (rowsA * lda * 4 >= (1LL << 31) || rowsB * ldb * 4 >= (1LL << 31)) return MIS_ERR_UNSUPPORTED;
     GemmArgs a{A, lda, B, ldb, C, ldc, bias, workspace, M, N, K, 1, K, accumulate};
     a.ex_P = 0;
+    a.ep = EP_NONE;
+    a.vec4 = (!trans && N % 4 == 0 && ldc % 4 == 0 && a16(C) && (!bias || a16(bias))) ? 1 : 0;
     a.KS = pick_ks(M, N, K, trans);
     if (a.KS > 1) {
         if (!workspace || workspace_bytes < (long long)a.KS * M * N * 4) return MIS_ERR_WORKSPACE;

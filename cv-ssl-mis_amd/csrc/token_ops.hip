@@ -374,6 +374,17 @@ __device__ __forceinline__ float droppath_scale(float p, unsigned salt, const Mi
     return mis_u01(r[0]) >= p ? 1.f / (1.f - p) : 0.f;
 }
 
+// table[site][b] = DropPath scale of sample b at residual site `site` (the values residual_kernel derives on the fly):
+// one launch per forward gives the GEMM epilogues that fuse the residual add their per-row scales
+__global__ __launch_bounds__(256) void droppath_table_kernel(float* __restrict__ table, const float* __restrict__ p,
+                                                             const unsigned* __restrict__ salt, int nsites, int B,
+                                                             const MisStepState* st) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= nsites * B) return;
+    const int site = i / B, b = i - site * B;
+    table[i] = droppath_scale(p[site], salt[site], st, b);
+}
+
 // forward:  out[row] = a[row] + s_b * y[row]           (rows of sample b = row / rows_per_sample)
 // backward: d_a[row] = dout[row] ; d_y[row] = s_b * dout[row]   (a == dout, y == nullptr)
 __global__ __launch_bounds__(256) void residual_kernel(const float* __restrict__ a, long long lda,
@@ -707,6 +718,16 @@ extern "C" int mis_residual_droppath(const float* a, long long lda, const float*
     if (C % 4 || lda % 4 || ldy % 4 || ldo % 4 || ldo2 % 4) return MIS_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(residual_kernel, dim3(sgrid(M * (C >> 2))), dim3(256), 0, stream, a, lda, y, ldy, out, ldo, out2,
                        ldo2, M, C, rows_per_sample, drop_p, salt, state, scale_override, backward);
+    return mis_launch_status();
+}
+
+// table[site*B + b] = DropPath scale (0 or 1/(1-p[site])) of sample b at site `site`, from Philox(state, salt[site], b):
+// exactly what mis_residual_droppath applies.  p / salt: device arrays of nsites entries; p[site] == 0 gives 1.
+extern "C" int mis_droppath_table(float* table, const float* p, const unsigned* salt, int nsites, int B,
+                                  const MisStepState* state, hipStream_t stream) {
+    if (!table || !p || !salt || nsites <= 0 || B <= 0 || !state) return MIS_ERR_ARG;
+    hipLaunchKernelGGL(droppath_table_kernel, dim3((nsites * B + 255) / 256), dim3(256), 0, stream, table, p, salt, nsites,
+                       B, state);
     return mis_launch_status();
 }
 

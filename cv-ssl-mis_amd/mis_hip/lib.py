@@ -95,6 +95,9 @@ PROTOTYPES = {
     "mis_gemm_workspace_bytes": (c_ll, [c_i, c_i, c_i, c_i]),
     "mis_gemm_expand": (c_i, [c_p, c_ll, c_p, c_ll, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
     "mis_gemm": (c_i, [c_p, c_ll, c_p, c_ll, c_p, c_ll, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_ll, c_p]),
+    "mis_gemm_ex": (c_i, [c_p, c_ll, c_p, c_ll, c_p, c_ll, c_p, c_i, c_i, c_i, c_i, c_p, c_ll, c_p, c_ll, c_p, c_ll, c_p,
+                          c_ll, c_p]),
+    "mis_droppath_table": (c_i, [c_p, c_p, c_p, c_i, c_i, c_p, c_p]),
     "mis_transpose": (c_i, [c_p, c_ll, c_p, c_ll, c_i, c_i, c_p]),
     "mis_layernorm_fwd": (c_i, [c_p, c_ll, c_p, c_ll, c_p, c_p, c_p, c_p, c_ll, c_i, c_f, c_p]),
     "mis_colreduce_workspace_bytes": (c_ll, [c_ll, c_i]),

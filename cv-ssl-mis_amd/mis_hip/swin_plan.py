@@ -7,11 +7,16 @@ column slices of one buffer; roll / window_partition / window_reverse never mate
 token-index arithmetic inside the attention kernel).
 """
 import itertools
+import os
 
 import torch
 
 from . import tops
 from .plan import Act
+
+# GEMM epilogue fusions (GELU into fc1 / fc2-dX, DropPath + residual add into proj / fc2); MIS_SWIN_FUSE=0 runs the
+# separate element-wise passes (A/B timing, and the reference point of the fusion tests)
+FUSE = int(os.environ.get("MIS_SWIN_FUSE", "7"))      # bit 0: GELU forward, bit 1: GELU backward, bit 2: residual
 
 
 class TAct:
@@ -63,16 +68,36 @@ class TAct:
 
 
 class LinearOp:
-    """nn.Linear: y = x W^T + b;  dW = dy^T x, db = colsum(dy), dx (+)= dy W."""
+    """nn.Linear: y = x W^T + b;  dW = dy^T x, db = colsum(dy), dx (+)= dy W.
+
+    Optional epilogue fusions (set by the network when it builds a block, executed when ``FUSE``):
+      ``gelu``     the GeluOp that consumes y: the GEMM writes y AND gelu(y); that op's forward pass is skipped
+      ``res``      the ResidualOp that consumes y: the GEMM writes shortcut + DropPath(y) straight into the
+                   residual's output (y itself is never written, only its gradient exists)
+      ``dx_gelu``  the GeluOp that produced x: the dX GEMM multiplies by gelu'(pre-activation) and writes the gradient
+                   of the GELU's input; that op's backward pass is skipped."""
 
     def __init__(self, x, y, w, b, need_dx=True):
         self.x, self.y, self.w, self.b, self.need_dx = x, y, w, b, need_dx
         self.w2 = w.data.view(w.data.shape[0], -1)
         self.gw2 = w.grad.view(w.grad.shape[0], -1)
         self.wT = None
+        self.gelu = self.res = self.dx_gelu = None
 
     def fwd(self, ctx):
-        tops.gemm(self.x.t, self.w2, self.y.t, bias=None if self.b is None else self.b.data)
+        bias = None if self.b is None else self.b.data
+        if (FUSE & 1) and self.gelu is not None:
+            if tops.gemm_ex(self.x.t, self.w2, self.y.t, tops.EP_GELU_FWD, bias=bias, C2=self.gelu.y.t):
+                self.gelu.skip_fwd = True
+                return
+        if (FUSE & 4) and self.res is not None:
+            r = self.res
+            scales = r.prepare(ctx)
+            if tops.gemm_ex(self.x.t, self.w2, r.out.t, tops.EP_RESIDUAL, bias=bias, E1=r.a.t, rowscale=scales,
+                            rows_per_scale=r.rps):
+                r.skip_fwd = True
+                return
+        tops.gemm(self.x.t, self.w2, self.y.t, bias=bias)
 
     def bwd(self, ctx):
         dy = self.y.grad()
@@ -83,6 +108,12 @@ class LinearOp:
             if self.wT is None:
                 self.wT = torch.empty((self.w2.shape[1], self.w2.shape[0]), dtype=torch.float32, device="cuda")
             tops.transpose(self.w2, self.wT)
+            g = self.dx_gelu
+            if (FUSE & 2) and g is not None and not g.x.written and \
+                    tops.gemm_ex(dy, self.wT, g.x.grad(), tops.EP_GELU_BWD, E1=g.x.t):
+                g.skip_bwd = True        # d(pre-activation) is written; d(gelu output) never exists
+                g.x.mark_written()
+                return
             tops.gemm(dy, self.wT, self.x.grad(), accumulate=self.x.written)
             self.x.mark_written()
 
@@ -105,11 +136,18 @@ class LayerNormOp:
 class GeluOp:
     def __init__(self, x, y):
         self.x, self.y = x, y
+        self.skip_fwd = self.skip_bwd = False     # set for one pass by the LinearOp that fused this op's work
 
     def fwd(self, ctx):
+        if self.skip_fwd:
+            self.skip_fwd = False
+            return
         tops.gelu(self.x.t, self.y.t)
 
     def bwd(self, ctx):
+        if self.skip_bwd:
+            self.skip_bwd = False
+            return
         assert not self.x.written
         tops.gelu(self.x.t, self.x.grad(), dy=self.y.grad())
         self.x.mark_written()
@@ -139,14 +177,27 @@ class ResidualOp:
         self.a, self.y, self.out = a, y, out
         self.rps, self.drop_p, self.site = rows_per_sample, drop_p, site
         self._p, self._salt, self._state, self._scale = 0.0, 0, None, None
+        self.plan = None            # set by SwinPlan.add: the per-forward DropPath scale table lives there
+        self.skip_fwd = False
 
-    def fwd(self, ctx):
+    def prepare(self, ctx):
+        """Fix this pass's DropPath parameters (also used by backward); returns the per-sample scale vector a fused
+        GEMM epilogue multiplies the branch by (None: all ones)."""
         self._p = self.drop_p if (ctx.training and ctx.dropout) else 0.0
         self._scale = ctx.drop_masks.get(self.site) if (ctx.drop_masks and self._p > 0) else None
         self._salt = ((ctx.rng_stream & 0xFFFF) << 16) | self.site
         self._state = ctx.state
         if self._p > 0 and self._scale is None and ctx.state is None:
             raise RuntimeError("DropPath is active but no device step state was supplied")
+        if self._p <= 0:
+            return None
+        return self._scale if self._scale is not None else self.plan.droppath_scales(ctx)[self.site]
+
+    def fwd(self, ctx):
+        if self.skip_fwd:           # the producing GEMM wrote shortcut + DropPath(branch) already
+            self.skip_fwd = False
+            return
+        self.prepare(ctx)
         tops.residual_fwd(self.a.t, self.y.t, self.out.t, self.rps, self._p, self._salt, self._state, self._scale)
 
     def bwd(self, ctx):
@@ -232,6 +283,7 @@ class SwinPlan:
         self.out = None
         self.generation = 0      # forwards run on this plan (see mis_hip.plan.Plan / _NetFn.backward)
         self._progress = None
+        self._dp_gen, self._dp_const = -1, None
 
     def new(self, rows, C):
         a = TAct(rows, C)
@@ -244,8 +296,28 @@ class SwinPlan:
         return a
 
     def add(self, op):
+        if isinstance(op, ResidualOp):
+            op.plan = self
         self.ops.append(op)
         return op
+
+    def droppath_scales(self, ctx):
+        """[sites][B] DropPath scales of THIS forward pass (one launch per forward, cached by generation): the values
+        ResidualOp derives on the fly from (state, salt, sample), as a table for the fused GEMM epilogues."""
+        if self._dp_gen != self.generation:
+            res = [op for op in self.ops if isinstance(op, ResidualOp)]
+            n, B = len(res), self.in_shape[0]
+            key = ctx.rng_stream
+            if self._dp_const is None or self._dp_const[0] != key:
+                p = torch.tensor([op.drop_p for op in res], dtype=torch.float32).cuda()
+                salt = torch.tensor([(((ctx.rng_stream & 0xFFFF) << 16) | op.site) for op in res],
+                                    dtype=torch.int64).to(torch.int32).cuda()       # bit pattern of the unsigned salt
+                assert [op.site for op in res] == list(range(n))
+                self._dp_const = (key, p, salt, torch.empty((n, B), dtype=torch.float32, device="cuda"))
+            _, p, salt, table = self._dp_const
+            tops.droppath_table(table, p, salt, n, B, ctx.state)
+            self._dp_gen = self.generation
+        return self._dp_const[3]
 
     def next_site(self):
         return next(self._site)

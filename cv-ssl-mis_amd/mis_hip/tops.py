@@ -45,8 +45,48 @@ def gemm(A, B, C, bias=None, trans=False, accumulate=False):
         if trans:
             name = "gemm_tn_kernel<96>" if (M % 96 == 0 and N % 96 == 0 and (M % 128 or N % 128)) else "gemm_tn_kernel<128>"
         else:
-            name = "gemm_nt_kernel<96>" if (N % 96 == 0 and N % 128) else "gemm_nt_kernel<128>"
+            name = "gemm_nt_kernel<96, 0>" if (N % 96 == 0 and N % 128) else "gemm_nt_kernel<128, 0>"
         prof.append((name, 2.0 * M * N * K, e0, e1))
+
+
+EP_GELU_FWD, EP_GELU_BWD, EP_RESIDUAL = 1, 2, 3
+
+
+def gemm_ex(A, B, C, epilogue, bias=None, E1=None, C2=None, rowscale=None, rows_per_scale=1):
+    """C = epilogue(A[M,K] @ B[N,K]^T + bias) (mis_gemm_ex): EP_GELU_FWD also writes C2 = gelu(.), EP_GELU_BWD multiplies
+    by gelu'(E1), EP_RESIDUAL gives E1 + rowscale[row // rows_per_scale] * (.).  Returns False when the shape is
+    outside the fused form (the caller then runs the un-fused ops)."""
+    L = _l.load()
+    M, K, lda = _mat(A)
+    N, K2, ldb = _mat(B)
+    Mc, Nc, ldc = _mat(C)
+    assert K == K2 and (Mc, Nc) == (M, N)
+    lde1 = _mat(E1)[2] if E1 is not None else 0
+    ldc2 = _mat(C2)[2] if C2 is not None else 0
+    nb = L.mis_gemm_workspace_bytes(M, N, K, 0)
+    ws = scratch(nb, "gemm") if nb > 0 else None
+    prof = _ops.PROFILE
+    if prof is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    st = L.mis_gemm_ex(_l.ptr(A), lda, _l.ptr(B), ldb, _l.ptr(C), ldc, _l.ptr(bias), M, N, K, int(epilogue),
+                       _l.ptr(E1), lde1, _l.ptr(C2), ldc2, _l.ptr(rowscale), int(rows_per_scale), _l.ptr(ws),
+                       ws.numel() if ws is not None else 0, _l.stream_ptr())
+    if st == -2:
+        return False
+    _l.check(st, "mis_gemm_ex")
+    if prof is not None:
+        e1.record()
+        # (split-K shapes run the plain instantiation + the reduce kernel; the label keeps the requested epilogue)
+        prof.append((("gemm_nt_kernel<96, %d>" if (N % 96 == 0 and N % 128) else "gemm_nt_kernel<128, %d>") % epilogue,
+                     2.0 * M * N * K, e0, e1))
+    return True
+
+
+def droppath_table(table, p_dev, salt_dev, nsites, B, state):
+    L = _l.load()
+    _l.check(L.mis_droppath_table(_l.ptr(table), _l.ptr(p_dev), _l.ptr(salt_dev), nsites, B, _l.ptr(state),
+                                  _l.stream_ptr()), "mis_droppath_table")
 
 
 def gemm_expand(x, w, out, B, H, W, P, c):
@@ -66,7 +106,8 @@ def gemm_expand(x, w, out, B, H, W, P, c):
     _l.check(st, "mis_gemm_expand")
     if prof is not None:
         e1.record()
-        prof.append(("gemm_nt_kernel<96>" if (N % 96 == 0 and N % 128) else "gemm_nt_kernel<128>", 2.0 * M * N * K, e0, e1))
+        prof.append(("gemm_nt_kernel<96, 0>" if (N % 96 == 0 and N % 128) else "gemm_nt_kernel<128, 0>", 2.0 * M * N * K,
+                     e0, e1))
     return True
 
 

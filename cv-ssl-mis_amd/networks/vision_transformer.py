@@ -199,20 +199,21 @@ class SwinUnet(HipNet):
         plan.add(sp.AttnOp(qkv, att, P(p + ".attn.relative_position_bias_table"), B, res, res, heads, shift,
                            window=self.ws))
         pr = plan.new(rows, dim)
-        plan.add(sp.LinearOp(att, pr, P(p + ".attn.proj.weight"), P(p + ".attn.proj.bias")))
+        proj = plan.add(sp.LinearOp(att, pr, P(p + ".attn.proj.weight"), P(p + ".attn.proj.bias")))
         x1 = plan.new(rows, dim)
-        plan.add(sp.ResidualOp(x, pr, x1, L, dp, plan.next_site()))
+        proj.res = plan.add(sp.ResidualOp(x, pr, x1, L, dp, plan.next_site()))    # fused into proj's epilogue
         n2 = plan.new(rows, dim)
         plan.add(sp.LayerNormOp(x1, n2, P(p + ".norm2.weight"), P(p + ".norm2.bias")))
         hdim = int(dim * self.mlp_ratio)
         h = plan.new(rows, hdim)
-        plan.add(sp.LinearOp(n2, h, P(p + ".mlp.fc1.weight"), P(p + ".mlp.fc1.bias")))
+        fc1 = plan.add(sp.LinearOp(n2, h, P(p + ".mlp.fc1.weight"), P(p + ".mlp.fc1.bias")))
         hg = plan.new(rows, hdim)
-        plan.add(sp.GeluOp(h, hg))
+        fc1.gelu = gelu = plan.add(sp.GeluOp(h, hg))                               # GELU in fc1's epilogue
         m = plan.new(rows, dim)
-        plan.add(sp.LinearOp(hg, m, P(p + ".mlp.fc2.weight"), P(p + ".mlp.fc2.bias")))
+        fc2 = plan.add(sp.LinearOp(hg, m, P(p + ".mlp.fc2.weight"), P(p + ".mlp.fc2.bias")))
+        fc2.dx_gelu = gelu                                                         # gelu' in fc2's dX epilogue
         x2 = out if out is not None else plan.new(rows, dim)
-        plan.add(sp.ResidualOp(x1, m, x2, L, dp, plan.next_site()))
+        fc2.res = plan.add(sp.ResidualOp(x1, m, x2, L, dp, plan.next_site()))      # residual add in fc2's epilogue
         return x2
 
     def _expand(self, plan, p, x, out, B, res, dim, P_):

@@ -268,6 +268,19 @@ int mis_gemm_expand(const float* x, long long lda, const float* W, long long ldb
 int mis_gemm(const float* A, long long lda, const float* B, long long ldb, float* C, long long ldc,
              const float* bias, int M, int N, int K, int trans, int accumulate, float* workspace,
              long long workspace_bytes, mis_stream_t stream);
+/* NT form with a fused epilogue, v = A.B^T + bias (reference ...sys.py: Mlp :9-25, SwinTransformerBlock.forward
+ * :244-288):  1: C = v and C2 = gelu(v) (fc1 + GELU; the pre-activation stays for the backward);
+ *             2: C = v * gelu'(E1) (the dX of fc2 lands directly in the gradient of fc1's output);
+ *             3: C = E1 + rowscale[m / rows_per_scale] * v (proj / fc2 + DropPath + residual add; rowscale NULL = 1).
+ * E1, C2: [M][N] views with their own row strides.  Workspace as mis_gemm (trans = 0). */
+int mis_gemm_ex(const float* A, long long lda, const float* B, long long ldb, float* C, long long ldc,
+                const float* bias, int M, int N, int K, int epilogue, const float* E1, long long lde1, float* C2,
+                long long ldc2, const float* rowscale, long long rows_per_scale, float* workspace,
+                long long workspace_bytes, mis_stream_t stream);
+/* table[site*B + b] = DropPath scale of sample b at residual site `site` (what mis_residual_droppath derives on the
+ * fly from (state, salt[site], b)); p, salt: device arrays of nsites entries */
+int mis_droppath_table(float* table, const float* p, const unsigned* salt, int nsites, int B,
+                       const MisStepState* state, mis_stream_t stream);
 /* out[c][r] = in[r][c]: weight^T for the input-gradient GEMM (packed once per step) */
 int mis_transpose(const float* in, long long ldi, float* out, long long ldo, int rows, int cols, mis_stream_t stream);
 /* nn.LayerNorm over the last dim (:204,211,323,365,393,716-717); mean/rstd: M floats saved for backward */

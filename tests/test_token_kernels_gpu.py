@@ -265,3 +265,66 @@ def test_gemm_expand_equals_gemm_plus_pixel_shuffle(B, H, K, P, c):
     # reference semantics of the shuffle itself
     want = (x.double() @ w.double().t()).view(B, H, H, P, P, c).permute(0, 1, 3, 2, 4, 5).reshape(M * P * P, c)
     _close(ref, want)
+
+
+@pytest.mark.parametrize("M,N,K", [(6272, 384, 96), (6272, 96, 384), (200, 96, 48), (98, 3072, 768), (98, 768, 3072)])
+def test_gemm_fused_epilogues(M, N, K):
+    """mis_gemm_ex: GELU forward / backward and DropPath + residual add in the NT GEMM's epilogue (also through the
+    split-K reduction for the deep-stage shapes) against torch in float64."""
+    tops = _t()
+    A, W = _rand(M, K, seed=31), _rand(N, K, seed=32, scale=K ** -0.5)
+    bias = _rand(N, seed=33)
+    v = A.double() @ W.double().t() + bias.double()
+    Ad, Wd, bd = A.cuda(), W.cuda(), bias.cuda()
+    # 1: C = v, C2 = gelu(v)
+    C, C2 = torch.empty(M, N, device="cuda"), torch.empty(M, N, device="cuda")
+    assert tops.gemm_ex(Ad, Wd, C, tops.EP_GELU_FWD, bias=bd, C2=C2)
+    _close(C, v)
+    _close(C2, F.gelu(v))
+    # 2: C = (A @ W^T) * gelu'(E1)
+    h = _rand(M, N, seed=34, scale=1.5).double().requires_grad_(True)
+    F.gelu(h).backward(torch.ones(M, N, dtype=torch.float64))
+    assert tops.gemm_ex(Ad, Wd, C, tops.EP_GELU_BWD, E1=h.detach().float().cuda())
+    _close(C, (A.double() @ W.double().t()) * h.grad)
+    # 3: C = E1 + rowscale[row // rps] * v, with E1 a column slice of a wider buffer (the decoder's concat)
+    rps = M // 2 if M % 2 == 0 else M
+    wide = _rand(M, N + 32, seed=35)
+    sc = torch.tensor([0.0, 1.25] if rps < M else [1.25])
+    assert tops.gemm_ex(Ad, Wd, C, tops.EP_RESIDUAL, bias=bd, E1=wide.cuda()[:, 16:16 + N], rowscale=sc.cuda(),
+                        rows_per_scale=rps)
+    _close(C, wide[:, 16:16 + N].double() + sc.repeat_interleave(rps)[:, None].double() * v)
+    assert tops.gemm_ex(Ad, Wd, C, tops.EP_RESIDUAL, bias=bd, E1=wide.cuda()[:, 16:16 + N])
+    _close(C, wide[:, 16:16 + N].double() + v)
+
+
+def test_swin_step_fused_equals_unfused():
+    """The epilogue fusions change where the element-wise work runs, not its arithmetic: a Mean-Teacher step of SwinUnet
+    with DropPath active (device RNG) gives the same losses, gradients and weights with MIS_SWIN_FUSE on and off."""
+    from config import lite_config
+    from mis_hip import swin_plan
+    from mis_hip.step import MeanTeacherTrainer
+    from networks.vision_transformer import SwinUnet
+    from oracle import filler
+    from oracle.swin import OracleSwinUnet
+    sd0 = filler.fill_state_dict(OracleSwinUnet(4).new_state())
+    vol = filler.image((4, 1, 224, 224), "volume").cuda()
+    lab = filler.labels((4, 224, 224), 4, torch.uint8).cuda()
+    res = []
+    for fuse in (7, 0):
+        swin_plan.FUSE = fuse
+        try:
+            m, e = SwinUnet(lite_config(), num_classes=4), SwinUnet(lite_config(), num_classes=4)
+            m.load_state_dict(sd0); e.load_state_dict(sd0)
+            tr = MeanTeacherTrainer(m, e, labeled_bs=2, num_classes=4, cons_start_iter=0, seed=11, iter_num=1500)
+            for _ in range(2):
+                tr.step(vol, lab)
+            torch.cuda.synchronize()
+            res.append((tr.losses(), m.flat_grad.clone(), m.flat_param.clone(), e.flat_param.clone()))
+        finally:
+            swin_plan.FUSE = 7
+    (l0, g0, p0, t0), (l1, g1, p1, t1) = res
+    for k in l0:
+        assert abs(l0[k] - l1[k]) <= 1e-6, (k, l0[k], l1[k])
+    gs = float(g1.abs().max())
+    assert (g0 - g1).abs().max().item() <= 1e-5 * gs
+    assert (p0 - p1).abs().max().item() <= 1e-6 and (t0 - t1).abs().max().item() <= 1e-6
