@@ -1,26 +1,34 @@
 #!/bin/bash
 # Re-measure everything that DESIGN.md quotes, on the GPU box (run through gpurun from the repo root):
-#   gpurun --timeout 2400 -- 'bash scripts/refresh_profiles.sh v6'
-# Writes gpurun_out/<tag>/: bench JSON lines of every workload, rocprofv3 kernel-trace databases (turned into the
-# committed CSV summaries by scripts/db_to_stats_csv.py) and the two PMC passes that scripts/pmc_traffic.py turns
-# into profiles/r01_<workload>_pmc_traffic.json.  PMC passes run without any trace domain but --kernel-trace.
-tag=${1:-v6}
+#   gpurun --timeout 2400 -- 'bash scripts/refresh_profiles.sh r02'
+# Writes gpurun_out/<tag>/: the default bench JSON line (config 3 + the "others" block + thread-swept CPU baseline),
+# the bench lines of the other workloads, rocprofv3 kernel-trace statistics (CSV), and the two PMC passes that
+# scripts/pmc_traffic.py turns into profiles/<tag>_<workload>_pmc_traffic.json.  PMC passes run without any trace
+# domain but --kernel-trace (separate FETCH_SIZE / WRITE_SIZE passes, MI355X_MICROARCH.md "HBM").
+tag=${1:-r02}
 out=gpurun_out/$tag
 mkdir -p "$out"
 export TMPDIR=/tmp
-for w in unet2d unet3d vnet uamt3d swin cross cnnvit; do
-    python bench.py --workload $w > "$out/bench_$w.json" 2> "$out/bench_$w.err"
-    tail -c 400 "$out/bench_$w.json" | head -c 0
+python bench.py > "$out/bench_default.json" 2> "$out/bench_default.err"
+for w in unet2d vnet uamt3d swin cross cross224 cnnvit; do
+    python bench.py --workload $w --no-cpu-baseline > "$out/bench_$w.json" 2> "$out/bench_$w.err"
 done
-for w in unet2d unet3d vnet swin; do
+python bench.py --overlap-teacher --no-cpu-baseline --no-others > "$out/bench_unet3d_overlap.json" 2> "$out/bench_unet3d_overlap.err"
+for w in unet3d unet2d vnet swin; do
     rocprofv3 --kernel-trace --stats -d "$out/prof_$w" -o "$w" --output-format csv -- \
-        python bench.py --workload $w --steps 10 --warmup 3 --no-cpu-baseline > "$out/prof_$w.log" 2>&1
+        python bench.py --workload $w --steps 10 --warmup 3 --no-cpu-baseline --no-others > "$out/prof_$w.log" 2>&1
+    cp "$out/prof_$w/${w}_kernel_stats.csv" "$out/${tag}_${w}_kernel_stats.csv" 2>/dev/null
 done
-for w in ${PMC_WORKLOADS:-swin}; do
+for w in ${PMC_WORKLOADS:-unet3d swin}; do
     for c in FETCH_SIZE WRITE_SIZE; do
         rocprofv3 --pmc $c --kernel-trace -d "$out/pmc_${w}_$c" -o "$w" --output-format csv -- \
-            python bench.py --workload $w --steps 3 --warmup 1 --no-cpu-baseline --no-kernel-events \
+            python bench.py --workload $w --steps 3 --warmup 1 --no-cpu-baseline --no-others --no-kernel-events \
             > "$out/pmc_${w}_$c.log" 2>&1
     done
+    python scripts/pmc_traffic.py "$out/pmc_${w}_FETCH_SIZE/${w}_counter_collection.csv" \
+        "$out/pmc_${w}_WRITE_SIZE/${w}_counter_collection.csv" "$out/${tag}_${w}_pmc_traffic.json" \
+        "bench.py --workload $w, 4 steps" > "$out/pmc_${w}.txt" 2>&1
+    rm -rf "$out/pmc_${w}_FETCH_SIZE" "$out/pmc_${w}_WRITE_SIZE"
 done
-ls -R "$out" | head -80
+rm -rf "$out"/prof_*/*_kernel_trace.csv
+ls -R "$out" | head -60

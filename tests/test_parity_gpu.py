@@ -175,7 +175,9 @@ def test_step_matches_reference_golden_and_oracle(name):
         # 4 x that measured noise + 2e-3.
         gn = np.array([float(g.double().norm()) for _, g in model.named_flat(model.flat_grad)])
         ref_gn, gn64 = z[pre + "grad_norms"], z[pre + "grad_norms64"]
-        env = 6.0 * z[pre + "grad_relerr32"] + 2e-3
+        # (GroupNorm nets: the reference's own noise is ~3x lower because torch's CPU GroupNorm accumulates in double,
+        #  see F64_GN below; the factor keeps the envelope at the same ABSOLUTE level as for the BatchNorm nets)
+        env = (F64_GN["K"] if "groupnorm" in kind else 6.0) * z[pre + "grad_relerr32"] + 2e-3
         gmax = z[pre + "grad_max64"]
         numel = np.array([v.numel() for _, v in model.named_flat(model.flat_param)], dtype=np.float64)
         assert np.all(np.abs(gn - ref_gn) <= env * np.maximum(ref_gn, gn64) + 1e-5 * ref_gn.max()), \
