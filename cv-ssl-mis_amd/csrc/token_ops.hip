@@ -481,6 +481,60 @@ __global__ __launch_bounds__(256) void patch_im2col_kernel(const float* __restri
     }
 }
 
+// ------------------------------------------------------------------ UNETR patch embedding helpers
+// MONAI PatchEmbeddingBlock, pos_embed = "perceptron" (reference code/networks/unetr.py:88-99 builds ViT with it):
+//   Rearrange("b c (h p1) (w p2) (d p3) -> b (h w d) (p1 p2 p3 c)") -> Linear -> + position_embeddings[1, L, hidden]
+// out[(b*L + (h*Wp + w)*Dp + d)][((p1*P + p2)*P + p3)*C + c] = x[b][c][h*P + p1][w*P + p2][d*P + p3];  C == 1 here
+// (the reference builds UNETR with in_channels = 1): 4 consecutive p3 = one float4.
+__global__ __launch_bounds__(256) void patch3d_im2col_kernel(const float* __restrict__ x, long long x_bs,
+                                                             float* __restrict__ out, int B, int H, int W, int D, int P) {
+    const int Hp = H / P, Wp = W / P, Dp = D / P, P4 = P >> 2;
+    const long long total = (long long)B * Hp * Wp * Dp * P * P * P4;
+    for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        long long t = i;
+        const int q3 = (int)(t % P4); t /= P4;
+        const int p2 = (int)(t % P); t /= P;
+        const int p1 = (int)(t % P); t /= P;
+        const int d = (int)(t % Dp); t /= Dp;
+        const int w = (int)(t % Wp); t /= Wp;
+        const int h = (int)(t % Hp);
+        const int b = (int)(t / Hp);
+        const float4 v = *reinterpret_cast<const float4*>(
+            x + (long long)b * x_bs + ((long long)(h * P + p1) * W + (w * P + p2)) * D + d * P + q3 * 4);
+        float* o = out + ((((long long)b * Hp + h) * Wp + w) * Dp + d) * ((long long)P * P * P) + ((p1 * P + p2) * P + q3 * 4);
+        *reinterpret_cast<float4*>(o) = v;
+    }
+}
+
+// out[row][c] = x[row][c] + pos[row % L][c]
+__global__ __launch_bounds__(256) void add_rowcycle_kernel(const float* __restrict__ x, long long ldx,
+                                                           const float* __restrict__ pos, float* __restrict__ out,
+                                                           long long ldo, long long M, int C, int L) {
+    const int c4 = C >> 2;
+    for (long long i = blockIdx.x * 256LL + threadIdx.x; i < M * c4; i += (long long)gridDim.x * 256) {
+        const long long row = i / c4;
+        const int c = (int)(i - row * c4) * 4;
+        const float4 a = *reinterpret_cast<const float4*>(x + row * ldx + c);
+        const float4 p = *reinterpret_cast<const float4*>(pos + (row % L) * C + c);
+        *reinterpret_cast<float4*>(out + row * ldo + c) = make_float4(a.x + p.x, a.y + p.y, a.z + p.z, a.w + p.w);
+    }
+}
+
+// dpos[l][c] = sum_b dy[b*L + l][c]     (fixed order over b: deterministic)
+__global__ __launch_bounds__(256) void sum_rowcycle_kernel(const float* __restrict__ dy, long long ld,
+                                                           float* __restrict__ dpos, long long M, int C, int L) {
+    const int c4 = C >> 2;
+    const long long i = blockIdx.x * 256LL + threadIdx.x;
+    if (i >= (long long)L * c4) return;
+    const int l = (int)(i / c4), c = (int)(i - (long long)l * c4) * 4;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (long long row = l; row < M; row += L) {
+        const float4 v = *reinterpret_cast<const float4*>(dy + row * ld + c);
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    *reinterpret_cast<float4*>(dpos + (long long)l * C + c) = s;
+}
+
 // ------------------------------------------------------------------ output head (token-major -> NCHW logits)
 // logits[b][n][pix] = sum_k x[b*S + pix][k] * w[n][k]      (K % 4 == 0, NC <= 8)
 template <int NC>
@@ -760,6 +814,33 @@ extern "C" int mis_patch_im2col_c(const float* x, long long x_bs, float* out, in
 extern "C" int mis_patch_im2col(const float* x, long long x_bs, float* out, int B, int H, int W, int in_chans,
                                 hipStream_t stream) {
     return mis_patch_im2col_c(x, x_bs, out, B, H, W, in_chans, 1, stream);
+}
+
+extern "C" int mis_patch3d_im2col(const float* x, long long x_bs, float* out, int B, int H, int W, int D, int P,
+                                  hipStream_t stream) {
+    if (!x || !out || B <= 0 || H <= 0 || W <= 0 || D <= 0 || P <= 0) return MIS_ERR_ARG;
+    if (H % P || W % P || D % P || P % 4 || D % 4 || x_bs % 4 || !a16(x) || !a16(out)) return MIS_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(patch3d_im2col_kernel, dim3(sgrid((long long)B * H * W * D / 4)), dim3(256), 0, stream, x, x_bs,
+                       out, B, H, W, D, P);
+    return mis_launch_status();
+}
+
+extern "C" int mis_add_rowcycle(const float* x, long long ldx, const float* pos, float* out, long long ldo,
+                                long long M, int C, int L, hipStream_t stream) {
+    if (!x || !pos || !out || M <= 0 || C <= 0 || L <= 0) return MIS_ERR_ARG;
+    if (C % 4 || ldx % 4 || ldo % 4 || !a16(x) || !a16(pos) || !a16(out)) return MIS_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(add_rowcycle_kernel, dim3(sgrid(M * (C >> 2))), dim3(256), 0, stream, x, ldx, pos, out, ldo, M,
+                       C, L);
+    return mis_launch_status();
+}
+
+extern "C" int mis_sum_rowcycle(const float* dy, long long ld, float* dpos, long long M, int C, int L,
+                                hipStream_t stream) {
+    if (!dy || !dpos || M <= 0 || C <= 0 || L <= 0 || M % L) return MIS_ERR_ARG;
+    if (C % 4 || ld % 4 || !a16(dy) || !a16(dpos)) return MIS_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(sum_rowcycle_kernel, dim3((unsigned)mis_cdiv((long long)L * (C >> 2), 256)), dim3(256), 0, stream,
+                       dy, ld, dpos, M, C, L);
+    return mis_launch_status();
 }
 
 extern "C" int mis_head_fwd(const float* x, long long ldx, const float* w, float* logits, long long y_bs, int B,

@@ -121,6 +121,12 @@ PROTOTYPES = {
     "mis_window_attention_workspace_bytes_ws": (c_ll, [c_i, c_i, c_i, c_i, c_i]),
     "mis_window_attention_bwd_ws": (c_i, [c_p, c_ll, c_p, c_ll, c_p, c_ll, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_f,
                                           c_i, c_p, c_ll, c_p]),
+    "mis_full_attention_fwd": (c_i, [c_p, c_ll, c_p, c_ll, c_p, c_i, c_i, c_i, c_f, c_p]),
+    "mis_full_attention_workspace_bytes": (c_ll, [c_i, c_i, c_i]),
+    "mis_full_attention_bwd": (c_i, [c_p, c_ll, c_p, c_ll, c_p, c_ll, c_p, c_i, c_i, c_i, c_f, c_p, c_ll, c_p]),
+    "mis_patch3d_im2col": (c_i, [c_p, c_ll, c_p, c_i, c_i, c_i, c_i, c_i, c_p]),
+    "mis_add_rowcycle": (c_i, [c_p, c_ll, c_p, c_p, c_ll, c_ll, c_i, c_i, c_p]),
+    "mis_sum_rowcycle": (c_i, [c_p, c_ll, c_p, c_ll, c_i, c_i, c_p]),
     "mis_augment2d": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_p, c_p, c_p]),
     "mis_crop_rotflip3d": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_i, c_p]),
 }

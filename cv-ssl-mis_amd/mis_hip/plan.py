@@ -96,6 +96,7 @@ class ConvOp:
         self.batched = False     # True: the plan repacks all conv weights in one launch (Plan._pack)
         self.stat = None         # (partials, stride_channel, stride_image): statistics for the NormActOp that follows
         self.stat_norm = None
+        self._dx_tmp = None
 
     def fwd(self, ctx):
         if not self.batched:
@@ -113,10 +114,17 @@ class ConvOp:
         # bias_grad False: the conv feeds a normalisation, its bias gradient is exactly 0
         # (sum over a normalisation group of dL/dx vanishes); the flat grad buffer keeps its zeros.
         if self.need_dx:
-            assert not self.x.written, "conv data-gradient must be the first writer of its input grad"
             if not self.batched:
                 self.wpd = ops.conv_pack(self.w.data, 1, out=self.wpd)
-            ops.conv_fwd(dy, self.wpd, None, self.x.grad(), self.cout, self.cin, self.ksize)
+            if self.x.written:
+                # the input has another consumer whose gradient is already there (residual blocks: UNETR's
+                # UnetResBlock feeds its input to conv1 AND to the shortcut): data gradient into a scratch, then add
+                if self._dx_tmp is None:
+                    self._dx_tmp = torch.empty(self.x.shape, dtype=torch.float32, device="cuda")
+                ops.conv_fwd(dy, self.wpd, None, self._dx_tmp, self.cout, self.cin, self.ksize)
+                ops.add(self.x.grad(), self._dx_tmp, self.x.grad())
+            else:
+                ops.conv_fwd(dy, self.wpd, None, self.x.grad(), self.cout, self.cin, self.ksize)
             self.x.mark_written()
 
 
@@ -251,14 +259,14 @@ class UpConvOp:
     def fwd(self, ctx):
         self.wp = ops.conv_pack_raw(self.w.data, self.cout8, self.cin, 1, 2, out=self.wp)
         ops.conv_fwd(self.x.t, self.wp, None, self.y8, self.cin, self.cout8, (1, 1, 1))
-        ops.space_to_depth2(self.y8, self.y.t, self.y.shape, False, bias=self.b.data)
+        ops.space_to_depth2(self.y8, self.y.t, self.y.shape, False, bias=None if self.b is None else self.b.data)
 
     def bwd(self, ctx):
         from . import tops
         if self.dy8 is None:
             self.dy8 = torch.empty_like(self.y8)
             self.dw8 = torch.empty((self.cout8, self.cin), dtype=torch.float32, device="cuda")
-        if self.bias_grad:
+        if self.bias_grad and self.b is not None:
             ops.channel_sum(self.y.grad(), self.b.grad)
         ops.space_to_depth2(self.y.grad(), self.dy8, self.y.shape, True)
         ops.conv_wgrad(self.x.t, self.dy8, self.dw8, (1, 1, 1))                  # [8Cout][Cin]

@@ -271,6 +271,74 @@ class HeadOp:
         self.x.mark_written()
 
 
+# ---------------------------------------------------------------- UNETR ops (token part of networks/unetr.py)
+class Patch3dOp:
+    """MONAI PatchEmbeddingBlock('perceptron') re-arrangement: volume [B,1,H,W,D] -> rows of 16^3 voxels per patch."""
+
+    def __init__(self, plan, cols, P=16):
+        self.plan, self.cols, self.P = plan, cols, P
+
+    def fwd(self, ctx):
+        tops.patch3d_im2col(self.plan.inp.t, self.cols.t, self.P)
+
+    def bwd(self, ctx):
+        pass                                   # the input volume needs no gradient
+
+
+class PosAddOp:
+    """out = x + position_embeddings[row % L];  d(pos) = sum over the batch, d(x) = d(out) (aliased, no copy)."""
+
+    def __init__(self, x, pos, out, L):
+        self.x, self.pos, self.out, self.L = x, pos, out, L
+
+    def fwd(self, ctx):
+        tops.add_rowcycle(self.x.t, self.pos.data.view(self.L, -1), self.out.t, self.L)
+
+    def bwd(self, ctx):
+        assert not self.x.written
+        tops.sum_rowcycle(self.out.grad(), self.pos.grad.view(self.L, -1), self.L)
+        self.x.g = self.out.grad()
+        self.x.mark_written()
+
+
+class FullAttnOp:
+    """softmax(q k^T / sqrt(64)) v over all N tokens of a sample, per head (MONAI SABlock core)."""
+
+    def __init__(self, qkv, out, B, N, nH):
+        self.qkv, self.out, self.geo = qkv, out, (B, N, nH)
+        self.scale = 64 ** -0.5
+        self.stats = torch.empty(B * nH * N * 2, dtype=torch.float32, device="cuda")
+
+    def fwd(self, ctx):
+        tops.full_attention_fwd(self.qkv.t, self.out.t, self.stats, *self.geo, self.scale)
+
+    def bwd(self, ctx):
+        assert not self.qkv.written
+        tops.full_attention_bwd(self.qkv.t, self.out.grad(), self.qkv.grad(), self.stats, *self.geo, self.scale)
+        self.qkv.mark_written()
+
+
+class TokToVolOp:
+    """proj_feat (reference code/networks/unetr.py:183-186): tokens [B*L, C] -> volume [B, C, h, w, d] (a transpose per
+    sample); backward transposes the volume gradient back into the (so far untouched) token gradient."""
+
+    def __init__(self, tok, vol, B, L):
+        self.tok, self.vol, self.B, self.L = tok, vol, B, L
+
+    def fwd(self, ctx):
+        C = self.tok.C
+        for b in range(self.B):
+            tops.transpose(self.tok.t[b * self.L:(b + 1) * self.L], self.vol.t[b].reshape(C, self.L))
+
+    def bwd(self, ctx):
+        assert not self.tok.written, "the conv branch must be the first consumer to run backward"
+        C = self.tok.C
+        g, gv = self.tok.grad(), self.vol.grad()
+        for b in range(self.B):
+            tops.transpose(gv[b].reshape(C, self.L), g[b * self.L:(b + 1) * self.L])
+        self.tok.mark_written()
+
+
 class SwinPlan:
     """Op list + buffers of one SwinUnet for one input geometry; same interface as ``plan.Plan``."""
 

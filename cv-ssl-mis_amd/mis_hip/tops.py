@@ -237,3 +237,47 @@ def window_attention_bwd(qkv, dout, dqkv, table, dtable, B, H, W, nH, shift, sca
     _l.check(L.mis_window_attention_bwd_ws(_l.ptr(qkv), ldq, _l.ptr(dout), ldo, _l.ptr(dqkv), lddq, _l.ptr(table),
                                            _l.ptr(dtable), int(accumulate_table), B, H, W, nH, shift, scale, window,
                                            _l.ptr(ws), ws.numel(), _l.stream_ptr()), "mis_window_attention_bwd_ws")
+
+
+# ---------------------------------------------------------------- UNETR (full attention, 3-D patch embedding)
+def full_attention_fwd(qkv, out, stats, B, N, nH, scale):
+    L = _l.load()
+    _, _, ldq = _mat(qkv)
+    _, _, ldo = _mat(out)
+    _l.check(L.mis_full_attention_fwd(_l.ptr(qkv), ldq, _l.ptr(out), ldo, _l.ptr(stats), B, N, nH, scale,
+                                      _l.stream_ptr()), "mis_full_attention_fwd")
+
+
+def full_attention_bwd(qkv, dout, dqkv, stats, B, N, nH, scale):
+    L = _l.load()
+    _, _, ldq = _mat(qkv)
+    _, _, ldo = _mat(dout)
+    _, _, lddq = _mat(dqkv)
+    ws = scratch(L.mis_full_attention_workspace_bytes(B, N, nH), "attn")
+    _l.check(L.mis_full_attention_bwd(_l.ptr(qkv), ldq, _l.ptr(dout), ldo, _l.ptr(dqkv), lddq, _l.ptr(stats), B, N, nH,
+                                      scale, _l.ptr(ws), ws.numel(), _l.stream_ptr()), "mis_full_attention_bwd")
+
+
+def patch3d_im2col(x5, out, P):
+    """x5 [B,1,H,W,D] -> out [B*(H/P)(W/P)(D/P), P^3] (einops 'b c (h p1) (w p2) (d p3) -> b (h w d) (p1 p2 p3 c)')."""
+    L = _l.load()
+    B, C, H, W, D = x5.shape
+    assert C == 1 and x5.stride(4) == 1 and x5.stride(3) == D and x5.stride(2) == W * D
+    _l.check(L.mis_patch3d_im2col(_l.ptr(x5), x5.stride(0), _l.ptr(out), B, H, W, D, P, _l.stream_ptr()),
+             "mis_patch3d_im2col")
+
+
+def add_rowcycle(x, pos, out, L_rows):
+    L = _l.load()
+    M, C, ldx = _mat(x)
+    _, _, ldo = _mat(out)
+    assert pos.is_contiguous() and pos.numel() == L_rows * C
+    _l.check(L.mis_add_rowcycle(_l.ptr(x), ldx, _l.ptr(pos), _l.ptr(out), ldo, M, C, L_rows, _l.stream_ptr()),
+             "mis_add_rowcycle")
+
+
+def sum_rowcycle(dy, dpos, L_rows):
+    L = _l.load()
+    M, C, ld = _mat(dy)
+    assert dpos.is_contiguous() and dpos.numel() == L_rows * C
+    _l.check(L.mis_sum_rowcycle(_l.ptr(dy), ld, _l.ptr(dpos), M, C, L_rows, _l.stream_ptr()), "mis_sum_rowcycle")

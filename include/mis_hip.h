@@ -342,6 +342,24 @@ int mis_window_attention_bwd_ws(const float* qkv, long long ldq, const float* do
                                 int B, int H, int W, int nH, int shift, float scale, int window, void* workspace,
                                 long long workspace_bytes, mis_stream_t stream);
 
+/* ---- UNETR (reference code/networks/unetr.py, built from MONAI blocks that are NOT vendored in the reference:
+ * parity of these entry points is pinned to a torch restatement of the published algorithm only) --------------------
+ * full multi-head self-attention over N <= 256 tokens, head_dim 64: qkv [B*N][3*nH*64] (q | k | v, head, dim) ->
+ * out [B*N][nH*64]; stats (B*nH*N*2 floats: row max, row sum) are kept for the backward */
+int mis_full_attention_fwd(const float* qkv, long long ldq, float* out, long long ldo, float* stats, int B, int N,
+                           int nH, float scale, mis_stream_t stream);
+long long mis_full_attention_workspace_bytes(int B, int N, int nH);
+int mis_full_attention_bwd(const float* qkv, long long ldq, const float* dout, long long ldo, float* dqkv,
+                           long long lddq, const float* stats, int B, int N, int nH, float scale, void* workspace,
+                           long long workspace_bytes, mis_stream_t stream);
+/* 'b c (h p1) (w p2) (d p3) -> b (h w d) (p1 p2 p3 c)' for c = 1: x [B][1][H][W][D] -> out [B*(H/P)(W/P)(D/P)][P^3] */
+int mis_patch3d_im2col(const float* x, long long x_bs, float* out, int B, int H, int W, int D, int P,
+                       mis_stream_t stream);
+/* out[row] = x[row] + pos[row % L] (position embeddings); dpos[l] = sum over the rows with row % L == l of dy[row] */
+int mis_add_rowcycle(const float* x, long long ldx, const float* pos, float* out, long long ldo, long long M, int C,
+                     int L, mis_stream_t stream);
+int mis_sum_rowcycle(const float* dy, long long ld, float* dpos, long long M, int C, int L, mis_stream_t stream);
+
 /* ---- input pipeline on the device (SURVEY s.8 row n4): the training set is resident in HBM as one float pool
  * (images) and one byte pool (labels); a batch is one gather launch that applies the reference's per-sample
  * augmentation.  Random draws stay on the host in the reference's order and arrive as B parameter records in

@@ -169,8 +169,11 @@ def mean_teacher_step(net, student, teacher, momentum, volume, label, noise, ite
     else:
         cons = torch.mean((outputs_soft[labeled_bs:] - ema_output_soft) ** 2)
     loss = supervised + w * cons
-    grads = torch.autograd.grad(loss, [work[n] for n in params])
-    grads = OrderedDict(zip(params, grads))
+    # allow_unused: a parameter that takes no part in the forward (UNETR's ViT cls_token with classification off) gets a
+    # zero gradient here.  (torch's optimizer would SKIP such a parameter -- grad None: no weight decay either; the HIP
+    # step treats the flat buffer uniformly, i.e. like the zero gradient written here.)
+    grads = torch.autograd.grad(loss, [work[n] for n in params], allow_unused=True)
+    grads = OrderedDict((n, g if g is not None else torch.zeros_like(work[n])) for n, g in zip(params, grads))
     if grad_hook is not None:       # e.g. data-parallel averaging across shards
         grads = grad_hook(grads)
     lr = lr_for_step(iter_num, base_lr, max_iterations)

@@ -298,3 +298,21 @@ def test_product_path_never_imports_the_oracle():
             if f.endswith(".py"):
                 src = open(os.path.join(d, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, re.M), os.path.join(d, f)
+
+
+def test_unetr_oracle_runs_and_has_the_documented_keys():
+    """oracle/unetr.py (parity unpinned: MONAI is not vendored in the reference) -- shape / key sanity on CPU."""
+    from oracle.unetr import OracleUNETR
+    o = OracleUNETR(2, img_size=(32, 32, 32))
+    sd = o.new_state()
+    keys = list(sd)
+    assert keys[0] == "vit.patch_embedding.position_embeddings" and keys[-1] == "out.conv.conv.bias"
+    assert "vit.blocks.11.attn.qkv.weight" in sd and "encoder2.blocks.1.1.conv2.conv.weight" in sd
+    assert "decoder2.conv_block.conv3.conv.weight" in sd and "encoder1.layer.conv3.conv.weight" in sd
+    g = torch.Generator().manual_seed(0)
+    for v in sd.values():
+        if v.dim() >= 2:
+            v.copy_(torch.randn(v.shape, generator=g) * 0.05)
+    y = o.forward(sd, torch.rand(1, 1, 32, 32, 32, generator=g), training=False)
+    assert y.shape == (1, 2, 32, 32, 32) and torch.isfinite(y).all()
+    assert sum(v.numel() for v in OracleUNETR(2).new_state().values()) > 90e6     # the 96^3 network: ~92.8 M parameters
