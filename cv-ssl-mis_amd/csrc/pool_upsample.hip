@@ -84,6 +84,79 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const PoolBwdArgs a) {
     *p = g;
 }
 
+// 3-D pooling, 4 outputs per thread (W % 8 == 0, volumes < 2^31 elements).  The one-output-per-thread kernels above
+// spend ~50 instructions (64-bit index arithmetic, byte loads) per 8 bytes of dx and are VALU-issue bound on the
+// 16-lane SIMDs (measured 2.3 TB/s backward); here a thread owns 4 consecutive pooled outputs = a 2 x 2 x 8 block of
+// the fine tensor: float4 loads / stores only, one uchar4 of argmax codes, 32-bit index arithmetic.
+// grid = (ceil(Ho*Wo/4 / 256), Do, N*C)
+__global__ __launch_bounds__(256) void maxpool3d_fwd4_kernel(const PoolArgs a) {
+    const int Wq = a.Wo >> 2;
+    const int pl = blockIdx.x * 256 + threadIdx.x;
+    if (pl >= a.Ho * Wq) return;
+    const int zo = blockIdx.y, nc = blockIdx.z;
+    const int n = nc / a.C, c = nc - n * a.C;
+    const int yo = pl / Wq, xq = pl - yo * Wq;
+    const unsigned S = (unsigned)(a.D * a.H * a.W), So = (unsigned)(a.Do * a.Ho * a.Wo);
+    const float* __restrict__ xb = a.x + (long long)n * a.x_bs + (long long)c * S;
+    float best[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    unsigned bi[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int dz = 0; dz < 2; ++dz)
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy) {
+            const float* __restrict__ r = xb + (unsigned)(((zo * 2 + dz) * a.H + (yo * 2 + dy)) * a.W + xq * 8);
+            const float4 v0 = *reinterpret_cast<const float4*>(r), v1 = *reinterpret_cast<const float4*>(r + 4);
+            const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int dx = 0; dx < 2; ++dx) {
+                    const float t = v[2 * j + dx];
+                    // first maximum wins (torch semantics); NaN propagates like torch's ">" || isnan
+                    if (t > best[j] || t != t) { best[j] = t; bi[j] = dz * 4 + dy * 2 + dx; }
+                }
+        }
+    const unsigned o = (unsigned)((zo * a.Ho + yo) * a.Wo + xq * 4);
+    *reinterpret_cast<float4*>(a.y + (long long)n * a.y_bs + (long long)c * So + o) =
+        make_float4(best[0], best[1], best[2], best[3]);
+    if (a.idx)
+        *reinterpret_cast<unsigned*>(a.idx + (long long)nc * So + o) = bi[0] | (bi[1] << 8) | (bi[2] << 16) | (bi[3] << 24);
+}
+
+__global__ __launch_bounds__(256) void maxpool3d_bwd4_kernel(const PoolBwdArgs a) {
+    const int Wq = a.Wo >> 2;
+    const int pl = blockIdx.x * 256 + threadIdx.x;
+    if (pl >= a.Ho * Wq) return;
+    const int zo = blockIdx.y, nc = blockIdx.z;
+    const int n = nc / a.C, c = nc - n * a.C;
+    const int yo = pl / Wq, xq = pl - yo * Wq;
+    const unsigned S = (unsigned)(a.D * a.H * a.W), So = (unsigned)(a.Do * a.Ho * a.Wo);
+    const unsigned o = (unsigned)((zo * a.Ho + yo) * a.Wo + xq * 4);
+    const float4 d4 = *reinterpret_cast<const float4*>(a.dy + (long long)n * a.dy_bs + (long long)c * So + o);
+    const unsigned code = *reinterpret_cast<const unsigned*>(a.idx + (long long)nc * So + o);
+    const float d[4] = {d4.x, d4.y, d4.z, d4.w};
+    float* __restrict__ dxb = a.dx + (long long)n * a.dx_bs + (long long)c * S;
+#pragma unroll
+    for (int dz = 0; dz < 2; ++dz)
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy) {
+            float g[8];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const unsigned bi = (code >> (8 * j)) & 0xff;
+                g[2 * j] = bi == (unsigned)(dz * 4 + dy * 2) ? d[j] : 0.f;
+                g[2 * j + 1] = bi == (unsigned)(dz * 4 + dy * 2 + 1) ? d[j] : 0.f;
+            }
+            float* r = dxb + (unsigned)(((zo * 2 + dz) * a.H + (yo * 2 + dy)) * a.W + xq * 8);
+            if (a.accumulate) {
+                const float4 o0 = *reinterpret_cast<const float4*>(r), o1 = *reinterpret_cast<const float4*>(r + 4);
+                g[0] += o0.x; g[1] += o0.y; g[2] += o0.z; g[3] += o0.w; g[4] += o1.x; g[5] += o1.y; g[6] += o1.z; g[7] += o1.w;
+            }
+            *reinterpret_cast<float4*>(r) = make_float4(g[0], g[1], g[2], g[3]);
+            *reinterpret_cast<float4*>(r + 4) = make_float4(g[4], g[5], g[6], g[7]);
+        }
+}
+
 // ---- linear 2x up-sampling ----
 // source coordinate of output index o (torch's area_pixel_compute_source_index)
 __device__ __forceinline__ void src_index(int o, int in, int out, int align, int& i0, int& i1, float& l1) {
@@ -575,7 +648,12 @@ extern "C" int mis_maxpool2_fwd(const float* x, long long x_bs, float* y, long l
     PoolArgs a{x, x_bs, y, y_bs, idx, N, C, D, H, W, D > 1 ? D / 2 : 1, H / 2, W / 2, D > 1 ? 2 : 1};
     if (y_bs < (long long)C * a.Do * a.Ho * a.Wo || x_bs < (long long)C * D * H * W) return MIS_ERR_ARG;
     if (!grid_ok(a.Do, (long long)N * C)) return MIS_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(maxpool_fwd_kernel, dim3((a.Ho * a.Wo + 255) / 256, a.Do, N * C), dim3(256), 0, stream, a);
+    const long long S = (long long)D * H * W;
+    if (D > 1 && D % 2 == 0 && H % 2 == 0 && W % 8 == 0 && S < (1LL << 31) && !(x_bs & 3) && !(y_bs & 3) &&
+        !((uintptr_t)x & 15) && !((uintptr_t)y & 15) && (!idx || !((uintptr_t)idx & 3)))
+        hipLaunchKernelGGL(maxpool3d_fwd4_kernel, dim3((a.Ho * (a.Wo / 4) + 255) / 256, a.Do, N * C), dim3(256), 0, stream, a);
+    else
+        hipLaunchKernelGGL(maxpool_fwd_kernel, dim3((a.Ho * a.Wo + 255) / 256, a.Do, N * C), dim3(256), 0, stream, a);
     return mis_launch_status();
 }
 
@@ -587,7 +665,12 @@ extern "C" int mis_maxpool2_bwd(const float* dy, long long dy_bs, const unsigned
     PoolBwdArgs a{dy, dy_bs, idx, dx, dx_bs, N, C, D, H, W, D > 1 ? D / 2 : 1, H / 2, W / 2, D > 1 ? 2 : 1,
                   accumulate};
     if (!grid_ok(D, (long long)N * C)) return MIS_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3((H * (W / 2) + 255) / 256, D, N * C), dim3(256), 0, stream, a);
+    const long long S = (long long)D * H * W;
+    if (D > 1 && D % 2 == 0 && H % 2 == 0 && W % 8 == 0 && S < (1LL << 31) && !(dx_bs & 3) && !(dy_bs & 3) &&
+        !((uintptr_t)dx & 15) && !((uintptr_t)dy & 15) && !((uintptr_t)idx & 3))
+        hipLaunchKernelGGL(maxpool3d_bwd4_kernel, dim3((a.Ho * (a.Wo / 4) + 255) / 256, a.Do, N * C), dim3(256), 0, stream, a);
+    else
+        hipLaunchKernelGGL(maxpool_bwd_kernel, dim3((H * (W / 2) + 255) / 256, D, N * C), dim3(256), 0, stream, a);
     return mis_launch_status();
 }
 

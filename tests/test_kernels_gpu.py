@@ -281,7 +281,8 @@ def test_norm_act_dropout_mask_injected_and_philox():
     assert not torch.equal(a2, a3)
 
 
-@pytest.mark.parametrize("shape", [(2, 8, 1, 32, 32), (2, 4, 8, 16, 16)])
+@pytest.mark.parametrize("shape", [(2, 8, 1, 32, 32), (2, 4, 8, 16, 16), (1, 3, 4, 8, 24), (1, 2, 6, 12, 12),
+                                   (2, 2, 4, 4, 8)])
 def test_maxpool(shape):
     ops = _ops()
     x = _rand(*shape, seed=12)
@@ -300,6 +301,27 @@ def test_maxpool(shape):
     assert torch.equal(dx.cpu(), x.grad)
     ops.maxpool2_bwd(dy.cuda(), idx, dx, accumulate=True)
     assert torch.equal(dx.cpu(), 2 * x.grad)
+
+
+def test_maxpool3d_ties_and_strided_views():
+    """First maximum of a window wins (torch semantics) also in the 4-outputs-per-thread kernels; inputs / outputs may be
+    channel slices of a wider buffer; accumulate adds to what is there."""
+    ops = _ops()
+    x = torch.zeros(1, 2, 4, 4, 16)                     # all ties
+    x[0, 1, 0, 1, 3] = 1.0
+    x.requires_grad_(True)
+    y_ref = F.max_pool3d(x, 2)
+    dy = _rand(*y_ref.shape, seed=41)
+    y_ref.backward(dy)
+    wide = torch.zeros(1, 5, 4, 4, 16, device="cuda")
+    wide[:, 2:4] = x.detach().cuda()
+    ywide = torch.zeros(1, 3, 2, 2, 8, device="cuda")
+    idx = torch.empty(y_ref.numel(), dtype=torch.uint8, device="cuda")
+    ops.maxpool2_fwd(wide[:, 2:4], ywide[:, 1:3], idx)
+    assert torch.equal(ywide[:, 1:3].cpu(), y_ref.detach()) and float(ywide[:, 0].abs().max()) == 0.0
+    dxw = torch.ones(1, 5, 4, 4, 16, device="cuda")
+    ops.maxpool2_bwd(dy.cuda(), idx, dxw[:, 2:4], accumulate=True)
+    assert torch.equal(dxw[:, 2:4].cpu(), 1.0 + x.grad) and float((dxw[:, :2] - 1).abs().max()) == 0.0
 
 
 @pytest.mark.parametrize("shape,align", [((2, 8, 1, 16, 16), True), ((1, 4, 1, 8, 24), True),
