@@ -316,3 +316,47 @@ def test_unetr_oracle_runs_and_has_the_documented_keys():
     y = o.forward(sd, torch.rand(1, 1, 32, 32, 32, generator=g), training=False)
     assert y.shape == (1, 2, 32, 32, 32) and torch.isfinite(y).all()
     assert sum(v.numel() for v in OracleUNETR(2).new_state().values()) > 90e6     # the 96^3 network: ~92.8 M parameters
+
+
+def _brute_surface(mask):
+    """Surface voxels by definition: object voxels with at least one face neighbour outside the object (or the volume)."""
+    m = np.pad(mask, 1)
+    inner = np.ones_like(m)
+    for ax in range(m.ndim):
+        inner &= np.roll(m, 1, ax) & np.roll(m, -1, ax)
+    return (m & ~inner)[tuple(slice(1, -1) for _ in range(m.ndim))]
+
+
+@pytest.mark.parametrize("shape,spacing,seed", [((12, 14), None, 0), ((9, 10, 11), None, 1), ((8, 9, 10), (1.0, 0.5, 2.0), 2),
+                                                ((16, 16), (0.7, 1.3), 3)])
+def test_surface_metrics_against_brute_force(shape, spacing, seed):
+    """hd95 / asd of utils/metrics.py (medpy's published algorithm: erosion surfaces + Euclidean distance transform)
+    against an independent brute-force evaluation of the definition (explicit surface voxels, all pairwise distances)
+    on random blobs.  medpy itself is not installed: this is the strongest pin available for these metrics here."""
+    from utils import metrics
+    rng = np.random.default_rng(seed)
+
+    def blob():
+        z = rng.random(shape)
+        for ax in range(len(shape)):          # smooth a little so that the objects have interiors
+            z = (z + np.roll(z, 1, ax) + np.roll(z, -1, ax)) / 3
+        m = z > np.quantile(z, 0.6)
+        m[tuple(s // 2 for s in shape)] = True
+        return m
+
+    a, b = blob(), blob()
+    sp = np.ones(len(shape)) if spacing is None else np.asarray(spacing)
+
+    def directed(x, y):
+        sx, sy = np.argwhere(_brute_surface(x)) * sp, np.argwhere(_brute_surface(y)) * sp
+        d = np.sqrt(((sx[:, None, :] - sy[None, :, :]) ** 2).sum(-1))
+        return d.min(1)
+
+    d_ab, d_ba = directed(a, b), directed(b, a)
+    np.testing.assert_allclose(metrics.hd95(a, b, voxelspacing=spacing), np.percentile(np.hstack((d_ab, d_ba)), 95),
+                               rtol=0, atol=1e-9)
+    np.testing.assert_allclose(metrics.asd(a, b, voxelspacing=spacing), d_ab.mean(), rtol=0, atol=1e-9)
+    np.testing.assert_allclose(metrics.asd(b, a, voxelspacing=spacing), d_ba.mean(), rtol=0, atol=1e-9)
+    inter = np.count_nonzero(a & b)
+    assert abs(metrics.dc(a, b) - 2.0 * inter / (a.sum() + b.sum())) < 1e-12
+    assert abs(metrics.ravd(a, b) - (a.sum() - b.sum()) / b.sum()) < 1e-12
