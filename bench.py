@@ -59,6 +59,12 @@ WORKLOADS = {
                           "passes (SURVEY s.8 row n1; BASELINE configs[2] geometry)",
                    shape=(8, 1, 96, 96, 96), labeled=4, classes=2, cons_start=0, label="int64",
                    cpu_sample=None, step_gflop=121.98 * (28 + 32)),
+    # UNETR forward: ViT 12 x (qkv + proj + MLP) on 216 tokens 18.3 GMAC + attention core 0.9 + patch embedding 0.7,
+    # conv decoder / encoders (MONAI res blocks, k2s2 transposed convs) 52.9 GMAC -> 145.6 GFLOP per 96^3 volume
+    "unetr": dict(config="Mean-Teacher UNETR (--model unetr), synthetic BraTS 96x96x96 2-class, bs=4+4 (SURVEY s.8 row "
+                         "n4; BASELINE configs[2] geometry; parity unpinned: MONAI-based in the reference)",
+                  shape=(8, 1, 96, 96, 96), labeled=4, classes=2, cons_start=0, label="int64",
+                  cpu_sample=None, step_gflop=145.6 * 28),
     "swin": dict(config="Mean-Teacher ViT (SwinUNet 2D), synthetic ACDC 224x224 4-class, bs=24+24 "
                         "(BASELINE configs[3])",
                  shape=(48, 1, 224, 224), labeled=24, classes=4, cons_start=1000, label="uint8",
@@ -79,7 +85,7 @@ WORKLOADS = {
                    cpu_sample=None, step_gflop=(4.52 + 12.17) * 48 + 12.17 * 8),
 }
 OTHERS = ("unet2d", "swin", "cross", "vnet")     # reported under "others" beside the default workload (N=1)
-UNIT = {"unet3d": "volumes/s", "vnet": "volumes/s", "uamt3d": "volumes/s"}
+UNIT = {"unet3d": "volumes/s", "vnet": "volumes/s", "uamt3d": "volumes/s", "unetr": "volumes/s"}
 
 
 # ------------------------------------------------------------------------------------------------ launcher
@@ -128,7 +134,7 @@ def build_trainer(name, wl, world, stub=False):
         ema.load_state_dict(model.state_dict())
     else:
         from networks.net_factory_3d import net_factory_3d
-        key = "vnet" if name == "vnet" else "unet_3D"
+        key = {"vnet": "vnet", "unetr": "unetr"}.get(name, "unet_3D")
         model, ema = net_factory_3d(key, 1, C), net_factory_3d(key, 1, C)
         ema.load_state_dict(model.state_dict())
     if world > 1:   # identical initial weights on every rank

@@ -9,9 +9,10 @@
 // restatement of the published algorithm only (oracle/unetr.py, "parity unpinned").
 //
 // N <= 256 tokens, head_dim 64, fp32 on the vector pipe (the whole encoder's attention is 14 GFLOP per step
-// against 3.4 TFLOP of convolutions: HBM / latency matter here, not MFMA).  One 256-thread workgroup per
-// (sample, head); K and V of that head live in LDS (rows padded to 68 floats: 16-byte aligned, conflict-free
-// ds_read_b128 across consecutive rows).  A wave owns query rows i = wave, wave + 4, ...:
+// against 3.4 TFLOP of convolutions: HBM / latency matter here, not MFMA).  One 512-thread workgroup per
+// (sample, head, chunk of query rows) -- B * nH alone is 48 .. 96 workgroups for 256 CUs, so the rows are split until
+// the launch holds >= 512 of them; K and V of that head live in LDS (rows padded to 68 floats: 16-byte aligned, conflict-free
+// ds_read_b128 across consecutive rows).  A wave owns query rows i = wave, wave + 8, ... of its chunk:
 //   scores   lane j (4 passes of 64 keys): s_j = sum_d q_i[d] K[j][d]   q_i[d] broadcast by v_readlane (no LDS)
 //   softmax  wave reductions; row statistics (max, sum) are kept for the backward
 //   output   lane d: o[d] = sum_j p_j V[j][d]                           p_j broadcast by v_readlane
@@ -24,13 +25,13 @@
 
 namespace {
 
-constexpr int HD = 64, LDR = 68, MAXN = 256, PASSES = MAXN / 64;
+constexpr int HD = 64, LDR = 68, MAXN = 256, PASSES = MAXN / 64, NT = 512, NW = NT / 64;
 
 struct FullAttnArgs {
     const float* qkv; long long ldq;     // [B*N][3*nH*64]
     float* out; long long ldo;           // [B*N][nH*64]
     float* stats;                        // [B*nH][N][2] (row max, row sum of exp)
-    int B, N, nH;
+    int B, N, nH, rows;                  // rows: query rows per workgroup (blockIdx.y = chunk)
     float scale;
 };
 
@@ -40,7 +41,7 @@ struct FullAttnBwdArgs {
     float* dqkv; long long lddq;
     const float* stats;                  // from the forward
     float* delta;                        // [B*nH][N] workspace (written by pass Q, read by pass K)
-    int B, N, nH;
+    int B, N, nH, rows;
     float scale;
 };
 
@@ -58,27 +59,37 @@ __device__ __forceinline__ float dot_bcast(const float* __restrict__ row, float 
     return acc;
 }
 
-// lane d: sum over the rows j < N of w_j * M[j][d], the weights w held one per lane in PASSES registers
+// lane d: sum over the rows j < N of w_j * M[j][d], the weights w held one per lane in PASSES registers.
+// Groups of 8 rows: the 8 ds_reads are issued together (a rolled loop pays one LDS round trip per row).
 __device__ __forceinline__ float wsum_rows(const float* __restrict__ M, const float (&w)[PASSES], int N, int lane) {
-    float acc = 0.f;
+    float acc0 = 0.f, acc1 = 0.f;
 #pragma unroll
     for (int p = 0; p < PASSES; ++p) {
         if (p * 64 >= N) break;                          // uniform
         const int cnt = N - p * 64 < 64 ? N - p * 64 : 64;
-
-        for (int jj = 0; jj < 64; ++jj) {
-            if (jj >= cnt) break;                        // uniform
-            const float wj = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, w[p]), jj));
-            acc = fmaf(wj, M[(p * 64 + jj) * LDR + lane], acc);
+        const float* __restrict__ Mp = M + p * 64 * LDR + lane;
+        const int wbits = __builtin_bit_cast(int, w[p]);
+        int jj = 0;
+        for (; jj + 8 <= cnt; jj += 8) {
+            float m[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) m[u] = Mp[(jj + u) * LDR];
+#pragma unroll
+            for (int u = 0; u < 8; u += 2) {
+                acc0 = fmaf(__builtin_bit_cast(float, __builtin_amdgcn_readlane(wbits, jj + u)), m[u], acc0);
+                acc1 = fmaf(__builtin_bit_cast(float, __builtin_amdgcn_readlane(wbits, jj + u + 1)), m[u + 1], acc1);
+            }
         }
+        for (; jj < cnt; ++jj)
+            acc0 = fmaf(__builtin_bit_cast(float, __builtin_amdgcn_readlane(wbits, jj)), Mp[jj * LDR], acc0);
     }
-    return acc;
+    return acc0 + acc1;
 }
 
 // stage rows [N][64] of one head (column offset `col`) into LDS [N][LDR], optionally scaled
 __device__ __forceinline__ void stage_rows(const float* __restrict__ base, long long ld, int col, int N, float scale,
                                            float* __restrict__ dst) {
-    for (int e = threadIdx.x; e < N * (HD / 4); e += 256) {
+    for (int e = threadIdx.x; e < N * (HD / 4); e += NT) {
         const int r = e / (HD / 4), q = e - r * (HD / 4);
         float4 v = *reinterpret_cast<const float4*>(base + (long long)r * ld + col + q * 4);
         v.x *= scale; v.y *= scale; v.z *= scale; v.w *= scale;
@@ -88,7 +99,7 @@ __device__ __forceinline__ void stage_rows(const float* __restrict__ base, long 
 
 extern __shared__ __attribute__((aligned(16))) float mis_fattn_lds[];
 
-__global__ __launch_bounds__(256) void full_attn_fwd_kernel(const FullAttnArgs a) {
+__global__ __launch_bounds__(NT) void full_attn_fwd_kernel(const FullAttnArgs a) {
     float* const sk = mis_fattn_lds;
     float* const sv = sk + a.N * LDR;
     const int bh = blockIdx.x, b = bh / a.nH, h = bh - b * a.nH;
@@ -97,7 +108,8 @@ __global__ __launch_bounds__(256) void full_attn_fwd_kernel(const FullAttnArgs a
     stage_rows(base, a.ldq, C + h * HD, a.N, 1.f, sk);
     stage_rows(base, a.ldq, 2 * C + h * HD, a.N, 1.f, sv);
     __syncthreads();
-    for (int i = wave; i < a.N; i += 4) {
+    const int i0 = blockIdx.y * a.rows, i1 = i0 + a.rows < a.N ? i0 + a.rows : a.N;
+    for (int i = i0 + wave; i < i1; i += NW) {
         const float q = base[(long long)i * a.ldq + h * HD + lane] * a.scale;
         float s[PASSES], mx = -INFINITY;
 #pragma unroll
@@ -130,7 +142,7 @@ __global__ __launch_bounds__(256) void full_attn_fwd_kernel(const FullAttnArgs a
 // pass Q (KEYS == false): rows = queries, LDS = K, V; writes dQ and delta.
 // pass K (KEYS == true):  rows = keys,    LDS = scale*Q, dO; writes dK and dV.
 template <bool KEYS>
-__global__ __launch_bounds__(256) void full_attn_bwd_kernel(const FullAttnBwdArgs a) {
+__global__ __launch_bounds__(NT) void full_attn_bwd_kernel(const FullAttnBwdArgs a) {
     float* const s0 = mis_fattn_lds;               // K      | scale * Q
     float* const s1 = s0 + a.N * LDR;              // V      | dO
     const int bh = blockIdx.x, b = bh / a.nH, h = bh - b * a.nH;
@@ -147,7 +159,8 @@ __global__ __launch_bounds__(256) void full_attn_bwd_kernel(const FullAttnBwdArg
         stage_rows(dob, a.ldo, h * HD, a.N, 1.f, s1);
     }
     __syncthreads();
-    for (int i = wave; i < a.N; i += 4) {
+    const int i0 = blockIdx.y * a.rows, i1 = i0 + a.rows < a.N ? i0 + a.rows : a.N;
+    for (int i = i0 + wave; i < i1; i += NW) {
         // this row's two vectors, one element per lane
         float u, w;
         if (!KEYS) {
@@ -210,6 +223,15 @@ int check(const void* qkv, long long ldq, int B, int N, int nH) {
     return MIS_OK;
 }
 
+// rows per workgroup: enough chunks that the launch is >= 2 workgroups per CU (B * nH alone is 48 .. 96 here)
+int rows_per_wg(int B, int N, int nH) {
+    int chunks = (512 + B * nH - 1) / (B * nH);
+    if (chunks < 1) chunks = 1;
+    int rows = (N + chunks - 1) / chunks;
+    rows = (rows + NW - 1) / NW * NW;
+    return rows;
+}
+
 template <int ID, class K>       // ID: one attribute record per kernel (the two backward kernels share a type)
 int set_lds(K kernel, int bytes) {
     static std::atomic<unsigned long long> done{0};
@@ -224,10 +246,10 @@ extern "C" int mis_full_attention_fwd(const float* qkv, long long ldq, float* ou
     int st = check(qkv, ldq, B, N, nH);
     if (st) return st;
     if (!out || !stats || ldo < (long long)nH * HD || ((uintptr_t)stats & 7)) return MIS_ERR_ARG;
-    FullAttnArgs a{qkv, ldq, out, ldo, stats, B, N, nH, scale};
+    FullAttnArgs a{qkv, ldq, out, ldo, stats, B, N, nH, rows_per_wg(B, N, nH), scale};
     const int lds = 2 * N * LDR * 4;
     if (set_lds<0>(full_attn_fwd_kernel, lds) != MIS_OK) return MIS_ERR_LAUNCH;
-    hipLaunchKernelGGL(full_attn_fwd_kernel, dim3(B * nH), dim3(256), lds, stream, a);
+    hipLaunchKernelGGL(full_attn_fwd_kernel, dim3(B * nH, (N + a.rows - 1) / a.rows), dim3(NT), lds, stream, a);
     return mis_launch_status();
 }
 
@@ -245,11 +267,13 @@ extern "C" int mis_full_attention_bwd(const float* qkv, long long ldq, const flo
     if (!dout || !dqkv || !stats || !workspace || ldo < (long long)nH * HD || lddq < 3LL * nH * HD) return MIS_ERR_ARG;
     if (ldo % 4 || ((uintptr_t)dout & 15)) return MIS_ERR_UNSUPPORTED;
     if (workspace_bytes < mis_full_attention_workspace_bytes(B, N, nH)) return MIS_ERR_WORKSPACE;
-    FullAttnBwdArgs a{qkv, ldq, dout, ldo, dqkv, lddq, stats, reinterpret_cast<float*>(workspace), B, N, nH, scale};
+    FullAttnBwdArgs a{qkv, ldq, dout, ldo, dqkv, lddq, stats, reinterpret_cast<float*>(workspace), B, N, nH,
+                      rows_per_wg(B, N, nH), scale};
     const int lds = 2 * N * LDR * 4;
     if (set_lds<1>(full_attn_bwd_kernel<false>, lds) != MIS_OK || set_lds<2>(full_attn_bwd_kernel<true>, lds) != MIS_OK)
         return MIS_ERR_LAUNCH;
-    hipLaunchKernelGGL(full_attn_bwd_kernel<false>, dim3(B * nH), dim3(256), lds, stream, a);
-    hipLaunchKernelGGL(full_attn_bwd_kernel<true>, dim3(B * nH), dim3(256), lds, stream, a);
+    const dim3 grid(B * nH, (N + a.rows - 1) / a.rows);
+    hipLaunchKernelGGL(full_attn_bwd_kernel<false>, grid, dim3(NT), lds, stream, a);
+    hipLaunchKernelGGL(full_attn_bwd_kernel<true>, grid, dim3(NT), lds, stream, a);
     return mis_launch_status();
 }

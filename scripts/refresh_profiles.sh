@@ -10,7 +10,7 @@ out=gpurun_out/$tag
 mkdir -p "$out"
 export TMPDIR=/tmp
 python bench.py > "$out/bench_default.json" 2> "$out/bench_default.err"
-for w in unet2d vnet uamt3d swin cross cross224 cnnvit; do
+for w in unet2d vnet uamt3d swin cross cross224 cnnvit unetr; do
     python bench.py --workload $w --no-cpu-baseline > "$out/bench_$w.json" 2> "$out/bench_$w.err"
 done
 python bench.py --overlap-teacher --no-cpu-baseline --no-others > "$out/bench_unet3d_overlap.json" 2> "$out/bench_unet3d_overlap.err"
