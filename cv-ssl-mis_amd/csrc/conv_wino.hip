@@ -1,0 +1,537 @@
+// Winograd F(2x2x2, 3x3x3) convolution forward (and, with the flipped / transposed transformed filter, the data
+// gradient) for the stride-1 'same' 3x3x3 convolutions of unet_3D / V-Net.
+//
+// Replaces: nn.Conv3d(k=3, pad=1) of the reference's UnetConv3 / UnetUp3_CT / ConvBlock
+//           (code/networks/utils.py:99-123, code/networks/unet_3D.py:28-57, code/networks/vnet.py:15-22).
+//
+// Why: the direct kernel (conv_fwd.hip) runs the fp32 matrix pipe at 0.77 of its 157 TF peak and the step is bound by
+// it.  The minimal-filtering form needs 64 multiplies per 2x2x2 outputs instead of 216 (3.375x fewer MFMA flops); the
+// arithmetic stays fp32 end to end (the transforms only add / subtract inputs and outputs; the filter transform has
+// the factors 1/2), so the result differs from the direct form by fp32 rounding only (tests: tolerance vs fp64).
+//
+//   Y = A^T [ sum_ci (G g G^T) (.) (B^T d B) ] A      per dimension:
+//   B^T d = (d0 - d2, d1 + d2, d2 - d1, d1 - d3)      input tile of 4 (2 outputs + halo)
+//   G g   = (g0, (g0 + g1 + g2) / 2, (g0 - g1 + g2) / 2, g2)
+//   A^T m = (m0 + m1 + m2, m1 - m2 - m3)
+//
+// Mapping (gfx950): a wave owns a GROUP of 16 output tiles (2x2x2 voxels each) x 16 output channels.  For each of the
+// 64 transform points xi one v_mfma_f32_16x16x4_f32 per 4 input channels contracts
+//   A[i = lane&15][k = lane>>4] = W_xi[co0 + i][ci0 + k]      (LDS, transformed once per step by mis_wino_pack)
+//   B[k = lane>>4][j = lane&15] = U_xi[ci0 + k][tile j]       (registers: the lane transforms its own 4x4x4 patch)
+//   D[row = (lane>>4)*4 + r][col = lane&15]                   -> 64 x 4 accumulator registers (AGPRs)
+// so a lane holds all 64 points of 4 (channel, tile) outputs and inverse-transforms them in registers.  The wave runs
+// alone on its SIMD (512 registers); the transform of input-channel chunk s+1 (192 adds) is issued between the 64
+// MFMAs of chunk s.  Chunks of 4 input channels (haloed box of the workgroup + the 64 x 16 x 4 filter points of each
+// 16-channel block) arrive by LDS-DMA into a ring of NBUF stage buffers, issued NBUF-1 chunks ahead; one barrier per
+// chunk.
+#include "common.h"
+#include <stdio.h>
+#include <stdlib.h>
+#include <type_traits>
+
+namespace {
+
+using namespace mis_dma;
+
+struct WinoArgs {
+    const float* x; long long x_bs;
+    const float* wt;      // [co_blocks][Cin_pad/4][16][64 lanes][4]  (mis_wino_pack)
+    const float* bias;    // [Cout] or nullptr
+    float* y; long long y_bs;
+    int N, Cin, Cout, D, H, W;
+    int nci4;             // input-channel chunks (Cin_pad / 4)
+    int boxes_z, boxes_y, boxes_x, co_groups;
+    unsigned n_blocks, n_blocks_padded;
+    float2* stat; long long stat_sc, stat_sn;
+};
+
+// group = GZ x GY x GX tiles (16) per wave; workgroup = WZ x WY x WX groups x COB blocks of 16 output channels (4 waves)
+template <int GZ_, int GY_, int GX_, int WZ_, int WY_, int WX_, int COB_, int NBUF_>
+struct WinoCfg {
+    static constexpr int GZ = GZ_, GY = GY_, GX = GX_, WZ = WZ_, WY = WY_, WX = WX_, COB = COB_, NBUF = NBUF_;
+    static constexpr int BZ = GZ * WZ, BY = GY * WY, BX = GX * WX;          // tiles per box
+    static constexpr int OZ = 2 * BZ, OY = 2 * BY, OX = 2 * BX;             // output voxels per box
+    static constexpr int HZ = OZ + 2, HY = OY + 2;
+    // LDS rows hold x in [x0 - 4, x0 + OX + 4): whole 16-byte groups of the image row (W % 4 == 0), so a row arrives as
+    // NQ buffer_load_dwordx4 ... lds lanes; the halo column x0 - 1 sits at float 3 of the row
+    static constexpr int NQ = (OX + 8) / 4, RX = NQ * 4;
+    static constexpr int GROUPS = HZ * HY * NQ;                              // 16-byte groups per channel
+    static constexpr int NCH = (GROUPS + 63) / 64;                           // DMA instructions per channel
+    static constexpr int CS = GROUPS * 4 + (32 - (GROUPS * 4) % 64 + 64) % 64;  // channel stride (floats), == 32 (mod 64)
+    static constexpr int IN_FLOATS = 4 * CS;
+    static constexpr int W_FLOATS = COB * 4096;
+    static constexpr int STAGE = IN_FLOATS + W_FLOATS;
+    static constexpr int MAX_COUT = 384;
+    static constexpr int LDS_BYTES = NBUF * STAGE * 4 + 512 + MAX_COUT * 4 + NCH * 256;   // + statistics scratch, bias, DMA geometry
+    static constexpr int WPW = COB * 4;                                     // 1 KiB filter pieces per wave
+    static constexpr int P = NCH + WPW;                                     // DMA instructions per wave and stage
+    static_assert(CS % 64 == 32 && CS % 4 == 0, "channel stride == 32 (mod 64)");
+    static_assert(GZ * GY * GX == 16, "16 tiles per wave");
+    static_assert(WZ * WY * WX * COB == 4, "4 waves");
+    static_assert(NBUF == 3 || NBUF == 4, "ring depth");
+    static_assert(P <= 63, "vmcnt range");
+    static_assert(LDS_BYTES <= 160 * 1024, "LDS");
+};
+
+#ifndef MIS_WINO_DBG_CT
+#define MIS_WINO_DBG_CT 0
+#endif
+constexpr int DBG = MIS_WINO_DBG_CT;     // development builds: 1 no stores, 2 no epilogue, 4 no cursor recompute
+
+extern __shared__ __attribute__((aligned(16))) float mis_wino_lds[];
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// Packed fp32 adds on register pairs, written as asm: hipcc scalarises <2 x float> arithmetic whose results are read
+// one half at a time (the MFMA operands), and it sinks a C++ transform of chunk s+1 into the next iteration, in front
+// of the MFMAs that consume it.  Volatile asm keeps the program order of the slots below.
+__device__ __forceinline__ f32x2 pk_add(f32x2 a, f32x2 b) {
+    f32x2 r; asm volatile("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r;
+}
+__device__ __forceinline__ f32x2 pk_sub(f32x2 a, f32x2 b) {
+    f32x2 r; asm volatile("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b)); return r;
+}
+// rows 2h, 2h+1 of an accumulator tile, read from its AGPRs at this point of the program
+__device__ __forceinline__ f32x2 acc_pair(const f32x4& q, int h) {
+    float lo, hi;
+    asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(lo) : "a"(q[2 * h]));
+    asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(hi) : "a"(q[2 * h + 1]));
+    return f32x2{lo, hi};
+}
+// B^T d = (d0 - d2, d1 + d2, d2 - d1, d1 - d3) on four pairs (elementwise)
+__device__ __forceinline__ void bt4(f32x2& a, f32x2& b, f32x2& c, f32x2& d) {
+    const f32x2 t0 = pk_sub(a, c), t3 = pk_sub(b, d), t1 = pk_add(b, c), t2 = pk_sub(c, b);
+    a = t0; b = t1; c = t2; d = t3;
+}
+// ... and inside two pairs p0 = (d0, d1), p1 = (d2, d3): op_sel picks the halves
+__device__ __forceinline__ void bt4_inner(f32x2& p0, f32x2& p1) {
+    f32x2 q0, q1;
+    asm volatile("v_pk_add_f32 %0, %1, %2 op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(q0) : "v"(p0), "v"(p1));            // (d0 - d2, d1 + d2)
+    asm volatile("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[1,0]" : "=v"(q1) : "v"(p1), "v"(p0));  // (d2 - d1, d1 - d3)
+    p0 = q0; p1 = q1;
+}
+
+// The 4x4x4 patch of a lane lives in 32 register pairs u[(z*4 + y)*2 + x/2] = (x even, x odd) -- what one ds_read2_b32
+// of two neighbouring floats delivers.  Every pass is packed adds (v_pk_add_f32), 96 instructions instead of 192.
+// 24 units of 4 instructions: 0..7 x pass of two (z, y) rows, 8..15 y pass of (z, x pair), 16..23 z pass of (y, x pair).
+template <int U>
+__device__ __forceinline__ void in_unit(f32x2 (&u)[32]) {
+    if constexpr (U < 8) {
+        bt4_inner(u[U * 4], u[U * 4 + 1]);
+        bt4_inner(u[U * 4 + 2], u[U * 4 + 3]);
+    } else if constexpr (U < 16) {
+        constexpr int z = (U - 8) / 2, xp = (U - 8) % 2, b = z * 8 + xp;
+        bt4(u[b], u[b + 2], u[b + 4], u[b + 6]);
+    } else if constexpr (U < 24) {
+        constexpr int j = U - 16;            // (y, x pair)
+        bt4(u[j], u[8 + j], u[16 + j], u[24 + j]);
+    }
+}
+
+template <int T, int END>
+__device__ __forceinline__ void in_units(f32x2 (&u)[32]) {
+    if constexpr (T < END) { in_unit<T>(u); in_units<T + 1, END>(u); }
+}
+
+// dma_dwordx4 with the uniform part of the address in the instruction's scalar offset (no per-lane add)
+__device__ __forceinline__ void dma_dwordx4_s(unsigned lds_byte, unsigned voff, unsigned soff, i32x4 rsrc) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\t"
+                 "buffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "s"(lds_byte), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+}
+
+template <int N> struct vmwait { static __device__ __forceinline__ void go() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); } };
+
+// Everything a wave needs to issue the DMAs of one (box, chunk) stage.  voff / wvoff are per lane, the rest is uniform.
+template <class C>
+struct Issue {
+    unsigned voff[C::NCH];      // this lane's 16-byte group of piece p (byte offset in the image, OOB = padding)
+    unsigned wvoff[C::WPW];     // filter piece, relative to the (channel group, chunk) base
+    i32x4 rx, rw;
+    unsigned st;                // LDS byte address of the stage buffer being filled
+    unsigned cbase;             // byte offset of this wave's input channel of the chunk
+    unsigned wbase;             // byte offset of the (channel group, chunk) filter block
+
+    template <int I>
+    __device__ __forceinline__ void piece(int wave) const {
+        if constexpr (I >= 0 && I < C::NCH) {
+            if (I * 64 + 64 <= C::GROUPS || I * 64 + (int)(threadIdx.x & 63) < C::GROUPS)   // ragged last piece
+                dma_dwordx4_s(st + (unsigned)(wave * C::CS + I * 256) * 4u, voff[I], cbase, rx);
+        } else if constexpr (I >= C::NCH && I < C::P) {
+            dma_dwordx4_s(st + (unsigned)(C::IN_FLOATS + (wave + 4 * (I - C::NCH)) * 256) * 4u, wvoff[I - C::NCH], wbase, rw);
+        }
+    }
+    template <int I, int END>
+    __device__ __forceinline__ void pieces(int wave) const {
+        if constexpr (I < END) { piece<I>(wave); pieces<I + 1, END>(wave); }
+    }
+};
+
+// One chunk = 64 slots, one MFMA each (transform point xi = K of `cur`), in program order (a scheduling barrier closes
+// every slot: a wave alone on its SIMD issues one instruction per 4 cycles, so at most 7 others fit under an MFMA):
+//   K % 4 == 0   ds_read_b128 of the filter points of group K/4 + 2 (the last two: groups 0, 1 of the next stage)
+//   K < 16       two ds_read2_b32 of the next chunk's patch
+//   2, 7, 12 ..  one DMA of the stage NBUF-1 ahead (spread out: the CU's one texture-address unit serves all 4 waves)
+//   16 .. 39     one unit of the transform of the next chunk
+template <class C, bool FIRST, int K>
+__device__ __forceinline__ void slots(const f32x4* __restrict__ wl, const f32x4* __restrict__ wl_next,
+                                      const float* __restrict__ raw, const f32x2 (&cur)[32], f32x2 (&nxt)[32],
+                                      f32x4 (&acc)[64], f32x4 (&ar)[4], const Issue<C>& is, int wave) {
+    if constexpr (K < 64) {
+        constexpr int G = K / 4;
+        if constexpr (K % 4 == 0 && !(DBG & 32)) ar[(G + 2) % 4] = G < 14 ? wl[(G + 2) * 64] : wl_next[(G - 14) * 64];
+        {
+            const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+            acc[K] = __builtin_amdgcn_mfma_f32_16x16x4f32(ar[G % 4][K % 4], cur[K / 2][K % 2],
+                                                          FIRST ? zero : acc[K], 0, 0, 0);
+        }
+        if constexpr (K < 16 && !(DBG & 16)) {
+#pragma unroll
+            for (int j = 2 * K; j < 2 * K + 2; ++j) {
+                const int z = j / 8, y = (j / 2) % 4, xp = j % 2;
+                typedef const __attribute__((address_space(3))) float* lds_ptr;
+                lds_ptr rz = (lds_ptr)raw + z * C::HY * C::RX;       // one base per z plane: ds_read2 offsets < 256 dwords
+                asm volatile("" : "+v"(rz));
+                nxt[j] = f32x2{rz[y * C::RX + 2 * xp], rz[y * C::RX + 2 * xp + 1]};
+            }
+        }
+        if constexpr (K >= 2 && (K - 2) % 5 == 0 && (K - 2) / 5 < C::P && !(DBG & 8)) is.template piece<(K - 2) / 5>(wave);
+        if constexpr (K >= 16 && K < 40 && !(DBG & 16)) in_unit<K - 16>(nxt);
+        __builtin_amdgcn_sched_barrier(0);
+        slots<C, FIRST, K + 1>(wl, wl_next, raw, cur, nxt, acc, ar, is, wave);
+    }
+}
+
+template <class C>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void wino_fwd_kernel(const WinoArgs a) {
+    float* const lds = mis_wino_lds;
+    // persistent: XCD x owns the boxes [x * per, (x + 1) * per); its workgroups walk them 32 apart, so the 32 resident
+    // workgroups of an XCD always work on neighbouring boxes (shared halos and filter points in one L2)
+    const int xcd = blockIdx.x % MIS_NUM_XCD, slot = blockIdx.x / MIS_NUM_XCD, nslot = gridDim.x / MIS_NUM_XCD;
+    const unsigned per = a.n_blocks_padded / MIS_NUM_XCD;
+    const unsigned box_end = (xcd + 1) * per < a.n_blocks ? (xcd + 1) * per : a.n_blocks;
+    unsigned box = xcd * per + slot;
+    if (box >= box_end) return;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lk = lane >> 4, lj = lane & 15;
+    const int cb = wave % C::COB, grp = wave / C::COB;                       // this wave's channel block and group
+    const int gx = grp % C::WX, gy = (grp / C::WX) % C::WY, gz = grp / (C::WX * C::WY);
+    const int tx = gx * C::GX + lj % C::GX, ty = gy * C::GY + (lj / C::GX) % C::GY, tz = gz * C::GZ + lj / (C::GX * C::GY);
+    const long long S = (long long)a.D * a.H * a.W;
+    const unsigned s_bytes = (unsigned)S * 4u;
+    const unsigned lds0 = lds_addr(lds);
+    const int nst = a.nci4;
+
+    struct Box { int cg, n, z0, y0, x0; long long idx; };
+    auto decode = [&](unsigned L) {
+        Box b;
+        unsigned t = L;
+        b.cg = t % a.co_groups; t /= a.co_groups;
+        const int bx = t % a.boxes_x;   t /= a.boxes_x;
+        const int by = t % a.boxes_y;   t /= a.boxes_y;
+        const int bz = t % a.boxes_z;   t /= a.boxes_z;
+        b.n = t; b.z0 = bz * C::OZ; b.y0 = by * C::OY; b.x0 = bx * C::OX;
+        b.idx = ((long long)bz * a.boxes_y + by) * a.boxes_x + bx;
+        return b;
+    };
+
+    // ---- DMA issue cursor: (box, chunk) of the next stage to issue; runs NBUF-1 stages ahead of the compute ----
+    Issue<C> is;
+    is.rw = make_rsrc(a.wt, (unsigned)a.co_groups * C::COB * (unsigned)nst * 16384u);
+#pragma unroll
+    for (int i = 0; i < C::WPW; ++i) {
+        const int j = wave + 4 * i, b = j / 16, pp = j % 16;
+        is.wvoff[i] = (unsigned)((b * nst) * 4096 + pp * 256 + lane * 4) * 4u;
+    }
+    int icg = 0;                 // channel group of the cursor's box
+    // per-lane geometry of the DMA pieces, packed (hz | hy << 4 | q << 9 | valid << 13), kept in LDS: as registers
+    // hipcc spills these box-invariant values to scratch, and a scratch reload waits on vmcnt(0) -- on the DMAs in flight
+    unsigned* const s_geo = reinterpret_cast<unsigned*>(lds + C::NBUF * C::STAGE + 128 + C::MAX_COUT);
+    if (tid < 64) {
+#pragma unroll
+        for (int p = 0; p < C::NCH; ++p) {
+            const int e = p * 64 + tid;
+            const int row = e / C::NQ, q = e - row * C::NQ;
+            const int hz = row / C::HY, hy = row - hz * C::HY;
+            s_geo[p * 64 + tid] = (unsigned)(hz | hy << 4 | q << 9 | (e < C::GROUPS ? 1 << 13 : 0));
+        }
+    }
+    __syncthreads();
+    auto cursor_box = [&](unsigned L) {          // per-lane offsets and descriptors of box L (all OOB past the end)
+        const bool live = L < box_end;
+        const Box b = decode(live ? L : box);
+        icg = b.cg;
+        is.rx = make_rsrc(a.x + (long long)b.n * a.x_bs, live ? (unsigned)a.Cin * s_bytes : 0u);
+#pragma unroll
+        for (int p = 0; p < C::NCH; ++p) {
+            const unsigned g = s_geo[p * 64 + lane];
+            const int qz = b.z0 - 1 + (int)(g & 15u), qy = b.y0 - 1 + (int)((g >> 4) & 31u), qx = b.x0 - 4 + 4 * (int)((g >> 9) & 15u);
+            const bool ok = (g >> 13) && (unsigned)qz < (unsigned)a.D && (unsigned)qy < (unsigned)a.H &&
+                            (unsigned)qx < (unsigned)a.W;
+            is.voff[p] = ok ? (unsigned)((qz * a.H + qy) * a.W + qx) * 4u : OOB;
+        }
+    };
+    auto cursor_set = [&](unsigned gs_issue, int istage) {      // uniform parts of the stage about to be issued
+        is.st = lds0 + (gs_issue % C::NBUF) * (unsigned)(C::STAGE * 4);
+        is.cbase = (unsigned)(istage * 4 + wave) * s_bytes;              // channel >= Cin: beyond the descriptor
+        is.wbase = (unsigned)(icg * C::COB * nst + istage) * 16384u;
+    };
+
+    // this lane's patch: tile (tz, ty, tx) of the box, channel lk of the chunk
+    const int poff = ((2 * tz) * C::HY + 2 * ty) * C::RX + 3 + 2 * tx + lk * C::CS;
+    auto raw_of = [&](unsigned gs) { return lds + (gs % C::NBUF) * C::STAGE + poff; };
+    auto wl_of = [&](unsigned gs) {
+        return reinterpret_cast<const f32x4*>(lds + (gs % C::NBUF) * C::STAGE + C::IN_FLOATS + cb * 4096) + lane;
+    };
+
+    float* const s_bias = lds + C::NBUF * C::STAGE + 128;
+    for (int i = tid; i < a.Cout; i += 256) s_bias[i] = a.bias ? a.bias[i] : 0.f;      // published by the barrier below
+    constexpr int A = C::NBUF - 1;
+    const unsigned nslot_u = (unsigned)nslot;
+    cursor_box(box);
+#pragma unroll
+    for (int s = 0; s < A; ++s) { cursor_set((unsigned)s, s); is.template pieces<0, C::P>(wave); }   // nst > A
+    static_assert(A == 3, "the waits below are written for a ring of 4");
+    vmwait<2 * C::P>::go();                // stage 0 has landed when only the later prologue stages are in flight
+    __syncthreads();
+    f32x2 ua[32], ub[32];
+    f32x4 acc[64];
+    f32x4 ar[4];
+    {
+        const float* __restrict__ raw = raw_of(0);
+#pragma unroll
+        for (int j = 0; j < 32; ++j) {
+            const int z = j / 8, y = (j / 2) % 4, xp = j % 2;
+            ua[j] = f32x2{raw[(z * C::HY + y) * C::RX + 2 * xp], raw[(z * C::HY + y) * C::RX + 2 * xp + 1]};
+        }
+    }
+    ar[0] = wl_of(0)[0]; ar[1] = wl_of(0)[64];
+    in_units<0, 24>(ua);                   // chunk 0 of the first box: not overlapped
+    vmwait<C::P>::go();                    // stage 1
+    __syncthreads();
+
+    unsigned gs = 0;                       // global stage counter of the compute
+    const int sw = nst - A;                // from this step on the cursor issues the NEXT box's first stages
+    // On entry stage gs+1 has landed for every wave and everyone is done with stage gs-1 (the barrier at the end of the
+    // previous iteration).  The wait for stage gs+2 sits at the END of the iteration, in front of the epilogue's stores
+    // (vmcnt counts stores too: a wait behind them would wait for their write acknowledgements).
+    auto iter = [&](auto first, f32x2 (&cur)[32], f32x2 (&nxt)[32], int s) {
+        cursor_set(gs + A, s + A < nst ? s + A : s + A - nst);
+        slots<C, decltype(first)::value, 0>(wl_of(gs), wl_of(gs + 1), raw_of(gs + 1), cur, nxt, acc, ar, is, wave);
+        ++gs;
+        vmwait<C::P>::go();                // stage gs+1 landed (mine) ...
+        if (!(DBG & 64)) __syncthreads();  // ... and everyone's; everyone is done with stage gs-1
+    };
+
+    for (; box < box_end; box += nslot_u) {
+        const Box bb = decode(box);
+        if (sw == 0 && !(DBG & 4)) cursor_box(box + nslot_u);
+        iter(std::true_type{}, ua, ub, 0);
+        if (sw == 1 && !(DBG & 4)) cursor_box(box + nslot_u);
+        iter(std::false_type{}, ub, ua, 1);
+        for (int s = 2; s < nst; s += 2) {      // nst is even (Cin % 8 == 0)
+            if (sw == s && !(DBG & 4)) cursor_box(box + nslot_u);
+            iter(std::false_type{}, ua, ub, s);
+            if (sw == s + 1 && !(DBG & 4)) cursor_box(box + nslot_u);
+            iter(std::false_type{}, ub, ua, s + 1);
+        }
+
+        // ---- epilogue: inverse transform (64 -> 2x2x2 per (channel, tile)), bias, store, optional statistics ----
+        if (DBG & 2) continue;
+        const int oz = bb.z0 + 2 * tz, oy = bb.y0 + 2 * ty, ox = bb.x0 + 2 * tx;
+        const bool ok = oz < a.D && oy < a.H && ox < a.W;
+        const int co0 = (bb.cg * C::COB + cb) * 16;
+        const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)(a.y + (long long)bb.n * a.y_bs + (long long)co0 * S), 0, (int)(16u * s_bytes), 0x00020000);
+        const unsigned vo = ok && !(DBG & 1) ? (unsigned)(lk * 4) * s_bytes + (unsigned)((oz * a.H + oy) * a.W + ox) * 4u : OOB;
+        // Two of the lane's four channel rows at a time (register pairs: packed adds), one (x, y) column of points at a
+        // time, folded into the y and x sums as it is read.  Few live registers (the next box's first chunk is already
+        // waiting in 64 of them) and no spills: a scratch reload here would wait on vmcnt(0), i.e. on the DMAs in
+        // flight and on the write acknowledgements of the stores.
+        float st1[4], st2[4];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            f32x2 o[2][2][2];
+#pragma unroll
+            for (int x = 0; x < 4; ++x) {
+                f32x2 py[2][2];
+#pragma unroll
+                for (int y = 0; y < 4; ++y) {
+                    // read in place, here: left to itself hipcc copies all 256 accumulators to VGPRs first
+                    const f32x2 m0 = acc_pair(acc[y * 4 + x], h), m1 = acc_pair(acc[16 + y * 4 + x], h),
+                                m2 = acc_pair(acc[32 + y * 4 + x], h), m3 = acc_pair(acc[48 + y * 4 + x], h);
+                    const f32x2 pz0 = m0 + m1 + m2, pz1 = m1 - m2 - m3;
+                    if (y == 0) { py[0][0] = pz0; py[1][0] = pz1; }
+                    if (y == 1) { py[0][0] += pz0; py[1][0] += pz1; py[0][1] = pz0; py[1][1] = pz1; }
+                    if (y == 2) { py[0][0] += pz0; py[1][0] += pz1; py[0][1] -= pz0; py[1][1] -= pz1; }
+                    if (y == 3) { py[0][1] -= pz0; py[1][1] -= pz1; }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+                for (int zz = 0; zz < 2; ++zz)
+#pragma unroll
+                    for (int yy = 0; yy < 2; ++yy) {
+                        if (x == 0) { o[zz][yy][0] = py[zz][yy]; }
+                        if (x == 1) { o[zz][yy][0] += py[zz][yy]; o[zz][yy][1] = py[zz][yy]; }
+                        if (x == 2) { o[zz][yy][0] += py[zz][yy]; o[zz][yy][1] -= py[zz][yy]; }
+                        if (x == 3) { o[zz][yy][1] -= py[zz][yy]; }
+                    }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            const f32x2 bv = *reinterpret_cast<const f32x2*>(s_bias + co0 + lk * 4 + 2 * h);     // LDS: lgkmcnt, not vmcnt
+            f32x2 s1 = {0.f, 0.f}, s2 = s1;
+#pragma unroll
+            for (int zz = 0; zz < 2; ++zz)
+#pragma unroll
+                for (int yy = 0; yy < 2; ++yy) {
+                    const f32x2 v0 = o[zz][yy][0] + bv, v1 = o[zz][yy][1] + bv;
+                    s1 += v0 + v1;
+                    s2 += v0 * v0 + v1 * v1;
+#pragma unroll
+                    for (int rr = 0; rr < 2; ++rr) {
+                        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+                        const f32x2 v = {v0[rr], v1[rr]};
+                        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), ry,
+                                                              (int)(vo + (unsigned)((zz * a.H + yy) * a.W) * 4u),
+                                                              (int)((unsigned)(2 * h + rr) * s_bytes), 0);
+                    }
+                }
+            st1[2 * h] = s1[0]; st1[2 * h + 1] = s1[1]; st2[2 * h] = s2[0]; st2[2 * h + 1] = s2[1];
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (a.stat) {
+            // every box is full here (the host only passes `stat` then): per-channel (sum, sum of squares) of the box.
+            // The scratch is a piece of LDS beyond the ring (the ring is live: later stages are in flight).
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) {
+                    st1[r] += __shfl_xor(st1[r], o, 64);
+                    st2[r] += __shfl_xor(st2[r], o, 64);
+                }
+            float2* red = reinterpret_cast<float2*>(lds + C::NBUF * C::STAGE);
+            if (lj == 0) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) red[wave * 16 + lk * 4 + r] = make_float2(st1[r], st2[r]);
+            }
+            __syncthreads();
+            if (tid < C::COB * 16) {
+                const int b = tid / 16, c = tid % 16;
+                float sx = 0.f, sq = 0.f;
+#pragma unroll
+                for (int g = 0; g < 4 / C::COB; ++g) {      // waves g * COB + b share the channel block
+                    const float2 p = red[(g * C::COB + b) * 16 + c];
+                    sx += p.x; sq += p.y;
+                }
+                a.stat[(long long)((bb.cg * C::COB + b) * 16 + c) * a.stat_sc + (long long)bb.n * a.stat_sn + bb.idx] =
+                    make_float2(sx, sq);
+            }
+            // the next write of `red` is a whole box (>= 2 barriers) away
+        }
+    }
+}
+
+// ---- filter transform: w [Cout][Cin][27] -> wt [M/16][K4][16][64][4] with M = output, K = input channels of the launch
+// mode 0: forward (M = Cout, K = Cin); mode 1: data gradient (M = Cin, K = Cout, taps flipped)
+__global__ __launch_bounds__(256) void wino_pack_kernel(const float* __restrict__ w, float* __restrict__ wt, int Cout,
+                                                        int Cin, int mode, int Mp, int Kp) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= Mp * Kp) return;
+    const int m = idx / Kp, k = idx - m * Kp;
+    float g[27];
+    const int M = mode == 0 ? Cout : Cin, K = mode == 0 ? Cin : Cout;
+    const bool live = m < M && k < K;
+#pragma unroll
+    for (int tp = 0; tp < 27; ++tp) {
+        float v = 0.f;
+        if (live) v = mode == 0 ? w[((long long)m * Cin + k) * 27 + tp] : w[((long long)k * Cin + m) * 27 + (26 - tp)];
+        g[tp] = v;
+    }
+    // x: 3 -> 4 for the 9 (z, y) rows
+    float gx[9][4];
+#pragma unroll
+    for (int r = 0; r < 9; ++r) {
+        const float g0 = g[r * 3], g1 = g[r * 3 + 1], g2 = g[r * 3 + 2];
+        gx[r][0] = g0; gx[r][1] = 0.5f * (g0 + g1 + g2); gx[r][2] = 0.5f * (g0 - g1 + g2); gx[r][3] = g2;
+    }
+    float gy[3][4][4];
+#pragma unroll
+    for (int z = 0; z < 3; ++z)
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+            const float g0 = gx[z * 3][x], g1 = gx[z * 3 + 1][x], g2 = gx[z * 3 + 2][x];
+            gy[z][0][x] = g0; gy[z][1][x] = 0.5f * (g0 + g1 + g2); gy[z][2][x] = 0.5f * (g0 - g1 + g2); gy[z][3][x] = g2;
+        }
+    float* dst = wt + ((long long)(m / 16) * (Kp / 4) + k / 4) * 4096 + ((k % 4) * 16 + m % 16) * 4;
+#pragma unroll
+    for (int y = 0; y < 4; ++y)
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+            const float g0 = gy[0][y][x], g1 = gy[1][y][x], g2 = gy[2][y][x];
+            const float v[4] = {g0, 0.5f * (g0 + g1 + g2), 0.5f * (g0 - g1 + g2), g2};
+#pragma unroll
+            for (int z = 0; z < 4; ++z) {
+                const int xi = z * 16 + y * 4 + x;
+                dst[(xi / 4) * 256 + xi % 4] = v[z];
+            }
+        }
+}
+
+template <class C>
+int launch_wino(WinoArgs a, hipStream_t stream) {
+    a.boxes_z = (int)mis_cdiv(a.D, C::OZ);
+    a.boxes_y = (int)mis_cdiv(a.H, C::OY);
+    a.boxes_x = (int)mis_cdiv(a.W, C::OX);
+    a.co_groups = a.Cout / (16 * C::COB);
+    const long long nb = (long long)a.N * a.boxes_z * a.boxes_y * a.boxes_x * a.co_groups;
+    if (nb <= 0 || nb > 0x7fffffffLL) return MIS_ERR_ARG;
+    a.n_blocks = (unsigned)nb;
+    a.n_blocks_padded = (unsigned)(mis_cdiv(nb, MIS_NUM_XCD) * MIS_NUM_XCD);
+    static std::atomic<unsigned long long> attr_done{0};
+    if (mis_set_lds_attr(reinterpret_cast<const void*>(&wino_fwd_kernel<C>), C::LDS_BYTES, attr_done) != MIS_OK)
+        return MIS_ERR_LAUNCH;
+    const unsigned grid = a.n_blocks_padded < 256u ? a.n_blocks_padded : 256u;      // persistent: one workgroup per CU
+    hipLaunchKernelGGL(wino_fwd_kernel<C>, dim3(grid), dim3(256), C::LDS_BYTES, stream, a);
+    return mis_launch_status();
+}
+
+}  // namespace
+
+extern "C" long long mis_wino_packed_floats(int Cout, int Cin, int mode) {
+    if (Cout <= 0 || Cin <= 0 || (mode != 0 && mode != 1)) return MIS_ERR_ARG;
+    const int M = mode == 0 ? Cout : Cin, K = mode == 0 ? Cin : Cout;
+    return (long long)((M + 15) / 16) * ((K + 3) / 4) * 4096;
+}
+
+extern "C" int mis_wino_pack(const float* w, float* wt, int Cout, int Cin, int mode, hipStream_t stream) {
+    if (!w || !wt || Cout <= 0 || Cin <= 0 || (mode != 0 && mode != 1)) return MIS_ERR_ARG;
+    const int M = mode == 0 ? Cout : Cin, K = mode == 0 ? Cin : Cout;
+    const int Mp = (M + 15) / 16 * 16, Kp = (K + 3) / 4 * 4;
+    hipLaunchKernelGGL(wino_pack_kernel, dim3((unsigned)mis_cdiv((long long)Mp * Kp, 256)), dim3(256), 0, stream, w, wt,
+                       Cout, Cin, mode, Mp, Kp);
+    return mis_launch_status();
+}
+
+// y = conv3d(x, w, k = 3, 'same') + bias from the transformed filter; Cout % 16 == 0, even D, H, W.
+// variant: 0 = 4 x 4 x 32 boxes (1 channel block), 1 = 4 x 4 x 16 boxes (2 channel blocks)
+extern "C" int mis_conv3d_wino_fwd(const float* x, long long x_bs, const float* wt, const float* bias, float* y,
+                                   long long y_bs, int N, int Cin, int Cout, int D, int H, int W, float* stat,
+                                   long long stat_sc, long long stat_sn, int variant, hipStream_t stream) {
+    if (!x || !wt || !y || N <= 0 || Cin <= 0 || Cout <= 0 || D <= 0 || H <= 0 || W <= 0) return MIS_ERR_ARG;
+    const long long S = (long long)D * H * W;
+    if (x_bs < (long long)Cin * S || y_bs < (long long)Cout * S) return MIS_ERR_ARG;
+    if (Cout % 16 || Cout > 384 || Cin % 8 || Cin < 8 * 0 + 16 || W % 4 || D % 2 || H % 2 || W % 2 || y_bs % 2 || ((uintptr_t)y & 7) || ((uintptr_t)wt & 15))
+        return MIS_ERR_UNSUPPORTED;
+    if (((long long)Cin + 32) * S * 4 >= (1LL << 30)) return MIS_ERR_UNSUPPORTED;
+    WinoArgs a{};
+    a.x = x; a.x_bs = x_bs; a.wt = wt; a.bias = bias; a.y = y; a.y_bs = y_bs;
+    a.N = N; a.Cin = Cin; a.Cout = Cout; a.D = D; a.H = H; a.W = W;
+    a.nci4 = (Cin + 3) / 4;
+    a.stat = reinterpret_cast<float2*>(stat); a.stat_sc = stat_sc; a.stat_sn = stat_sn;
+    if (variant == 0) return launch_wino<WinoCfg<1, 1, 16, 2, 2, 1, 1, 4>>(a, stream);
+    if (variant == 1) return launch_wino<WinoCfg<1, 2, 8, 2, 2, 1, 1, 4>>(a, stream);
+    return MIS_ERR_UNSUPPORTED;
+}

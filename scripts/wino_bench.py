@@ -1,0 +1,100 @@
+"""Development harness: Winograd F(2^3, 3^3) conv (mis_conv3d_wino_fwd) vs the direct kernel and torch, on the GPU.
+    python scripts/wino_bench.py            correctness at small shapes + timing at the config-3 layer shapes"""
+import ctypes
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "cv-ssl-mis_amd"))
+from mis_hip import lib as _l, ops  # noqa: E402
+
+L = _l.load()
+c_p, c_i, c_ll = ctypes.c_void_p, ctypes.c_int, ctypes.c_longlong
+L.mis_wino_packed_floats.restype = c_ll
+L.mis_wino_packed_floats.argtypes = [c_i, c_i, c_i]
+L.mis_wino_pack.argtypes = [c_p, c_p, c_i, c_i, c_i, c_p]
+L.mis_conv3d_wino_fwd.argtypes = [c_p, c_ll, c_p, c_p, c_p, c_ll, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_ll, c_ll, c_i, c_p]
+
+
+def wino(x, w, bias, variant, stat=None):
+    N, Cin, D, H, W = x.shape
+    Cout = w.shape[0]
+    wt = torch.empty(L.mis_wino_packed_floats(Cout, Cin, 0), device="cuda")
+    _l.check(L.mis_wino_pack(_l.ptr(w), _l.ptr(wt), Cout, Cin, 0, _l.stream_ptr()), "pack")
+    y = torch.empty(N, Cout, D, H, W, device="cuda")
+    S = D * H * W
+
+    def run():
+        _l.check(L.mis_conv3d_wino_fwd(_l.ptr(x), Cin * S, _l.ptr(wt), _l.ptr(bias), _l.ptr(y), Cout * S, N, Cin, Cout,
+                                       D, H, W, None, 0, 0, variant, _l.stream_ptr()), "wino")
+    run()
+    return y, run
+
+
+def direct(x, w, bias):
+    N, Cin, D, H, W = x.shape
+    Cout = w.shape[0]
+    wp = ops.conv_pack(w, 0)
+    y = torch.empty(N, Cout, D, H, W, device="cuda")
+
+    def run():
+        ops.conv_fwd(x, wp, bias, y, Cin, Cout, (3, 3, 3))
+    run()
+    return y, run
+
+
+def timeit(fn, n=30):
+    for _ in range(40):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n * 1e3
+
+
+def main():
+    torch.manual_seed(0)
+    if os.environ.get("MIS_WINO_DBG"):
+        for (N, Cin, Cout, S, var) in [(8, 16, 16, 96, 0), (8, 48, 16, 96, 0)]:
+            x = torch.randn(N, Cin, S, S, S, device="cuda")
+            w = torch.randn(Cout, Cin, 3, 3, 3, device="cuda") * 0.05
+            b = torch.randn(Cout, device="cuda")
+            yw, rw = wino(x, w, b, var)
+            print(f"dbg {os.environ['MIS_WINO_DBG']} N{N} {Cin}->{Cout} {S}^3: {timeit(rw):8.1f} us", flush=True)
+        return
+    for (N, Cin, Cout, D, H, W, var) in [(1, 16, 16, 4, 4, 32, 0), (2, 16, 16, 8, 12, 64, 0), (1, 24, 32, 6, 10, 20, 0),
+                                         (2, 16, 32, 8, 8, 16, 1), (1, 32, 32, 6, 6, 36, 1), (3, 48, 16, 10, 6, 40, 0)]:
+        x = torch.randn(N, Cin, D, H, W, device="cuda")
+        w = torch.randn(Cout, Cin, 3, 3, 3, device="cuda") * 0.1
+        b = torch.randn(Cout, device="cuda")
+        ref = torch.nn.functional.conv3d(x.double(), w.double(), b.double(), padding=1)
+        yw, _ = wino(x, w, b, var)
+        yd, _ = direct(x, w, b)
+        ew = (yw.double() - ref).abs().max().item()
+        ed = (yd.double() - ref).abs().max().item()
+        print(f"shape N{N} {Cin}->{Cout} {D}x{H}x{W} v{var}: wino err {ew:.3e}  direct err {ed:.3e}  ref max {ref.abs().max().item():.2f}",
+              flush=True)
+    for (N, Cin, Cout, S, var) in [(8, 16, 16, 96, 0), (8, 48, 16, 96, 0), (8, 16, 48, 96, 0), (8, 32, 32, 48, 1),
+                                   (8, 32, 32, 48, 0), (8, 96, 32, 48, 1), (8, 64, 64, 24, 1)]:
+        x = torch.randn(N, Cin, S, S, S, device="cuda")
+        w = torch.randn(Cout, Cin, 3, 3, 3, device="cuda") * 0.05
+        b = torch.randn(Cout, device="cuda")
+        fl = 2.0 * N * Cout * Cin * 27 * S ** 3
+        try:
+            yw, rw = wino(x, w, b, var)
+        except RuntimeError as e:
+            print("skip", N, Cin, Cout, S, var, e)
+            continue
+        yd, rd = direct(x, w, b)
+        err = (yw - yd).abs().max().item()
+        tw, td = timeit(rw), timeit(rd)
+        print(f"N{N} {Cin}->{Cout} {S}^3 v{var}: wino {tw:8.1f} us ({fl / tw / 1e6:6.1f} TF eq)  direct {td:8.1f} us "
+              f"({fl / td / 1e6:6.1f} TF)  speedup {td / tw:.2f}  maxdiff {err:.2e}", flush=True)
+
+
+if __name__ == "__main__":
+    main()
