@@ -434,52 +434,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     }
 }
 
-// ---- filter transform: w [Cout][Cin][27] -> wt [M/16][K4][16][64][4] with M = output, K = input channels of the launch
-// mode 0: forward (M = Cout, K = Cin); mode 1: data gradient (M = Cin, K = Cout, taps flipped)
-__global__ __launch_bounds__(256) void wino_pack_kernel(const float* __restrict__ w, float* __restrict__ wt, int Cout,
-                                                        int Cin, int mode, int Mp, int Kp) {
-    const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= Mp * Kp) return;
-    const int m = idx / Kp, k = idx - m * Kp;
-    float g[27];
-    const int M = mode == 0 ? Cout : Cin, K = mode == 0 ? Cin : Cout;
-    const bool live = m < M && k < K;
-#pragma unroll
-    for (int tp = 0; tp < 27; ++tp) {
-        float v = 0.f;
-        if (live) v = mode == 0 ? w[((long long)m * Cin + k) * 27 + tp] : w[((long long)k * Cin + m) * 27 + (26 - tp)];
-        g[tp] = v;
-    }
-    // x: 3 -> 4 for the 9 (z, y) rows
-    float gx[9][4];
-#pragma unroll
-    for (int r = 0; r < 9; ++r) {
-        const float g0 = g[r * 3], g1 = g[r * 3 + 1], g2 = g[r * 3 + 2];
-        gx[r][0] = g0; gx[r][1] = 0.5f * (g0 + g1 + g2); gx[r][2] = 0.5f * (g0 - g1 + g2); gx[r][3] = g2;
-    }
-    float gy[3][4][4];
-#pragma unroll
-    for (int z = 0; z < 3; ++z)
-#pragma unroll
-        for (int x = 0; x < 4; ++x) {
-            const float g0 = gx[z * 3][x], g1 = gx[z * 3 + 1][x], g2 = gx[z * 3 + 2][x];
-            gy[z][0][x] = g0; gy[z][1][x] = 0.5f * (g0 + g1 + g2); gy[z][2][x] = 0.5f * (g0 - g1 + g2); gy[z][3][x] = g2;
-        }
-    float* dst = wt + ((long long)(m / 16) * (Kp / 4) + k / 4) * 4096 + ((k % 4) * 16 + m % 16) * 4;
-#pragma unroll
-    for (int y = 0; y < 4; ++y)
-#pragma unroll
-        for (int x = 0; x < 4; ++x) {
-            const float g0 = gy[0][y][x], g1 = gy[1][y][x], g2 = gy[2][y][x];
-            const float v[4] = {g0, 0.5f * (g0 + g1 + g2), 0.5f * (g0 - g1 + g2), g2};
-#pragma unroll
-            for (int z = 0; z < 4; ++z) {
-                const int xi = z * 16 + y * 4 + x;
-                dst[(xi / 4) * 256 + xi % 4] = v[z];
-            }
-        }
-}
-
 template <class C>
 int launch_wino(WinoArgs a, hipStream_t stream) {
     a.boxes_z = (int)mis_cdiv(a.D, C::OZ);
@@ -500,19 +454,42 @@ int launch_wino(WinoArgs a, hipStream_t stream) {
 
 }  // namespace
 
-extern "C" long long mis_wino_packed_floats(int Cout, int Cin, int mode) {
-    if (Cout <= 0 || Cin <= 0 || (mode != 0 && mode != 1)) return MIS_ERR_ARG;
-    const int M = mode == 0 ? Cout : Cin, K = mode == 0 ? Cin : Cout;
-    return (long long)((M + 15) / 16) * ((K + 3) / 4) * 4096;
+// Which Winograd variant serves this 3x3x3 'same' convolution, or -1 (use the direct kernel, mis_conv_fwd):
+//   0: boxes of 4 x 4 x 32 outputs (W a multiple of 32: the 96^3 level),  1: 4 x 8 x 16 (W a multiple of 16: 48^3).
+// Needs Cin % 8 == 0 (two 4-channel chunks per loop trip), Cin >= 16 (the DMA ring runs 3 chunks ahead),
+// Cout % 16 == 0 (MFMA rows), Cout <= 384 (bias table in LDS), even D / H and W % 4 == 0 (2x2x2 tiles, 16-byte rows).
+extern "C" int mis_conv3d_wino_select(int N, int Cin, int Cout, int D, int H, int W) {
+    if (N <= 0 || Cin < 16 || Cin % 8 || Cout <= 0 || Cout % 16 || Cout > 384 || D <= 0 || H <= 0 || W <= 0) return -1;
+    if (D % 2 || H % 2 || W % 4) return -1;
+    if (((long long)Cin + 32) * D * H * W * 4 >= (1LL << 30)) return -1;
+    if (W % 32 == 0 && D % 4 == 0 && H % 4 == 0) return 0;
+    if (W % 16 == 0 && D % 4 == 0 && H % 8 == 0) return 1;
+    return -1;
 }
 
-extern "C" int mis_wino_pack(const float* w, float* wt, int Cout, int Cin, int mode, hipStream_t stream) {
-    if (!w || !wt || Cout <= 0 || Cin <= 0 || (mode != 0 && mode != 1)) return MIS_ERR_ARG;
-    const int M = mode == 0 ? Cout : Cin, K = mode == 0 ? Cin : Cout;
-    const int Mp = (M + 15) / 16 * 16, Kp = (K + 3) / 4 * 4;
-    hipLaunchKernelGGL(wino_pack_kernel, dim3((unsigned)mis_cdiv((long long)Mp * Kp, 256)), dim3(256), 0, stream, w, wt,
-                       Cout, Cin, mode, Mp, Kp);
-    return mis_launch_status();
+namespace {
+template <class C>
+long long boxes_per_image(int D, int H, int W) {
+    return mis_cdiv(D, C::OZ) * mis_cdiv(H, C::OY) * mis_cdiv(W, C::OX);
+}
+}  // namespace
+
+// partial-statistics entries per image that mis_conv3d_wino_fwd writes with `stat` (one per box), as
+// mis_conv_fwd_stat_tiles does for the direct kernel
+extern "C" long long mis_conv3d_wino_stat_tiles(int D, int H, int W, int variant) {
+    if (D <= 0 || H <= 0 || W <= 0) return MIS_ERR_ARG;
+    if (variant == 0) return boxes_per_image<WinoCfg<1, 1, 16, 2, 2, 1, 1, 4>>(D, H, W);
+    if (variant == 1) return boxes_per_image<WinoCfg<1, 2, 8, 2, 2, 1, 1, 4>>(D, H, W);
+    return MIS_ERR_UNSUPPORTED;
+}
+
+// kernel name as rocprofv3 prints it (minus the anonymous-namespace prefix), for bench.py's attribution
+extern "C" int mis_conv3d_wino_kernel_name(int variant, char* name, int name_len) {
+    if (!name || name_len <= 0) return MIS_ERR_ARG;
+    if (variant == 0) snprintf(name, name_len, "wino_fwd_kernel<WinoCfg<1, 1, 16, 2, 2, 1, 1, 4>>");
+    else if (variant == 1) snprintf(name, name_len, "wino_fwd_kernel<WinoCfg<1, 2, 8, 2, 2, 1, 1, 4>>");
+    else return MIS_ERR_UNSUPPORTED;
+    return MIS_OK;
 }
 
 // y = conv3d(x, w, k = 3, 'same') + bias from the transformed filter; Cout % 16 == 0, even D, H, W.
@@ -523,7 +500,7 @@ extern "C" int mis_conv3d_wino_fwd(const float* x, long long x_bs, const float* 
     if (!x || !wt || !y || N <= 0 || Cin <= 0 || Cout <= 0 || D <= 0 || H <= 0 || W <= 0) return MIS_ERR_ARG;
     const long long S = (long long)D * H * W;
     if (x_bs < (long long)Cin * S || y_bs < (long long)Cout * S) return MIS_ERR_ARG;
-    if (Cout % 16 || Cout > 384 || Cin % 8 || Cin < 8 * 0 + 16 || W % 4 || D % 2 || H % 2 || W % 2 || y_bs % 2 || ((uintptr_t)y & 7) || ((uintptr_t)wt & 15))
+    if (Cout % 16 || Cout > 384 || Cin % 8 || Cin < 16 || W % 4 || D % 2 || H % 2 || y_bs % 2 || ((uintptr_t)y & 7) || ((uintptr_t)wt & 15))
         return MIS_ERR_UNSUPPORTED;
     if (((long long)Cin + 32) * S * 4 >= (1LL << 30)) return MIS_ERR_UNSUPPORTED;
     WinoArgs a{};

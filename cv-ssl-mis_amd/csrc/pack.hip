@@ -9,19 +9,54 @@
 // zero-padded to (roundup(K-channels,4), TAPS, roundup(M-channels,16)).
 // Mode 1 is the spatially flipped, channel-transposed filter, so conv_fwd on dy
 // with it is exactly the autograd input-gradient of the reference conv.
+//   mode 4 / 5 (3x3x3 only): the Winograd F(2x2x2, 3x3x3) filter transform G g G^T of the forward / data-gradient
+//   filter in the operand layout of conv_wino.hip:  wt[M/16][K/4][16][64 lanes][4]  with transform point
+//   xi = 4 * (third index) + (last index), lane = (k % 4) * 16 + m % 16  (M, K = output, input channels of the launch).
 #include "common.h"
 
 namespace {
 
+// G g of one dimension: point xi of (g0, g1, g2)
+__device__ __forceinline__ float wino_g(int xi, float g0, float g1, float g2) {
+    return xi == 0 ? g0 : (xi == 3 ? g2 : 0.5f * (xi == 1 ? (g0 + g1 + g2) : (g0 - g1 + g2)));
+}
+
+// element i of the transformed filter of one layer (mode 4: forward, mode 5: data gradient)
+__device__ __forceinline__ float wino_element(const float* __restrict__ w, int Cout, int Cin, int mode, int Kp, unsigned i) {
+    const int e4 = i & 3, lane = (i >> 2) & 63, x4 = (i >> 8) & 15;
+    const unsigned blk = i >> 12;                         // (m / 16) * (Kp / 4) + k / 4
+    const int k4 = blk % (unsigned)(Kp / 4), mb = blk / (unsigned)(Kp / 4);
+    const int xi = x4 * 4 + e4, m = mb * 16 + (lane & 15), k = k4 * 4 + (lane >> 4);
+    const int M = mode == 4 ? Cout : Cin, K = mode == 4 ? Cin : Cout;
+    if (m >= M || k >= K) return 0.f;
+    const float* g = mode == 4 ? w + ((long long)m * Cin + k) * 27 : w + ((long long)k * Cin + m) * 27;
+    const int xz = xi >> 4, xy = (xi >> 2) & 3, xx = xi & 3;
+    float pz[3];
+#pragma unroll
+    for (int z = 0; z < 3; ++z) {
+        float py[3];
+#pragma unroll
+        for (int y = 0; y < 3; ++y) {
+            const int t = (z * 3 + y) * 3;
+            // data gradient: the spatially flipped filter (tap 26 - t)
+            py[y] = mode == 4 ? wino_g(xx, g[t], g[t + 1], g[t + 2]) : wino_g(xx, g[26 - t], g[25 - t], g[24 - t]);
+        }
+        pz[z] = wino_g(xy, py[0], py[1], py[2]);
+    }
+    return wino_g(xz, pz[0], pz[1], pz[2]);
+}
+
 __global__ __launch_bounds__(256) void pack_kernel(const float* __restrict__ w, float* __restrict__ wp,
                                                    int Cout, int Cin, int taps, int mode, int Kp, int Mp) {
-    const long long total = (long long)Kp * taps * Mp;
+    const long long total = (long long)Kp * (mode >= 4 ? 64 : taps) * Mp;
     for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
         const int m = (int)(i % Mp);
         const int t = (int)((i / Mp) % taps);
         const int k = (int)(i / ((long long)Mp * taps));
         float v = 0.f;
-        if (mode == 0) {
+        if (mode >= 4) {
+            v = wino_element(w, Cout, Cin, mode, Kp, (unsigned)i);
+        } else if (mode == 0) {
             if (k < Cin && m < Cout) v = w[((long long)m * Cin + k) * taps + t];
         } else if (mode == 1) {
             if (k < Cout && m < Cin) v = w[((long long)k * Cin + m) * taps + (taps - 1 - t)];
@@ -57,6 +92,7 @@ __global__ __launch_bounds__(256) void pack_batch_kernel(const PackJob* __restri
         }
         const PackJob& j = s_jobs[lo];
         const unsigned i = (unsigned)(g - j.start);          // one layer's pack is far below 2^32 floats
+        if (j.mode >= 4) { j.wp[i] = wino_element(j.w, j.Cout, j.Cin, j.mode, j.Kp, i); continue; }
         const unsigned mt = (unsigned)j.Mp * (unsigned)j.taps;
         const int k = (int)(i / mt);
         const unsigned r = i - (unsigned)k * mt;
@@ -78,11 +114,14 @@ __global__ __launch_bounds__(256) void pack_batch_kernel(const PackJob* __restri
 // Returns the job's packed size in floats (the increment of `start` for the next job), or a negative error.
 extern "C" long long mis_conv_pack_job(void* job_out, const float* w, float* wp, int Cout, int Cin, int taps, int mode,
                                        long long start) {
-    if (!job_out || !w || !wp || Cout <= 0 || Cin <= 0 || taps <= 0 || (mode != 0 && mode != 1)) return MIS_ERR_ARG;
-    const int K = mode == 0 ? Cin : Cout, M = mode == 0 ? Cout : Cin;
+    if (!job_out || !w || !wp || Cout <= 0 || Cin <= 0 || taps <= 0 || (mode != 0 && mode != 1 && mode != 4 && mode != 5))
+        return MIS_ERR_ARG;
+    if (mode >= 4 && taps != 27) return MIS_ERR_ARG;
+    const bool fwd = mode == 0 || mode == 4;
+    const int K = fwd ? Cin : Cout, M = fwd ? Cout : Cin;
     PackJob j{w, wp, Cout, Cin, taps, mode, (K + 3) / 4 * 4, (M + 15) / 16 * 16, start};
     *reinterpret_cast<PackJob*>(job_out) = j;
-    return (long long)j.Kp * taps * j.Mp;
+    return (long long)j.Kp * (mode >= 4 ? 64 : taps) * j.Mp;
 }
 
 extern "C" int mis_conv_pack_job_bytes() { return (int)sizeof(PackJob); }
@@ -98,20 +137,21 @@ extern "C" int mis_conv_pack_batch(const void* jobs_device, int n, long long tot
 }
 
 extern "C" long long mis_conv_packed_floats(int Cout, int Cin, int taps, int mode) {
-    if (Cout <= 0 || Cin <= 0 || taps <= 0) return MIS_ERR_ARG;
-    const bool fwd = mode == 0 || mode == 2;
+    if (Cout <= 0 || Cin <= 0 || taps <= 0 || (mode >= 4 && taps != 27)) return MIS_ERR_ARG;
+    const bool fwd = mode == 0 || mode == 2 || mode == 4;
     const int K = fwd ? Cin : Cout, M = fwd ? Cout : Cin;
-    return (long long)((K + 3) / 4 * 4) * taps * ((M + 15) / 16 * 16);
+    return (long long)((K + 3) / 4 * 4) * (mode >= 4 ? 64 : taps) * ((M + 15) / 16 * 16);
 }
 
 extern "C" int mis_conv_pack_weights(const float* w, float* wp, int Cout, int Cin, int taps, int mode,
                                      hipStream_t stream) {
-    if (!w || !wp || Cout <= 0 || Cin <= 0 || taps <= 0 || mode < 0 || mode > 3) return MIS_ERR_ARG;
-    if (mode >= 2 && taps != 1) return MIS_ERR_ARG;   // input-major storage is only defined for 1x1 weights
-    const bool fwd = mode == 0 || mode == 2;
+    if (!w || !wp || Cout <= 0 || Cin <= 0 || taps <= 0 || mode < 0 || mode > 5) return MIS_ERR_ARG;
+    if ((mode == 2 || mode == 3) && taps != 1) return MIS_ERR_ARG;   // input-major storage is only defined for 1x1 weights
+    if (mode >= 4 && taps != 27) return MIS_ERR_ARG;                 // Winograd transform: 3x3x3 only
+    const bool fwd = mode == 0 || mode == 2 || mode == 4;
     const int K = fwd ? Cin : Cout, M = fwd ? Cout : Cin;
     const int Kp = (K + 3) / 4 * 4, Mp = (M + 15) / 16 * 16;
-    const long long total = (long long)Kp * taps * Mp;
+    const long long total = (long long)Kp * (mode >= 4 ? 64 : taps) * Mp;
     long long blocks = mis_cdiv(total, 256);
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(pack_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, w, wp, Cout, Cin, taps, mode,

@@ -46,6 +46,10 @@ PROTOTYPES = {
                                  c_ll, c_p]),
     "mis_norm_stats_finalize": (c_i, [c_p, c_i, c_i, c_ll, c_i, c_i, c_f, c_p, c_p, c_p, c_p, c_p, c_f, c_p]),
     "mis_conv_fwd_kernel_name": (c_i, [c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, ctypes.c_char_p, c_i]),
+    "mis_conv3d_wino_select": (c_i, [c_i, c_i, c_i, c_i, c_i, c_i]),
+    "mis_conv3d_wino_stat_tiles": (c_ll, [c_i, c_i, c_i, c_i]),
+    "mis_conv3d_wino_kernel_name": (c_i, [c_i, ctypes.c_char_p, c_i]),
+    "mis_conv3d_wino_fwd": (c_i, [c_p, c_ll, c_p, c_p, c_p, c_ll, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_ll, c_ll, c_i, c_p]),
     "mis_conv_wgrad_workspace_bytes": (c_ll, [c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i]),
     "mis_conv_wgrad": (c_i, [c_p, c_ll, c_p, c_ll, c_p, c_p, c_ll, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i,
                              c_i, c_p]),

@@ -7,6 +7,7 @@ Every function launches on torch's current stream and returns nothing (outputs a
 caller-allocated), mirroring the C signatures in ``include/mis_hip.h``.
 """
 import ctypes as _ctypes
+import os as _os
 
 import torch
 
@@ -49,6 +50,8 @@ def conv_pack(weight, mode, out=None):
     Cout, Cin = weight.shape[0], weight.shape[1]
     taps = weight[0, 0].numel()
     n = L.mis_conv_packed_floats(Cout, Cin, taps, mode)
+    if n < 0:
+        _l.check(n, "mis_conv_packed_floats")
     if out is None:
         out = torch.empty(n, dtype=torch.float32, device=weight.device)
     assert out.numel() >= n and weight.is_contiguous()
@@ -120,10 +123,23 @@ def _ksize(k):
     return tuple(k)
 
 
-def conv_stat_tiles(N, Cin, Cout, D, H, W, ksize):
+WINO = int(_os.environ.get("MIS_WINO", "1"))      # 0: never use the Winograd form of the 3x3x3 convolutions
+
+
+def conv_wino_select(N, Cin, Cout, D, H, W, ksize):
+    """Winograd variant serving this convolution (mis_conv3d_wino_select), or -1: use the direct kernel."""
+    if not WINO or _ksize(ksize) != (3, 3, 3):
+        return -1
+    return int(_l.load().mis_conv3d_wino_select(N, Cin, Cout, D, H, W))
+
+
+def conv_stat_tiles(N, Cin, Cout, D, H, W, ksize, wino=-1):
     """Partial-statistics tiles per image of the fused conv+stats form for this geometry (0: not eligible)."""
     kd, kh, kw = _ksize(ksize)
-    t = _l.load().mis_conv_fwd_stat_tiles(N, Cin, Cout, D, H, W, kd, kh, kw)
+    if wino >= 0:
+        t = _l.load().mis_conv3d_wino_stat_tiles(D, H, W, wino)
+    else:
+        t = _l.load().mis_conv_fwd_stat_tiles(N, Cin, Cout, D, H, W, kd, kh, kw)
     if t < 0:
         _l.check(t, "mis_conv_fwd_stat_tiles")
     return int(t)
@@ -137,9 +153,11 @@ def norm_stats_finalize(part, N, C, S, tiles, per_sample, eps, mean, rstd, runni
                                        _l.stream_ptr()), "mis_norm_stats_finalize")
 
 
-def conv_fwd(x, wp, bias, y, Cin, Cout, ksize, stat=None):
+def conv_fwd(x, wp, bias, y, Cin, Cout, ksize, stat=None, wino=-1):
     """y = conv(x) with packed weights ``wp``; stride 1, 'same' zero padding, k in {1,3}.
-    ``stat = (buffer, stride_channel, stride_image)``: also emit the per-tile (sum, sumsq) of y (mis_conv_fwd_stats)."""
+    ``stat = (buffer, stride_channel, stride_image)``: also emit the per-tile (sum, sumsq) of y (mis_conv_fwd_stats).
+    ``wino >= 0``: ``wp`` is the Winograd-transformed filter (pack mode 4 / 5) and that variant of
+    mis_conv3d_wino_fwd runs."""
     L = _l.load()
     N, Cx, D, H, W, S, xbs = _geom(x)
     Ny, Cy, Dy, Hy, Wy, _, ybs = _geom(y)
@@ -149,7 +167,11 @@ def conv_fwd(x, wp, bias, y, Cin, Cout, ksize, stat=None):
     if prof is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    if stat is not None:
+    if wino >= 0:
+        st = stat if stat is not None else (None, 0, 0)
+        _l.check(L.mis_conv3d_wino_fwd(_l.ptr(x), xbs, _l.ptr(wp), _l.ptr(bias), _l.ptr(y), ybs, N, Cin, Cout, D, H, W,
+                                       _l.ptr(st[0]), st[1], st[2], wino, _l.stream_ptr()), "mis_conv3d_wino_fwd")
+    elif stat is not None:
         _l.check(L.mis_conv_fwd_stats(_l.ptr(x), xbs, _l.ptr(wp), _l.ptr(bias), _l.ptr(y), ybs, N, Cin, Cout, D, H, W,
                                       kd, kh, kw, _l.ptr(stat[0]), stat[1], stat[2], _l.stream_ptr()),
                  "mis_conv_fwd_stats")
@@ -159,7 +181,10 @@ def conv_fwd(x, wp, bias, y, Cin, Cout, ksize, stat=None):
     if prof is not None:
         e1.record()
         buf = _ctypes.create_string_buffer(128)
-        L.mis_conv_fwd_kernel_name(N, Cin, Cout, D, H, W, kd, kh, kw, buf, 128)
+        if wino >= 0:
+            L.mis_conv3d_wino_kernel_name(wino, buf, 128)
+        else:
+            L.mis_conv_fwd_kernel_name(N, Cin, Cout, D, H, W, kd, kh, kw, buf, 128)
         prof.append((buf.value.decode(), 2.0 * N * Cout * Cin * kd * kh * kw * S, e0, e1))
 
 

@@ -91,6 +91,10 @@ class ConvOp:
         self.x, self.y, self.w, self.b = x, y, w, b
         self.ksize, self.need_dx, self.bias_grad = tuple(ksize), need_dx, bias_grad
         self.cout, self.cin = w.data.shape[0], w.data.shape[1]
+        # Winograd F(2^3, 3^3) variant of the forward / of the data gradient (conv_wino.hip), or -1: direct kernel
+        N, _, D, H, W = y.shape          # stride 1, 'same': the geometry of x (the plan's input has no buffer yet)
+        self.wino_f = ops.conv_wino_select(N, self.cin, self.cout, D, H, W, self.ksize)
+        self.wino_b = ops.conv_wino_select(N, self.cout, self.cin, D, H, W, self.ksize) if need_dx else -1
         self.wp = None
         self.wpd = None
         self.batched = False     # True: the plan repacks all conv weights in one launch (Plan._pack)
@@ -100,11 +104,11 @@ class ConvOp:
 
     def fwd(self, ctx):
         if not self.batched:
-            self.wp = ops.conv_pack(self.w.data, 0, out=self.wp)
+            self.wp = ops.conv_pack(self.w.data, 4 if self.wino_f >= 0 else 0, out=self.wp)
         # the consumer needs batch statistics unless it is a BatchNorm in eval mode (running statistics)
         stat = self.stat if (self.stat is not None and (self.stat_norm.per_sample or ctx.training)) else None
         ops.conv_fwd(self.x.t, self.wp, None if self.b is None else self.b.data, self.y.t, self.cin, self.cout,
-                     self.ksize, stat=stat)
+                     self.ksize, stat=stat, wino=self.wino_f)
 
     def bwd(self, ctx):
         dy = self.y.grad()
@@ -115,16 +119,16 @@ class ConvOp:
         # (sum over a normalisation group of dL/dx vanishes); the flat grad buffer keeps its zeros.
         if self.need_dx:
             if not self.batched:
-                self.wpd = ops.conv_pack(self.w.data, 1, out=self.wpd)
+                self.wpd = ops.conv_pack(self.w.data, 5 if self.wino_b >= 0 else 1, out=self.wpd)
             if self.x.written:
                 # the input has another consumer whose gradient is already there (residual blocks: UNETR's
                 # UnetResBlock feeds its input to conv1 AND to the shortcut): data gradient into a scratch, then add
                 if self._dx_tmp is None:
                     self._dx_tmp = torch.empty(self.x.shape, dtype=torch.float32, device="cuda")
-                ops.conv_fwd(dy, self.wpd, None, self._dx_tmp, self.cout, self.cin, self.ksize)
+                ops.conv_fwd(dy, self.wpd, None, self._dx_tmp, self.cout, self.cin, self.ksize, wino=self.wino_b)
                 ops.add(self.x.grad(), self._dx_tmp, self.x.grad())
             else:
-                ops.conv_fwd(dy, self.wpd, None, self.x.grad(), self.cout, self.cin, self.ksize)
+                ops.conv_fwd(dy, self.wpd, None, self.x.grad(), self.cout, self.cin, self.ksize, wino=self.wino_b)
             self.x.mark_written()
 
 
@@ -335,7 +339,7 @@ class Plan:
         prev = self.ops[-1] if self.ops else None
         if FUSE_CONV_STATS and not no_norm and type(prev) is ConvOp and prev.y is x:
             N, C, D, H, W = x.shape
-            T = ops.conv_stat_tiles(N, prev.cin, prev.cout, D, H, W, prev.ksize)
+            T = ops.conv_stat_tiles(N, prev.cin, prev.cout, D, H, W, prev.ksize, wino=prev.wino_f)
             if T > 0:
                 part = torch.empty((C * N * T, 2), dtype=torch.float32, device="cuda")
                 prev.stat = (part, T, C * T) if per_sample else (part, N * T, T)
@@ -374,13 +378,14 @@ class Plan:
             fj, bj = [], []
             for op in convs:
                 taps = op.w.data[0, 0].numel()
-                op.wp = torch.empty(L.mis_conv_packed_floats(op.cout, op.cin, taps, 0), dtype=torch.float32,
+                mf, mb = (4 if op.wino_f >= 0 else 0), (5 if op.wino_b >= 0 else 1)
+                op.wp = torch.empty(L.mis_conv_packed_floats(op.cout, op.cin, taps, mf), dtype=torch.float32,
                                     device="cuda")
-                fj.append((op.w.data, op.wp, 0))
+                fj.append((op.w.data, op.wp, mf))
                 if op.need_dx:
-                    op.wpd = torch.empty(L.mis_conv_packed_floats(op.cout, op.cin, taps, 1), dtype=torch.float32,
+                    op.wpd = torch.empty(L.mis_conv_packed_floats(op.cout, op.cin, taps, mb), dtype=torch.float32,
                                          device="cuda")
-                    bj.append((op.w.data, op.wpd, 1))
+                    bj.append((op.w.data, op.wpd, mb))
                 op.batched = True
             self._packs = (ops.PackBatch(fj) if fj else None, ops.PackBatch(bj) if bj else None)
         if self._packs[mode] is not None:

@@ -48,7 +48,8 @@ int mis_abi_version(void);
  * Contraction runs on v_mfma_f32_16x16x4_f32 (fp32 in / fp32 accumulate == an fmaf chain). */
 int mis_conv_cin_pad(int cin);   /* K-channel padding of packed weights (multiple of 4)  */
 int mis_conv_cout_pad(int cout); /* M-channel padding of packed weights (multiple of 16) */
-/* floats of the packed buffer; mode 0 = forward, 1 = data-gradient */
+/* floats of the packed buffer; mode 0 = forward, 1 = data-gradient, 4 / 5 = the Winograd-transformed forward /
+ * data-gradient filter of a 3x3x3 conv (taps = 27; consumed by mis_conv3d_wino_fwd) */
 long long mis_conv_packed_floats(int Cout, int Cin, int taps, int mode);
 /* w: [Cout][Cin][taps] (torch layout) -> wp.  mode 0: wp[ci][tap][co]; mode 1: wp[co][tap][ci] with
  * the taps reversed (the flipped, transposed filter of the autograd input-gradient). */
@@ -83,6 +84,20 @@ int mis_norm_stats_finalize(const float* part, int N, int C, long long S, int ti
 /* name of the kernel instantiation mis_conv_fwd launches for this geometry (profiling attribution) */
 int mis_conv_fwd_kernel_name(int N, int Cin, int Cout, int D, int H, int W, int kd, int kh, int kw, char* name,
                              int name_len);
+/* ---- Winograd F(2x2x2, 3x3x3) form of the stride-1 'same' 3x3x3 convolution (csrc/conv_wino.hip) -----------
+ * reference: nn.Conv3d(k=3, pad=1) of UnetConv3 / UnetUp3_CT (code/networks/utils.py:99-123), unet_3D.py:28-57,
+ * vnet.py:15-22.  Same contract as mis_conv_fwd / mis_conv_fwd_stats (x, y NCDHW fp32, optional bias, optional per-box
+ * (sum, sumsq) partials for the normalisation that follows), 3.375x fewer matrix-pipe flops; fp32 end to end, the result
+ * differs from the direct form by rounding only.  The filter comes transformed (mis_conv_pack_weights / pack jobs,
+ * mode 4 = forward, 5 = data gradient: the same launch on dy with Cin and Cout swapped).
+ * mis_conv3d_wino_select: variant serving this geometry, or -1 (use mis_conv_fwd).
+ * mis_conv3d_wino_stat_tiles: partial-statistics entries per image (boxes) of that variant. */
+int mis_conv3d_wino_select(int N, int Cin, int Cout, int D, int H, int W);
+long long mis_conv3d_wino_stat_tiles(int D, int H, int W, int variant);
+int mis_conv3d_wino_kernel_name(int variant, char* name, int name_len);
+int mis_conv3d_wino_fwd(const float* x, long long x_bs, const float* wt, const float* bias, float* y, long long y_bs,
+                        int N, int Cin, int Cout, int D, int H, int W, float* stat, long long stat_sc,
+                        long long stat_sn, int variant, mis_stream_t stream);
 long long mis_conv_wgrad_workspace_bytes(int N, int Cin, int Cout, int D, int H, int W, int kd, int kh, int kw);
 /* dw[Cout][Cin][taps] (+)= sum_{n,p} dy[n][co][p] * x[n][ci][p + tap - pad]  (autograd weight gradient) */
 int mis_conv_wgrad(const float* x, long long x_bs, const float* dy, long long dy_bs, float* dw, float* workspace,

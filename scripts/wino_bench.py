@@ -11,17 +11,12 @@ from mis_hip import lib as _l, ops  # noqa: E402
 
 L = _l.load()
 c_p, c_i, c_ll = ctypes.c_void_p, ctypes.c_int, ctypes.c_longlong
-L.mis_wino_packed_floats.restype = c_ll
-L.mis_wino_packed_floats.argtypes = [c_i, c_i, c_i]
-L.mis_wino_pack.argtypes = [c_p, c_p, c_i, c_i, c_i, c_p]
-L.mis_conv3d_wino_fwd.argtypes = [c_p, c_ll, c_p, c_p, c_p, c_ll, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_ll, c_ll, c_i, c_p]
 
 
 def wino(x, w, bias, variant, stat=None):
     N, Cin, D, H, W = x.shape
     Cout = w.shape[0]
-    wt = torch.empty(L.mis_wino_packed_floats(Cout, Cin, 0), device="cuda")
-    _l.check(L.mis_wino_pack(_l.ptr(w), _l.ptr(wt), Cout, Cin, 0, _l.stream_ptr()), "pack")
+    wt = ops.conv_pack(w, 4)
     y = torch.empty(N, Cout, D, H, W, device="cuda")
     S = D * H * W
 
