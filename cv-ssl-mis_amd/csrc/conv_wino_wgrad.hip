@@ -1,0 +1,399 @@
+// Winograd F(2x2x2, 3x3x3) weight gradient of the stride-1 'same' 3x3x3 convolutions of unet_3D / V-Net.
+//
+// Replaces the autograd weight gradient of nn.Conv3d(k=3, pad=1) in UnetConv3 / UnetUp3_CT / ConvBlock
+// (reference code/networks/utils.py:99-123, code/networks/unet_3D.py:28-57, code/networks/vnet.py:15-22):
+//     dw[co][ci][tap] = sum_{n, voxel} dy[n][co][voxel] * x[n][ci][voxel + tap - 1]
+//
+// The bilinear form of conv_wino.hip, differentiated with respect to the filter:
+//     dW = G^T [ sum_tiles (A dy A^T) (.) (B^T d B) ] G          per dimension
+//     A dy  = (y0, y0 + y1, y0 - y1, -y1)            the 2 outputs of a tile
+//     B^T d = (d0 - d2, d1 + d2, d2 - d1, d1 - d3)   its 4 inputs
+//     G^T m = (m0 + (m1 + m2) / 2, (m1 - m2) / 2, (m1 + m2) / 2 + m3)
+// 64 multiplies per tile and (co, ci) instead of 216; fp32 end to end (rounding differs from the direct form).
+//
+// Mapping (gfx950): a workgroup owns one block of 16 output x 16 input channels and a run of STAGES (boxes of 32 tiles
+// of one image).  For each transform point xi one v_mfma_f32_16x16x4_f32 contracts 4 tiles:
+//   A[i = lane&15][k = lane>>4] = V_xi[co0 + i][tile k]     the lane transforms the dy patch of its (co, tile)
+//   B[k = lane>>4][j = lane&15] = U_xi[ci0 + j][tile k]     ... and the x patch of its (ci, tile)
+//   D[row = (lane>>4)*4 + r][col = lane&15]                 64 x 4 accumulators (AGPRs), kept for the whole run
+// A wave takes 2 of the stage's 8 chunks of 4 tiles.  Both operands of a stage (haloed x of 16 channels, dy of 16
+// channels) arrive by LDS-DMA (buffer_load_dwordx4 ... lds) into a double buffer, one stage ahead; the LDS image is
+// linear in (row, channel, 16-byte group), so every DMA instruction is a full 64-lane piece and the patch of a lane is
+// contiguous in x.  VALU work does not overlap a wave's own MFMAs on this hardware (scripts/ubench/mfma_overlap.hip),
+// so the transforms sit between the MFMA runs; LDS reads and DMA issue sit inside them.
+// At the end: G^T . G in registers, the 4 waves summed through LDS, one partial per workgroup; a second kernel sums the
+// partials in a fixed order (deterministic) into dw[Cout][Cin][27].
+#include "common.h"
+#include "wino.h"
+
+namespace {
+
+using namespace mis_dma;
+using namespace mis_wino;
+
+struct WgArgs {
+    const float* x; long long x_bs;
+    const float* dy; long long dy_bs;
+    float* ws;                          // [task][27][16 co][16 ci]
+    int N, Cin, Cout, D, H, W;
+    int sz, sy, sx, n_stage;            // stages per image along z, y, x; N * sz * sy * sx
+    int ci_blocks, co_blocks, splits;   // tasks = co_blocks * ci_blocks * splits
+};
+
+// stage = TZ x TY x TX tiles (32), TX a multiple of 4: 8 chunks of 4 x-adjacent tiles
+template <int TZ_, int TY_, int TX_>
+struct WgCfg {
+    static constexpr int TZ = TZ_, TY = TY_, TX = TX_;
+    static constexpr int OZ = 2 * TZ, OY = 2 * TY, OX = 2 * TX;
+    static constexpr int HZ = OZ + 2, HY = OY + 2;
+    static constexpr int NQ = (OX + 8) / 4, RX = NQ * 4;          // x rows hold [x0 - 4, x0 + OX + 4)
+    static constexpr int XROWS = HZ * HY, XG = XROWS * 16 * NQ, XF = XG * 4;
+    static constexpr int DQ = OX / 4 + 1, DRX = DQ * 4;           // dy rows: OX floats + one pad group (bank spread)
+    static constexpr int DROWS = OZ * OY, DG = DROWS * 16 * DQ, DF = DG * 4;
+    static constexpr int STAGE = XF + DF;
+    static constexpr int XP = XG / 64, DP = DG / 64, P = XP + DP, PW = (P + 3) / 4;
+    static constexpr int CX = TX / 4;                             // chunks along x
+    static constexpr int LDS_BYTES = 2 * STAGE * 4;
+    static_assert(TZ * TY * TX == 32 && TX % 4 == 0, "32 tiles, chunks of 4 along x");
+    static_assert(XG % 64 == 0 && DG % 64 == 0, "whole DMA pieces");
+    static_assert(LDS_BYTES <= 160 * 1024, "LDS");
+    static_assert(4 * 27 * 256 * 4 <= LDS_BYTES, "the final cross-wave sum reuses the stage buffers");
+    static_assert(PW <= 20, "class bits: 5 pieces per register, 4 registers");
+};
+
+extern __shared__ __attribute__((aligned(16))) float mis_wgw_lds[];
+
+// V = A dy A^T in z and y of the 2x2x2 patch r[z][y] (pairs over x): 16 pairs vzy[z'][y'], 18 packed adds
+__device__ __forceinline__ void vzy_transform(const f32x2 (&r)[4], f32x2 (&v)[16], f32x2 zero) {
+    f32x2 a[4][2];      // z' x y
+#pragma unroll
+    for (int y = 0; y < 2; ++y) {
+        a[0][y] = r[y];
+        a[1][y] = pk_add(r[y], r[2 + y]);
+        a[2][y] = pk_sub(r[y], r[2 + y]);
+        a[3][y] = pk_sub(zero, r[2 + y]);
+    }
+#pragma unroll
+    for (int z = 0; z < 4; ++z) {
+        v[z * 4 + 0] = a[z][0];
+        v[z * 4 + 1] = pk_add(a[z][0], a[z][1]);
+        v[z * 4 + 2] = pk_sub(a[z][0], a[z][1]);
+        v[z * 4 + 3] = pk_sub(zero, a[z][1]);
+    }
+}
+
+__device__ __forceinline__ float f_add(float a, float b) { float r; asm volatile("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float f_sub(float a, float b) { float r; asm volatile("v_sub_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+
+template <class C>
+struct WgIssue {
+    unsigned rel[C::PW];        // per lane: byte offset of this lane's 16-byte group of piece i (biased, >= 0)
+    unsigned cls[4];            // 6 class bits per piece, 5 pieces per register: which faces of the box the group lies beyond
+    i32x4 rx, rd;               // x / dy of the image under the cursor
+    unsigned st;                // LDS byte address of the stage buffer
+    unsigned soff;              // byte offset of the box origin
+    unsigned flags;             // faces of the volume the box touches
+
+    template <int I>
+    __device__ __forceinline__ void piece(int wave) const {
+        if constexpr (I < C::PW) {
+            // uniform; the 4 * PW - P surplus slots repeat the last piece (same data to the same place: no branch
+            // in the MFMA run -- a branch there makes hipcc rename the accumulators through VGPR copies)
+            const int p = wave + 4 * I < C::P ? wave + 4 * I : C::P - 1;
+            const unsigned c = (cls[I / 5] >> ((I % 5) * 6)) & 63u;
+            const unsigned vo = (c & flags) ? OOB : rel[I];
+            dma_dwordx4_s(st + (unsigned)p * 1024u, vo, soff, p < C::XP ? rx : rd);
+        }
+    }
+};
+
+// One chunk: 64 MFMAs (point xi = K).  The A operand of a group of 4 points is generated from the pair vzy[K/4] by 3
+// VALU instructions; inside the run: the LDS reads of the next chunk's patches, and (second chunk of a stage) the DMAs of
+// the next stage.
+template <class C, bool ISSUE, int K>
+__device__ __forceinline__ void wg_slots(f32x2 (&u)[32], const f32x2 (&v)[16], f32x4 (&acc)[64],
+                                         f32x2 (&rn)[4], const float* __restrict__ xsrc, const float* __restrict__ dsrc,
+                                         const WgIssue<C>& is, int wave, float (&av)[4]) {
+    if constexpr (K < 64) {
+        if constexpr (K % 4 == 0) {
+            const f32x2 p = v[K / 4];
+            av[0] = p[0]; av[1] = f_add(p[0], p[1]); av[2] = f_sub(p[0], p[1]); av[3] = f_sub(0.f, p[1]);
+        }
+        acc[K] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[K % 4], u[K / 2][K % 2], acc[K], 0, 0, 0);
+        {   // next chunk's x patch, float K of the 4x4x4 patch (z, y, x) = (K / 16, (K / 4) % 4, K % 4): into the register
+            // the MFMA above has just consumed (one patch buffer instead of two: 64 registers)
+            constexpr int z = K / 16, y = (K / 4) % 4, xx = K % 4;
+            u[K / 2][K % 2] = xsrc[(z * C::HY + y) * 16 * C::RX + xx];
+        }
+        if constexpr (K < 4) {   // ... and its dy patch: (z, y) = (K / 2, K % 2), both x
+            rn[K] = *reinterpret_cast<const f32x2*>(dsrc + ((K / 2) * C::OY + (K % 2)) * 16 * C::DRX);
+        }
+        if constexpr (ISSUE && K % 3 == 1) is.template piece<K / 3>(wave);
+        __builtin_amdgcn_sched_barrier(0);
+        wg_slots<C, ISSUE, K + 1>(u, v, acc, rn, xsrc, dsrc, is, wave, av);
+    }
+}
+
+template <class C>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void wino_wgrad_kernel(const WgArgs a) {
+    float* const lds = mis_wgw_lds;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lt = lane >> 4, lc = lane & 15;
+    const long long S = (long long)a.D * a.H * a.W;
+    const unsigned s_bytes = (unsigned)S * 4u;
+
+    const int task = blockIdx.x;
+    const int split = task % a.splits, pair = task / a.splits;
+    const int cib = pair % a.ci_blocks, cob = pair / a.ci_blocks;
+    const int per = (a.n_stage + a.splits - 1) / a.splits;
+    const int s_begin = split * per, s_end = s_begin + per < a.n_stage ? s_begin + per : a.n_stage;
+
+    // ---- per-lane DMA geometry (stage-invariant) ----
+    const int BIAS = (a.H * a.W + a.W + 4) * 4;             // keeps the halo's negative offsets >= 0 (see rx below)
+    WgIssue<C> is;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) is.cls[i] = 0;
+#pragma unroll
+    for (int i = 0; i < C::PW; ++i) {
+        const int p = wave + 4 * i < C::P ? wave + 4 * i : C::P - 1;
+        unsigned rel = OOB, cls = 0;
+        if (p < C::XP) {
+            const int g = p * 64 + lane;
+            const int row = g / (16 * C::NQ), rem = g - row * (16 * C::NQ), ci = rem / C::NQ, q = rem - ci * C::NQ;
+            const int hz = row / C::HY, hy = row - hz * C::HY;
+            rel = (unsigned)((((hz - 1) * a.H + (hy - 1)) * a.W + 4 * q - 4) * 4 + BIAS) + (unsigned)ci * s_bytes;
+            cls = (hz == 0 ? 1 : 0) | (hz == C::HZ - 1 ? 2 : 0) | (hy == 0 ? 4 : 0) | (hy == C::HY - 1 ? 8 : 0) |
+                  (q == 0 ? 16 : 0) | (q == C::NQ - 1 ? 32 : 0);
+            if (cib * 16 + ci >= a.Cin) rel = OOB;          // channel padding of the last block
+        } else {
+            const int g = (p - C::XP) * 64 + lane;
+            const int row = g / (16 * C::DQ), rem = g - row * (16 * C::DQ), co = rem / C::DQ, q = rem - co * C::DQ;
+            const int oz = row / C::OY, oy = row - oz * C::OY;
+            if (q < C::DQ - 1 && cob * 16 + co < a.Cout) {
+                rel = (unsigned)(((oz * a.H + oy) * a.W + 4 * q) * 4) + (unsigned)co * s_bytes;
+            }
+        }
+        is.rel[i] = rel;
+        is.cls[i / 5] |= cls << ((i % 5) * 6);
+    }
+    const unsigned lds0 = lds_addr(lds);
+
+    struct Box { int n, bz, by, bx; };
+    auto decode = [&](int s) {
+        Box b;
+        int t = s;
+        b.bx = t % a.sx; t /= a.sx;
+        b.by = t % a.sy; t /= a.sy;
+        b.bz = t % a.sz; t /= a.sz;
+        b.n = t;
+        return b;
+    };
+    auto cursor = [&](int s, int buf) {       // uniform parts of stage s
+        const Box b = decode(s < s_end ? s : s_begin);
+        const bool live = s < s_end;
+        // x: the descriptor starts BIAS bytes before the channel block, so that halo offsets are never negative; the
+        // groups that would fall before the tensor are exactly the ones the class bits turn into padding
+        is.rx = make_rsrc(reinterpret_cast<const char*>(a.x + (long long)b.n * a.x_bs + (long long)cib * 16 * S) - BIAS,
+                          live ? 17u * s_bytes + (unsigned)BIAS : 0u);     // covers voffset + soffset
+
+        is.rd = make_rsrc(a.dy + (long long)b.n * a.dy_bs + (long long)cob * 16 * S, live ? 17u * s_bytes : 0u);
+        is.soff = (unsigned)(((b.bz * C::OZ) * a.H + b.by * C::OY) * a.W + b.bx * C::OX) * 4u;
+        is.flags = (b.bz == 0 ? 1u : 0u) | (b.bz == a.sz - 1 ? 2u : 0u) | (b.by == 0 ? 4u : 0u) | (b.by == a.sy - 1 ? 8u : 0u) |
+                   (b.bx == 0 ? 16u : 0u) | (b.bx == a.sx - 1 ? 32u : 0u);
+        is.st = lds0 + (unsigned)buf * (C::STAGE * 4);
+    };
+    auto issue_all = [&]() {
+        is.template piece<0>(wave); is.template piece<1>(wave); is.template piece<2>(wave); is.template piece<3>(wave);
+        is.template piece<4>(wave); is.template piece<5>(wave); is.template piece<6>(wave); is.template piece<7>(wave);
+        is.template piece<8>(wave); is.template piece<9>(wave); is.template piece<10>(wave); is.template piece<11>(wave);
+        is.template piece<12>(wave); is.template piece<13>(wave); is.template piece<14>(wave); is.template piece<15>(wave);
+        is.template piece<16>(wave); is.template piece<17>(wave); is.template piece<18>(wave); is.template piece<19>(wave);
+    };
+
+    // ---- this wave's two chunks (c = wave, wave + 4) and this lane's patch inside them ----
+    int xoff[2], doff[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int c = wave + 4 * h;
+        const int cx = c % C::CX, cy = (c / C::CX) % C::TY, cz = c / (C::CX * C::TY);
+        const int tx = 4 * cx + lt;
+        xoff[h] = ((2 * cz) * C::HY + 2 * cy) * 16 * C::RX + lc * C::RX + 3 + 2 * tx;
+        doff[h] = ((2 * cz) * C::OY + 2 * cy) * 16 * C::DRX + lc * C::DRX + 2 * tx;
+    }
+
+    // accumulators zeroed by an MFMA (0 * 0 + 0): a tuple defined by v_accvgpr_write x 4 does not coalesce with the loop's
+    // MFMA results and hipcc then copies half of the accumulators through VGPRs on every trip
+    f32x4 acc[64];
+    const f32x2 zero = {0.f, 0.f};
+    {
+        float z0 = 0.f;
+        asm volatile("" : "+v"(z0));
+#pragma unroll
+        for (int i = 0; i < 64; ++i)
+            acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(z0, z0, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+    }
+    f32x2 u[32], v[16], rn[4];
+    float av[4];
+
+    if (s_begin < s_end) {
+        cursor(s_begin, 0);
+        issue_all();
+        cursor(s_begin + 1, 1);
+        issue_all();
+        vmwait<0>::go();
+        __syncthreads();
+        // first chunk of the first stage: loaded and transformed without overlap
+        {
+            const float* __restrict__ xs = lds + xoff[0];
+            const float* __restrict__ ds = lds + C::XF + doff[0];
+#pragma unroll
+            for (int k = 0; k < 64; ++k) {
+                const int z = k / 16, y = (k / 4) % 4, xx = k % 4;
+                u[k / 2][k % 2] = xs[(z * C::HY + y) * 16 * C::RX + xx];
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) rn[k] = *reinterpret_cast<const f32x2*>(ds + ((k / 2) * C::OY + (k % 2)) * 16 * C::DRX);
+            in_units<0, 24>(u);
+            vzy_transform(rn, v, zero);
+        }
+        for (int s = s_begin; s < s_end; ++s) {
+            const int buf = (s - s_begin) & 1;
+            const float* __restrict__ sb = lds + buf * C::STAGE;
+            // chunk A; LDS reads of chunk B of the same stage
+            wg_slots<C, false, 0>(u, v, acc, rn, sb + xoff[1], sb + C::XF + doff[1], is, wave, av);
+            in_units<0, 24>(u);
+            vzy_transform(rn, v, zero);
+            // every wave has read stage s completely; stage s+1 (issued one stage ago) has landed
+            vmwait<0>::go();
+            __syncthreads();
+            cursor(s + 2, buf);              // refill this buffer with stage s+2 while chunk B runs
+            const float* __restrict__ nb = lds + (buf ^ 1) * C::STAGE;
+            // chunk B; LDS reads of chunk A of stage s+1 (zeros after the last stage: unused)
+            wg_slots<C, true, 0>(u, v, acc, rn, nb + xoff[0], nb + C::XF + doff[0], is, wave, av);
+            in_units<0, 24>(u);
+            vzy_transform(rn, v, zero);
+        }
+    }
+    vmwait<0>::go();
+    __syncthreads();
+
+    // ---- G^T . G: 64 points -> 27 taps for the lane's 4 (co, ci) pairs, two accumulator rows at a time ----
+    float* const red = lds + wave * (27 * 256);
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");          // the last MFMAs have left the pipe
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        f32x2 gz[3][16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const f32x2 m0 = acc_pair(acc[i], h), m1 = acc_pair(acc[16 + i], h), m2 = acc_pair(acc[32 + i], h),
+                        m3 = acc_pair(acc[48 + i], h);
+            const f32x2 t = (m1 + m2) * 0.5f;
+            gz[0][i] = m0 + t; gz[1][i] = (m1 - m2) * 0.5f; gz[2][i] = t + m3;
+        }
+#pragma unroll
+        for (int z = 0; z < 3; ++z) {
+            f32x2 gy[3][4];
+#pragma unroll
+            for (int x = 0; x < 4; ++x) {
+                const f32x2 t = (gz[z][4 + x] + gz[z][8 + x]) * 0.5f;
+                gy[0][x] = gz[z][x] + t; gy[1][x] = (gz[z][4 + x] - gz[z][8 + x]) * 0.5f; gy[2][x] = t + gz[z][12 + x];
+            }
+#pragma unroll
+            for (int y = 0; y < 3; ++y) {
+                const f32x2 t = (gy[y][1] + gy[y][2]) * 0.5f;
+                const f32x2 w0 = gy[y][0] + t, w1 = (gy[y][1] - gy[y][2]) * 0.5f, w2 = t + gy[y][3];
+                const int tap = (z * 3 + y) * 3;
+#pragma unroll
+                for (int rr = 0; rr < 2; ++rr) {
+                    const int e = (lt * 4 + 2 * h + rr) * 16 + lc;          // co * 16 + ci
+                    red[(tap + 0) * 256 + e] = w0[rr];
+                    red[(tap + 1) * 256 + e] = w1[rr];
+                    red[(tap + 2) * 256 + e] = w2[rr];
+                }
+            }
+        }
+    }
+    __syncthreads();
+    float* __restrict__ out = a.ws + (long long)task * (27 * 256);
+    for (int e = tid; e < 27 * 256; e += 256)
+        out[e] = (lds[e] + lds[27 * 256 + e]) + (lds[2 * 27 * 256 + e] + lds[3 * 27 * 256 + e]);
+}
+
+// dw[co][ci][tap] (+)= sum over the splits of the task partials, fixed order
+__global__ __launch_bounds__(256) void wino_wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw,
+                                                                int Cout, int Cin, int ci_blocks, int splits,
+                                                                int accumulate) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= Cout * Cin * 27) return;
+    const int tap = idx % 27, ci = (idx / 27) % Cin, co = idx / (27 * Cin);
+    const float* p = ws + ((long long)((co / 16) * ci_blocks + ci / 16) * splits) * (27 * 256) + tap * 256 + (co % 16) * 16 + ci % 16;
+    float s = 0.f;
+    for (int k = 0; k < splits; ++k) s += p[(long long)k * (27 * 256)];
+    dw[idx] = accumulate ? dw[idx] + s : s;
+}
+
+template <class C>
+void geometry(WgArgs& a) {
+    a.sz = a.D / C::OZ; a.sy = a.H / C::OY; a.sx = a.W / C::OX;
+    a.n_stage = a.N * a.sz * a.sy * a.sx;
+    a.ci_blocks = (a.Cin + 15) / 16; a.co_blocks = (a.Cout + 15) / 16;
+    const int pairs = a.ci_blocks * a.co_blocks;
+    int splits = 512 / pairs;                       // ~2 workgroups per CU in total (one resident at a time)
+    if (splits < 1) splits = 1;
+    if (splits > a.n_stage) splits = a.n_stage;
+    a.splits = splits;
+}
+
+template <class C>
+int launch_wg(WgArgs a, float* dw, int accumulate, hipStream_t stream) {
+    geometry<C>(a);
+    static std::atomic<unsigned long long> attr_done{0};
+    if (mis_set_lds_attr(reinterpret_cast<const void*>(&wino_wgrad_kernel<C>), C::LDS_BYTES, attr_done) != MIS_OK)
+        return MIS_ERR_LAUNCH;
+    const int tasks = a.ci_blocks * a.co_blocks * a.splits;
+    hipLaunchKernelGGL(wino_wgrad_kernel<C>, dim3(tasks), dim3(256), C::LDS_BYTES, stream, a);
+    const int total = a.Cout * a.Cin * 27;
+    hipLaunchKernelGGL(wino_wgrad_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, a.ws, dw, a.Cout, a.Cin,
+                       a.ci_blocks, a.splits, accumulate);
+    return mis_launch_status();
+}
+
+using WgV0 = WgCfg<1, 2, 16>;     // stages of 2 x 4 x 32 voxels (W a multiple of 32)
+using WgV1 = WgCfg<2, 2, 8>;      // stages of 4 x 4 x 16 voxels (W a multiple of 16)
+
+}  // namespace
+
+// Which variant serves the weight gradient of this 3x3x3 'same' convolution, or -1 (use mis_conv_wgrad)
+extern "C" int mis_conv3d_wino_wgrad_select(int N, int Cin, int Cout, int D, int H, int W) {
+    if (N <= 0 || Cin < 8 || Cout < 8 || D <= 0 || H <= 0 || W <= 0) return -1;
+    if (((long long)17 * D * H * W + (long long)H * W + W + 64) * 4 >= (1LL << 31)) return -1;
+    if (W % 32 == 0 && H % 4 == 0 && D % 2 == 0) return 0;
+    if (W % 16 == 0 && H % 4 == 0 && D % 4 == 0) return 1;
+    return -1;
+}
+
+extern "C" long long mis_conv3d_wino_wgrad_workspace_bytes(int N, int Cin, int Cout, int D, int H, int W, int variant) {
+    if (N <= 0 || Cin <= 0 || Cout <= 0 || D <= 0 || H <= 0 || W <= 0) return MIS_ERR_ARG;
+    WgArgs a{};
+    a.N = N; a.Cin = Cin; a.Cout = Cout; a.D = D; a.H = H; a.W = W;
+    if (variant == 0) geometry<WgV0>(a); else if (variant == 1) geometry<WgV1>(a); else return MIS_ERR_UNSUPPORTED;
+    return (long long)a.ci_blocks * a.co_blocks * a.splits * 27 * 256 * 4;
+}
+
+// dw[Cout][Cin][27] (+)= the weight gradient; workspace: mis_conv3d_wino_wgrad_workspace_bytes
+extern "C" int mis_conv3d_wino_wgrad(const float* x, long long x_bs, const float* dy, long long dy_bs, float* dw,
+                                     float* workspace, long long workspace_bytes, int N, int Cin, int Cout, int D, int H,
+                                     int W, int accumulate, int variant, hipStream_t stream) {
+    if (!x || !dy || !dw || !workspace || N <= 0 || Cin <= 0 || Cout <= 0 || D <= 0 || H <= 0 || W <= 0) return MIS_ERR_ARG;
+    const long long S = (long long)D * H * W;
+    if (x_bs < (long long)Cin * S || dy_bs < (long long)Cout * S) return MIS_ERR_ARG;
+    if (mis_conv3d_wino_wgrad_select(N, Cin, Cout, D, H, W) < 0 || (variant != 0 && variant != 1)) return MIS_ERR_UNSUPPORTED;
+    if ((variant == 0 && (W % 32 || H % 4 || D % 2)) || (variant == 1 && (W % 16 || H % 4 || D % 4))) return MIS_ERR_UNSUPPORTED;
+    if (((uintptr_t)x & 15) || ((uintptr_t)dy & 15) || x_bs % 4 || dy_bs % 4 || W % 4) return MIS_ERR_UNSUPPORTED;
+    if (workspace_bytes < mis_conv3d_wino_wgrad_workspace_bytes(N, Cin, Cout, D, H, W, variant)) return MIS_ERR_WORKSPACE;
+    WgArgs a{};
+    a.x = x; a.x_bs = x_bs; a.dy = dy; a.dy_bs = dy_bs; a.ws = workspace;
+    a.N = N; a.Cin = Cin; a.Cout = Cout; a.D = D; a.H = H; a.W = W;
+    return variant == 0 ? launch_wg<WgV0>(a, dw, accumulate, stream) : launch_wg<WgV1>(a, dw, accumulate, stream);
+}

@@ -51,6 +51,60 @@ def timeit(fn, n=30):
     return e0.elapsed_time(e1) / n * 1e3
 
 
+def wgrad_main():
+    """Winograd weight gradient vs the direct kernel and torch."""
+    torch.manual_seed(0)
+
+    def wino_wg(x, dy, var):
+        N, Cin, D, H, W = x.shape
+        Cout = dy.shape[1]
+        S = D * H * W
+        nb = L.mis_conv3d_wino_wgrad_workspace_bytes(N, Cin, Cout, D, H, W, var)
+        ws = torch.empty(nb // 4, device="cuda")
+        dw = torch.zeros(Cout, Cin, 3, 3, 3, device="cuda")
+
+        def run():
+            _l.check(L.mis_conv3d_wino_wgrad(_l.ptr(x), Cin * S, _l.ptr(dy), Cout * S, _l.ptr(dw), _l.ptr(ws), nb, N, Cin,
+                                             Cout, D, H, W, 0, var, _l.stream_ptr()), "wino wgrad")
+        run()
+        return dw, run
+
+    def direct_wg(x, dy):
+        dw = torch.zeros(dy.shape[1], x.shape[1], 3, 3, 3, device="cuda")
+
+        def run():
+            ops.WINO = 0
+            ops.conv_wgrad(x, dy, dw, (3, 3, 3))
+            ops.WINO = 1
+        run()
+        return dw, run
+
+    for (N, Cin, Cout, D, H, W, var) in [(1, 16, 16, 2, 4, 32, 0), (2, 16, 16, 4, 8, 64, 0), (1, 24, 40, 6, 4, 32, 0),
+                                         (2, 16, 32, 4, 8, 16, 1), (1, 48, 16, 8, 4, 48, 1), (3, 16, 16, 6, 12, 96, 0)]:
+        x = torch.randn(N, Cin, D, H, W, device="cuda")
+        dy = torch.randn(N, Cout, D, H, W, device="cuda")
+        xr = x.double().requires_grad_(False)
+        w = torch.zeros(Cout, Cin, 3, 3, 3, device="cuda", dtype=torch.float64, requires_grad=True)
+        torch.nn.functional.conv3d(xr, w, padding=1).backward(dy.double())
+        ref = w.grad
+        dww, _ = wino_wg(x, dy, var)
+        dwd, _ = direct_wg(x, dy)
+        sc = ref.abs().max().item()
+        print(f"wgrad N{N} {Cin}->{Cout} {D}x{H}x{W} v{var}: wino err {(dww.double() - ref).abs().max().item() / sc:.3e}  "
+              f"direct err {(dwd.double() - ref).abs().max().item() / sc:.3e} (rel. to max {sc:.1f})", flush=True)
+    for (N, Cin, Cout, S, var) in [(8, 16, 16, 96, 0), (8, 48, 16, 96, 0), (8, 32, 32, 48, 1), (8, 96, 32, 48, 1),
+                                   (8, 16, 32, 48, 1)]:
+        x = torch.randn(N, Cin, S, S, S, device="cuda")
+        dy = torch.randn(N, Cout, S, S, S, device="cuda")
+        fl = 2.0 * N * Cout * Cin * 27 * S ** 3
+        dww, rw = wino_wg(x, dy, var)
+        dwd, rd = direct_wg(x, dy)
+        err = (dww - dwd).abs().max().item() / dwd.abs().max().item()
+        tw, td = timeit(rw), timeit(rd)
+        print(f"wgrad N{N} {Cin}->{Cout} {S}^3 v{var}: wino {tw:8.1f} us ({fl / tw / 1e6:6.1f} TF eq)  direct {td:8.1f} us "
+              f"({fl / td / 1e6:6.1f} TF)  speedup {td / tw:.2f}  rel diff {err:.2e}", flush=True)
+
+
 def main():
     torch.manual_seed(0)
     if os.environ.get("MIS_WINO_DBG"):
@@ -92,4 +146,4 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    wgrad_main() if "wgrad" in sys.argv[1:] else main()
