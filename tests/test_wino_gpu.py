@@ -1,0 +1,216 @@
+"""Winograd F(2x2x2, 3x3x3) kernels (csrc/conv_wino.hip, csrc/conv_wino_wgrad.hip) through the C-ABI, against torch
+fp64 on the CPU and against the direct MFMA kernels.
+
+What they replace: nn.Conv3d(k=3, pad=1) forward, its autograd data gradient and weight gradient in UnetConv3 /
+UnetUp3_CT / ConvBlock (reference code/networks/utils.py:99-123, unet_3D.py:28-57, vnet.py:15-22).  The arithmetic is
+fp32 end to end; the tolerance is the one the direct kernels are held to in test_kernels_gpu.py (2e-4 relative to the
+largest reference value, fp32 with another summation order)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _ops():
+    from mis_hip import ops
+    return ops
+
+
+def _rand(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.rand(*shape, generator=g, dtype=torch.float64) * 2 - 1) * scale
+
+
+def _close(a, b, rtol=2e-4, atol=2e-5):
+    a = a.detach().cpu().double()
+    b = b.detach().cpu().double()
+    err = (a - b).abs().max().item()
+    ref = b.abs().max().item()
+    assert err <= atol + rtol * ref, f"max err {err:.3e} vs ref scale {ref:.3e}"
+
+
+# N, Cin, Cout, D, H, W, expected forward variant
+FWD_CASES = [
+    (1, 16, 16, 4, 4, 32, 0),
+    (2, 16, 32, 8, 12, 64, 0),
+    (1, 48, 16, 4, 8, 96, 0),       # the decoder's concat conv (3 chunks of 16 input channels)
+    (2, 24, 48, 4, 8, 32, 0),       # 6 chunks, 3 output blocks
+    (2, 16, 32, 4, 8, 16, 1),
+    (1, 32, 32, 8, 8, 48, 1),
+    (3, 96, 32, 4, 8, 16, 1),
+]
+
+
+@pytest.mark.parametrize("case", FWD_CASES)
+def test_wino_forward_and_data_gradient(case):
+    ops = _ops()
+    N, Cin, Cout, D, H, W, variant = case
+    assert ops.conv_wino_select(N, Cin, Cout, D, H, W, (3, 3, 3)) == variant
+    x = _rand(N, Cin, D, H, W, seed=1).requires_grad_(True)
+    w = _rand(Cout, Cin, 3, 3, 3, seed=2, scale=0.2).requires_grad_(True)
+    b = _rand(Cout, seed=3)
+    y_ref = F.conv3d(x, w, b, padding=1)
+    dy = _rand(*y_ref.shape, seed=4)
+    y_ref.backward(dy)
+
+    xd, wd, bd, dyd = x.detach().float().cuda(), w.detach().float().cuda(), b.float().cuda(), dy.float().cuda()
+    y = torch.full((N, Cout, D, H, W), float("nan"), device="cuda")
+    ops.conv_fwd(xd, ops.conv_pack(wd, 4), bd, y, Cin, Cout, (3, 3, 3), wino=variant)
+    _close(y, y_ref)
+
+    # the same launch on dy with the flipped / transposed transformed filter is the data gradient
+    vb = ops.conv_wino_select(N, Cout, Cin, D, H, W, (3, 3, 3))
+    if vb >= 0:
+        dx = torch.full((N, Cin, D, H, W), float("nan"), device="cuda")
+        ops.conv_fwd(dyd, ops.conv_pack(wd, 5), None, dx, Cout, Cin, (3, 3, 3), wino=vb)
+        _close(dx, x.grad)
+
+    # ... and both agree with the direct kernels
+    yd = torch.empty_like(y)
+    ops.conv_fwd(xd, ops.conv_pack(wd, 0), bd, yd, Cin, Cout, (3, 3, 3))
+    _close(y, yd)
+
+
+@pytest.mark.parametrize("N,Cin,Cout,D,H,W,per_sample", [(2, 16, 16, 4, 8, 32, True), (3, 32, 32, 4, 8, 16, False),
+                                                         (2, 48, 16, 8, 4, 64, True)])
+def test_wino_fused_statistics(N, Cin, Cout, D, H, W, per_sample):
+    """The per-box (sum, sumsq) partials of the Winograd epilogue + mis_norm_stats_finalize == the statistics of the
+    InstanceNorm / BatchNorm that follows the conv (reference utils.py:104-107: Conv3d -> norm -> ReLU)."""
+    ops = _ops()
+    v = ops.conv_wino_select(N, Cin, Cout, D, H, W, (3, 3, 3))
+    assert v >= 0
+    T = ops.conv_stat_tiles(N, Cin, Cout, D, H, W, (3, 3, 3), wino=v)
+    assert T > 0
+    x = _rand(N, Cin, D, H, W, seed=21)
+    w = _rand(Cout, Cin, 3, 3, 3, seed=22, scale=0.3)
+    b = _rand(Cout, seed=23)
+    y_ref = F.conv3d(x, w, b, padding=1)
+    part = torch.full((Cout * N * T, 2), float("nan"), device="cuda")
+    y = torch.empty(N, Cout, D, H, W, device="cuda")
+    strides = (T, Cout * T) if per_sample else (N * T, T)
+    ops.conv_fwd(x.float().cuda(), ops.conv_pack(w.float().cuda(), 4), b.float().cuda(), y, Cin, Cout, (3, 3, 3),
+                 stat=(part, *strides), wino=v)
+    _close(y, y_ref)
+    assert torch.isfinite(part).all()
+    G = N * Cout if per_sample else Cout
+    mean = torch.empty(G, device="cuda"); rstd = torch.empty(G, device="cuda")
+    rm, rv = torch.zeros(Cout, device="cuda"), torch.ones(Cout, device="cuda")
+    nbt = torch.zeros((), dtype=torch.long, device="cuda")
+    ops.norm_stats_finalize(part, N, Cout, D * H * W, T, per_sample, 1e-5, mean, rstd,
+                            None if per_sample else rm, None if per_sample else rv, None if per_sample else nbt)
+    dims = (2, 3, 4) if per_sample else (0, 2, 3, 4)
+    m_ref = y_ref.mean(dim=dims).flatten()
+    v_ref = y_ref.var(dim=dims, unbiased=False).flatten()
+    _close(mean, m_ref, rtol=1e-5, atol=1e-6)
+    _close(rstd, 1.0 / torch.sqrt(v_ref + 1e-5), rtol=1e-5, atol=1e-6)
+
+
+def test_wino_channel_slices_of_concat_buffers():
+    """Input = a channel slice of a concat buffer, output = a slice of another one (batch strides != C * S)."""
+    ops = _ops()
+    N, C0, Cin, Cout, D, H, W = 2, 16, 16, 32, 4, 8, 32
+    cat = _rand(N, C0 + Cin, D, H, W, seed=5).float().cuda()
+    w = _rand(Cout, Cin, 3, 3, 3, seed=6, scale=0.2).float().cuda()
+    ycat = torch.zeros(N, 16 + Cout, D, H, W, device="cuda")
+    v = ops.conv_wino_select(N, Cin, Cout, D, H, W, (3, 3, 3))
+    assert v >= 0
+    ops.conv_fwd(cat[:, C0:], ops.conv_pack(w, 4), None, ycat[:, 16:], Cin, Cout, (3, 3, 3), wino=v)
+    ref = F.conv3d(cat[:, C0:].cpu().double(), w.cpu().double(), padding=1)
+    _close(ycat[:, 16:], ref)
+    assert ycat[:, :16].abs().max().item() == 0.0
+    # weight gradient from slices
+    dy = _rand(N, 16 + Cout, D, H, W, seed=7).float().cuda()
+    dw = torch.empty_like(w)
+    ops.conv_wgrad(cat[:, C0:], dy[:, 16:], dw, (3, 3, 3))
+    wr = w.cpu().double().requires_grad_(True)
+    F.conv3d(cat[:, C0:].cpu().double(), wr, padding=1).backward(dy[:, 16:].cpu().double())
+    _close(dw, wr.grad, rtol=3e-4, atol=1e-4)
+
+
+# N, Cin, Cout, D, H, W
+WGRAD_CASES = [
+    (1, 16, 16, 2, 4, 32),
+    (2, 16, 16, 4, 8, 64),
+    (1, 24, 40, 6, 4, 32),        # ragged channel blocks on both sides
+    (2, 48, 16, 4, 8, 96),
+    (2, 16, 32, 4, 8, 16),
+    (1, 48, 16, 8, 4, 48),
+    (3, 8, 8, 4, 4, 16),
+]
+
+
+@pytest.mark.parametrize("case", WGRAD_CASES)
+def test_wino_weight_gradient(case):
+    ops = _ops()
+    from mis_hip import lib
+    N, Cin, Cout, D, H, W = case
+    assert lib.load().mis_conv3d_wino_wgrad_select(N, Cin, Cout, D, H, W) >= 0
+    x = _rand(N, Cin, D, H, W, seed=11)
+    dy = _rand(N, Cout, D, H, W, seed=12)
+    w = torch.zeros(Cout, Cin, 3, 3, 3, dtype=torch.float64, requires_grad=True)
+    F.conv3d(x, w, padding=1).backward(dy)
+    xd, dyd = x.float().cuda(), dy.float().cuda()
+    dw = torch.full((Cout, Cin, 3, 3, 3), float("nan"), device="cuda")
+    ops.conv_wgrad(xd, dyd, dw, (3, 3, 3))
+    _close(dw, w.grad, rtol=1e-5, atol=1e-6)
+    # deterministic (fixed summation order), and `accumulate` adds
+    dw2 = torch.empty_like(dw)
+    ops.conv_wgrad(xd, dyd, dw2, (3, 3, 3))
+    assert torch.equal(dw, dw2)
+    ops.conv_wgrad(xd, dyd, dw2, (3, 3, 3), accumulate=True)
+    _close(dw2, 2 * w.grad, rtol=1e-5, atol=1e-6)
+    # the direct kernel agrees
+    ops.WINO = 0
+    try:
+        dwd = torch.empty_like(dw)
+        ops.conv_wgrad(xd, dyd, dwd, (3, 3, 3))
+    finally:
+        ops.WINO = 1
+    _close(dw, dwd, rtol=1e-5, atol=1e-6)
+
+
+def test_wino_select_and_refusal():
+    """Geometries the Winograd kernels do not cover are reported by the select functions and refused by the entry points
+    (no silent fallback inside the library: the caller picks the direct kernel)."""
+    ops = _ops()
+    from mis_hip import lib
+    L = lib.load()
+    sel = lambda *a: ops.conv_wino_select(*a, (3, 3, 3))
+    assert sel(2, 16, 16, 96, 96, 96) == 0 and sel(2, 32, 32, 48, 48, 48) == 1
+    assert sel(2, 1, 16, 96, 96, 96) == -1          # first layer: 1 input channel
+    assert sel(2, 16, 2, 96, 96, 96) == -1          # Cout not a multiple of 16
+    assert sel(2, 64, 64, 24, 24, 24) == -1         # 24^3 and deeper: direct kernel
+    assert sel(2, 16, 16, 6, 6, 30) == -1
+    assert ops.conv_wino_select(2, 16, 16, 1, 64, 64, (3, 3)) == -1
+    x = torch.zeros(1, 16, 6, 6, 30, device="cuda")
+    y = torch.zeros(1, 16, 6, 6, 30, device="cuda")
+    wt = ops.conv_pack(torch.zeros(16, 16, 3, 3, 3, device="cuda"), 4)
+    with pytest.raises(RuntimeError, match="UNSUPPORTED"):
+        ops.conv_fwd(x, wt, None, y, 16, 16, (3, 3, 3), wino=0)
+    assert L.mis_conv3d_wino_wgrad_select(1, 16, 16, 6, 6, 30) == -1
+    with pytest.raises(RuntimeError):
+        ops.conv_pack(torch.zeros(16, 16, 3, 3, device="cuda"), 4)      # the transform is defined for 3x3x3 only
+
+
+def test_wino_full_size_layer_matches_direct():
+    """One config-3 layer at its real size (8 x 16 -> 16 at 96^3, BASELINE configs[2]): Winograd == direct within fp32
+    rounding, forward and weight gradient."""
+    ops = _ops()
+    N, C, S = 8, 16, 96
+    g = torch.Generator(device="cuda").manual_seed(5)
+    x = torch.randn(N, C, S, S, S, device="cuda", generator=g)
+    dy = torch.randn(N, C, S, S, S, device="cuda", generator=g)
+    w = torch.randn(C, C, 3, 3, 3, device="cuda", generator=g) * 0.05
+    y0, y1 = torch.empty_like(x), torch.empty_like(x)
+    ops.conv_fwd(x, ops.conv_pack(w, 0), None, y0, C, C, (3, 3, 3))
+    ops.conv_fwd(x, ops.conv_pack(w, 4), None, y1, C, C, (3, 3, 3), wino=ops.conv_wino_select(N, C, C, S, S, S, (3, 3, 3)))
+    assert (y0 - y1).abs().max().item() <= 2e-5 * y0.abs().max().item()
+    d0, d1 = torch.empty_like(w), torch.empty_like(w)
+    ops.conv_wgrad(x, dy, d1, (3, 3, 3))
+    ops.WINO = 0
+    try:
+        ops.conv_wgrad(x, dy, d0, (3, 3, 3))
+    finally:
+        ops.WINO = 1
+    assert (d0 - d1).abs().max().item() <= 2e-5 * d0.abs().max().item()
