@@ -94,10 +94,10 @@ struct Issue {
 
     template <int I>
     __device__ __forceinline__ void piece(int wave) const {
-        if constexpr (I >= 0 && I < C::NCH) {
+        if constexpr (I >= 0 && I < C::NCH && !(DBG & 256)) {
             if (I * 64 + 64 <= C::GROUPS || I * 64 + (int)(threadIdx.x & 63) < C::GROUPS)   // ragged last piece
                 dma_dwordx4_s(st + (unsigned)(wave * C::CS + I * 256) * 4u, voff[I], cbase, rx);
-        } else if constexpr (I >= C::NCH && I < C::P) {
+        } else if constexpr (I >= C::NCH && I < C::P && !(DBG & 128)) {
             dma_dwordx4_s(st + (unsigned)(C::IN_FLOATS + (wave + 4 * (I - C::NCH)) * 256) * 4u, wvoff[I - C::NCH], wbase, rw);
         }
     }

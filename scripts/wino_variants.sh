@@ -8,7 +8,7 @@ for v in "$@"; do
     n=$1; shift
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -ffp-contract=fast \
         -DMIS_WINO_DBG_CT=$n "$@" -c conv_wino.hip -o /tmp/conv_wino_v$i.o || exit 1
-    objs=$(ls *.o | grep -v conv_wino)
+    objs=$(ls *.o | grep -v "^conv_wino.o$")
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../mis_hip/libmis_hip_v$i.so $objs /tmp/conv_wino_v$i.o || exit 1
     i=$((i + 1))
 done
