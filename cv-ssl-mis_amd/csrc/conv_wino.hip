@@ -112,7 +112,7 @@ struct Issue {
 //   K % 4 == 0   ds_read_b128 of the filter points of group K/4 + 2 (the last two: groups 0, 1 of the next stage)
 //   K < 16       two ds_read2_b32 of the next chunk's patch
 //   2, 7, 12 ..  one DMA of the stage NBUF-1 ahead (spread out: the CU's one texture-address unit serves all 4 waves)
-//   16 .. 39     one unit of the transform of the next chunk
+//   (the transform of the next chunk follows the run, see iter)
 template <class C, bool FIRST, int K>
 __device__ __forceinline__ void slots(const f32x4* __restrict__ wl, const f32x4* __restrict__ wl_next,
                                       const float* __restrict__ raw, const f32x2 (&cur)[32], f32x2 (&nxt)[32],
@@ -136,7 +136,7 @@ __device__ __forceinline__ void slots(const f32x4* __restrict__ wl, const f32x4*
             }
         }
         if constexpr (K >= 2 && (K - 2) % 5 == 0 && (K - 2) / 5 < C::P && !(DBG & 8)) is.template piece<(K - 2) / 5>(wave);
-        if constexpr (K >= 16 && K < 40 && !(DBG & 16)) in_unit<K - 16>(nxt);
+        if constexpr (K >= 16 && K < 40 && !(DBG & 16) && (DBG & 512)) in_unit<K - 16>(nxt);      // development: interleaved
         __builtin_amdgcn_sched_barrier(0);
         slots<C, FIRST, K + 1>(wl, wl_next, raw, cur, nxt, acc, ar, is, wave);
     }
@@ -260,6 +260,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     auto iter = [&](auto first, f32x2 (&cur)[32], f32x2 (&nxt)[32], int s) {
         cursor_set(gs + A, s + A < nst ? s + A : s + A - nst);
         slots<C, decltype(first)::value, 0>(wl_of(gs), wl_of(gs + 1), raw_of(gs + 1), cur, nxt, acc, ar, is, wave);
+        // the transform of the next chunk, after the run: VALU work does not overlap this wave's MFMAs wherever it is placed
+        // (scripts/ubench/mfma_overlap.hip), and in one block it costs 4 % less than spread over the slots
+        if (!(DBG & 16) && !(DBG & 512)) in_units<0, 24>(nxt);
         ++gs;
         vmwait<C::P>::go();                // stage gs+1 landed (mine) ...
         if (!(DBG & 64)) __syncthreads();  // ... and everyone's; everyone is done with stage gs-1
