@@ -48,7 +48,7 @@ struct WinoArgs {
 };
 
 // group = GZ x GY x GX tiles (16) per wave; workgroup = WZ x WY x WX groups x COB blocks of 16 output channels (4 waves)
-template <int GZ_, int GY_, int GX_, int WZ_, int WY_, int WX_, int COB_, int NBUF_>
+template <int GZ_, int GY_, int GX_, int WZ_, int WY_, int WX_, int COB_, int NBUF_, int DW_ = 0>
 struct WinoCfg {
     static constexpr int GZ = GZ_, GY = GY_, GX = GX_, WZ = WZ_, WY = WY_, WX = WX_, COB = COB_, NBUF = NBUF_;
     static constexpr int BZ = GZ * WZ, BY = GY * WY, BX = GX * WX;          // tiles per box
@@ -56,10 +56,14 @@ struct WinoCfg {
     static constexpr int HZ = OZ + 2, HY = OY + 2;
     // LDS rows hold x in [x0 - 4, x0 + OX + 4): whole 16-byte groups of the image row (W % 4 == 0), so a row arrives as
     // NQ buffer_load_dwordx4 ... lds lanes; the halo column x0 - 1 sits at float 3 of the row
-    static constexpr int NQ = (OX + 8) / 4, RX = NQ * 4;
-    static constexpr int GROUPS = HZ * HY * NQ;                              // 16-byte groups per channel
+    // DW = 1 (narrow boxes, OX = 8: the padded rows would not fit 4 ring stages): rows hold exactly [x0 - 1, x0 + OX + 1)
+    // and arrive as single dwords (buffer_load_dword ... lds), 64 halo elements per instruction
+    static constexpr int DW = DW_;
+    static constexpr int NQ = DW ? OX + 2 : (OX + 8) / 4, RX = DW ? OX + 2 : NQ * 4, X0 = DW ? 0 : 3;
+    static constexpr int GROUPS = HZ * HY * NQ;                              // DMA lanes (16-byte groups / dwords) per channel
     static constexpr int NCH = (GROUPS + 63) / 64;                           // DMA instructions per channel
-    static constexpr int CS = GROUPS * 4 + (32 - (GROUPS * 4) % 64 + 64) % 64;  // channel stride (floats), == 32 (mod 64)
+    static constexpr int CS_RAW = DW ? NCH * 64 : GROUPS * 4;                // DW: whole pieces (surplus lanes land in the pad)
+    static constexpr int CS = CS_RAW + (32 - CS_RAW % 64 + 64) % 64;         // channel stride (floats), == 32 (mod 64)
     static constexpr int IN_FLOATS = 4 * CS;
     static constexpr int W_FLOATS = COB * 4096;
     static constexpr int STAGE = IN_FLOATS + W_FLOATS;
@@ -71,7 +75,7 @@ struct WinoCfg {
     static_assert(GZ * GY * GX == 16, "16 tiles per wave");
     static_assert(WZ * WY * WX * COB == 4, "4 waves");
     static_assert(NBUF == 3 || NBUF == 4, "ring depth");
-    static_assert(P <= 63, "vmcnt range");
+    static_assert(2 * P <= 63 && P <= 21, "vmcnt range (two stages in flight), DMA slots");
     static_assert(LDS_BYTES <= 160 * 1024, "LDS");
 };
 
@@ -95,8 +99,11 @@ struct Issue {
     template <int I>
     __device__ __forceinline__ void piece(int wave) const {
         if constexpr (I >= 0 && I < C::NCH && !(DBG & 256)) {
-            if (I * 64 + 64 <= C::GROUPS || I * 64 + (int)(threadIdx.x & 63) < C::GROUPS)   // ragged last piece
+            if constexpr (C::DW) {
+                dma_dword_s(st + (unsigned)(wave * C::CS + I * 64) * 4u, voff[I], cbase, rx);
+            } else if (I * 64 + 64 <= C::GROUPS || I * 64 + (int)(threadIdx.x & 63) < C::GROUPS) {   // ragged last piece
                 dma_dwordx4_s(st + (unsigned)(wave * C::CS + I * 256) * 4u, voff[I], cbase, rx);
+            }
         } else if constexpr (I >= C::NCH && I < C::P && !(DBG & 128)) {
             dma_dwordx4_s(st + (unsigned)(C::IN_FLOATS + (wave + 4 * (I - C::NCH)) * 256) * 4u, wvoff[I - C::NCH], wbase, rw);
         }
@@ -135,7 +142,8 @@ __device__ __forceinline__ void slots(const f32x4* __restrict__ wl, const f32x4*
                 nxt[j] = f32x2{rz[y * C::RX + 2 * xp], rz[y * C::RX + 2 * xp + 1]};
             }
         }
-        if constexpr (K >= 2 && (K - 2) % 5 == 0 && (K - 2) / 5 < C::P && !(DBG & 8)) is.template piece<(K - 2) / 5>(wave);
+        constexpr int SP = C::P <= 12 ? 5 : 3;      // DMA spacing in slots
+        if constexpr (K >= 2 && (K - 2) % SP == 0 && (K - 2) / SP < C::P && !(DBG & 8)) is.template piece<(K - 2) / SP>(wave);
         if constexpr (K >= 16 && K < 40 && !(DBG & 16) && (DBG & 512)) in_unit<K - 16>(nxt);      // development: interleaved
         __builtin_amdgcn_sched_barrier(0);
         slots<C, FIRST, K + 1>(wl, wl_next, raw, cur, nxt, acc, ar, is, wave);
@@ -186,7 +194,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         is.wvoff[i] = (unsigned)((b * nst) * 4096 + pp * 256 + lane * 4) * 4u;
     }
     int icg = 0;                 // channel group of the cursor's box
-    // per-lane geometry of the DMA pieces, packed (hz | hy << 4 | q << 9 | valid << 13), kept in LDS: as registers
+    // per-lane geometry of the DMA pieces, packed (hz | hy << 4 | q << 9 | valid << 14), kept in LDS: as registers
     // hipcc spills these box-invariant values to scratch, and a scratch reload waits on vmcnt(0) -- on the DMAs in flight
     unsigned* const s_geo = reinterpret_cast<unsigned*>(lds + C::NBUF * C::STAGE + 128 + C::MAX_COUT);
     if (tid < 64) {
@@ -195,7 +203,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             const int e = p * 64 + tid;
             const int row = e / C::NQ, q = e - row * C::NQ;
             const int hz = row / C::HY, hy = row - hz * C::HY;
-            s_geo[p * 64 + tid] = (unsigned)(hz | hy << 4 | q << 9 | (e < C::GROUPS ? 1 << 13 : 0));
+            s_geo[p * 64 + tid] = (unsigned)(hz | hy << 4 | q << 9 | (e < C::GROUPS ? 1 << 14 : 0));
         }
     }
     __syncthreads();
@@ -207,8 +215,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
         for (int p = 0; p < C::NCH; ++p) {
             const unsigned g = s_geo[p * 64 + lane];
-            const int qz = b.z0 - 1 + (int)(g & 15u), qy = b.y0 - 1 + (int)((g >> 4) & 31u), qx = b.x0 - 4 + 4 * (int)((g >> 9) & 15u);
-            const bool ok = (g >> 13) && (unsigned)qz < (unsigned)a.D && (unsigned)qy < (unsigned)a.H &&
+            const int qz = b.z0 - 1 + (int)(g & 15u), qy = b.y0 - 1 + (int)((g >> 4) & 31u);
+            const int qx = C::DW ? b.x0 - 1 + (int)((g >> 9) & 31u) : b.x0 - 4 + 4 * (int)((g >> 9) & 31u);
+            const bool ok = (g >> 14) && (unsigned)qz < (unsigned)a.D && (unsigned)qy < (unsigned)a.H &&
                             (unsigned)qx < (unsigned)a.W;
             is.voff[p] = ok ? (unsigned)((qz * a.H + qy) * a.W + qx) * 4u : OOB;
         }
@@ -220,7 +229,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     };
 
     // this lane's patch: tile (tz, ty, tx) of the box, channel lk of the chunk
-    const int poff = ((2 * tz) * C::HY + 2 * ty) * C::RX + 3 + 2 * tx + lk * C::CS;
+    const int poff = ((2 * tz) * C::HY + 2 * ty) * C::RX + C::X0 + 2 * tx + lk * C::CS;
     auto raw_of = [&](unsigned gs) { return lds + (gs % C::NBUF) * C::STAGE + poff; };
     auto wl_of = [&](unsigned gs) {
         return reinterpret_cast<const f32x4*>(lds + (gs % C::NBUF) * C::STAGE + C::IN_FLOATS + cb * 4096) + lane;
@@ -397,7 +406,8 @@ int launch_wino(WinoArgs a, hipStream_t stream) {
 }  // namespace
 
 // Which Winograd variant serves this 3x3x3 'same' convolution, or -1 (use the direct kernel, mis_conv_fwd):
-//   0: boxes of 4 x 4 x 32 outputs (W a multiple of 32: the 96^3 level),  1: 4 x 8 x 16 (W a multiple of 16: 48^3).
+//   0: boxes of 4 x 4 x 32 outputs (W a multiple of 32: the 96^3 level),  1: 4 x 8 x 16 (W a multiple of 16: 48^3),
+//   2: 8 x 8 x 8 (W a multiple of 8: 24^3; halo rows as single dwords).
 // Needs Cin % 8 == 0 (two 4-channel chunks per loop trip), Cin >= 16 (the DMA ring runs 3 chunks ahead),
 // Cout % 16 == 0 (MFMA rows), Cout <= 384 (bias table in LDS), even D / H and W % 4 == 0 (2x2x2 tiles, 16-byte rows).
 extern "C" int mis_conv3d_wino_select(int N, int Cin, int Cout, int D, int H, int W) {
@@ -406,6 +416,7 @@ extern "C" int mis_conv3d_wino_select(int N, int Cin, int Cout, int D, int H, in
     if (((long long)Cin + 32) * D * H * W * 4 >= (1LL << 30)) return -1;
     if (W % 32 == 0 && D % 4 == 0 && H % 4 == 0) return 0;
     if (W % 16 == 0 && D % 4 == 0 && H % 8 == 0) return 1;
+    if (W % 8 == 0 && D % 8 == 0 && H % 8 == 0 && Cin >= 32) return 2;      // the 24^3 level: boxes of 8 x 8 x 8
     return -1;
 }
 
@@ -422,14 +433,16 @@ extern "C" long long mis_conv3d_wino_stat_tiles(int D, int H, int W, int variant
     if (D <= 0 || H <= 0 || W <= 0) return MIS_ERR_ARG;
     if (variant == 0) return boxes_per_image<WinoCfg<1, 1, 16, 2, 2, 1, 1, 4>>(D, H, W);
     if (variant == 1) return boxes_per_image<WinoCfg<1, 2, 8, 2, 2, 1, 1, 4>>(D, H, W);
+    if (variant == 2) return boxes_per_image<WinoCfg<1, 4, 4, 4, 1, 1, 1, 4, 1>>(D, H, W);
     return MIS_ERR_UNSUPPORTED;
 }
 
 // kernel name as rocprofv3 prints it (minus the anonymous-namespace prefix), for bench.py's attribution
 extern "C" int mis_conv3d_wino_kernel_name(int variant, char* name, int name_len) {
     if (!name || name_len <= 0) return MIS_ERR_ARG;
-    if (variant == 0) snprintf(name, name_len, "wino_fwd_kernel<WinoCfg<1, 1, 16, 2, 2, 1, 1, 4>>");
-    else if (variant == 1) snprintf(name, name_len, "wino_fwd_kernel<WinoCfg<1, 2, 8, 2, 2, 1, 1, 4>>");
+    if (variant == 0) snprintf(name, name_len, "wino_fwd_kernel<WinoCfg<1, 1, 16, 2, 2, 1, 1, 4, 0>>");
+    else if (variant == 1) snprintf(name, name_len, "wino_fwd_kernel<WinoCfg<1, 2, 8, 2, 2, 1, 1, 4, 0>>");
+    else if (variant == 2) snprintf(name, name_len, "wino_fwd_kernel<WinoCfg<1, 4, 4, 4, 1, 1, 1, 4, 1>>");
     else return MIS_ERR_UNSUPPORTED;
     return MIS_OK;
 }
@@ -442,7 +455,7 @@ extern "C" int mis_conv3d_wino_fwd(const float* x, long long x_bs, const float* 
     if (!x || !wt || !y || N <= 0 || Cin <= 0 || Cout <= 0 || D <= 0 || H <= 0 || W <= 0) return MIS_ERR_ARG;
     const long long S = (long long)D * H * W;
     if (x_bs < (long long)Cin * S || y_bs < (long long)Cout * S) return MIS_ERR_ARG;
-    if (Cout % 16 || Cout > 384 || Cin % 8 || Cin < 16 || W % 4 || D % 2 || H % 2 || y_bs % 2 || ((uintptr_t)y & 7) || ((uintptr_t)wt & 15))
+    if (Cout % 16 || Cout > 384 || Cin % 8 || Cin < 16 || (W % 4 && variant != 2) || D % 2 || H % 2 || W % 2 || y_bs % 2 || ((uintptr_t)y & 7) || ((uintptr_t)wt & 15))
         return MIS_ERR_UNSUPPORTED;
     if (((long long)Cin + 32) * S * 4 >= (1LL << 30)) return MIS_ERR_UNSUPPORTED;
     WinoArgs a{};
@@ -452,5 +465,6 @@ extern "C" int mis_conv3d_wino_fwd(const float* x, long long x_bs, const float* 
     a.stat = reinterpret_cast<float2*>(stat); a.stat_sc = stat_sc; a.stat_sn = stat_sn;
     if (variant == 0) return launch_wino<WinoCfg<1, 1, 16, 2, 2, 1, 1, 4>>(a, stream);
     if (variant == 1) return launch_wino<WinoCfg<1, 2, 8, 2, 2, 1, 1, 4>>(a, stream);
+    if (variant == 2) return launch_wino<WinoCfg<1, 4, 4, 4, 1, 1, 1, 4, 1>>(a, stream);
     return MIS_ERR_UNSUPPORTED;
 }

@@ -41,14 +41,14 @@ struct WgArgs {
 };
 
 // stage = TZ x TY x TX tiles (32), TX a multiple of 4: 8 chunks of 4 x-adjacent tiles
-template <int TZ_, int TY_, int TX_>
+template <int TZ_, int TY_, int TX_, int DPAD_ = 1>
 struct WgCfg {
     static constexpr int TZ = TZ_, TY = TY_, TX = TX_;
     static constexpr int OZ = 2 * TZ, OY = 2 * TY, OX = 2 * TX;
     static constexpr int HZ = OZ + 2, HY = OY + 2;
     static constexpr int NQ = (OX + 8) / 4, RX = NQ * 4;          // x rows hold [x0 - 4, x0 + OX + 4)
     static constexpr int XROWS = HZ * HY, XG = XROWS * 16 * NQ, XF = XG * 4;
-    static constexpr int DQ = OX / 4 + 1, DRX = DQ * 4;           // dy rows: OX floats + one pad group (bank spread)
+    static constexpr int DQ = OX / 4 + DPAD_, DRX = DQ * 4;       // dy rows: OX floats (+ one pad group: bank spread)
     static constexpr int DROWS = OZ * OY, DG = DROWS * 16 * DQ, DF = DG * 4;
     static constexpr int STAGE = XF + DF;
     static constexpr int XP = XG / 64, DP = DG / 64, P = XP + DP, PW = (P + 3) / 4;
@@ -177,7 +177,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             const int g = (p - C::XP) * 64 + lane;
             const int row = g / (16 * C::DQ), rem = g - row * (16 * C::DQ), co = rem / C::DQ, q = rem - co * C::DQ;
             const int oz = row / C::OY, oy = row - oz * C::OY;
-            if (q < C::DQ - 1 && cob * 16 + co < a.Cout) {
+            if (q < C::OX / 4 && cob * 16 + co < a.Cout) {
                 rel = (unsigned)(((oz * a.H + oy) * a.W + 4 * q) * 4) + (unsigned)co * s_bytes;
             }
         }
@@ -371,6 +371,7 @@ int launch_wg(WgArgs a, float* dw, int accumulate, hipStream_t stream) {
 
 using WgV0 = WgCfg<1, 2, 16>;     // stages of 2 x 4 x 32 voxels (W a multiple of 32)
 using WgV1 = WgCfg<2, 2, 8>;      // stages of 4 x 4 x 16 voxels (W a multiple of 16)
+using WgV2 = WgCfg<4, 2, 4, 0>;   // stages of 8 x 4 x 8 voxels (W a multiple of 8: the 24^3 level); no dy pad group: LDS
 
 }  // namespace
 
@@ -380,6 +381,7 @@ extern "C" int mis_conv3d_wino_wgrad_select(int N, int Cin, int Cout, int D, int
     if (((long long)17 * D * H * W + (long long)H * W + W + 64) * 4 >= (1LL << 31)) return -1;
     if (W % 32 == 0 && H % 4 == 0 && D % 2 == 0) return 0;
     if (W % 16 == 0 && H % 4 == 0 && D % 4 == 0) return 1;
+    if (W % 8 == 0 && H % 4 == 0 && D % 8 == 0) return 2;
     return -1;
 }
 
@@ -387,7 +389,8 @@ extern "C" long long mis_conv3d_wino_wgrad_workspace_bytes(int N, int Cin, int C
     if (N <= 0 || Cin <= 0 || Cout <= 0 || D <= 0 || H <= 0 || W <= 0) return MIS_ERR_ARG;
     WgArgs a{};
     a.N = N; a.Cin = Cin; a.Cout = Cout; a.D = D; a.H = H; a.W = W;
-    if (variant == 0) geometry<WgV0>(a); else if (variant == 1) geometry<WgV1>(a); else return MIS_ERR_UNSUPPORTED;
+    if (variant == 0) geometry<WgV0>(a); else if (variant == 1) geometry<WgV1>(a); else if (variant == 2) geometry<WgV2>(a);
+    else return MIS_ERR_UNSUPPORTED;
     return (long long)a.ci_blocks * a.co_blocks * a.splits * 27 * 256 * 4;
 }
 
@@ -398,12 +401,16 @@ extern "C" int mis_conv3d_wino_wgrad(const float* x, long long x_bs, const float
     if (!x || !dy || !dw || !workspace || N <= 0 || Cin <= 0 || Cout <= 0 || D <= 0 || H <= 0 || W <= 0) return MIS_ERR_ARG;
     const long long S = (long long)D * H * W;
     if (x_bs < (long long)Cin * S || dy_bs < (long long)Cout * S) return MIS_ERR_ARG;
-    if (mis_conv3d_wino_wgrad_select(N, Cin, Cout, D, H, W) < 0 || (variant != 0 && variant != 1)) return MIS_ERR_UNSUPPORTED;
-    if ((variant == 0 && (W % 32 || H % 4 || D % 2)) || (variant == 1 && (W % 16 || H % 4 || D % 4))) return MIS_ERR_UNSUPPORTED;
+    if (mis_conv3d_wino_wgrad_select(N, Cin, Cout, D, H, W) < 0 || variant < 0 || variant > 2) return MIS_ERR_UNSUPPORTED;
+    if ((variant == 0 && (W % 32 || H % 4 || D % 2)) || (variant == 1 && (W % 16 || H % 4 || D % 4)) ||
+        (variant == 2 && (W % 8 || H % 4 || D % 8)))
+        return MIS_ERR_UNSUPPORTED;
     if (((uintptr_t)x & 15) || ((uintptr_t)dy & 15) || x_bs % 4 || dy_bs % 4 || W % 4) return MIS_ERR_UNSUPPORTED;
     if (workspace_bytes < mis_conv3d_wino_wgrad_workspace_bytes(N, Cin, Cout, D, H, W, variant)) return MIS_ERR_WORKSPACE;
     WgArgs a{};
     a.x = x; a.x_bs = x_bs; a.dy = dy; a.dy_bs = dy_bs; a.ws = workspace;
     a.N = N; a.Cin = Cin; a.Cout = Cout; a.D = D; a.H = H; a.W = W;
-    return variant == 0 ? launch_wg<WgV0>(a, dw, accumulate, stream) : launch_wg<WgV1>(a, dw, accumulate, stream);
+    if (variant == 0) return launch_wg<WgV0>(a, dw, accumulate, stream);
+    if (variant == 1) return launch_wg<WgV1>(a, dw, accumulate, stream);
+    return launch_wg<WgV2>(a, dw, accumulate, stream);
 }

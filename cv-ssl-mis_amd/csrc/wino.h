@@ -68,6 +68,13 @@ __device__ __forceinline__ void dma_dwordx4_s(unsigned lds_byte, unsigned voff, 
                  : "=&s"(keep) : "s"(lds_byte), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
 }
 
+__device__ __forceinline__ void dma_dword_s(unsigned lds_byte, unsigned voff, unsigned soff, i32x4 rsrc) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\t"
+                 "buffer_load_dword %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "s"(lds_byte), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+}
+
 template <int N> struct vmwait { static __device__ __forceinline__ void go() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); } };
 
 

@@ -80,7 +80,8 @@ def wgrad_main():
         return dw, run
 
     for (N, Cin, Cout, D, H, W, var) in [(1, 16, 16, 2, 4, 32, 0), (2, 16, 16, 4, 8, 64, 0), (1, 24, 40, 6, 4, 32, 0),
-                                         (2, 16, 32, 4, 8, 16, 1), (1, 48, 16, 8, 4, 48, 1), (3, 16, 16, 6, 12, 96, 0)]:
+                                         (2, 16, 32, 4, 8, 16, 1), (1, 48, 16, 8, 4, 48, 1), (3, 16, 16, 6, 12, 96, 0),
+                                         (2, 32, 16, 8, 4, 8, 2), (1, 64, 64, 8, 12, 24, 2)]:
         x = torch.randn(N, Cin, D, H, W, device="cuda")
         dy = torch.randn(N, Cout, D, H, W, device="cuda")
         xr = x.double().requires_grad_(False)
@@ -93,7 +94,7 @@ def wgrad_main():
         print(f"wgrad N{N} {Cin}->{Cout} {D}x{H}x{W} v{var}: wino err {(dww.double() - ref).abs().max().item() / sc:.3e}  "
               f"direct err {(dwd.double() - ref).abs().max().item() / sc:.3e} (rel. to max {sc:.1f})", flush=True)
     for (N, Cin, Cout, S, var) in [(8, 16, 16, 96, 0), (8, 48, 16, 96, 0), (8, 32, 32, 48, 1), (8, 96, 32, 48, 1),
-                                   (8, 16, 32, 48, 1)]:
+                                   (8, 16, 32, 48, 1), (8, 64, 64, 24, 2), (8, 192, 64, 24, 2), (8, 32, 64, 24, 2)]:
         x = torch.randn(N, Cin, S, S, S, device="cuda")
         dy = torch.randn(N, Cout, S, S, S, device="cuda")
         fl = 2.0 * N * Cout * Cin * 27 * S ** 3
@@ -116,7 +117,8 @@ def main():
             print(f"dbg {os.environ['MIS_WINO_DBG']} N{N} {Cin}->{Cout} {S}^3: {timeit(rw):8.1f} us", flush=True)
         return
     for (N, Cin, Cout, D, H, W, var) in [(1, 16, 16, 4, 4, 32, 0), (2, 16, 16, 8, 12, 64, 0), (1, 24, 32, 6, 10, 20, 0),
-                                         (2, 16, 32, 8, 8, 16, 1), (1, 32, 32, 6, 6, 36, 1), (3, 48, 16, 10, 6, 40, 0)]:
+                                         (2, 16, 32, 8, 8, 16, 1), (1, 32, 32, 6, 6, 36, 1), (3, 48, 16, 10, 6, 40, 0),
+                                         (1, 32, 32, 8, 8, 8, 2), (2, 64, 48, 8, 16, 24, 2), (1, 40, 16, 6, 10, 12 + 2, 2)]:
         x = torch.randn(N, Cin, D, H, W, device="cuda")
         w = torch.randn(Cout, Cin, 3, 3, 3, device="cuda") * 0.1
         b = torch.randn(Cout, device="cuda")
@@ -128,7 +130,7 @@ def main():
         print(f"shape N{N} {Cin}->{Cout} {D}x{H}x{W} v{var}: wino err {ew:.3e}  direct err {ed:.3e}  ref max {ref.abs().max().item():.2f}",
               flush=True)
     for (N, Cin, Cout, S, var) in [(8, 16, 16, 96, 0), (8, 48, 16, 96, 0), (8, 16, 48, 96, 0), (8, 32, 32, 48, 1),
-                                   (8, 32, 32, 48, 0), (8, 96, 32, 48, 1), (8, 64, 64, 24, 1)]:
+                                   (8, 32, 32, 48, 0), (8, 96, 32, 48, 1), (8, 64, 64, 24, 2), (8, 192, 64, 24, 2), (4, 64, 64, 24, 2), (8, 64, 192, 24, 2)]:
         x = torch.randn(N, Cin, S, S, S, device="cuda")
         w = torch.randn(Cout, Cin, 3, 3, 3, device="cuda") * 0.05
         b = torch.randn(Cout, device="cuda")

@@ -39,6 +39,8 @@ FWD_CASES = [
     (2, 16, 32, 4, 8, 16, 1),
     (1, 32, 32, 8, 8, 48, 1),
     (3, 96, 32, 4, 8, 16, 1),
+    (1, 32, 32, 8, 8, 8, 2),        # the 24^3 level's boxes (8 x 8 x 8 voxels, dword halo rows)
+    (2, 64, 48, 8, 16, 24, 2),
 ]
 
 
@@ -137,6 +139,8 @@ WGRAD_CASES = [
     (2, 16, 32, 4, 8, 16),
     (1, 48, 16, 8, 4, 48),
     (3, 8, 8, 4, 4, 16),
+    (2, 32, 16, 8, 4, 8),         # stages of 8 x 4 x 8 voxels (24^3 level)
+    (1, 64, 64, 8, 12, 24),
 ]
 
 
@@ -180,7 +184,8 @@ def test_wino_select_and_refusal():
     assert sel(2, 16, 16, 96, 96, 96) == 0 and sel(2, 32, 32, 48, 48, 48) == 1
     assert sel(2, 1, 16, 96, 96, 96) == -1          # first layer: 1 input channel
     assert sel(2, 16, 2, 96, 96, 96) == -1          # Cout not a multiple of 16
-    assert sel(2, 64, 64, 24, 24, 24) == -1         # 24^3 and deeper: direct kernel
+    assert sel(2, 64, 64, 24, 24, 24) == 2
+    assert sel(2, 128, 128, 12, 12, 12) == -1       # 12^3 and deeper: direct kernel
     assert sel(2, 16, 16, 6, 6, 30) == -1
     assert ops.conv_wino_select(2, 16, 16, 1, 64, 64, (3, 3)) == -1
     x = torch.zeros(1, 16, 6, 6, 30, device="cuda")
