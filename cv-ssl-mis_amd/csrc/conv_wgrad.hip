@@ -461,9 +461,24 @@ WgradArgs make_args(const float* x, long long x_bs, const float* dy, long long d
 
 }  // namespace
 
+// conv_wgrad_cin1.hip: the first layer of the 3-D networks (1 -> 16 channels, taps on the MFMA's N side)
+bool mis_wgrad_cin1_eligible(int N, int Cin, int Cout, int D, int H, int W, int kd, int kh, int kw);
+long long mis_wgrad_cin1_workspace_bytes(int N, int D, int H, int W);
+int mis_wgrad_cin1(const float* x, long long x_bs, const float* dy, long long dy_bs, float* dw, float* ws,
+                   long long ws_bytes, int N, int D, int H, int W, int accumulate, hipStream_t stream);
+
 extern "C" long long mis_conv_wgrad_workspace_bytes(int N, int Cin, int Cout, int D, int H, int W, int kd,
                                                     int kh, int kw) {
     if (N <= 0 || Cin <= 0 || Cout <= 0 || D <= 0 || H <= 0 || W <= 0) return MIS_ERR_ARG;
+    if (mis_wgrad_cin1_eligible(N, Cin, Cout, D, H, W, kd, kh, kw)) {
+        // either kernel may run (the special one needs 16-byte aligned dy): room for both
+        WgradArgs g = make_args(nullptr, 0, nullptr, 0, nullptr, N, Cin, Cout, D, H, W);
+        long long generic = 0;
+        const int st = dispatch(g, kd, kh, kw, nullptr, 0, 0, nullptr, &generic);
+        if (st) return st;
+        const long long special = mis_wgrad_cin1_workspace_bytes(N, D, H, W);
+        return generic > special ? generic : special;
+    }
     WgradArgs a = make_args(nullptr, 0, nullptr, 0, nullptr, N, Cin, Cout, D, H, W);
     long long out = 0;
     int st = dispatch(a, kd, kh, kw, nullptr, 0, 0, nullptr, &out);
@@ -480,6 +495,8 @@ extern "C" int mis_conv_wgrad(const float* x, long long x_bs, const float* dy, l
     // the DMA descriptors address one image's channels with 32-bit byte offsets
     const long long cmax = (Cin > Cout ? Cin : Cout) + 32;
     if (cmax * S * 4 >= (1LL << 30)) return MIS_ERR_UNSUPPORTED;
+    if (mis_wgrad_cin1_eligible(N, Cin, Cout, D, H, W, kd, kh, kw) && ((uintptr_t)dy & 15) == 0 && dy_bs % 4 == 0)
+        return mis_wgrad_cin1(x, x_bs, dy, dy_bs, dw, workspace, workspace_bytes, N, D, H, W, accumulate, stream);
     WgradArgs a = make_args(x, x_bs, dy, dy_bs, workspace, N, Cin, Cout, D, H, W);
     return dispatch(a, kd, kh, kw, dw, workspace_bytes, accumulate, stream, nullptr);
 }

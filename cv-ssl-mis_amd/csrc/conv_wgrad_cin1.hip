@@ -1,0 +1,122 @@
+// Weight gradient of the FIRST convolution of the 3-D networks: Conv3d(1 -> 16, k = 3, pad = 1) on the full-resolution
+// volume (reference code/networks/unet_3D.py:28 conv1 = UnetConv3(in_channels = 1, 16), utils.py:99-107;
+// vnet.py:123 block_one; unetr.py encoder1).
+//
+// With one input channel the generic kernel (conv_wgrad.hip: N = 16 input channels per MFMA) runs 15/16 padding and
+// needed 0.82 ms per step for 6 GFLOP.  Here the 27 taps take the place of the input channels:
+//   D[co][tap] += sum_voxel dy[co][voxel] * x[voxel + tap]        v_mfma_f32_16x16x4_f32, K = 4 voxels
+//   A[i = lane&15][k = lane>>4] = dy[co = i][voxel 4k + s]   -- the lane's own float4 of dy, component s (4 MFMA steps)
+//   B[k = lane>>4][j = lane&15] = x[voxel 4k + s + offset(tap = 16 g + j)]   -- one ds_read_b32 of the haloed x tile
+// dy (the only large operand, 16 channels) is read exactly once, 16 bytes per lane; x lives in LDS.  A workgroup walks
+// tiles of 4 x 8 x 32 voxels (a wave per z plane); per-wave partials, summed in a fixed order by a second kernel.
+#include "common.h"
+
+namespace {
+
+constexpr int TZ = 4, TY = 8, TX = 32, HZ = TZ + 2, HY = TY + 2, HX = TX + 2, HALO = HZ * HY * HX;
+
+struct Cin1Args {
+    const float* x; long long x_bs;
+    const float* dy; long long dy_bs;
+    float* ws;                      // [gridDim.x * 4 waves][2][16 co][16 taps]
+    int N, D, H, W;
+    int tz, ty, tx, n_tiles;
+};
+
+__global__ __launch_bounds__(256) void wgrad_cin1_kernel(const Cin1Args a) {
+    __shared__ float sx[HALO];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lk = lane >> 4, lj = lane & 15;
+    const long long S = (long long)a.D * a.H * a.W;
+    // LDS offset of the two taps this lane serves (tap 16 g + j; taps 27 .. 31 repeat tap 26 and are never stored)
+    int toff[2];
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        const int tap = g * 16 + lj < 27 ? g * 16 + lj : 26;
+        toff[g] = ((tap / 9) * HY + (tap / 3) % 3) * HX + tap % 3;
+    }
+    f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    for (int t = blockIdx.x; t < a.n_tiles; t += gridDim.x) {
+        int r = t;
+        const int bx = r % a.tx; r /= a.tx;
+        const int by = r % a.ty; r /= a.ty;
+        const int bz = r % a.tz; r /= a.tz;
+        const int n = r;
+        const int z0 = bz * TZ, y0 = by * TY, x0 = bx * TX;
+        const float* __restrict__ xn = a.x + (long long)n * a.x_bs;
+        __syncthreads();                                   // the previous tile's reads are done
+        for (int e = tid; e < HALO; e += 256) {
+            const int hz = e / (HY * HX), r2 = e - hz * (HY * HX), hy = r2 / HX, hx = r2 - hy * HX;
+            const int gz = z0 + hz - 1, gy = y0 + hy - 1, gx = x0 + hx - 1;
+            const bool ok = (unsigned)gz < (unsigned)a.D && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
+            sx[e] = ok ? xn[((long long)gz * a.H + gy) * a.W + gx] : 0.f;
+        }
+        __syncthreads();
+        // this wave: plane z0 + wave; 8 rows x 2 halves of 16 voxels; the lane's dy: channel lj, voxels 4 lk .. 4 lk + 3
+        const float* __restrict__ dyp = a.dy + (long long)n * a.dy_bs + (long long)lj * S +
+                                        ((long long)(z0 + wave) * a.H + y0) * a.W + x0 + 4 * lk;
+        const float* __restrict__ sb = sx + (wave * HY) * HX + 4 * lk;
+#pragma unroll 4
+        for (int it = 0; it < 16; ++it) {
+            const int row = it >> 1, half = it & 1;
+            const f32x4 d4 = *reinterpret_cast<const f32x4*>(dyp + (long long)row * a.W + half * 16);
+            const float* __restrict__ sp = sb + row * HX + half * 16;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(d4[s], sp[toff[0] + s], acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(d4[s], sp[toff[1] + s], acc[1], 0, 0, 0);
+            }
+        }
+    }
+    // D[row = lk * 4 + r -> co][col = lj -> tap within the group]
+    float* __restrict__ out = a.ws + ((long long)blockIdx.x * 4 + wave) * 512;
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) out[g * 256 + (lk * 4 + r) * 16 + lj] = acc[g][r];
+}
+
+// dw[co][tap] (+)= sum of the partials: 16 lanes per output, each a strided share, combined in a fixed order
+__global__ __launch_bounds__(256) void wgrad_cin1_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw,
+                                                                int parts, int Cout, int accumulate) {
+    const int o = blockIdx.x * 16 + (threadIdx.x >> 4), sub = threadIdx.x & 15;
+    if (o >= Cout * 27) return;                            // whole 16-lane groups leave together
+    const int co = o / 27, tap = o - co * 27;
+    const float* p = ws + (tap / 16) * 256 + co * 16 + tap % 16;
+    float s = 0.f;
+    for (int k = sub; k < parts; k += 16) s += p[(long long)k * 512];
+#pragma unroll
+    for (int d = 8; d > 0; d >>= 1) s += __shfl_xor(s, d, 16);
+    if (sub == 0) dw[o] = accumulate ? dw[o] + s : s;
+}
+
+int grid_for(long long n_tiles) { return (int)(n_tiles < 1024 ? n_tiles : 1024); }
+
+}  // namespace
+
+bool mis_wgrad_cin1_eligible(int N, int Cin, int Cout, int D, int H, int W, int kd, int kh, int kw) {
+    return kd == 3 && kh == 3 && kw == 3 && Cin == 1 && Cout == 16 && D % TZ == 0 && H % TY == 0 && W % TX == 0;
+}
+
+long long mis_wgrad_cin1_workspace_bytes(int N, int D, int H, int W) {
+    const long long n_tiles = (long long)N * (D / TZ) * (H / TY) * (W / TX);
+    return (long long)grid_for(n_tiles) * 4 * 512 * 4;
+}
+
+int mis_wgrad_cin1(const float* x, long long x_bs, const float* dy, long long dy_bs, float* dw, float* ws,
+                   long long ws_bytes, int N, int D, int H, int W, int accumulate, hipStream_t stream) {
+    if (((uintptr_t)dy & 15) || dy_bs % 4) return MIS_ERR_UNSUPPORTED;
+    if (ws_bytes < mis_wgrad_cin1_workspace_bytes(N, D, H, W)) return MIS_ERR_WORKSPACE;
+    Cin1Args a{};
+    a.x = x; a.x_bs = x_bs; a.dy = dy; a.dy_bs = dy_bs; a.ws = ws;
+    a.N = N; a.D = D; a.H = H; a.W = W;
+    a.tz = D / TZ; a.ty = H / TY; a.tx = W / TX;
+    const long long n_tiles = (long long)N * a.tz * a.ty * a.tx;
+    if (n_tiles > 0x7fffffffLL) return MIS_ERR_ARG;
+    a.n_tiles = (int)n_tiles;
+    const int grid = grid_for(n_tiles);
+    hipLaunchKernelGGL(wgrad_cin1_kernel, dim3(grid), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL(wgrad_cin1_reduce_kernel, dim3((16 * 27 + 15) / 16), dim3(256), 0, stream, ws, dw, grid * 4, 16,
+                       accumulate);
+    return mis_launch_status();
+}
