@@ -12,6 +12,7 @@
 //   mode 4 / 5 (3x3x3 only): the Winograd F(2x2x2, 3x3x3) filter transform G g G^T of the forward / data-gradient
 //   filter in the operand layout of conv_wino.hip:  wt[M/16][K/4][16][64 lanes][4]  with transform point
 //   xi = 4 * (third index) + (last index), lane = (k % 4) * 16 + m % 16  (M, K = output, input channels of the launch).
+//   mode 6 / 7 (3x3 only): the same for F(2x2, 3x3), 16 points:  wt[M/16][K/4][4][64 lanes][4]  (conv_wino2d.hip).
 #include "common.h"
 
 namespace {
@@ -46,15 +47,36 @@ __device__ __forceinline__ float wino_element(const float* __restrict__ w, int C
     return wino_g(xz, pz[0], pz[1], pz[2]);
 }
 
+// ... and of the 2-D transform F(2x2, 3x3) (mode 6: forward, mode 7: data gradient): wt[M/16][K/4][4][64 lanes][4]
+__device__ __forceinline__ float wino2_element(const float* __restrict__ w, int Cout, int Cin, int mode, int Kp, unsigned i) {
+    const int e4 = i & 3, lane = (i >> 2) & 63, x4 = (i >> 8) & 3;
+    const unsigned blk = i >> 10;
+    const int k4 = blk % (unsigned)(Kp / 4), mb = blk / (unsigned)(Kp / 4);
+    const int xi = x4 * 4 + e4, m = mb * 16 + (lane & 15), k = k4 * 4 + (lane >> 4);
+    const int M = mode == 6 ? Cout : Cin, K = mode == 6 ? Cin : Cout;
+    if (m >= M || k >= K) return 0.f;
+    const float* g = mode == 6 ? w + ((long long)m * Cin + k) * 9 : w + ((long long)k * Cin + m) * 9;
+    const int xy = xi >> 2, xx = xi & 3;
+    float py[3];
+#pragma unroll
+    for (int y = 0; y < 3; ++y) {
+        const int t = y * 3;
+        py[y] = mode == 6 ? wino_g(xx, g[t], g[t + 1], g[t + 2]) : wino_g(xx, g[8 - t], g[7 - t], g[6 - t]);
+    }
+    return wino_g(xy, py[0], py[1], py[2]);
+}
+
 __global__ __launch_bounds__(256) void pack_kernel(const float* __restrict__ w, float* __restrict__ wp,
                                                    int Cout, int Cin, int taps, int mode, int Kp, int Mp) {
-    const long long total = (long long)Kp * (mode >= 4 ? 64 : taps) * Mp;
+    const long long total = (long long)Kp * (mode >= 6 ? 16 : mode >= 4 ? 64 : taps) * Mp;
     for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
         const int m = (int)(i % Mp);
         const int t = (int)((i / Mp) % taps);
         const int k = (int)(i / ((long long)Mp * taps));
         float v = 0.f;
-        if (mode >= 4) {
+        if (mode >= 6) {
+            v = wino2_element(w, Cout, Cin, mode, Kp, (unsigned)i);
+        } else if (mode >= 4) {
             v = wino_element(w, Cout, Cin, mode, Kp, (unsigned)i);
         } else if (mode == 0) {
             if (k < Cin && m < Cout) v = w[((long long)m * Cin + k) * taps + t];
@@ -92,6 +114,7 @@ __global__ __launch_bounds__(256) void pack_batch_kernel(const PackJob* __restri
         }
         const PackJob& j = s_jobs[lo];
         const unsigned i = (unsigned)(g - j.start);          // one layer's pack is far below 2^32 floats
+        if (j.mode >= 6) { j.wp[i] = wino2_element(j.w, j.Cout, j.Cin, j.mode, j.Kp, i); continue; }
         if (j.mode >= 4) { j.wp[i] = wino_element(j.w, j.Cout, j.Cin, j.mode, j.Kp, i); continue; }
         const unsigned mt = (unsigned)j.Mp * (unsigned)j.taps;
         const int k = (int)(i / mt);
@@ -114,14 +137,14 @@ __global__ __launch_bounds__(256) void pack_batch_kernel(const PackJob* __restri
 // Returns the job's packed size in floats (the increment of `start` for the next job), or a negative error.
 extern "C" long long mis_conv_pack_job(void* job_out, const float* w, float* wp, int Cout, int Cin, int taps, int mode,
                                        long long start) {
-    if (!job_out || !w || !wp || Cout <= 0 || Cin <= 0 || taps <= 0 || (mode != 0 && mode != 1 && mode != 4 && mode != 5))
+    if (!job_out || !w || !wp || Cout <= 0 || Cin <= 0 || taps <= 0 || mode < 0 || mode > 7 || mode == 2 || mode == 3)
         return MIS_ERR_ARG;
-    if (mode >= 4 && taps != 27) return MIS_ERR_ARG;
-    const bool fwd = mode == 0 || mode == 4;
+    if (((mode == 4 || mode == 5) && taps != 27) || (mode >= 6 && taps != 9)) return MIS_ERR_ARG;
+    const bool fwd = mode == 0 || mode == 4 || mode == 6;
     const int K = fwd ? Cin : Cout, M = fwd ? Cout : Cin;
     PackJob j{w, wp, Cout, Cin, taps, mode, (K + 3) / 4 * 4, (M + 15) / 16 * 16, start};
     *reinterpret_cast<PackJob*>(job_out) = j;
-    return (long long)j.Kp * (mode >= 4 ? 64 : taps) * j.Mp;
+    return (long long)j.Kp * (mode >= 6 ? 16 : mode >= 4 ? 64 : taps) * j.Mp;
 }
 
 extern "C" int mis_conv_pack_job_bytes() { return (int)sizeof(PackJob); }
@@ -137,21 +160,22 @@ extern "C" int mis_conv_pack_batch(const void* jobs_device, int n, long long tot
 }
 
 extern "C" long long mis_conv_packed_floats(int Cout, int Cin, int taps, int mode) {
-    if (Cout <= 0 || Cin <= 0 || taps <= 0 || (mode >= 4 && taps != 27)) return MIS_ERR_ARG;
-    const bool fwd = mode == 0 || mode == 2 || mode == 4;
+    if (Cout <= 0 || Cin <= 0 || taps <= 0 || mode < 0 || mode > 7) return MIS_ERR_ARG;
+    if (((mode == 4 || mode == 5) && taps != 27) || (mode >= 6 && taps != 9)) return MIS_ERR_ARG;
+    const bool fwd = mode == 0 || mode == 2 || mode == 4 || mode == 6;
     const int K = fwd ? Cin : Cout, M = fwd ? Cout : Cin;
-    return (long long)((K + 3) / 4 * 4) * (mode >= 4 ? 64 : taps) * ((M + 15) / 16 * 16);
+    return (long long)((K + 3) / 4 * 4) * (mode >= 6 ? 16 : mode >= 4 ? 64 : taps) * ((M + 15) / 16 * 16);
 }
 
 extern "C" int mis_conv_pack_weights(const float* w, float* wp, int Cout, int Cin, int taps, int mode,
                                      hipStream_t stream) {
-    if (!w || !wp || Cout <= 0 || Cin <= 0 || taps <= 0 || mode < 0 || mode > 5) return MIS_ERR_ARG;
+    if (!w || !wp || Cout <= 0 || Cin <= 0 || taps <= 0 || mode < 0 || mode > 7) return MIS_ERR_ARG;
     if ((mode == 2 || mode == 3) && taps != 1) return MIS_ERR_ARG;   // input-major storage is only defined for 1x1 weights
-    if (mode >= 4 && taps != 27) return MIS_ERR_ARG;                 // Winograd transform: 3x3x3 only
-    const bool fwd = mode == 0 || mode == 2 || mode == 4;
+    if (((mode == 4 || mode == 5) && taps != 27) || (mode >= 6 && taps != 9)) return MIS_ERR_ARG;   // Winograd: 3x3x3 / 3x3
+    const bool fwd = mode == 0 || mode == 2 || mode == 4 || mode == 6;
     const int K = fwd ? Cin : Cout, M = fwd ? Cout : Cin;
     const int Kp = (K + 3) / 4 * 4, Mp = (M + 15) / 16 * 16;
-    const long long total = (long long)Kp * (mode >= 4 ? 64 : taps) * Mp;
+    const long long total = (long long)Kp * (mode >= 6 ? 16 : mode >= 4 ? 64 : taps) * Mp;
     long long blocks = mis_cdiv(total, 256);
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(pack_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, w, wp, Cout, Cin, taps, mode,

@@ -123,20 +123,37 @@ def _ksize(k):
     return tuple(k)
 
 
-WINO = int(_os.environ.get("MIS_WINO", "1"))      # 0: never use the Winograd form of the 3x3x3 convolutions
+WINO = int(_os.environ.get("MIS_WINO", "3"))      # bit 0: Winograd form of the 3x3x3 convolutions, bit 1: of the 3x3 ones
+
+
+WINO2D = 10       # ids >= WINO2D: variant id - WINO2D of the 2-D kernels (conv_wino2d.hip); below: 3-D (conv_wino.hip)
 
 
 def conv_wino_select(N, Cin, Cout, D, H, W, ksize):
-    """Winograd variant serving this convolution (mis_conv3d_wino_select), or -1: use the direct kernel."""
-    if not WINO or _ksize(ksize) != (3, 3, 3):
+    """Winograd variant serving this convolution (mis_conv3d_wino_select / mis_conv2d_wino_select), or -1: use the
+    direct kernel."""
+    if not WINO:
         return -1
-    return int(_l.load().mis_conv3d_wino_select(N, Cin, Cout, D, H, W))
+    k = _ksize(ksize)
+    if k == (3, 3, 3):
+        return int(_l.load().mis_conv3d_wino_select(N, Cin, Cout, D, H, W))
+    if k == (1, 3, 3) and D == 1 and (WINO & 2):
+        v = int(_l.load().mis_conv2d_wino_select(N, Cin, Cout, H, W))
+        return v + WINO2D if v >= 0 else -1
+    return -1
+
+
+def conv_wino_pack_mode(wino, dgrad):
+    """Pack mode of the transformed filter for this variant (4 / 5: 3x3x3, 6 / 7: 3x3; forward / data gradient)."""
+    return (6 if wino >= WINO2D else 4) + (1 if dgrad else 0)
 
 
 def conv_stat_tiles(N, Cin, Cout, D, H, W, ksize, wino=-1):
     """Partial-statistics tiles per image of the fused conv+stats form for this geometry (0: not eligible)."""
     kd, kh, kw = _ksize(ksize)
-    if wino >= 0:
+    if wino >= WINO2D:
+        t = _l.load().mis_conv2d_wino_stat_tiles(H, W, wino - WINO2D)
+    elif wino >= 0:
         t = _l.load().mis_conv3d_wino_stat_tiles(D, H, W, wino)
     else:
         t = _l.load().mis_conv_fwd_stat_tiles(N, Cin, Cout, D, H, W, kd, kh, kw)
@@ -167,7 +184,11 @@ def conv_fwd(x, wp, bias, y, Cin, Cout, ksize, stat=None, wino=-1):
     if prof is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    if wino >= 0:
+    if wino >= WINO2D:
+        st = stat if stat is not None else (None, 0, 0)
+        _l.check(L.mis_conv2d_wino_fwd(_l.ptr(x), xbs, _l.ptr(wp), _l.ptr(bias), _l.ptr(y), ybs, N, Cin, Cout, H, W,
+                                       _l.ptr(st[0]), st[1], st[2], wino - WINO2D, _l.stream_ptr()), "mis_conv2d_wino_fwd")
+    elif wino >= 0:
         st = stat if stat is not None else (None, 0, 0)
         _l.check(L.mis_conv3d_wino_fwd(_l.ptr(x), xbs, _l.ptr(wp), _l.ptr(bias), _l.ptr(y), ybs, N, Cin, Cout, D, H, W,
                                        _l.ptr(st[0]), st[1], st[2], wino, _l.stream_ptr()), "mis_conv3d_wino_fwd")
@@ -181,7 +202,9 @@ def conv_fwd(x, wp, bias, y, Cin, Cout, ksize, stat=None, wino=-1):
     if prof is not None:
         e1.record()
         buf = _ctypes.create_string_buffer(128)
-        if wino >= 0:
+        if wino >= WINO2D:
+            L.mis_conv2d_wino_kernel_name(wino - WINO2D, buf, 128)
+        elif wino >= 0:
             L.mis_conv3d_wino_kernel_name(wino, buf, 128)
         else:
             L.mis_conv_fwd_kernel_name(N, Cin, Cout, D, H, W, kd, kh, kw, buf, 128)

@@ -104,7 +104,8 @@ class ConvOp:
 
     def fwd(self, ctx):
         if not self.batched:
-            self.wp = ops.conv_pack(self.w.data, 4 if self.wino_f >= 0 else 0, out=self.wp)
+            self.wp = ops.conv_pack(self.w.data, ops.conv_wino_pack_mode(self.wino_f, False) if self.wino_f >= 0 else 0,
+                                    out=self.wp)
         # the consumer needs batch statistics unless it is a BatchNorm in eval mode (running statistics)
         stat = self.stat if (self.stat is not None and (self.stat_norm.per_sample or ctx.training)) else None
         ops.conv_fwd(self.x.t, self.wp, None if self.b is None else self.b.data, self.y.t, self.cin, self.cout,
@@ -119,7 +120,8 @@ class ConvOp:
         # (sum over a normalisation group of dL/dx vanishes); the flat grad buffer keeps its zeros.
         if self.need_dx:
             if not self.batched:
-                self.wpd = ops.conv_pack(self.w.data, 5 if self.wino_b >= 0 else 1, out=self.wpd)
+                self.wpd = ops.conv_pack(self.w.data, ops.conv_wino_pack_mode(self.wino_b, True) if self.wino_b >= 0 else 1,
+                                         out=self.wpd)
             if self.x.written:
                 # the input has another consumer whose gradient is already there (residual blocks: UNETR's
                 # UnetResBlock feeds its input to conv1 AND to the shortcut): data gradient into a scratch, then add
@@ -378,7 +380,8 @@ class Plan:
             fj, bj = [], []
             for op in convs:
                 taps = op.w.data[0, 0].numel()
-                mf, mb = (4 if op.wino_f >= 0 else 0), (5 if op.wino_b >= 0 else 1)
+                mf = ops.conv_wino_pack_mode(op.wino_f, False) if op.wino_f >= 0 else 0
+                mb = ops.conv_wino_pack_mode(op.wino_b, True) if op.wino_b >= 0 else 1
                 op.wp = torch.empty(L.mis_conv_packed_floats(op.cout, op.cin, taps, mf), dtype=torch.float32,
                                     device="cuda")
                 fj.append((op.w.data, op.wp, mf))

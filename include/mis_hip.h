@@ -49,7 +49,8 @@ int mis_abi_version(void);
 int mis_conv_cin_pad(int cin);   /* K-channel padding of packed weights (multiple of 4)  */
 int mis_conv_cout_pad(int cout); /* M-channel padding of packed weights (multiple of 16) */
 /* floats of the packed buffer; mode 0 = forward, 1 = data-gradient, 4 / 5 = the Winograd-transformed forward /
- * data-gradient filter of a 3x3x3 conv (taps = 27; consumed by mis_conv3d_wino_fwd) */
+ * data-gradient filter of a 3x3x3 conv (taps = 27; consumed by mis_conv3d_wino_fwd), 6 / 7 = of a 3x3 conv (taps = 9;
+ * mis_conv2d_wino_fwd) */
 long long mis_conv_packed_floats(int Cout, int Cin, int taps, int mode);
 /* w: [Cout][Cin][taps] (torch layout) -> wp.  mode 0: wp[ci][tap][co]; mode 1: wp[co][tap][ci] with
  * the taps reversed (the flipped, transposed filter of the autograd input-gradient). */
@@ -98,6 +99,15 @@ int mis_conv3d_wino_kernel_name(int variant, char* name, int name_len);
 int mis_conv3d_wino_fwd(const float* x, long long x_bs, const float* wt, const float* bias, float* y, long long y_bs,
                         int N, int Cin, int Cout, int D, int H, int W, float* stat, long long stat_sc,
                         long long stat_sn, int variant, mis_stream_t stream);
+/* ---- Winograd F(2x2, 3x3) form of the stride-1 'same' 3x3 convolution of the 2-D UNet (csrc/conv_wino2d.hip) ----
+ * reference: nn.Conv2d(k=3, padding=1) of ConvBlock (code/networks/unet.py:30-45).  Same contract as the 3-D entry
+ * points above with D = 1; filter transformed by pack modes 6 (forward) / 7 (data gradient). */
+int mis_conv2d_wino_select(int N, int Cin, int Cout, int H, int W);
+long long mis_conv2d_wino_stat_tiles(int H, int W, int variant);
+int mis_conv2d_wino_kernel_name(int variant, char* name, int name_len);
+int mis_conv2d_wino_fwd(const float* x, long long x_bs, const float* wt, const float* bias, float* y, long long y_bs,
+                        int N, int Cin, int Cout, int H, int W, float* stat, long long stat_sc, long long stat_sn,
+                        int variant, mis_stream_t stream);
 /* Winograd F(2x2x2, 3x3x3) weight gradient (csrc/conv_wino_wgrad.hip): the same result as mis_conv_wgrad for a 3x3x3
  * 'same' convolution up to fp32 rounding, deterministic (fixed summation order).  _select: variant or -1 (use
  * mis_conv_wgrad); needs 16-byte aligned x / dy, batch strides and W multiples of 4 floats. */

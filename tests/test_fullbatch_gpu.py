@@ -59,9 +59,11 @@ MT_CASES = {
                                  ["Cfg<1, 3, 3, 1, 16, 32, 16, 8, 8>", "Cfg<1, 3, 3, 1, 16, 32, 32, 8, 8>",
                                   "Cfg<1, 3, 3, 1, 16, 16, 32, 8, 4>"]),
     "config3_unet3d_4+4_96": ("unet3d", (8, 1, 96, 96, 96), 4, 2, torch.int64, 1200, 0,
-                              ["Cfg<3, 3, 3, 4, 8, 16, 16, 4, 8>", "Cfg<3, 3, 3, 4, 8, 16, 32, 4, 8>",
-                               "Cfg<3, 3, 3, 8, 8, 8, 32, 4, 8>",      # 24^3, student batch 8: enough workgroups
-                               "Cfg<3, 3, 3, 4, 8, 8, 32, 4, 4>"]),    # 24^3, teacher batch 4: smaller tiles
+                              ["Cfg<3, 3, 3, 4, 8, 16, 16, 4, 8>",                 # first layer (1 input channel): direct
+                               "Cfg<3, 3, 3, 2, 4, 16, 16, 4, 2>",                 # 12^3 level: direct
+                               "wino:WinoCfg<1, 1, 16, 2, 2, 1, 1, 4, 0>",         # 96^3: Winograd, 4 x 4 x 32 boxes
+                               "wino:WinoCfg<1, 2, 8, 2, 2, 1, 1, 4, 0>",          # 48^3: 4 x 8 x 16 boxes
+                               "wino:WinoCfg<1, 4, 4, 4, 1, 1, 1, 4, 1>"]),        # 24^3: 8 x 8 x 8 boxes
     "config4_swin_24+24_224": ("swin", (48, 1, 224, 224), 24, 4, torch.uint8, 1200, 1000, []),
 }
 
@@ -93,7 +95,8 @@ def test_mean_teacher_step_at_full_batch(name):
     vol_d, lab_d, noise_d = volume.cuda(), label.cuda(), noise.cuda()
     names = _record_kernels(lambda: tr.step(vol_d, lab_d, noise=noise_d))
     for e in expect:
-        assert f"conv_fwd_kernel<{e}>" in names, (e, sorted(names))
+        kname = f"wino_fwd_kernel<{e[5:]}>" if e.startswith("wino:") else f"conv_fwd_kernel<{e}>"
+        assert kname in names, (e, sorted(names))
     got = tr.losses()
     s_logits = model._last[0].out.t.cpu()
     t_logits = ema._last[0].out.t.cpu()
