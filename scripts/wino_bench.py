@@ -73,9 +73,9 @@ def wgrad_main():
         dw = torch.zeros(dy.shape[1], x.shape[1], 3, 3, 3, device="cuda")
 
         def run():
-            ops.WINO = 0
+            keep, ops.WINO = ops.WINO, 0
             ops.conv_wgrad(x, dy, dw, (3, 3, 3))
-            ops.WINO = 1
+            ops.WINO = keep
         run()
         return dw, run
 

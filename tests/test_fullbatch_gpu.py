@@ -56,8 +56,9 @@ MT_CASES = {
     # name: (kind, shape, labeled, classes, label dtype, iter_num, cons_start_iter, conv instantiations that only the
     #        full batch reaches)
     "config2_unet2d_24+24_256": ("unet2d", (48, 1, 256, 256), 24, 4, torch.uint8, 1200, 1000,
-                                 ["Cfg<1, 3, 3, 1, 16, 32, 16, 8, 8>", "Cfg<1, 3, 3, 1, 16, 32, 32, 8, 8>",
-                                  "Cfg<1, 3, 3, 1, 16, 16, 32, 8, 4>"]),
+                                 ["Cfg<1, 3, 3, 1, 16, 32, 16, 8, 8>",        # first layer (1 input channel): direct
+                                  "wino2d:W2Cfg<8, 8, 1, 4>",                 # 16 output channels: Winograd F(2x2, 3x3)
+                                  "wino2d:W2Cfg<8, 8, 2, 4>"]),               # 32 and more
     "config3_unet3d_4+4_96": ("unet3d", (8, 1, 96, 96, 96), 4, 2, torch.int64, 1200, 0,
                               ["Cfg<3, 3, 3, 4, 8, 16, 16, 4, 8>",                 # first layer (1 input channel): direct
                                "Cfg<3, 3, 3, 2, 4, 16, 16, 4, 2>",                 # 12^3 level: direct
@@ -95,7 +96,8 @@ def test_mean_teacher_step_at_full_batch(name):
     vol_d, lab_d, noise_d = volume.cuda(), label.cuda(), noise.cuda()
     names = _record_kernels(lambda: tr.step(vol_d, lab_d, noise=noise_d))
     for e in expect:
-        kname = f"wino_fwd_kernel<{e[5:]}>" if e.startswith("wino:") else f"conv_fwd_kernel<{e}>"
+        kname = (f"wino_fwd_kernel<{e[5:]}>" if e.startswith("wino:") else
+                 f"wino2d_fwd_kernel<{e[7:]}>" if e.startswith("wino2d:") else f"conv_fwd_kernel<{e}>")
         assert kname in names, (e, sorted(names))
     got = tr.losses()
     s_logits = model._last[0].out.t.cpu()

@@ -165,12 +165,12 @@ def test_wino_weight_gradient(case):
     ops.conv_wgrad(xd, dyd, dw2, (3, 3, 3), accumulate=True)
     _close(dw2, 2 * w.grad, rtol=1e-5, atol=1e-6)
     # the direct kernel agrees
-    ops.WINO = 0
+    keep, ops.WINO = ops.WINO, 0
     try:
         dwd = torch.empty_like(dw)
         ops.conv_wgrad(xd, dyd, dwd, (3, 3, 3))
     finally:
-        ops.WINO = 1
+        ops.WINO = keep
     _close(dw, dwd, rtol=1e-5, atol=1e-6)
 
 
@@ -187,7 +187,7 @@ def test_wino_select_and_refusal():
     assert sel(2, 64, 64, 24, 24, 24) == 2
     assert sel(2, 128, 128, 12, 12, 12) == -1       # 12^3 and deeper: direct kernel
     assert sel(2, 16, 16, 6, 6, 30) == -1
-    assert ops.conv_wino_select(2, 16, 16, 1, 64, 64, (3, 3)) == -1
+    assert ops.conv_wino_select(2, 16, 16, 1, 64, 64, (3, 3)) == ops.WINO2D          # 2-D: conv_wino2d.hip
     x = torch.zeros(1, 16, 6, 6, 30, device="cuda")
     y = torch.zeros(1, 16, 6, 6, 30, device="cuda")
     wt = ops.conv_pack(torch.zeros(16, 16, 3, 3, 3, device="cuda"), 4)
@@ -213,11 +213,11 @@ def test_wino_full_size_layer_matches_direct():
     assert (y0 - y1).abs().max().item() <= 2e-5 * y0.abs().max().item()
     d0, d1 = torch.empty_like(w), torch.empty_like(w)
     ops.conv_wgrad(x, dy, d1, (3, 3, 3))
-    ops.WINO = 0
+    keep, ops.WINO = ops.WINO, 0
     try:
         ops.conv_wgrad(x, dy, d0, (3, 3, 3))
     finally:
-        ops.WINO = 1
+        ops.WINO = keep
     assert (d0 - d1).abs().max().item() <= 2e-5 * d0.abs().max().item()
 
 
@@ -239,3 +239,48 @@ def test_first_layer_weight_gradient(N, D, H, W):
     assert torch.equal(dw, dw2)
     ops.conv_wgrad(xd, dyd, dw2, (3, 3, 3), accumulate=True)
     _close(dw2, 2 * w.grad, rtol=1e-5, atol=1e-6)
+
+
+# N, Cin, Cout, H, W
+W2D_CASES = [(1, 16, 16, 16, 16), (2, 16, 32, 32, 48), (3, 32, 16, 16, 32), (2, 64, 64, 32, 32), (1, 8, 16, 48, 16),
+             (2, 12, 48, 16, 64)]
+
+
+@pytest.mark.parametrize("case", W2D_CASES)
+def test_wino2d_forward_and_data_gradient(case):
+    """F(2x2, 3x3) (conv_wino2d.hip) for nn.Conv2d(k=3, padding=1) of the 2-D UNet's ConvBlock (unet.py:30-45):
+    forward, data gradient (same launch on dy with pack mode 7), fused statistics, against torch fp64 / the direct kernel."""
+    ops = _ops()
+    N, Cin, Cout, H, W = case
+    v = ops.conv_wino_select(N, Cin, Cout, 1, H, W, (3, 3))
+    assert v >= ops.WINO2D
+    x = _rand(N, Cin, H, W, seed=41).requires_grad_(True)
+    w = _rand(Cout, Cin, 3, 3, seed=42, scale=0.2).requires_grad_(True)
+    b = _rand(Cout, seed=43)
+    y_ref = F.conv2d(x, w, b, padding=1)
+    dy = _rand(*y_ref.shape, seed=44)
+    y_ref.backward(dy)
+    xd = x.detach().float().cuda().unsqueeze(2).contiguous()
+    wd, bd = w.detach().float().cuda(), b.float().cuda()
+    dyd = dy.float().cuda().unsqueeze(2).contiguous()
+    T = ops.conv_stat_tiles(N, Cin, Cout, 1, H, W, (3, 3), wino=v)
+    assert T == (H // 16) * (W // 16)
+    part = torch.full((Cout * N * T, 2), float("nan"), device="cuda")
+    y = torch.full((N, Cout, 1, H, W), float("nan"), device="cuda")
+    ops.conv_fwd(xd, ops.conv_pack(wd, 6), bd, y, Cin, Cout, (3, 3), stat=(part, N * T, T), wino=v)
+    _close(y[:, :, 0], y_ref)
+    mean = torch.empty(Cout, device="cuda"); rstd = torch.empty(Cout, device="cuda")
+    ops.norm_stats_finalize(part, N, Cout, H * W, T, False, 1e-5, mean, rstd)
+    _close(mean, y_ref.mean(dim=(0, 2, 3)), rtol=1e-5, atol=1e-6)
+    _close(rstd, 1.0 / torch.sqrt(y_ref.var(dim=(0, 2, 3), unbiased=False) + 1e-5), rtol=1e-5, atol=1e-6)
+    vb = ops.conv_wino_select(N, Cout, Cin, 1, H, W, (3, 3))
+    if vb >= 0:
+        dx = torch.full((N, Cin, 1, H, W), float("nan"), device="cuda")
+        ops.conv_fwd(dyd, ops.conv_pack(wd, 7), None, dx, Cout, Cin, (3, 3), wino=vb)
+        _close(dx[:, :, 0], x.grad)
+    yd = torch.empty_like(y)
+    ops.conv_fwd(xd, ops.conv_pack(wd, 0), bd, yd, Cin, Cout, (3, 3))
+    _close(y, yd)
+    # geometries the 2-D kernel does not cover
+    assert ops.conv_wino_select(2, 16, 16, 1, 56, 56, (3, 3)) == -1 and ops.conv_wino_select(2, 1, 16, 1, 64, 64, (3, 3)) == -1
+    assert ops.conv_wino_select(2, 16, 4, 1, 64, 64, (3, 3)) == -1
