@@ -54,6 +54,9 @@ PROTOTYPES = {
     "mis_conv2d_wino_stat_tiles": (c_ll, [c_i, c_i, c_i]),
     "mis_conv2d_wino_kernel_name": (c_i, [c_i, ctypes.c_char_p, c_i]),
     "mis_conv2d_wino_fwd": (c_i, [c_p, c_ll, c_p, c_p, c_p, c_ll, c_i, c_i, c_i, c_i, c_i, c_p, c_ll, c_ll, c_i, c_p]),
+    "mis_conv2d_wino_wgrad_select": (c_i, [c_i, c_i, c_i, c_i, c_i]),
+    "mis_conv2d_wino_wgrad_workspace_bytes": (c_ll, [c_i, c_i, c_i, c_i, c_i, c_i]),
+    "mis_conv2d_wino_wgrad": (c_i, [c_p, c_ll, c_p, c_ll, c_p, c_p, c_ll, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
     "mis_conv3d_wino_wgrad_select": (c_i, [c_i, c_i, c_i, c_i, c_i, c_i]),
     "mis_conv3d_wino_wgrad_workspace_bytes": (c_ll, [c_i, c_i, c_i, c_i, c_i, c_i, c_i]),
     "mis_conv3d_wino_wgrad": (c_i, [c_p, c_ll, c_p, c_ll, c_p, c_p, c_ll, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),

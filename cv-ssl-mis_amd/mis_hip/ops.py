@@ -135,7 +135,7 @@ def conv_wino_select(N, Cin, Cout, D, H, W, ksize):
     if not WINO:
         return -1
     k = _ksize(ksize)
-    if k == (3, 3, 3):
+    if k == (3, 3, 3) and (WINO & 1):
         return int(_l.load().mis_conv3d_wino_select(N, Cin, Cout, D, H, W))
     if k == (1, 3, 3) and D == 1 and (WINO & 2):
         v = int(_l.load().mis_conv2d_wino_select(N, Cin, Cout, H, W))
@@ -224,7 +224,7 @@ def conv_wgrad(x, dy, dw, ksize, accumulate=False):
     kd, kh, kw = _ksize(ksize)
     assert dw.is_contiguous() and dw.numel() == Cout * Cin * kd * kh * kw
     # 3x3x3 on large volumes: the Winograd F(2^3, 3^3) form (conv_wino_wgrad.hip), 3.375x fewer matrix-pipe flops
-    wino = int(L.mis_conv3d_wino_wgrad_select(N, Cin, Cout, D, H, W)) if (WINO and (kd, kh, kw) == (3, 3, 3)) else -1
+    wino = int(L.mis_conv3d_wino_wgrad_select(N, Cin, Cout, D, H, W)) if ((WINO & 1) and (kd, kh, kw) == (3, 3, 3)) else -1
     if wino >= 0 and xbs % 4 == 0 and dbs % 4 == 0 and x.data_ptr() % 16 == 0 and dy.data_ptr() % 16 == 0:
         nb = L.mis_conv3d_wino_wgrad_workspace_bytes(N, Cin, Cout, D, H, W, wino)
         if nb < 0:
@@ -232,6 +232,15 @@ def conv_wgrad(x, dy, dw, ksize, accumulate=False):
         ws = scratch(nb, "wgrad")
         _l.check(L.mis_conv3d_wino_wgrad(_l.ptr(x), xbs, _l.ptr(dy), dbs, _l.ptr(dw), _l.ptr(ws), ws.numel(), N, Cin,
                                          Cout, D, H, W, int(accumulate), wino, _l.stream_ptr()), "mis_conv3d_wino_wgrad")
+        return
+    wino2 = int(L.mis_conv2d_wino_wgrad_select(N, Cin, Cout, H, W)) if ((WINO & 2) and (kd, kh, kw) == (1, 3, 3) and D == 1) else -1
+    if wino2 >= 0 and xbs % 4 == 0 and dbs % 4 == 0 and x.data_ptr() % 16 == 0 and dy.data_ptr() % 16 == 0:
+        nb = L.mis_conv2d_wino_wgrad_workspace_bytes(N, Cin, Cout, H, W, wino2)
+        if nb < 0:
+            _l.check(nb, "mis_conv2d_wino_wgrad_workspace_bytes")
+        ws = scratch(nb, "wgrad")
+        _l.check(L.mis_conv2d_wino_wgrad(_l.ptr(x), xbs, _l.ptr(dy), dbs, _l.ptr(dw), _l.ptr(ws), ws.numel(), N, Cin, Cout,
+                                         H, W, int(accumulate), wino2, _l.stream_ptr()), "mis_conv2d_wino_wgrad")
         return
     nb = L.mis_conv_wgrad_workspace_bytes(N, Cin, Cout, D, H, W, kd, kh, kw)
     if nb < 0:

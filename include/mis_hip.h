@@ -108,6 +108,12 @@ int mis_conv2d_wino_kernel_name(int variant, char* name, int name_len);
 int mis_conv2d_wino_fwd(const float* x, long long x_bs, const float* wt, const float* bias, float* y, long long y_bs,
                         int N, int Cin, int Cout, int H, int W, float* stat, long long stat_sc, long long stat_sn,
                         int variant, mis_stream_t stream);
+/* ... and its weight gradient (csrc/conv_wino2d_wgrad.hip): dw[Cout][Cin][9], deterministic; _select: variant or -1 */
+int mis_conv2d_wino_wgrad_select(int N, int Cin, int Cout, int H, int W);
+long long mis_conv2d_wino_wgrad_workspace_bytes(int N, int Cin, int Cout, int H, int W, int variant);
+int mis_conv2d_wino_wgrad(const float* x, long long x_bs, const float* dy, long long dy_bs, float* dw, float* workspace,
+                          long long workspace_bytes, int N, int Cin, int Cout, int H, int W, int accumulate, int variant,
+                          mis_stream_t stream);
 /* Winograd F(2x2x2, 3x3x3) weight gradient (csrc/conv_wino_wgrad.hip): the same result as mis_conv_wgrad for a 3x3x3
  * 'same' convolution up to fp32 rounding, deterministic (fixed summation order).  _select: variant or -1 (use
  * mis_conv_wgrad); needs 16-byte aligned x / dy, batch strides and W multiples of 4 floats. */

@@ -29,3 +29,24 @@ for (N, Cin, Cout, S) in [(48, 16, 16, 256), (48, 32, 16, 256), (48, 32, 32, 128
     fl = 2.0 * N * Cout * Cin * 9 * S * S
     tw, td = timeit(fw), timeit(fd)
     print(f"N{N} {Cin}->{Cout} {S}^2 v{v}: wino {tw:7.1f} us ({fl/tw/1e6:6.1f} TF eq) direct {td:7.1f} us ({fl/td/1e6:6.1f} TF) speedup {td/tw:.2f} maxdiff {(y-yd).abs().max().item():.2e}", flush=True)
+print("---- weight gradient ----")
+for (N, Cin, Cout, H, W) in [(1, 16, 16, 8, 16), (2, 16, 32, 32, 48), (3, 24, 40, 16, 32), (2, 64, 64, 32, 32), (1, 8, 16, 48, 16)]:
+    x = torch.randn(N, Cin, 1, H, W, device="cuda"); dy = torch.randn(N, Cout, 1, H, W, device="cuda")
+    w = torch.zeros(Cout, Cin, 3, 3, dtype=torch.float64, requires_grad=True)
+    F.conv2d(x[:, :, 0].cpu().double(), w, padding=1).backward(dy[:, :, 0].cpu().double())
+    dw = torch.empty(Cout, Cin, 3, 3, device="cuda"); ops.conv_wgrad(x, dy, dw, (3, 3))
+    keep, ops.WINO = ops.WINO, 0
+    dwd = torch.empty_like(dw); ops.conv_wgrad(x, dy, dwd, (3, 3)); ops.WINO = keep
+    sc = w.grad.abs().max().item()
+    print(f"wgrad N{N} {Cin}->{Cout} {H}x{W}: wino err {(dw.cpu().double() - w.grad).abs().max().item()/sc:.3e} direct err {(dwd.cpu().double() - w.grad).abs().max().item()/sc:.3e}", flush=True)
+for (N, Cin, Cout, S) in [(48, 16, 16, 256), (48, 32, 16, 256), (48, 32, 32, 128), (48, 64, 64, 64), (48, 128, 128, 32), (48, 256, 256, 16), (48, 256, 128, 32)]:
+    x = torch.randn(N, Cin, 1, S, S, device="cuda"); dy = torch.randn(N, Cout, 1, S, S, device="cuda")
+    dw = torch.empty(Cout, Cin, 3, 3, device="cuda"); dwd = torch.empty_like(dw)
+    fw = lambda: ops.conv_wgrad(x, dy, dw, (3, 3))
+    def fd():
+        keep, ops.WINO = ops.WINO, 0
+        ops.conv_wgrad(x, dy, dwd, (3, 3)); ops.WINO = keep
+    fw(); fd()
+    fl = 2.0 * N * Cout * Cin * 9 * S * S
+    tw, td = timeit(fw), timeit(fd)
+    print(f"wgrad N{N} {Cin}->{Cout} {S}^2: wino {tw:7.1f} us ({fl/tw/1e6:6.1f} TF eq) direct {td:7.1f} us ({fl/td/1e6:6.1f} TF) speedup {td/tw:.2f} rel diff {(dw-dwd).abs().max().item()/dwd.abs().max().item():.2e}", flush=True)

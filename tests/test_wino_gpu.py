@@ -284,3 +284,34 @@ def test_wino2d_forward_and_data_gradient(case):
     # geometries the 2-D kernel does not cover
     assert ops.conv_wino_select(2, 16, 16, 1, 56, 56, (3, 3)) == -1 and ops.conv_wino_select(2, 1, 16, 1, 64, 64, (3, 3)) == -1
     assert ops.conv_wino_select(2, 16, 4, 1, 64, 64, (3, 3)) == -1
+
+
+@pytest.mark.parametrize("N,Cin,Cout,H,W", [(1, 16, 16, 8, 16), (2, 16, 32, 32, 48), (3, 24, 40, 16, 32), (2, 64, 64, 32, 32),
+                                            (1, 8, 16, 48, 16), (2, 32, 48, 24, 64)])
+def test_wino2d_weight_gradient(N, Cin, Cout, H, W):
+    """F(2x2, 3x3) weight gradient (conv_wino2d_wgrad.hip) behind ops.conv_wgrad for the 2-D UNet's 3x3 convs, against
+    torch fp64 and the direct kernel; ragged channel blocks; deterministic; `accumulate` adds."""
+    ops = _ops()
+    from mis_hip import lib
+    assert lib.load().mis_conv2d_wino_wgrad_select(N, Cin, Cout, H, W) >= 0
+    x = _rand(N, Cin, H, W, seed=51)
+    dy = _rand(N, Cout, H, W, seed=52)
+    w = torch.zeros(Cout, Cin, 3, 3, dtype=torch.float64, requires_grad=True)
+    F.conv2d(x, w, padding=1).backward(dy)
+    xd, dyd = x.float().cuda().unsqueeze(2).contiguous(), dy.float().cuda().unsqueeze(2).contiguous()
+    dw = torch.full((Cout, Cin, 3, 3), float("nan"), device="cuda")
+    ops.conv_wgrad(xd, dyd, dw, (3, 3))
+    _close(dw, w.grad, rtol=1e-5, atol=1e-6)
+    dw2 = torch.empty_like(dw)
+    ops.conv_wgrad(xd, dyd, dw2, (3, 3))
+    assert torch.equal(dw, dw2)
+    ops.conv_wgrad(xd, dyd, dw2, (3, 3), accumulate=True)
+    _close(dw2, 2 * w.grad, rtol=1e-5, atol=1e-6)
+    keep, ops.WINO = ops.WINO, 0
+    try:
+        dwd = torch.empty_like(dw)
+        ops.conv_wgrad(xd, dyd, dwd, (3, 3))
+    finally:
+        ops.WINO = keep
+    _close(dw, dwd, rtol=1e-5, atol=1e-6)
+    assert lib.load().mis_conv2d_wino_wgrad_select(2, 16, 16, 28, 28) == -1      # 28 x 28: direct kernel
