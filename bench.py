@@ -254,14 +254,15 @@ def run_workload(name, args, rank, world, kernel_events=True):
                                     achieved=round(fam_flops / fam_time / 1e12, 3),
                                     frac=round(fam_flops / fam_time / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
                                     share_of_step_time=round(fam_time / dt_local, 4)))
-        if dom.startswith("wino_fwd_kernel"):
-            # Winograd F(2x2x2, 3x3x3): 64 multiplies per 2x2x2 outputs instead of 216.  `achieved` / `frac` stay the
-            # ALGORITHMIC (direct-convolution) flops over time, which may exceed the matrix pipe's peak; `mfma_*` is
-            # what the pipe actually executes (algorithmic / 3.375), the figure that is bounded by `peak`.
-            roofline["algorithm"] = ("Winograd F(2x2x2,3x3x3): the matrix pipe executes algorithmic/3.375 flops; "
-                                     "achieved and frac are algorithmic, mfma_achieved and mfma_frac are executed")
-            roofline["mfma_achieved"] = round(achieved / 3.375, 3)
-            roofline["mfma_frac"] = round(achieved / 3.375 / PEAK_FP32_MFMA_TFLOPS, 4)
+        wino = 3.375 if dom.startswith("wino_fwd_kernel") else 2.25 if dom.startswith("wino2d_fwd_kernel") else 0.0
+        if wino:
+            # Winograd F(2x2x2, 3x3x3) / F(2x2, 3x3): 64 (16) multiplies per 2x2x2 (2x2) outputs instead of 216 (36).
+            # `achieved` / `frac` stay the ALGORITHMIC (direct-convolution) flops over time, which may exceed the matrix
+            # pipe's peak; `mfma_*` is what the pipe actually executes (algorithmic / 3.375 or / 2.25), bounded by `peak`.
+            roofline["algorithm"] = (f"Winograd: the matrix pipe executes algorithmic/{wino:g} flops; achieved and frac "
+                                     "are algorithmic, mfma_achieved and mfma_frac are executed")
+            roofline["mfma_achieved"] = round(achieved / wino, 3)
+            roofline["mfma_frac"] = round(achieved / wino / PEAK_FP32_MFMA_TFLOPS, 4)
     step_s = dt / args.steps
     step_frac = wl["step_gflop"] * 1e9 / step_s / (PEAK_FP32_MFMA_TFLOPS * 1e12)
     if roofline is not None:
