@@ -1,5 +1,5 @@
 // Micro-benchmark: how many independent VALU / SALU / LDS instructions issue under one v_mfma_f32_16x16x4_f32?
-// hipcc --offload-arch=gfx950 -O3 mfma_overlap.hip -o mfma_overlap && ./mfma_overlap
+// hipcc --offload-arch=gfx950 -O3 -w mfma_overlap.hip -o mfma_overlap.bin && ./mfma_overlap.bin   (the .bin travels with gpurun)
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 typedef float f32x4 __attribute__((ext_vector_type(4)));
