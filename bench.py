@@ -356,7 +356,7 @@ def cpu_baseline(kind, wl, timed=5, warm=2, budget_s=150.0):
     times = sorted(one() for _ in range(timed))
     t = times[len(times) // 2]
     torch.set_num_threads(default_threads)
-    return dict(value=B / t, unit="samples/s", cores=best, kind="port",
+    return dict(value=B / t, unit=UNIT.get(kind, "images/s"), cores=best, kind="port",
                 host=dict(logical_cpus=logical, physical_cores=physical),
                 thread_sweep_s_per_step={str(k): round(v, 3) for k, v in sweep.items()},
                 sample=f"oracle.step.mean_teacher_step, batch {L}+{B - L} of {'x'.join(map(str, shape[2:]))}, "
