@@ -16,14 +16,18 @@
 //
 // Mapping (gfx950): a wave owns a GROUP of 16 output tiles (2x2x2 voxels each) x 16 output channels.  For each of the
 // 64 transform points xi one v_mfma_f32_16x16x4_f32 per 4 input channels contracts
-//   A[i = lane&15][k = lane>>4] = W_xi[co0 + i][ci0 + k]      (LDS, transformed once per step by mis_wino_pack)
+//   A[i = lane&15][k = lane>>4] = W_xi[co0 + i][ci0 + k]      (LDS; transformed once per step: pack.hip modes 4 / 5)
 //   B[k = lane>>4][j = lane&15] = U_xi[ci0 + k][tile j]       (registers: the lane transforms its own 4x4x4 patch)
 //   D[row = (lane>>4)*4 + r][col = lane&15]                   -> 64 x 4 accumulator registers (AGPRs)
 // so a lane holds all 64 points of 4 (channel, tile) outputs and inverse-transforms them in registers.  The wave runs
-// alone on its SIMD (512 registers); the transform of input-channel chunk s+1 (192 adds) is issued between the 64
-// MFMAs of chunk s.  Chunks of 4 input channels (haloed box of the workgroup + the 64 x 16 x 4 filter points of each
-// 16-channel block) arrive by LDS-DMA into a ring of NBUF stage buffers, issued NBUF-1 chunks ahead; one barrier per
-// chunk.
+// alone on its SIMD (512 registers).  Per chunk of 4 input channels: 64 MFMAs in program-ordered slots that also carry
+// the LDS reads of the next chunk's patch, the filter points (fetched two groups ahead) and the DMA issue; then the
+// transform of the next chunk (96 v_pk_add_f32) -- VALU work does not overlap the issuing wave's own MFMAs on this
+// hardware (scripts/ubench/mfma_overlap.hip), wherever it is placed.  Chunks (haloed box of the workgroup + the
+// 64 x 16 x 4 filter points of each 16-channel block) arrive by LDS-DMA into a ring of NBUF stage buffers, issued
+// NBUF-1 chunks ahead; one barrier per chunk.  Workgroups are persistent (one per CU): XCD x owns a contiguous range of
+// boxes that its 32 workgroups walk interleaved, and the first stages of the next box are in flight during the
+// epilogue of the current one.
 #include "common.h"
 #include "wino.h"
 #include <stdio.h>
