@@ -233,7 +233,8 @@ int launch_w2(W2Args a, hipStream_t stream) {
 }
 
 using W2V0 = W2Cfg<8, 8, 1, 4>;      // 16 x 16 pixel boxes, one block of 16 output channels
-using W2V1 = W2Cfg<8, 8, 2, 4>;      // ... two blocks (Cout a multiple of 32): the transform is shared
+using W2V1 = W2Cfg<8, 8, 2, 3>;      // ... two blocks (Cout a multiple of 32): the transform is shared.  Ring of 3: 47 KB
+                                     // of LDS, three workgroups per CU (a ring of 4 is 10 % slower)
 
 }  // namespace
 
@@ -255,7 +256,7 @@ extern "C" long long mis_conv2d_wino_stat_tiles(int H, int W, int variant) {
 extern "C" int mis_conv2d_wino_kernel_name(int variant, char* name, int name_len) {
     if (!name || name_len <= 0) return MIS_ERR_ARG;
     if (variant == 0) snprintf(name, name_len, "wino2d_fwd_kernel<W2Cfg<8, 8, 1, 4>>");
-    else if (variant == 1) snprintf(name, name_len, "wino2d_fwd_kernel<W2Cfg<8, 8, 2, 4>>");
+    else if (variant == 1) snprintf(name, name_len, "wino2d_fwd_kernel<W2Cfg<8, 8, 2, 3>>");
     else return MIS_ERR_UNSUPPORTED;
     return MIS_OK;
 }

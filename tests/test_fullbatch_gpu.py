@@ -58,7 +58,7 @@ MT_CASES = {
     "config2_unet2d_24+24_256": ("unet2d", (48, 1, 256, 256), 24, 4, torch.uint8, 1200, 1000,
                                  ["Cfg<1, 3, 3, 1, 16, 32, 16, 8, 8>",        # first layer (1 input channel): direct
                                   "wino2d:W2Cfg<8, 8, 1, 4>",                 # 16 output channels: Winograd F(2x2, 3x3)
-                                  "wino2d:W2Cfg<8, 8, 2, 4>"]),               # 32 and more
+                                  "wino2d:W2Cfg<8, 8, 2, 3>"]),               # 32 and more
     "config3_unet3d_4+4_96": ("unet3d", (8, 1, 96, 96, 96), 4, 2, torch.int64, 1200, 0,
                               ["Cfg<3, 3, 3, 4, 8, 16, 16, 4, 8>",                 # first layer (1 input channel): direct
                                "Cfg<3, 3, 3, 2, 4, 16, 16, 4, 2>",                 # 12^3 level: direct
