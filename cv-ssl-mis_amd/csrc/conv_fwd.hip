@@ -425,6 +425,104 @@ __global__ __launch_bounds__(256) void conv_small_cout_kernel(const ConvFwdArgs 
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// First layer of the 3-D networks: Conv3d(1 -> 16, k = 3) on the full-resolution volume (reference unet_3D.py:28 conv1,
+// vnet.py:123 block_one, unetr.py encoder1).  In the generic form the single input channel is padded to the MFMA's K = 4
+// (27 MFMAs per 16 voxels x 16 channels, three quarters of them on zeros).  Here the 27 taps ARE the contraction:
+//   D[co][voxel] = sum_tap w[co][tap] * x[voxel + tap]:   7 MFMAs (K = 28) per 16 voxels
+//   A[i = lane&15][k = lane>>4] = w[co = i][tap 4 g + k]           (7 registers, loaded once)
+//   B[k = lane>>4][j = lane&15] = x[voxel j + offset(tap 4 g + k)]  (one ds_read_b32 of the haloed tile per MFMA)
+// Same tiles (4 x 8 x 16 voxels) and the same per-tile (sum, sumsq) epilogue as Cfg<3,3,3,4,8,16,16,4,8>, so the
+// statistics plumbing does not change.  A wave takes one z plane: 8 rows of 16 voxels.
+// ---------------------------------------------------------------------------------------------------------
+namespace cin1 {
+constexpr int TZ = 4, TY = 8, TX = 16, HZ = TZ + 2, HY = TY + 2, HX = TX + 2, HALO = HZ * HY * HX;
+}
+
+__global__ __launch_bounds__(256) void conv_fwd_cin1_kernel(const ConvFwdArgs a) {
+    __shared__ float sx[cin1::HALO];
+    __shared__ float2 red[4 * 16];
+    const unsigned L = mis_xcd_remap(blockIdx.x, a.n_blocks_padded);
+    if (L >= a.n_blocks) return;
+    unsigned t = L;
+    const int tx = t % a.tiles_x; t /= a.tiles_x;
+    const int ty = t % a.tiles_y; t /= a.tiles_y;
+    const int tz = t % a.tiles_z; t /= a.tiles_z;
+    const int n = t;
+    const int z0 = tz * cin1::TZ, y0 = ty * cin1::TY, x0 = tx * cin1::TX;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lk = lane >> 4, lj = lane & 15;
+    const long long S = (long long)a.D * a.H * a.W;
+    const float* __restrict__ xn = a.x + (long long)n * a.x_bs;
+    for (int e = tid; e < cin1::HALO; e += 256) {
+        const int hz = e / (cin1::HY * cin1::HX), r2 = e - hz * (cin1::HY * cin1::HX), hy = r2 / cin1::HX, hx = r2 - hy * cin1::HX;
+        const int gz = z0 + hz - 1, gy = y0 + hy - 1, gx = x0 + hx - 1;
+        const bool ok = (unsigned)gz < (unsigned)a.D && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
+        sx[e] = ok ? xn[((long long)gz * a.H + gy) * a.W + gx] : 0.f;
+    }
+    // weights (packed [1 -> 4][27][16]: wp[tap * 16 + co]) and the LDS offset of this lane's tap of every group
+    float wa[7];
+    int toff[7];
+#pragma unroll
+    for (int g = 0; g < 7; ++g) {
+        const int tap = 4 * g + lk;
+        wa[g] = tap < 27 ? a.wp[tap * a.Cout_pad + lj] : 0.f;
+        const int tc = tap < 27 ? tap : 26;
+        toff[g] = ((tc / 9) * cin1::HY + (tc / 3) % 3) * cin1::HX + tc % 3;
+    }
+    float bv[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) bv[r] = a.bias ? a.bias[lk * 4 + r] : 0.f;
+    __syncthreads();
+    const float* __restrict__ sb = sx + (wave * cin1::HY) * cin1::HX + lj;
+    float* __restrict__ yo = a.y + (long long)n * a.y_bs + ((long long)(z0 + wave) * a.H + y0) * a.W + x0 + lj;
+    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 2
+    for (int row = 0; row < cin1::TY; ++row) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int g = 0; g < 7; ++g)
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[g], sb[row * cin1::HX + toff[g]], acc, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float v = acc[r] + bv[r];
+            yo[(long long)(lk * 4 + r) * S + (long long)row * a.W] = v;
+            s1[r] += v; s2[r] += v * v;
+        }
+    }
+    if (a.stat) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) { s1[r] += __shfl_xor(s1[r], o, 64); s2[r] += __shfl_xor(s2[r], o, 64); }
+        if (lj == 0) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[wave * 16 + lk * 4 + r] = make_float2(s1[r], s2[r]);
+        }
+        __syncthreads();
+        if (tid < 16) {
+            const float2 p0 = red[tid], p1 = red[16 + tid], p2 = red[32 + tid], p3 = red[48 + tid];
+            const long long tile = ((long long)tz * a.tiles_y + ty) * a.tiles_x + tx;
+            a.stat[(long long)tid * a.stat_sc + (long long)n * a.stat_sn + tile] =
+                make_float2((p0.x + p1.x) + (p2.x + p3.x), (p0.y + p1.y) + (p2.y + p3.y));
+        }
+    }
+}
+
+bool cin1_eligible(const ConvFwdArgs& a, int kd, int kh, int kw) {
+    return kd == 3 && kh == 3 && kw == 3 && a.Cin == 1 && a.Cout == 16 && a.D % cin1::TZ == 0 && a.H % cin1::TY == 0 &&
+           a.W % cin1::TX == 0;
+}
+
+int launch_cin1(ConvFwdArgs a, hipStream_t stream) {
+    a.tiles_z = a.D / cin1::TZ; a.tiles_y = a.H / cin1::TY; a.tiles_x = a.W / cin1::TX;
+    const long long nb = (long long)a.N * a.tiles_z * a.tiles_y * a.tiles_x;
+    if (nb <= 0 || nb > 0x7fffffffLL) return MIS_ERR_ARG;
+    a.n_blocks = (unsigned)nb;
+    a.n_blocks_padded = (unsigned)(mis_cdiv(nb, MIS_NUM_XCD) * MIS_NUM_XCD);
+    hipLaunchKernelGGL(conv_fwd_cin1_kernel, dim3(a.n_blocks_padded), dim3(256), 0, stream, a);
+    return mis_launch_status();
+}
+
 int launch_small_cout(ConvFwdArgs a, hipStream_t stream) {
     a.tiles_y = (int)mis_cdiv(a.H, small::TY);
     a.tiles_x = (int)mis_cdiv(a.W, small::TX);
@@ -484,6 +582,11 @@ int dispatch_fwd(ConvFwdArgs a, int kd, int kh, int kw, hipStream_t stream, char
     // unet_3D's 48 -> 16 decoder conv): three exact 16-channel blocks beat 32 + a half-empty 32
     // (measured 2.4 ms vs 3.1 ms for 16 -> 48 at 96^3 x 8).
     const bool wide = a.Cout_pad >= 32 && a.Cout_pad % 32 == 0;
+    if (cin1_eligible(a, kd, kh, kw)) {      // first layer: the taps as the MFMA's contraction (same tiles as the generic form)
+        if (stat_tiles) { *stat_tiles = (long long)(a.D / cin1::TZ) * (a.H / cin1::TY) * (a.W / cin1::TX); return MIS_OK; }
+        if (name) { snprintf(name, name_len, "conv_fwd_cin1_kernel"); return MIS_OK; }
+        return launch_cin1(a, stream);
+    }
     if (kd == 3 && kh == 3 && kw == 3) {
         if (a.W % 16 == 0 || a.W >= 64) {
             if (wide) MIS_CF(3, 3, 3, 4, 8, 16, 32, 4, 8); else MIS_CF(3, 3, 3, 4, 8, 16, 16, 4, 8);

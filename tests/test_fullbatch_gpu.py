@@ -60,7 +60,7 @@ MT_CASES = {
                                   "wino2d:W2Cfg<8, 8, 1, 4>",                 # 16 output channels: Winograd F(2x2, 3x3)
                                   "wino2d:W2Cfg<8, 8, 2, 3>"]),               # 32 and more
     "config3_unet3d_4+4_96": ("unet3d", (8, 1, 96, 96, 96), 4, 2, torch.int64, 1200, 0,
-                              ["Cfg<3, 3, 3, 4, 8, 16, 16, 4, 8>",                 # first layer (1 input channel): direct
+                              ["name:conv_fwd_cin1_kernel",                        # first layer (1 input channel): taps as K
                                "Cfg<3, 3, 3, 2, 4, 16, 16, 4, 2>",                 # 12^3 level: direct
                                "wino:WinoCfg<1, 1, 16, 2, 2, 1, 1, 4, 0>",         # 96^3: Winograd, 4 x 4 x 32 boxes
                                "wino:WinoCfg<1, 2, 8, 2, 2, 1, 1, 4, 0>",          # 48^3: 4 x 8 x 16 boxes
@@ -96,7 +96,7 @@ def test_mean_teacher_step_at_full_batch(name):
     vol_d, lab_d, noise_d = volume.cuda(), label.cuda(), noise.cuda()
     names = _record_kernels(lambda: tr.step(vol_d, lab_d, noise=noise_d))
     for e in expect:
-        kname = (f"wino_fwd_kernel<{e[5:]}>" if e.startswith("wino:") else
+        kname = (e[5:] if e.startswith("name:") else f"wino_fwd_kernel<{e[5:]}>" if e.startswith("wino:") else
                  f"wino2d_fwd_kernel<{e[7:]}>" if e.startswith("wino2d:") else f"conv_fwd_kernel<{e}>")
         assert kname in names, (e, sorted(names))
     got = tr.losses()

@@ -95,7 +95,8 @@ def test_conv_fwd_dgrad_wgrad(case):
 
 @pytest.mark.parametrize("N,Cin,Cout,D,H,W,k,per_sample", [
     (3, 16, 32, 1, 32, 64, (3, 3), False), (2, 8, 16, 1, 128, 128, (3, 3), False),
-    (2, 16, 16, 8, 16, 16, (3, 3, 3), True), (2, 32, 32, 8, 16, 32, (3, 3, 3), True)])
+    (2, 16, 16, 8, 16, 16, (3, 3, 3), True), (2, 32, 32, 8, 16, 32, (3, 3, 3), True),
+    (2, 1, 16, 8, 16, 32, (3, 3, 3), True)])      # first layer: conv_fwd_cin1_kernel
 def test_conv_fused_statistics(N, Cin, Cout, D, H, W, k, per_sample):
     """mis_conv_fwd_stats + mis_norm_stats_finalize == conv followed by the statistics of BatchNorm / InstanceNorm."""
     ops = _ops()
