@@ -178,16 +178,34 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const unsigned lds0 = lds_addr(lds);
     const int nst = a.nci4;
 
-    struct Box { int cg, n, z0, y0, x0; long long idx; };
+    // box coordinates (channel group fastest, then x, y, z, image).  Decoded by division once; the walk L += nslot then
+    // advances them by the decoded stride with carries (a scalar division is a ~100-cycle dependent chain, and a lone
+    // wave per SIMD cannot hide it: 4 divisions per box were 0.5 us of the 2.9 us a box costs outside its MFMAs)
+    struct Box { int cg, bx, by, bz, n, z0, y0, x0; long long idx; };
+    auto finish = [&](Box& b) {
+        b.z0 = b.bz * C::OZ; b.y0 = b.by * C::OY; b.x0 = b.bx * C::OX;
+        b.idx = ((long long)b.bz * a.boxes_y + b.by) * a.boxes_x + b.bx;
+    };
     auto decode = [&](unsigned L) {
         Box b;
         unsigned t = L;
         b.cg = t % a.co_groups; t /= a.co_groups;
-        const int bx = t % a.boxes_x;   t /= a.boxes_x;
-        const int by = t % a.boxes_y;   t /= a.boxes_y;
-        const int bz = t % a.boxes_z;   t /= a.boxes_z;
-        b.n = t; b.z0 = bz * C::OZ; b.y0 = by * C::OY; b.x0 = bx * C::OX;
-        b.idx = ((long long)bz * a.boxes_y + by) * a.boxes_x + bx;
+        b.bx = t % a.boxes_x;   t /= a.boxes_x;
+        b.by = t % a.boxes_y;   t /= a.boxes_y;
+        b.bz = t % a.boxes_z;   t /= a.boxes_z;
+        b.n = t;
+        finish(b);
+        return b;
+    };
+    const Box stride = decode((unsigned)nslot);
+    auto advance = [&](Box b) {
+        int c;
+        b.cg += stride.cg;     c = b.cg >= a.co_groups; b.cg -= c ? a.co_groups : 0;
+        b.bx += stride.bx + c; c = b.bx >= a.boxes_x;   b.bx -= c ? a.boxes_x : 0;
+        b.by += stride.by + c; c = b.by >= a.boxes_y;   b.by -= c ? a.boxes_y : 0;
+        b.bz += stride.bz + c; c = b.bz >= a.boxes_z;   b.bz -= c ? a.boxes_z : 0;
+        b.n += stride.n + c;
+        finish(b);
         return b;
     };
 
@@ -213,9 +231,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         }
     }
     __syncthreads();
-    auto cursor_box = [&](unsigned L) {          // per-lane offsets and descriptors of box L (all OOB past the end)
-        const bool live = L < box_end;
-        const Box b = decode(live ? L : box);
+    auto cursor_box = [&](const Box& b, bool live) {     // per-lane offsets and descriptors of box b (all OOB past the end)
         icg = b.cg;
         is.rx = make_rsrc(a.x + (long long)b.n * a.x_bs, live ? (unsigned)a.Cin * s_bytes : 0u);
 #pragma unroll
@@ -245,7 +261,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     for (int i = tid; i < a.Cout; i += 256) s_bias[i] = a.bias ? a.bias[i] : 0.f;      // published by the barrier below
     constexpr int A = C::NBUF - 1;
     const unsigned nslot_u = (unsigned)nslot;
-    cursor_box(box);
+    Box bb = decode(box), nb = bb;       // the box being computed, the box under the DMA cursor
+    cursor_box(bb, true);
 #pragma unroll
     for (int s = 0; s < A; ++s) { cursor_set((unsigned)s, s); is.template pieces<0, C::P>(wave); }   // nst > A
     static_assert(A == 3, "the waits below are written for a ring of 4");
@@ -283,16 +300,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         if (!(DBG & 64)) __syncthreads();  // ... and everyone's; everyone is done with stage gs-1
     };
 
-    for (; box < box_end; box += nslot_u) {
-        const Box bb = decode(box);
-        if (sw == 0 && !(DBG & 4)) cursor_box(box + nslot_u);
+    for (; box < box_end; box += nslot_u, bb = nb) {
+        const bool nlive = box + nslot_u < box_end;
+        nb = advance(bb);
+        if (sw == 0 && !(DBG & 4)) cursor_box(nb, nlive);
         iter(std::true_type{}, ua, ub, 0);
-        if (sw == 1 && !(DBG & 4)) cursor_box(box + nslot_u);
+        if (sw == 1 && !(DBG & 4)) cursor_box(nb, nlive);
         iter(std::false_type{}, ub, ua, 1);
         for (int s = 2; s < nst; s += 2) {      // nst is even (Cin % 8 == 0)
-            if (sw == s && !(DBG & 4)) cursor_box(box + nslot_u);
+            if (sw == s && !(DBG & 4)) cursor_box(nb, nlive);
             iter(std::false_type{}, ua, ub, s);
-            if (sw == s + 1 && !(DBG & 4)) cursor_box(box + nslot_u);
+            if (sw == s + 1 && !(DBG & 4)) cursor_box(nb, nlive);
             iter(std::false_type{}, ub, ua, s + 1);
         }
 
