@@ -88,7 +88,10 @@ struct WinoCfg {
 #ifndef MIS_WINO_DBG_CT
 #define MIS_WINO_DBG_CT 0
 #endif
-constexpr int DBG = MIS_WINO_DBG_CT;     // development builds: 1 no stores, 2 no epilogue, 4 no cursor recompute
+// Ablation builds (scripts/wino_variants.sh; results are WRONG with any bit set, timing only -- DESIGN.md quotes them):
+// 1 no stores, 2 no epilogue (the MFMAs become dead code), 4 no cursor recompute, 8 no DMA, 16 no transform, 32 no filter
+// reads, 64 no barrier, 128 no filter DMA, 256 no input DMA, 512 transform interleaved with the MFMA slots
+constexpr int DBG = MIS_WINO_DBG_CT;
 
 extern __shared__ __attribute__((aligned(16))) float mis_wino_lds[];
 
