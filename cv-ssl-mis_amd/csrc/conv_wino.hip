@@ -123,6 +123,11 @@ struct Issue {
     }
 };
 
+// LDS address of the lane's patch, one base per z plane (pinned: the ds_read2_b32 offsets, 8 bits of dwords, then reach
+// every row of the plane and the compiler does not re-derive a base per load)
+typedef const __attribute__((address_space(3))) float* lds_ptr;
+struct RawPlanes { lds_ptr z[4]; };
+
 // One chunk = 64 slots, one MFMA each (transform point xi = K of `cur`), in program order (a scheduling barrier closes
 // every slot: a wave alone on its SIMD issues one instruction per 4 cycles, so at most 7 others fit under an MFMA):
 //   K % 4 == 0   ds_read_b128 of the filter points of group K/4 + 2 (the last two: groups 0, 1 of the next stage)
@@ -131,7 +136,7 @@ struct Issue {
 //   (the transform of the next chunk follows the run, see iter)
 template <class C, bool FIRST, int K>
 __device__ __forceinline__ void slots(const f32x4* __restrict__ wl, const f32x4* __restrict__ wl_next,
-                                      const float* __restrict__ raw, const f32x2 (&cur)[32], f32x2 (&nxt)[32],
+                                      const RawPlanes& raw, const f32x2 (&cur)[32], f32x2 (&nxt)[32],
                                       f32x4 (&acc)[64], f32x4 (&ar)[4], const Issue<C>& is, int wave) {
     if constexpr (K < 64) {
         constexpr int G = K / 4;
@@ -145,10 +150,7 @@ __device__ __forceinline__ void slots(const f32x4* __restrict__ wl, const f32x4*
 #pragma unroll
             for (int j = 2 * K; j < 2 * K + 2; ++j) {
                 const int z = j / 8, y = (j / 2) % 4, xp = j % 2;
-                typedef const __attribute__((address_space(3))) float* lds_ptr;
-                lds_ptr rz = (lds_ptr)raw + z * C::HY * C::RX;       // one base per z plane: ds_read2 offsets < 256 dwords
-                asm volatile("" : "+v"(rz));
-                nxt[j] = f32x2{rz[y * C::RX + 2 * xp], rz[y * C::RX + 2 * xp + 1]};
+                nxt[j] = f32x2{raw.z[z][y * C::RX + 2 * xp], raw.z[z][y * C::RX + 2 * xp + 1]};
             }
         }
         constexpr int SP = C::P <= 12 ? 5 : 3;      // DMA spacing in slots
@@ -294,7 +296,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // (vmcnt counts stores too: a wait behind them would wait for their write acknowledgements).
     auto iter = [&](auto first, f32x2 (&cur)[32], f32x2 (&nxt)[32], int s) {
         cursor_set(gs + A, s + A < nst ? s + A : s + A - nst);
-        slots<C, decltype(first)::value, 0>(wl_of(gs), wl_of(gs + 1), raw_of(gs + 1), cur, nxt, acc, ar, is, wave);
+        RawPlanes rp;
+        {
+            const float* r0 = raw_of(gs + 1);
+#pragma unroll
+            for (int z = 0; z < 4; ++z) {
+                rp.z[z] = (lds_ptr)r0 + z * C::HY * C::RX;
+                asm volatile("" : "+v"(rp.z[z]));
+            }
+        }
+        slots<C, decltype(first)::value, 0>(wl_of(gs), wl_of(gs + 1), rp, cur, nxt, acc, ar, is, wave);
         // the transform of the next chunk, after the run: VALU work does not overlap this wave's MFMAs wherever it is placed
         // (scripts/ubench/mfma_overlap.hip), and in one block it costs 4 % less than spread over the slots
         if (!(DBG & 16) && !(DBG & 512)) in_units<0, 24>(nxt);
