@@ -239,9 +239,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     auto cursor_box = [&](const Box& b, bool live) {     // per-lane offsets and descriptors of box b (all OOB past the end)
         icg = b.cg;
         is.rx = make_rsrc(a.x + (long long)b.n * a.x_bs, live ? (unsigned)a.Cin * s_bytes : 0u);
+        unsigned geo[C::NCH];
+#pragma unroll
+        for (int p = 0; p < C::NCH; ++p) geo[p] = s_geo[p * 64 + lane];
+        __builtin_amdgcn_sched_barrier(0);      // all the LDS reads in flight together, not one round trip per piece
 #pragma unroll
         for (int p = 0; p < C::NCH; ++p) {
-            const unsigned g = s_geo[p * 64 + lane];
+            const unsigned g = geo[p];
             const int qz = b.z0 - 1 + (int)(g & 15u), qy = b.y0 - 1 + (int)((g >> 4) & 31u);
             const int qx = C::DW ? b.x0 - 1 + (int)((g >> 9) & 31u) : b.x0 - 4 + 4 * (int)((g >> 9) & 31u);
             const bool ok = (g >> 14) && (unsigned)qz < (unsigned)a.D && (unsigned)qy < (unsigned)a.H &&
