@@ -142,9 +142,11 @@ __device__ __forceinline__ void slots(const f32x4* __restrict__ wl, const f32x4*
         constexpr int G = K / 4;
         if constexpr (K % 4 == 0 && !(DBG & 32)) ar[(G + 2) % 4] = G < 14 ? wl[(G + 2) * 64] : wl_next[(G - 14) * 64];
         {
-            const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-            acc[K] = __builtin_amdgcn_mfma_f32_16x16x4f32(ar[G % 4][K % 4], cur[K / 2][K % 2],
-                                                          FIRST ? zero : acc[K], 0, 0, 0);
+            // asm with the accumulator tied to an AGPR tuple: through the builtin hipcc placed 14 of the first chunk's
+            // (C = 0) results in VGPRs and copied them into AGPRs in the second chunk (112 v_accvgpr moves per box)
+            const float av = ar[G % 4][K % 4], bv = cur[K / 2][K % 2];
+            if constexpr (FIRST) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, 0" : "=a"(acc[K]) : "v"(av), "v"(bv));
+            else asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+a"(acc[K]) : "v"(av), "v"(bv));
         }
         if constexpr (K < 16 && !(DBG & 16)) {
 #pragma unroll
@@ -334,6 +336,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
         // ---- epilogue: inverse transform (64 -> 2x2x2 per (channel, tile)), bias, store, optional statistics ----
         if (DBG & 2) continue;
+        asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");        // the last (asm) MFMAs have left the pipe before their AGPRs are read
         const int oz = bb.z0 + 2 * tz, oy = bb.y0 + 2 * ty, ox = bb.x0 + 2 * tx;
         const bool ok = oz < a.D && oy < a.H && ox < a.W;
         const int co0 = (bb.cg * C::COB + cb) * 16;
