@@ -123,7 +123,9 @@ __device__ __forceinline__ void wg_slots(f32x2 (&u)[32], const f32x2 (&v)[16], f
         {   // next chunk's x patch, float K of the 4x4x4 patch (z, y, x) = (K / 16, (K / 4) % 4, K % 4): into the register
             // the MFMA above has just consumed (one patch buffer instead of two: 64 registers)
             constexpr int z = K / 16, y = (K / 4) % 4, xx = K % 4;
-            u[K / 2][K % 2] = xsrc[(z * C::HY + y) * 16 * C::RX + xx];
+            // volatile: one ds_read_b32 with an immediate offset per float.  Left alone hipcc pairs them into ds_read2_b32
+            // and pays a v_add_u32 per pair for the base (VALU time is the scarce resource here, LDS issue is free)
+            u[K / 2][K % 2] = ((const volatile __attribute__((address_space(3))) float*)xsrc)[(z * C::HY + y) * 16 * C::RX + xx];
         }
         if constexpr (K < 4) {   // ... and its dy patch: (z, y) = (K / 2, K % 2), both x
             rn[K] = *reinterpret_cast<const f32x2*>(dsrc + ((K / 2) * C::OY + (K % 2)) * 16 * C::DRX);
