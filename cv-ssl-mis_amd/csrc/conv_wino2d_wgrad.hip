@@ -89,7 +89,8 @@ __device__ __forceinline__ void wg2_slots(f32x2 (&u)[8], const f32x2 (&vy)[C::CO
         acc[b][xi] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[xi % 4], u[xi / 2][xi % 2], acc[b][xi], 0, 0, 0);
         if constexpr (b == C::COB - 1) {
             constexpr int y = xi / 4, xx = xi % 4;
-            u[xi / 2][xi % 2] = xsrc[y * 16 * C::RX + xx];
+            // volatile LDS pointer: one ds_read_b32 with an immediate offset (see conv_wino_wgrad.hip)
+            u[xi / 2][xi % 2] = ((const volatile __attribute__((address_space(3))) float*)xsrc)[y * 16 * C::RX + xx];
         }
         if constexpr (xi < 2) rn[b][xi] = *reinterpret_cast<const f32x2*>(dsrc + (xi * C::DC + b * 16) * C::DRX);
         constexpr int SP = C::COB == 1 ? 2 : 3;                              // DMA spacing: PW pieces fit the run

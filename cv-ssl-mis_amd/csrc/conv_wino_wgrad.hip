@@ -117,7 +117,10 @@ __device__ __forceinline__ void wg_slots(f32x2 (&u)[32], const f32x2 (&v)[16], f
     if constexpr (K < 64) {
         if constexpr (K % 4 == 0) {
             const f32x2 p = v[K / 4];
-            av[0] = p[0]; av[1] = f_add(p[0], p[1]); av[2] = f_sub(p[0], p[1]); av[3] = f_sub(0.f, p[1]);
+            // (p0 + p1, p0 - p1) in one packed add (op_sel picks p0 for both halves of src0 and p1 for both of src1)
+            f32x2 pm;
+            asm volatile("v_pk_add_f32 %0, %1, %1 op_sel:[0,1] op_sel_hi:[0,1] neg_hi:[0,1]" : "=v"(pm) : "v"(p));
+            av[0] = p[0]; av[1] = pm[0]; av[2] = pm[1]; av[3] = f_sub(0.f, p[1]);
         }
         acc[K] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[K % 4], u[K / 2][K % 2], acc[K], 0, 0, 0);
         {   // next chunk's x patch, float K of the 4x4x4 patch (z, y, x) = (K / 16, (K / 4) % 4, K % 4): into the register
