@@ -90,7 +90,8 @@ struct WinoCfg {
 #endif
 // Ablation builds (scripts/wino_variants.sh; results are WRONG with any bit set, timing only -- DESIGN.md quotes them):
 // 1 no stores, 2 no epilogue (the MFMAs become dead code), 4 no cursor recompute, 8 no DMA, 16 no transform, 32 no filter
-// reads, 64 no barrier, 128 no filter DMA, 256 no input DMA, 512 transform interleaved with the MFMA slots
+// reads, 64 no barrier, 128 no filter DMA, 256 no input DMA, 512 transform interleaved with the MFMA slots, 1024 no wait
+// for the DMA stage
 constexpr int DBG = MIS_WINO_DBG_CT;
 
 extern __shared__ __attribute__((aligned(16))) float mis_wino_lds[];
@@ -316,7 +317,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         // (scripts/ubench/mfma_overlap.hip), and in one block it costs 4 % less than spread over the slots
         if (!(DBG & 16) && !(DBG & 512)) in_units<0, 24>(nxt);
         ++gs;
-        vmwait<C::P>::go();                // stage gs+1 landed (mine) ...
+        vmwait<(DBG & 1024) ? 2 * C::P : C::P>::go();   // stage gs+1 landed (mine) ...  (1024: ablation, do not wait for it)
         if (!(DBG & 64)) __syncthreads();  // ... and everyone's; everyone is done with stage gs-1
     };
 
