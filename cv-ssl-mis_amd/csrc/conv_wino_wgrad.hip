@@ -61,6 +61,12 @@ struct WgCfg {
     static_assert(PW <= 20, "class bits: 5 pieces per register, 4 registers");
 };
 
+#ifndef MIS_WGW_DBG_CT
+#define MIS_WGW_DBG_CT 0
+#endif
+// ablation builds (timing only, results wrong): 1 no DMA issue in the loop, 2 no transforms, 4 no patch loads, 8 no barrier
+constexpr int WDBG = MIS_WGW_DBG_CT;
+
 extern __shared__ __attribute__((aligned(16))) float mis_wgw_lds[];
 
 // V = A dy A^T in z and y of the 2x2x2 patch r[z][y] (pairs over x): 16 pairs vzy[z'][y'], 18 packed adds
@@ -100,9 +106,17 @@ struct WgIssue {
             // uniform; the 4 * PW - P surplus slots repeat the last piece (same data to the same place: no branch
             // in the MFMA run -- a branch there makes hipcc rename the accumulators through VGPR copies)
             const int p = wave + 4 * I < C::P ? wave + 4 * I : C::P - 1;
-            const unsigned c = (cls[I / 5] >> ((I % 5) * 6)) & 63u;
-            const unsigned vo = (c & flags) ? OOB : rel[I];
-            dma_dwordx4_s(st + (unsigned)p * 1024u, vo, soff, p < C::XP ? rx : rd);
+            // which operand piece I belongs to is known at compile time when the x pieces split evenly over the waves
+            // (no descriptor select, and the dy pieces need no class test: they have no halo)
+            constexpr bool all_x = 4 * I + 3 < C::XP, all_d = 4 * I >= C::XP;
+            if constexpr (all_d) {
+                dma_dwordx4_s(st + (unsigned)p * 1024u, rel[I], soff, rd);
+            } else {
+                const unsigned c = (cls[I / 5] >> ((I % 5) * 6)) & 63u;
+                const unsigned vo = (c & flags) ? OOB : rel[I];
+                if constexpr (all_x) dma_dwordx4_s(st + (unsigned)p * 1024u, vo, soff, rx);
+                else dma_dwordx4_s(st + (unsigned)p * 1024u, vo, soff, p < C::XP ? rx : rd);
+            }
         }
     }
 };
@@ -123,17 +137,17 @@ __device__ __forceinline__ void wg_slots(f32x2 (&u)[32], const f32x2 (&v)[16], f
             av[0] = p[0]; av[1] = pm[0]; av[2] = pm[1]; av[3] = f_sub(0.f, p[1]);
         }
         acc[K] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[K % 4], u[K / 2][K % 2], acc[K], 0, 0, 0);
-        {   // next chunk's x patch, float K of the 4x4x4 patch (z, y, x) = (K / 16, (K / 4) % 4, K % 4): into the register
+        if constexpr (!(WDBG & 4)) {   // next chunk's x patch, float K of the 4x4x4 patch (z, y, x) = (K / 16, (K / 4) % 4, K % 4): into the register
             // the MFMA above has just consumed (one patch buffer instead of two: 64 registers)
             constexpr int z = K / 16, y = (K / 4) % 4, xx = K % 4;
             // volatile: one ds_read_b32 with an immediate offset per float.  Left alone hipcc pairs them into ds_read2_b32
             // and pays a v_add_u32 per pair for the base (VALU time is the scarce resource here, LDS issue is free)
             u[K / 2][K % 2] = ((const volatile __attribute__((address_space(3))) float*)xsrc)[(z * C::HY + y) * 16 * C::RX + xx];
         }
-        if constexpr (K < 4) {   // ... and its dy patch: (z, y) = (K / 2, K % 2), both x
+        if constexpr (K < 4 && !(WDBG & 4)) {   // ... and its dy patch: (z, y) = (K / 2, K % 2), both x
             rn[K] = *reinterpret_cast<const f32x2*>(dsrc + ((K / 2) * C::OY + (K % 2)) * 16 * C::DRX);
         }
-        if constexpr (ISSUE && K % 3 == 1) is.template piece<K / 3>(wave);
+        if constexpr (ISSUE && K % 3 == 1 && !(WDBG & 1)) is.template piece<K / 3>(wave);
         __builtin_amdgcn_sched_barrier(0);
         wg_slots<C, ISSUE, K + 1>(u, v, acc, rn, xsrc, dsrc, is, wave, av);
     }
@@ -274,17 +288,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             const float* __restrict__ sb = lds + buf * C::STAGE;
             // chunk A; LDS reads of chunk B of the same stage
             wg_slots<C, false, 0>(u, v, acc, rn, sb + xoff[1], sb + C::XF + doff[1], is, wave, av);
-            in_units<0, 24>(u);
-            vzy_transform(rn, v, zero);
+            if (!(WDBG & 2)) { in_units<0, 24>(u); vzy_transform(rn, v, zero); }
             // every wave has read stage s completely; stage s+1 (issued one stage ago) has landed
             vmwait<0>::go();
-            __syncthreads();
+            if (!(WDBG & 8)) __syncthreads();
             cursor(s + 2 * nt, buf);         // refill this buffer with the stage after next while chunk B runs
             const float* __restrict__ nb = lds + (buf ^ 1) * C::STAGE;
             // chunk B; LDS reads of chunk A of stage s+1 (zeros after the last stage: unused)
             wg_slots<C, true, 0>(u, v, acc, rn, nb + xoff[0], nb + C::XF + doff[0], is, wave, av);
-            in_units<0, 24>(u);
-            vzy_transform(rn, v, zero);
+            if (!(WDBG & 2)) { in_units<0, 24>(u); vzy_transform(rn, v, zero); }
         }
     }
     vmwait<0>::go();
