@@ -396,11 +396,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                                                               (int)((unsigned)(2 * h + rr) * s_bytes), 0);
                     }
                 }
+            if constexpr (C::DW) {      // this variant also runs partly filled boxes: tiles outside the volume do not count
+                if (!ok) { s1 = f32x2{0.f, 0.f}; s2 = s1; }
+            }
             st1[2 * h] = s1[0]; st1[2 * h + 1] = s1[1]; st2[2 * h] = s2[0]; st2[2 * h + 1] = s2[1];
             __builtin_amdgcn_sched_barrier(0);
         }
         if (a.stat) {
-            // every box is full here (the host only passes `stat` then): per-channel (sum, sum of squares) of the box.
+            // per-channel (sum, sum of squares) of the box.
             // The scratch is a piece of LDS beyond the ring (the ring is live: later stages are in flight).
 #pragma unroll
             for (int r = 0; r < 4; ++r)
@@ -453,16 +456,22 @@ int launch_wino(WinoArgs a, hipStream_t stream) {
 
 // Which Winograd variant serves this 3x3x3 'same' convolution, or -1 (use the direct kernel, mis_conv_fwd):
 //   0: boxes of 4 x 4 x 32 outputs (W a multiple of 32: the 96^3 level),  1: 4 x 8 x 16 (W a multiple of 16: 48^3),
-//   2: 8 x 8 x 8 (W a multiple of 8: 24^3; halo rows as single dwords).
+//   2: 8 x 8 x 8 (24^3; halo rows as single dwords; also partly filled boxes: the 12^3 level).
 // Needs Cin % 8 == 0 (two 4-channel chunks per loop trip), Cin >= 16 (the DMA ring runs 3 chunks ahead),
-// Cout % 16 == 0 (MFMA rows), Cout <= 384 (bias table in LDS), even D / H and W % 4 == 0 (2x2x2 tiles, 16-byte rows).
+// Cout % 16 == 0 (MFMA rows), Cout <= 384 (bias table in LDS), even D / H / W (2x2x2 tiles).
 extern "C" int mis_conv3d_wino_select(int N, int Cin, int Cout, int D, int H, int W) {
     if (N <= 0 || Cin < 16 || Cin % 8 || Cout <= 0 || Cout % 16 || Cout > 384 || D <= 0 || H <= 0 || W <= 0) return -1;
-    if (D % 2 || H % 2 || W % 4) return -1;
+    if (D % 2 || H % 2 || W % 2) return -1;
     if (((long long)Cin + 32) * D * H * W * 4 >= (1LL << 30)) return -1;
-    if (W % 32 == 0 && D % 4 == 0 && H % 4 == 0) return 0;
+    if (W % 32 == 0 && D % 4 == 0 && H % 4 == 0) return 0;      // 16-byte halo rows: W % 4 == 0
     if (W % 16 == 0 && D % 4 == 0 && H % 8 == 0) return 1;
     if (W % 8 == 0 && D % 8 == 0 && H % 8 == 0 && Cin >= 32) return 2;      // the 24^3 level: boxes of 8 x 8 x 8
+    if (Cin >= 32) {
+        // partly filled 8 x 8 x 8 boxes (the 12^3 level: 42 % of the box volume is output) still beat the direct kernel
+        // 1.3 - 1.8x when there are enough boxes for the 256 CUs; out-of-range tiles are not stored and not counted
+        const long long boxes = mis_cdiv(D, 8) * mis_cdiv(H, 8) * mis_cdiv(W, 8);
+        if ((long long)D * H * W * 5 >= boxes * 512 * 2 && (long long)N * boxes * (Cout / 16) >= 128) return 2;
+    }
     return -1;
 }
 

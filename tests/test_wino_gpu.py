@@ -41,6 +41,9 @@ FWD_CASES = [
     (3, 96, 32, 4, 8, 16, 1),
     (1, 32, 32, 8, 8, 8, 2),        # the 24^3 level's boxes (8 x 8 x 8 voxels, dword halo rows)
     (2, 64, 48, 8, 16, 24, 2),
+    (4, 64, 128, 12, 12, 12, 2),    # the 12^3 level: partly filled boxes (tiles outside the volume are not stored)
+    (8, 32, 64, 12, 8, 20, 2),
+    (8, 128, 256, 6, 6, 6, 2),
 ]
 
 
@@ -75,7 +78,8 @@ def test_wino_forward_and_data_gradient(case):
 
 
 @pytest.mark.parametrize("N,Cin,Cout,D,H,W,per_sample", [(2, 16, 16, 4, 8, 32, True), (3, 32, 32, 4, 8, 16, False),
-                                                         (2, 48, 16, 8, 4, 64, True)])
+                                                         (2, 48, 16, 8, 4, 64, True), (4, 64, 128, 12, 12, 12, True),
+                                                         (4, 32, 64, 12, 12, 12, False)])
 def test_wino_fused_statistics(N, Cin, Cout, D, H, W, per_sample):
     """The per-box (sum, sumsq) partials of the Winograd epilogue + mis_norm_stats_finalize == the statistics of the
     InstanceNorm / BatchNorm that follows the conv (reference utils.py:104-107: Conv3d -> norm -> ReLU)."""
@@ -185,7 +189,8 @@ def test_wino_select_and_refusal():
     assert sel(2, 1, 16, 96, 96, 96) == -1          # first layer: 1 input channel
     assert sel(2, 16, 2, 96, 96, 96) == -1          # Cout not a multiple of 16
     assert sel(2, 64, 64, 24, 24, 24) == 2
-    assert sel(2, 128, 128, 12, 12, 12) == -1       # 12^3 and deeper: direct kernel
+    assert sel(4, 128, 128, 12, 12, 12) == 2        # 12^3: partly filled boxes, when there are enough of them
+    assert sel(1, 32, 16, 12, 12, 12) == -1 and sel(8, 128, 256, 6, 6, 6) == 2 and sel(4, 128, 256, 6, 6, 6) == -1
     assert sel(2, 16, 16, 6, 6, 30) == -1
     assert ops.conv_wino_select(2, 16, 16, 1, 64, 64, (3, 3)) == ops.WINO2D          # 2-D: conv_wino2d.hip
     x = torch.zeros(1, 16, 6, 6, 30, device="cuda")
