@@ -163,3 +163,35 @@ struct MisStepState {
     float cons_weight;   // consistency weight of this step (0 while gated off)
     float cons_gate;     // 1 if the consistency term is live this step, else 0
 };
+
+// Exact-form (erf) GELU, nn.GELU() of the reference (swin_transformer_unet_skip_expand_decoder_sys.py:10,15):
+//   gelu(x) = x Phi(x),  gelu'(x) = Phi(x) + x u / sqrt(2 pi),  u = exp(-x^2 / 2).
+// Phi(-a) = u(a) P(t), t = 1 / (1 + 0.3 a): the rational-argument form of erfc (Abramowitz & Stegun 7.1.26) with a degree-8
+// polynomial fitted here for RELATIVE accuracy over a in [0, 13] (so the negative tail of x Phi(x) keeps its digits):
+// |Phi error| <= 2e-7 in fp32 (two ulp of 1), |gelu error| <= 4e-7 at |x| = 13.  2 transcendental + 14 plain VALU
+// instructions; libm's erff + expf are ~70, which made the fused GELU epilogues of the NT GEMM VALU-bound (a wave's VALU
+// work does not overlap its own MFMAs).
+__device__ __forceinline__ void mis_gelu_parts(float x, float& cdf, float& u) {
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3f, fabsf(x), 1.f));
+    float p = 3.664988946e-02f;
+    p = fmaf(p, t, -1.611761927e-01f);
+    p = fmaf(p, t, 2.130432014e-01f);
+    p = fmaf(p, t, -5.969779766e-02f);
+    p = fmaf(p, t, 1.316696142e-01f);
+    p = fmaf(p, t, 9.899286856e-02f);
+    p = fmaf(p, t, 1.208983674e-01f);
+    p = fmaf(p, t, 1.196200560e-01f);
+    u = __builtin_amdgcn_exp2f(x * x * -0.72134752044448170f);      // exp(-x^2 / 2)
+    const float e = p * t * u;
+    cdf = x < 0.f ? e : 1.f - e;
+}
+__device__ __forceinline__ float mis_gelu(float x) {
+    float cdf, u;
+    mis_gelu_parts(x, cdf, u);
+    return x * cdf;
+}
+__device__ __forceinline__ float mis_gelu_grad(float x) {
+    float cdf, u;
+    mis_gelu_parts(x, cdf, u);
+    return fmaf(x * 0.3989422804014327f, u, cdf);
+}

@@ -340,7 +340,7 @@ __global__ __launch_bounds__(1024) void col_final_kernel(const float2* __restric
     }
 }
 
-// ------------------------------------------------------------------ GELU (erf form)
+// ------------------------------------------------------------------ GELU (erf form; mis_gelu in common.h)
 __global__ __launch_bounds__(256) void gelu_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                    float* __restrict__ out, long long n4, int backward) {
     for (long long i = blockIdx.x * 256LL + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
@@ -349,16 +349,12 @@ __global__ __launch_bounds__(256) void gelu_kernel(const float* __restrict__ x, 
         float o[4];
         if (!backward) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) o[j] = 0.5f * xs[j] * (1.f + erff(xs[j] * 0.70710678118654752f));
+            for (int j = 0; j < 4; ++j) o[j] = mis_gelu(xs[j]);
         } else {
             const float4 g = reinterpret_cast<const float4*>(dy)[i];
             const float gs[4] = {g.x, g.y, g.z, g.w};
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float cdf = 0.5f * (1.f + erff(xs[j] * 0.70710678118654752f));
-                const float pdf = 0.3989422804014327f * expf(-0.5f * xs[j] * xs[j]);
-                o[j] = gs[j] * (cdf + xs[j] * pdf);
-            }
+            for (int j = 0; j < 4; ++j) o[j] = gs[j] * mis_gelu_grad(xs[j]);
         }
         reinterpret_cast<float4*>(out)[i] = make_float4(o[0], o[1], o[2], o[3]);
     }

@@ -4,6 +4,8 @@ residual+DropPath, token re-arrangements, patch im2col, output head, window atte
 Token tensors are 2-D ``[rows, C]`` fp32 views with a dense last dim and a free row stride (``ld``),
 so column slices of a wider buffer (the decoder's concat) are valid operands.
 """
+import ctypes
+
 import torch
 
 from . import lib as _l
@@ -17,6 +19,13 @@ def _mat(t):
         raise RuntimeError(f"expected 2-D fp32 row-major view, got {tuple(t.shape)} strides {t.stride()}")
     _l.require_gpu(t)
     return t.shape[0], t.shape[1], (t.stride(0) if t.shape[0] > 1 else max(t.stride(0), t.shape[1]))
+
+
+def _nt_name(L, M, N, K, epilogue):
+    """NT instantiation mis_gemm / mis_gemm_ex pick, as rocprofv3 names it."""
+    buf = ctypes.create_string_buffer(96)
+    _l.check(L.mis_gemm_nt_kernel_name(M, N, K, epilogue, buf, 96), "mis_gemm_nt_kernel_name")
+    return buf.value.decode()
 
 
 def gemm(A, B, C, bias=None, trans=False, accumulate=False):
@@ -45,7 +54,7 @@ def gemm(A, B, C, bias=None, trans=False, accumulate=False):
         if trans:
             name = "gemm_tn_kernel<96>" if (M % 96 == 0 and N % 96 == 0 and (M % 128 or N % 128)) else "gemm_tn_kernel<128>"
         else:
-            name = "gemm_nt_kernel<96, 0>" if (N % 96 == 0 and N % 128) else "gemm_nt_kernel<128, 0>"
+            name = _nt_name(L, M, N, K, 0)
         prof.append((name, 2.0 * M * N * K, e0, e1))
 
 
@@ -78,8 +87,7 @@ def gemm_ex(A, B, C, epilogue, bias=None, E1=None, C2=None, rowscale=None, rows_
     if prof is not None:
         e1.record()
         # (split-K shapes run the plain instantiation + the reduce kernel; the label keeps the requested epilogue)
-        prof.append((("gemm_nt_kernel<96, %d>" if (N % 96 == 0 and N % 128) else "gemm_nt_kernel<128, %d>") % epilogue,
-                     2.0 * M * N * K, e0, e1))
+        prof.append((_nt_name(L, M, N, K, epilogue), 2.0 * M * N * K, e0, e1))
     return True
 
 
@@ -106,8 +114,7 @@ def gemm_expand(x, w, out, B, H, W, P, c):
     _l.check(st, "mis_gemm_expand")
     if prof is not None:
         e1.record()
-        prof.append(("gemm_nt_kernel<96, 0>" if (N % 96 == 0 and N % 128) else "gemm_nt_kernel<128, 0>", 2.0 * M * N * K,
-                     e0, e1))
+        prof.append((_nt_name(L, M, N, K, 0), 2.0 * M * N * K, e0, e1))
     return True
 
 

@@ -297,6 +297,8 @@ int mis_add(const float* a, long long a_bs, const float* b, long long b_bs, floa
  *           (:14,16,107,109,320,361,390,690) and, with B = weight^T, its input gradient;
  *           trans = 1: C[M,N] (+)= A[K,M]^T . B[K,N]  -- weight gradient dY^T . X (split over K, deterministic). */
 long long mis_gemm_workspace_bytes(int M, int N, int K, int trans);
+/* the NT kernel instantiation mis_gemm / mis_gemm_ex run this shape with (aligned operands), as a profiler names it */
+int mis_gemm_nt_kernel_name(int M, int N, int K, int epilogue, char* name, int name_len);
 /* nn.Linear of PatchExpand / FinalPatchExpand_X4 fused with their pixel shuffle
  * 'b h w (p1 p2 c) -> b (h p1) (w p2) c' (swin_transformer_unet_skip_expand_decoder_sys.py:373-380, :401-408):
  * x [B*H*W][K] (row stride lda), W [P*P*c][K] (row stride ldb), out [B*H*P*W*P][c] dense.  No bias.

@@ -13,13 +13,11 @@ from mis_hip import ops, tops
 from mis_hip.step import MeanTeacherTrainer
 
 wl = bench.WORKLOADS["swin"]
-model, ema = bench.make_models("swin", wl["classes"])
-ema.load_state_dict(model.state_dict())
-tr = MeanTeacherTrainer(model, ema, labeled_bs=wl["labeled"], num_classes=wl["classes"], cons_start_iter=wl["cons_start"],
-                        seed=1337, iter_num=1000)
+torch.manual_seed(1337)
+tr = bench.build_trainer("swin", wl, 1)
 g = torch.Generator(device="cuda").manual_seed(1337)
 vol = torch.rand(wl["shape"], generator=g, device="cuda")
-lab = torch.randint(0, wl["classes"], (wl["shape"][0],) + wl["shape"][2:], generator=g, device="cuda").to(wl["label_dtype"])
+lab = torch.randint(0, wl["classes"], (wl["shape"][0],) + wl["shape"][2:], generator=g, device="cuda").to(getattr(torch, wl["label"]))
 for _ in range(3):
     tr.step(vol, lab)
 orig = tops.gemm
@@ -31,11 +29,26 @@ def wrapped(A, B, C, bias=None, trans=False, accumulate=False):
     return orig(A, B, C, bias=bias, trans=trans, accumulate=accumulate)
 
 
+orig_ex, orig_expand = tops.gemm_ex, tops.gemm_expand
+
+
+def wrapped_ex(A, B, C, epilogue, **kw):
+    ok = orig_ex(A, B, C, epilogue, **kw)
+    if ok:
+        geo.append((tuple(C.shape), A.shape[1], False))
+    return ok
+
+
+def wrapped_expand(x, w, out, B, H, W, P, c):
+    ok = orig_expand(x, w, out, B, H, W, P, c)
+    if ok:
+        geo.append(((x.shape[0], w.shape[0]), x.shape[1], False))
+    return ok
+
+
 tops.gemm = wrapped
-import mis_hip.swin_plan as sp
-for mod in (sp,):
-    if getattr(mod, "tops", None) is not None:
-        mod.tops.gemm = wrapped
+tops.gemm_ex = wrapped_ex
+tops.gemm_expand = wrapped_expand
 prof = []
 ops.PROFILE = prof
 steps = 5

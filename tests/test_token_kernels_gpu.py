@@ -1,4 +1,6 @@
 """Op-level parity of the token-major (SwinUnet) HIP kernels against stock torch CPU fp32/fp64 ops."""
+import ctypes
+
 import pytest
 import torch
 import torch.nn.functional as F
@@ -25,12 +27,18 @@ def _close(a, b, rtol=2e-4, atol=1e-5):
 @pytest.mark.parametrize("M,N,K", [(256, 128, 96), (3136, 288, 96), (200, 96, 48), (130, 1536, 96), (49, 768, 3072),
                                    (1000, 4, 96), (5000, 192, 384), (777, 576, 192), (100, 96, 100),
                                    # few tiles, long K: the NT form splits K too (ragged last slice for K = 1000)
-                                   (1176, 768, 3072), (300, 200, 1000)])
+                                   (1176, 768, 3072), (300, 200, 1000),
+                                   # short contraction over many rows: gemm_nt_short_kernel (64-row tiles, ragged last)
+                                   (50000, 288, 96), (33000, 384, 192)])
 def test_gemm_nt_and_tn(M, N, K):
     tops = _t()
     A, B, bias = _rand(M, K, seed=1), _rand(N, K, seed=2), _rand(N, seed=3)
     ref = (A.double() @ B.double().t() + bias.double())
     Ad, Bd = A.cuda(), B.cuda()
+    from mis_hip import lib
+    name = ctypes.create_string_buffer(96)
+    assert lib.load().mis_gemm_nt_kernel_name(M, N, K, 0, name, 96) == 0
+    assert name.value.decode().startswith("gemm_nt_short_kernel<") == (M >= 33000)
     C = torch.empty(M, N, device="cuda")
     tops.gemm(Ad, Bd, C, bias=bias.cuda())
     _close(C, ref)
@@ -267,7 +275,8 @@ def test_gemm_expand_equals_gemm_plus_pixel_shuffle(B, H, K, P, c):
     _close(ref, want)
 
 
-@pytest.mark.parametrize("M,N,K", [(6272, 384, 96), (6272, 96, 384), (200, 96, 48), (98, 3072, 768), (98, 768, 3072)])
+@pytest.mark.parametrize("M,N,K", [(6272, 384, 96), (6272, 96, 384), (200, 96, 48), (98, 3072, 768), (98, 768, 3072),
+                                   (33000, 384, 96), (65570, 96, 96)])       # the short-contraction kernel's epilogues
 def test_gemm_fused_epilogues(M, N, K):
     """mis_gemm_ex: GELU forward / backward and DropPath + residual add in the NT GEMM's epilogue (also through the
     split-K reduction for the deep-stage shapes) against torch in float64."""
