@@ -76,18 +76,25 @@ __global__ __launch_bounds__(256) void wgrad_cin1_kernel(const Cin1Args a) {
         for (int r = 0; r < 4; ++r) out[g * 256 + (lk * 4 + r) * 16 + lj] = acc[g][r];
 }
 
-// dw[co][tap] (+)= sum of the partials: 16 lanes per output, each a strided share, combined in a fixed order
+// dw[co][tap] (+)= sum of the partials: one workgroup per output (432 of them: with 16 lanes per output and 27 workgroups
+// this reduction was a latency chain of 256 dependent 2 KB-strided loads, 86 us), each thread a strided share, combined in
+// a fixed order
 __global__ __launch_bounds__(256) void wgrad_cin1_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw,
                                                                 int parts, int Cout, int accumulate) {
-    const int o = blockIdx.x * 16 + (threadIdx.x >> 4), sub = threadIdx.x & 15;
-    if (o >= Cout * 27) return;                            // whole 16-lane groups leave together
+    __shared__ float red[4];
+    const int o = blockIdx.x;
     const int co = o / 27, tap = o - co * 27;
     const float* p = ws + (tap / 16) * 256 + co * 16 + tap % 16;
     float s = 0.f;
-    for (int k = sub; k < parts; k += 16) s += p[(long long)k * 512];
+    for (int k = threadIdx.x; k < parts; k += 256) s += p[(long long)k * 512];
 #pragma unroll
-    for (int d = 8; d > 0; d >>= 1) s += __shfl_xor(s, d, 16);
-    if (sub == 0) dw[o] = accumulate ? dw[o] + s : s;
+    for (int d = 32; d > 0; d >>= 1) s += __shfl_xor(s, d, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        s = (red[0] + red[1]) + (red[2] + red[3]);
+        dw[o] = accumulate ? dw[o] + s : s;
+    }
 }
 
 int grid_for(long long n_tiles) { return (int)(n_tiles < 1024 ? n_tiles : 1024); }
@@ -116,7 +123,6 @@ int mis_wgrad_cin1(const float* x, long long x_bs, const float* dy, long long dy
     a.n_tiles = (int)n_tiles;
     const int grid = grid_for(n_tiles);
     hipLaunchKernelGGL(wgrad_cin1_kernel, dim3(grid), dim3(256), 0, stream, a);
-    hipLaunchKernelGGL(wgrad_cin1_reduce_kernel, dim3((16 * 27 + 15) / 16), dim3(256), 0, stream, ws, dw, grid * 4, 16,
-                       accumulate);
+    hipLaunchKernelGGL(wgrad_cin1_reduce_kernel, dim3(16 * 27), dim3(256), 0, stream, ws, dw, grid * 4, 16, accumulate);
     return mis_launch_status();
 }

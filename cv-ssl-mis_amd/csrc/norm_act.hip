@@ -538,3 +538,329 @@ extern "C" int mis_norm_act_bwd(const float* x, long long x_bs, const float* da,
                               slope, drop_p, drop_salt, state, drop_mask, dgamma, dbeta, accumulate_affine, workspace,
                               workspace_bytes, stream);
 }
+
+// =====================================================================================================================
+// Last block of the 3-D networks: normalisation + (Leaky)ReLU + dropout, then the 1x1x1 classifier (reference
+// code/networks/unet_3D.py: up_concat1 -> dropout2 -> final = nn.Conv3d(16, n_classes, 1); vnet.py:180-181 block_nine ->
+// Dropout3d -> out_conv; unetr.py out = UnetOutBlock).  The activation z = drop(act(norm(y))) has C = 16 channels on the
+// full-resolution volume and exactly one consumer with 2 .. 4 output channels.  Un-fused it costs: apply (read y, write
+// z), head (read z), and in backward head-dgrad (write dz), head-wgrad (read z), partial sums (read dz, y), apply (read
+// dz, y, write dy) -- 11 passes over a 16-channel volume.  Here z and dz are never stored: a thread takes 4 voxels of all
+// C channels, forward reads y once and writes the logits; backward recomputes z and dz = W^T dlogits from y and the
+// K-channel dlogits in both the partial-sum pass (which also yields the classifier's dW and db) and the apply pass:
+// 4 passes + 3 over the K-channel logits.
+// =====================================================================================================================
+namespace {
+
+struct HeadArgs {
+    const float* x; long long x_bs;       // y = conv output before the normalisation, [N][C][S]
+    int N, K, per_sample;
+    long long S;
+    const float* mean; const float* rstd; const float* gamma; const float* beta;
+    float slope;
+    const float* w; const float* b;       // classifier [K][C], [K] (or null)
+    float* logits; long long l_bs;        // forward: [N][K][S]
+    const float* dl; long long dl_bs;     // backward: dlogits
+    float* dx; long long dx_bs;           // backward: gradient at y
+    float2* part;                         // backward: (sum dz, sum dz*xhat) in bwd_final_kernel's layout
+    const float2* sums;                   // ... and its result
+    float* hpart;                         // backward: classifier partials [N*P][K*C + K]
+    int P;
+};
+
+// Dropout of the 4 voxels of unit u in all C channels.  Philox mode: the C draws in a rolled loop (inlined C times into the
+// unrolled channel loops the generator is 160 KB of code), kept as one bit per element; explicit-mask mode reads the scale.
+template <int C>
+__device__ __forceinline__ unsigned long long head_drop_bits(const DropCfg& d, int n, long long S, long long u) {
+    unsigned long long bits = 0;
+    if (d.p > 0.f && !d.mask) {
+#pragma unroll 1
+        for (int c = 0; c < C; ++c) {
+            float s[4];
+            drop_scale4(d, ((unsigned long long)n * C + c) * S + u * 4, (unsigned)(n * C + c), s);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bits |= (unsigned long long)(s[j] != 0.f) << (4 * c + j);
+        }
+    }
+    return bits;
+}
+template <int C>
+__device__ __forceinline__ void head_drop_scale(const DropCfg& d, unsigned long long bits, int n, long long S, long long u,
+                                                int c, float (&s)[4]) {
+    if (d.mask) {
+        const float4 m = *reinterpret_cast<const float4*>(d.mask + ((unsigned long long)n * C + c) * S + u * 4);
+        s[0] = m.x; s[1] = m.y; s[2] = m.z; s[3] = m.w;
+    } else {
+        const float keep = 1.f / (1.f - d.p);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) s[j] = ((bits >> (4 * c + j)) & 1ull) ? keep : 0.f;
+    }
+}
+
+// per-channel scale / shift (and, backward, rstd-normalised form) of sample n into LDS
+template <int C>
+__device__ __forceinline__ void head_coeffs(const HeadArgs& a, int n, float* sc, float* sh) {
+    if (threadIdx.x < C) {
+        const int c = threadIdx.x, grp = a.per_sample ? n * C + c : c;
+        const float s = (a.gamma ? a.gamma[c] : 1.f) * a.rstd[grp];
+        sc[c] = s;
+        sh[c] = (a.beta ? a.beta[c] : 0.f) - a.mean[grp] * s;
+    }
+}
+
+// grid = (ceil(S/4 / 256), N)
+template <int C, int K>
+__global__ __launch_bounds__(256) void head_fwd_fused_kernel(const HeadArgs a, DropCfg d) {
+    __shared__ float sc[C], sh[C], sw[K * C];
+    const int n = blockIdx.y;
+    head_coeffs<C>(a, n, sc, sh);
+    for (int i = threadIdx.x; i < K * C; i += 256) sw[i] = a.w[i];
+    __syncthreads();
+    const long long units = a.S >> 2, u = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (u >= units) return;
+    const float* __restrict__ xb = a.x + (long long)n * a.x_bs + u * 4;
+    float4 q[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) q[c] = *reinterpret_cast<const float4*>(xb + (long long)c * a.S);
+    const bool drop = d.p > 0.f;
+    const unsigned long long bits = head_drop_bits<C>(d, n, a.S, u);
+    float acc[K][4];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const float bk = a.b ? a.b[k] : 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[k][j] = bk;
+    }
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        float v[4] = {q[c].x * sc[c] + sh[c], q[c].y * sc[c] + sh[c], q[c].z * sc[c] + sh[c], q[c].w * sc[c] + sh[c]};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = v[j] > 0.f ? v[j] : v[j] * a.slope;
+        if (drop) {
+            float s[4];
+            head_drop_scale<C>(d, bits, n, a.S, u, c, s);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] *= s[j];
+        }
+#pragma unroll
+        for (int k = 0; k < K; ++k)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[k][j] = fmaf(sw[k * C + c], v[j], acc[k][j]);
+    }
+    float* __restrict__ lb = a.logits + (long long)n * a.l_bs + u * 4;
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+        *reinterpret_cast<float4*>(lb + (long long)k * a.S) = make_float4(acc[k][0], acc[k][1], acc[k][2], acc[k][3]);
+}
+
+// grid = (P, N): block (p, n) walks its share of the sample; per channel (sum dz, sum dz*xhat) into `part` (the layout
+// bwd_final_kernel reads), the classifier's sum dl[k]*z[c] and sum dl[k] into `hpart`
+template <int C, int K>
+__global__ __launch_bounds__(256) void head_bwd_partial_kernel(const HeadArgs a, DropCfg d) {
+    __shared__ float sc[C], sh[C], sw[K * C], red[4 * (2 * C + K * C + K)];
+    const int p = blockIdx.x, n = blockIdx.y;
+    head_coeffs<C>(a, n, sc, sh);
+    for (int i = threadIdx.x; i < K * C; i += 256) sw[i] = a.w[i];
+    __syncthreads();
+    const long long units = a.S >> 2;
+    const long long per = (units + a.P - 1) / a.P;
+    const long long u0 = p * per, u1 = (u0 + per < units) ? u0 + per : units;
+    const bool drop = d.p > 0.f;
+    constexpr int NV = 2 * C + K * C + K;
+    float v[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) v[i] = 0.f;
+    for (long long u = u0 + threadIdx.x; u < u1; u += 256) {
+        float4 g4[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            g4[k] = *reinterpret_cast<const float4*>(a.dl + (long long)n * a.dl_bs + (long long)k * a.S + u * 4);
+            v[2 * C + K * C + k] += (g4[k].x + g4[k].y) + (g4[k].z + g4[k].w);
+        }
+        const float* __restrict__ xb = a.x + (long long)n * a.x_bs + u * 4;
+        const unsigned long long bits = head_drop_bits<C>(d, n, a.S, u);
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            const float4 q = *reinterpret_cast<const float4*>(xb + (long long)c * a.S);
+            const float xs[4] = {q.x, q.y, q.z, q.w};
+            float s[4] = {1.f, 1.f, 1.f, 1.f};
+            if (drop) head_drop_scale<C>(d, bits, n, a.S, u, c, s);
+            // gamma * rstd = sc, so xhat = (x*sc + sh - beta) / gamma is avoided: xhat from mean / rstd directly
+            const int grp = a.per_sample ? n * C + c : c;
+            const float m = a.mean[grp], rs = a.rstd[grp];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float xh = (xs[j] - m) * rs;
+                const float z0 = xs[j] * sc[c] + sh[c];
+                const float act = (z0 > 0.f ? z0 : z0 * a.slope) * s[j];          // z as the classifier saw it
+                float dzd = 0.f;
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    const float gk = (&g4[k].x)[j];
+                    dzd = fmaf(sw[k * C + c], gk, dzd);
+                    v[2 * C + k * C + c] = fmaf(gk, act, v[2 * C + k * C + c]);
+                }
+                const float ds = dzd * s[j];
+                const float dz = z0 > 0.f ? ds : ds * a.slope;
+                v[2 * c] += dz;
+                v[2 * c + 1] = fmaf(dz, xh, v[2 * c + 1]);
+            }
+        }
+    }
+    mis_block_sum<NV>(v, red);
+    if (threadIdx.x == 0) {
+        const int nchunks = a.per_sample ? 1 : a.N;
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            const long long grp = a.per_sample ? (long long)n * C + c : c;
+            const int k = a.per_sample ? 0 : n;
+            a.part[(grp * nchunks + k) * a.P + p] = make_float2(v[2 * c], v[2 * c + 1]);
+        }
+        float* hp = a.hpart + ((long long)n * a.P + p) * (K * C + K);
+#pragma unroll
+        for (int i = 0; i < K * C + K; ++i) hp[i] = v[2 * C + i];
+    }
+}
+
+// dw[k][c] (+)= sum of the partial rows, db[k] likewise: one wave per output, fixed order
+__global__ __launch_bounds__(64) void head_final_kernel(const float* __restrict__ hpart, int rows, int KC, int K,
+                                                        float* __restrict__ dw, float* __restrict__ db, int accumulate) {
+    const int o = blockIdx.x, lane = threadIdx.x;
+    double s = 0.0;
+    for (int r = lane; r < rows; r += 64) s += hpart[(long long)r * (KC + K) + o];
+    s = mis_wave_sum_d(s);
+    if (lane == 0) {
+        if (o < KC) dw[o] = accumulate ? dw[o] + (float)s : (float)s;
+        else if (db) db[o - KC] = accumulate ? db[o - KC] + (float)s : (float)s;
+    }
+}
+
+// grid = (ceil(S/4 / 256), N): dx = gamma*rstd * (dz - mean(dz) - xhat * mean(dz*xhat))
+template <int C, int K>
+__global__ __launch_bounds__(256) void head_bwd_apply_kernel(const HeadArgs a, DropCfg d) {
+    __shared__ float sc[C], sh[C], sw[K * C];
+    const int n = blockIdx.y;
+    head_coeffs<C>(a, n, sc, sh);
+    for (int i = threadIdx.x; i < K * C; i += 256) sw[i] = a.w[i];
+    __syncthreads();
+    const long long units = a.S >> 2, u = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (u >= units) return;
+    float4 g4[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+        g4[k] = *reinterpret_cast<const float4*>(a.dl + (long long)n * a.dl_bs + (long long)k * a.S + u * 4);
+    const float* __restrict__ xb = a.x + (long long)n * a.x_bs + u * 4;
+    float* __restrict__ ob = a.dx + (long long)n * a.dx_bs + u * 4;
+    const bool drop = d.p > 0.f;
+    const unsigned long long bits = head_drop_bits<C>(d, n, a.S, u);
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        const float4 q = *reinterpret_cast<const float4*>(xb + (long long)c * a.S);
+        const float xs[4] = {q.x, q.y, q.z, q.w};
+        float s[4] = {1.f, 1.f, 1.f, 1.f};
+        if (drop) head_drop_scale<C>(d, bits, n, a.S, u, c, s);
+        const int grp = a.per_sample ? n * C + c : c;
+        const float m = a.mean[grp], rs = a.rstd[grp];
+        const float2 sm = a.sums[grp];
+        float o[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float dzd = 0.f;
+#pragma unroll
+            for (int k = 0; k < K; ++k) dzd = fmaf(sw[k * C + c], (&g4[k].x)[j], dzd);
+            const float xh = (xs[j] - m) * rs;
+            const float z0 = xs[j] * sc[c] + sh[c];
+            const float ds = dzd * s[j];
+            const float dz = z0 > 0.f ? ds : ds * a.slope;
+            o[j] = sc[c] * (dz - sm.x - xh * sm.y);
+        }
+        *reinterpret_cast<float4*>(ob + (long long)c * a.S) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+}
+
+template <int C>
+int head_launch_fwd(const HeadArgs& a, const DropCfg& d, hipStream_t stream) {
+    const dim3 grid((unsigned)mis_cdiv(a.S >> 2, 256), a.N);
+    hipLaunchKernelGGL((head_fwd_fused_kernel<C, 2>), grid, dim3(256), 0, stream, a, d);      // K == 2 (mis_norm_head_eligible)
+    return mis_launch_status();
+}
+
+template <int C>
+void head_launch_partial(const HeadArgs& a, const DropCfg& d, hipStream_t stream) {
+    const dim3 grid(a.P, a.N);
+    hipLaunchKernelGGL((head_bwd_partial_kernel<C, 2>), grid, dim3(256), 0, stream, a, d);      // K == 2 (mis_norm_head_eligible)
+}
+
+template <int C>
+void head_launch_apply(const HeadArgs& a, const DropCfg& d, hipStream_t stream) {
+    const dim3 grid((unsigned)mis_cdiv(a.S >> 2, 256), a.N);
+    hipLaunchKernelGGL((head_bwd_apply_kernel<C, 2>), grid, dim3(256), 0, stream, a, d);      // K == 2 (mis_norm_head_eligible)
+}
+
+}  // namespace
+
+// The fused form covers C = 16 channels and 2 classes (the binary 3-D tasks: BraTS whole tumour, LA, Pancreas), BatchNorm /
+// InstanceNorm statistics (one group per channel).  More classes: the partial-sum kernel's 2C + KC + K accumulators per
+// thread no longer fit the register file (K = 3: 2.3 KB of scratch).
+extern "C" int mis_norm_head_eligible(int C, int K) { return C == 16 && K == 2; }
+
+extern "C" long long mis_norm_head_workspace_bytes(int N, int C, long long S, int per_sample, int K) {
+    if (N <= 0 || C <= 0 || S <= 0 || K <= 0) return MIS_ERR_ARG;
+    const long long nb = mis_norm_workspace_bytes(N, C, S, per_sample);
+    return nb + (long long)N * pick_P(S) * (K * C + K) * 4;
+}
+
+// logits[N][K][S] = W . drop(act(norm(x))) + b  (mis_norm_act_fwd followed by a 1x1x1 mis_conv_fwd, without the
+// activation in between).  mean / rstd: per channel (per_sample = 0) or per (n, c).
+extern "C" int mis_norm_head_fwd(const float* x, long long x_bs, int N, int C, long long S, int per_sample,
+                                 const float* mean, const float* rstd, const float* gamma, const float* beta,
+                                 float slope, float drop_p, unsigned drop_salt, const MisStepState* state,
+                                 const float* drop_mask, const float* w, const float* b, int K, float* logits,
+                                 long long l_bs, hipStream_t stream) {
+    int st = check_geo(x, N, C, S, x_bs);
+    if (st) return st;
+    if (!mis_norm_head_eligible(C, K) || (per_sample && (gamma || beta))) return MIS_ERR_UNSUPPORTED;
+    if (!mean || !rstd || !w || !logits || l_bs < (long long)K * S) return MIS_ERR_ARG;
+    if (l_bs % 4 != 0 || !aligned16(logits)) return MIS_ERR_UNSUPPORTED;
+    if (drop_p < 0.f || drop_p >= 1.f || (drop_p > 0.f && !state && !drop_mask)) return MIS_ERR_ARG;
+    HeadArgs a{};
+    a.x = x; a.x_bs = x_bs; a.N = N; a.K = K; a.per_sample = per_sample; a.S = S;
+    a.mean = mean; a.rstd = rstd; a.gamma = gamma; a.beta = beta; a.slope = slope; a.w = w; a.b = b;
+    a.logits = logits; a.l_bs = l_bs;
+    const DropCfg d{drop_p, drop_salt, state, drop_mask};
+    return head_launch_fwd<16>(a, d, stream);
+}
+
+// Backward of mis_norm_head_fwd from dlogits: dx (gradient at x), dgamma / dbeta (BatchNorm), dw[K][C] and db[K]
+// (null: none) of the classifier.  accumulate_* as in mis_norm_act_bwd / mis_conv_wgrad.
+extern "C" int mis_norm_head_bwd(const float* x, long long x_bs, const float* dlogits, long long dl_bs, float* dx,
+                                 long long dx_bs, int N, int C, long long S, int per_sample, const float* mean,
+                                 const float* rstd, const float* gamma, const float* beta, float slope, float drop_p,
+                                 unsigned drop_salt, const MisStepState* state, const float* drop_mask, const float* w,
+                                 int K, float* dgamma, float* dbeta, int accumulate_affine, float* dw, float* db,
+                                 int accumulate_w, void* workspace, long long workspace_bytes, hipStream_t stream) {
+    int st = check_geo(x, N, C, S, x_bs);
+    if (st) return st;
+    if (!mis_norm_head_eligible(C, K) || (per_sample && (gamma || beta))) return MIS_ERR_UNSUPPORTED;
+    if (!dlogits || !dx || !mean || !rstd || !w || !dw || !workspace) return MIS_ERR_ARG;
+    if (dl_bs % 4 != 0 || dx_bs % 4 != 0 || !aligned16(dlogits) || !aligned16(dx)) return MIS_ERR_UNSUPPORTED;
+    if (dl_bs < (long long)K * S || dx_bs < (long long)C * S) return MIS_ERR_ARG;
+    if (drop_p < 0.f || drop_p >= 1.f || (drop_p > 0.f && !state && !drop_mask)) return MIS_ERR_ARG;
+    if (workspace_bytes < mis_norm_head_workspace_bytes(N, C, S, per_sample, K)) return MIS_ERR_WORKSPACE;
+    const Geo g = make_geo(N, C, S, x_bs, per_sample);
+    float2* part = reinterpret_cast<float2*>(workspace);
+    float2* sums = part + (long long)g.G * g.nchunks * g.P;
+    HeadArgs a{};
+    a.x = x; a.x_bs = x_bs; a.N = N; a.K = K; a.per_sample = per_sample; a.S = S;
+    a.mean = mean; a.rstd = rstd; a.gamma = gamma; a.beta = beta; a.slope = slope; a.w = w;
+    a.dl = dlogits; a.dl_bs = dl_bs; a.dx = dx; a.dx_bs = dx_bs;
+    a.part = part; a.sums = sums; a.hpart = reinterpret_cast<float*>(sums + g.G); a.P = g.P;
+    const DropCfg d{drop_p, drop_salt, state, drop_mask};
+    head_launch_partial<16>(a, d, stream);
+    hipLaunchKernelGGL(bwd_final_kernel, dim3((g.G + 3) / 4), dim3(256), 0, stream, part, g, sums,
+                       per_sample ? nullptr : dgamma, per_sample ? nullptr : dbeta, accumulate_affine);
+    hipLaunchKernelGGL(head_final_kernel, dim3(K * C + K), dim3(64), 0, stream, a.hpart, N * g.P, K * C, K, dw, db,
+                       accumulate_w);
+    head_launch_apply<16>(a, d, stream);
+    return mis_launch_status();
+}

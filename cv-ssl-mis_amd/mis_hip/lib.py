@@ -75,6 +75,12 @@ PROTOTYPES = {
                                  c_p, c_p]),
     "mis_norm_act_bwd_g": (c_i, [c_p, c_ll, c_p, c_ll, c_p, c_ll, c_i, c_i, c_ll, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_f,
                                  c_f, c_u, c_p, c_p, c_p, c_p, c_i, c_p, c_ll, c_p]),
+    "mis_norm_head_eligible": (c_i, [c_i, c_i]),
+    "mis_norm_head_workspace_bytes": (c_ll, [c_i, c_i, c_ll, c_i, c_i]),
+    "mis_norm_head_fwd": (c_i, [c_p, c_ll, c_i, c_i, c_ll, c_i, c_p, c_p, c_p, c_p, c_f, c_f, c_u, c_p, c_p, c_p, c_p, c_i,
+                                c_p, c_ll, c_p]),
+    "mis_norm_head_bwd": (c_i, [c_p, c_ll, c_p, c_ll, c_p, c_ll, c_i, c_i, c_ll, c_i, c_p, c_p, c_p, c_p, c_f, c_f, c_u,
+                                c_p, c_p, c_p, c_i, c_p, c_p, c_i, c_p, c_p, c_i, c_p, c_ll, c_p]),
     "mis_maxpool2_fwd": (c_i, [c_p, c_ll, c_p, c_ll, c_p, c_i, c_i, c_i, c_i, c_i, c_p]),
     "mis_maxpool2_bwd": (c_i, [c_p, c_ll, c_p, c_p, c_ll, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
     "mis_upsample2_fwd": (c_i, [c_p, c_ll, c_p, c_ll, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),

@@ -305,6 +305,39 @@ def norm_act_bwd(x, da, dx, per_sample, mean, rstd, gamma, beta, slope, drop_p=0
              "mis_norm_act_bwd_g")
 
 
+def norm_head_eligible(C, K, per_sample, gamma, beta, cg=1, no_norm=False):
+    """norm + act + dropout + 1x1x1 classifier as one pass (mis_norm_head_*): C == 16, K == 2, one statistics group per
+    channel, InstanceNorm only without affine."""
+    return bool(_l.load().mis_norm_head_eligible(C, K)) and cg == 1 and not no_norm and not (
+        per_sample and (gamma is not None or beta is not None))
+
+
+def norm_head_fwd(x, logits, per_sample, mean, rstd, gamma, beta, slope, w, b, drop_p=0.0, drop_salt=0, state=None,
+                  drop_mask=None):
+    """logits = W . drop(act(norm(x))) + b without storing the activation (w: [K, C] view of the 1x1x1 conv weight)."""
+    L = _l.load()
+    N, C, D, H, W, S, xbs = _geom(x)
+    _, K, _, _, _, _, lbs = _geom(logits)
+    _l.check(L.mis_norm_head_fwd(_l.ptr(x), xbs, N, C, S, int(per_sample), _l.ptr(mean), _l.ptr(rstd), _l.ptr(gamma),
+                                 _l.ptr(beta), slope, drop_p, drop_salt, _l.ptr(state), _l.ptr(drop_mask), _l.ptr(w),
+                                 _l.ptr(b), K, _l.ptr(logits), lbs, _l.stream_ptr()), "mis_norm_head_fwd")
+
+
+def norm_head_bwd(x, dlogits, dx, per_sample, mean, rstd, gamma, beta, slope, w, dw, db, drop_p=0.0, drop_salt=0,
+                  state=None, drop_mask=None, dgamma=None, dbeta=None, accumulate_affine=False, accumulate_w=False):
+    L = _l.load()
+    N, C, D, H, W, S, xbs = _geom(x)
+    _, K, _, _, _, _, dlbs = _geom(dlogits)
+    _, _, _, _, _, _, dxbs = _geom(dx)
+    nb = L.mis_norm_head_workspace_bytes(N, C, S, int(per_sample), K)
+    ws = scratch(nb, "norm")
+    _l.check(L.mis_norm_head_bwd(_l.ptr(x), xbs, _l.ptr(dlogits), dlbs, _l.ptr(dx), dxbs, N, C, S, int(per_sample),
+                                 _l.ptr(mean), _l.ptr(rstd), _l.ptr(gamma), _l.ptr(beta), slope, drop_p, drop_salt,
+                                 _l.ptr(state), _l.ptr(drop_mask), _l.ptr(w), K, _l.ptr(dgamma), _l.ptr(dbeta),
+                                 int(accumulate_affine), _l.ptr(dw), _l.ptr(db), int(accumulate_w), _l.ptr(ws),
+                                 ws.numel(), _l.stream_ptr()), "mis_norm_head_bwd")
+
+
 def group_norm_stats(x, cg, eps, mean, rstd):
     """(mean, rstd) per (n, group of ``cg`` consecutive channels): the groups are contiguous in NCDHW, so this is the
     InstanceNorm statistics kernel on the [N, C/cg, cg*S] view of the same memory."""

@@ -27,6 +27,8 @@ _net_ids = itertools.count(1)
 # conv -> norm pairs: the conv epilogue emits the statistics (mis_conv_fwd_stats); MIS_FUSE_STATS=0 keeps the
 # separate statistics pass (A/B timing)
 FUSE_CONV_STATS = os.environ.get("MIS_FUSE_STATS", "1") != "0"
+# norm + act + dropout + 1x1x1 classifier of the 3-D nets as one pass over the last conv's output (norm_act.hip, mis_norm_head_*)
+FUSE_HEAD = os.environ.get("MIS_FUSE_HEAD", "1") != "0"
 
 
 class Act:
@@ -101,8 +103,11 @@ class ConvOp:
         self.stat = None         # (partials, stride_channel, stride_image): statistics for the NormActOp that follows
         self.stat_norm = None
         self._dx_tmp = None
+        self.fused_into = None   # NormActOp that computes this 1x1x1 classifier in its own pass (Plan._fuse_head)
 
     def fwd(self, ctx):
+        if self.fused_into is not None:
+            return
         if not self.batched:
             self.wp = ops.conv_pack(self.w.data, ops.conv_wino_pack_mode(self.wino_f, False) if self.wino_f >= 0 else 0,
                                     out=self.wp)
@@ -112,6 +117,8 @@ class ConvOp:
                      self.ksize, stat=stat, wino=self.wino_f)
 
     def bwd(self, ctx):
+        if self.fused_into is not None:
+            return               # the NormActOp's backward writes w.grad / b.grad / its own input gradient
         dy = self.y.grad()
         ops.conv_wgrad(self.x.t, dy, self.w.grad, self.ksize)
         if self.b is not None and self.bias_grad:
@@ -153,6 +160,8 @@ class NormActOp:
         self.rstd = torch.ones(G, dtype=torch.float32, device="cuda")
         self._p = 0.0
         self._mask = None
+        self.head = None         # 1x1x1 classifier ConvOp computed in this op's pass (Plan._fuse_head); head_w / head_b:
+        self.head_w = self.head_b = None     # its parameters (their gradients are written by THIS op: dist.param_progress)
 
     def fwd(self, ctx):
         if self.no_norm:
@@ -178,6 +187,14 @@ class NormActOp:
         self._state = ctx.state
         if self._p > 0 and self._mask is None and ctx.state is None:
             raise RuntimeError("dropout is active but no device step state was supplied (Ctx.state)")
+        if self.head is not None:
+            h = self.head
+            ops.norm_head_fwd(self.x.t, h.y.t, self.per_sample, self.mean, self.rstd,
+                              None if self.gamma is None else self.gamma.data,
+                              None if self.beta is None else self.beta.data, self.slope,
+                              h.w.data.view(h.cout, h.cin), None if h.b is None else h.b.data, self._p, self.salt,
+                              self._state, self._mask)
+            return
         ops.norm_act_fwd(self.x.t, self.y.t, self.per_sample, self.mean, self.rstd,
                          None if self.gamma is None else self.gamma.data,
                          None if self.beta is None else self.beta.data, self.slope, self._p, self.salt,
@@ -185,6 +202,17 @@ class NormActOp:
 
     def bwd(self, ctx):
         assert not self.x.written
+        if self.head is not None:
+            h = self.head
+            ops.norm_head_bwd(self.x.t, h.y.grad(), self.x.grad(), self.per_sample, self.mean, self.rstd,
+                              None if self.gamma is None else self.gamma.data,
+                              None if self.beta is None else self.beta.data, self.slope,
+                              h.w.data.view(h.cout, h.cin), h.w.grad.view(h.cout, h.cin),
+                              h.b.grad if (h.b is not None and h.bias_grad) else None, self._p, self.salt, self._state,
+                              self._mask, None if self.gamma is None else self.gamma.grad,
+                              None if self.beta is None else self.beta.grad)
+            self.x.mark_written()
+            return
         ops.norm_act_bwd(self.x.t, self.y.grad(), self.x.grad(), self.per_sample, self.mean, self.rstd,
                          None if self.gamma is None else self.gamma.data,
                          None if self.beta is None else self.beta.data, self.slope, self._p, self.salt,
@@ -315,6 +343,7 @@ class Plan:
         self._salt = itertools.count(0)
         self.out = None
         self._packs = None
+        self._head_checked = False
         self.generation = 0      # forwards run on this plan (its buffers hold the activations of the LAST one)
         self._progress = None    # dist.param_progress(self.ops, net.flat_grad), built on the first overlapped backward
 
@@ -394,8 +423,31 @@ class Plan:
         if self._packs[mode] is not None:
             self._packs[mode].run()
 
+    def _fuse_head(self):
+        """Last two ops = norm/act(/dropout) -> 1x1x1 classifier, the activation in between read by nobody else: one op."""
+        self._head_checked = True
+        if not FUSE_HEAD or len(self.ops) < 2:
+            return
+        norm, conv = self.ops[-2], self.ops[-1]
+        if type(norm) is not NormActOp or type(conv) is not ConvOp or conv.ksize != (1, 1, 1) or conv.x is not norm.y:
+            return
+        if norm.y.parent is not None or conv.y is not self.out or not conv.need_dx:
+            return
+        for op in self.ops[:-1]:
+            for v in vars(op).values():
+                if isinstance(v, Act) and v is not norm.y and v._root() is norm.y:
+                    return
+                if v is norm.y and op is not norm:
+                    return
+        if not ops.norm_head_eligible(conv.cin, conv.cout, norm.per_sample, norm.gamma, norm.beta, norm.cg, norm.no_norm):
+            return
+        norm.head, norm.head_w, norm.head_b = conv, conv.w, conv.b
+        conv.fused_into = norm
+
     def forward(self, x5, ctx):
         assert tuple(x5.shape) == self.in_shape, (tuple(x5.shape), self.in_shape)
+        if not self._head_checked:
+            self._fuse_head()
         self.generation += 1
         self.inp.t = x5
         self._pack(0)

@@ -175,6 +175,25 @@ int mis_norm_act_bwd_g(const float* x, long long x_bs, const float* da, long lon
                        float* dbeta, int accumulate_affine, void* workspace, long long workspace_bytes,
                        mis_stream_t stream);
 
+/* Last block of the 3-D networks fused with the 1x1x1 classifier (reference code/networks/unet_3D.py: up_concat1 ->
+ * dropout2 -> final = nn.Conv3d(16, n_classes, 1); vnet.py:180-181; unetr.py out): logits[N][K][S] =
+ * W[K][C] . drop(act(norm(x))) + b, i.e. mis_norm_act_fwd followed by a 1x1x1 mis_conv_fwd, without storing the
+ * activation; the backward recomputes it from x and yields dx, dgamma / dbeta (BatchNorm) and the classifier's
+ * dw[K][C], db[K] (NULL: none) from dlogits in two passes.  mis_norm_head_eligible: C == 16, K == 2; per_sample != 0
+ * (InstanceNorm) only without affine.  Workspace: mis_norm_head_workspace_bytes. */
+int mis_norm_head_eligible(int C, int K);
+long long mis_norm_head_workspace_bytes(int N, int C, long long S, int per_sample, int K);
+int mis_norm_head_fwd(const float* x, long long x_bs, int N, int C, long long S, int per_sample, const float* mean,
+                      const float* rstd, const float* gamma, const float* beta, float slope, float drop_p,
+                      unsigned drop_salt, const MisStepState* state, const float* drop_mask, const float* w,
+                      const float* b, int K, float* logits, long long l_bs, mis_stream_t stream);
+int mis_norm_head_bwd(const float* x, long long x_bs, const float* dlogits, long long dl_bs, float* dx, long long dx_bs,
+                      int N, int C, long long S, int per_sample, const float* mean, const float* rstd,
+                      const float* gamma, const float* beta, float slope, float drop_p, unsigned drop_salt,
+                      const MisStepState* state, const float* drop_mask, const float* w, int K, float* dgamma,
+                      float* dbeta, int accumulate_affine, float* dw, float* db, int accumulate_w, void* workspace,
+                      long long workspace_bytes, mis_stream_t stream);
+
 /* ---- 2x max-pool / 2x linear up-sampling ----------------------------------------------------------
  * reference: nn.MaxPool2d(2) unet.py:56; nn.MaxPool3d(2) unet_3D.py:35-47;
  *            nn.Upsample(bilinear, align_corners=True) unet.py:74-75;
