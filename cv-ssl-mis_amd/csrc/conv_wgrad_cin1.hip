@@ -15,6 +15,18 @@ namespace {
 
 constexpr int TZ = 4, TY = 8, TX = 32, HZ = TZ + 2, HY = TY + 2, HX = TX + 2, HALO = HZ * HY * HX;
 
+// NORM form: the conv feeds BatchNorm / InstanceNorm + (Leaky)ReLU and nobody needs the gradient at the conv's input, so
+// the gradient at the conv output is only ever read here: it is formed on the load path from the gradient at the
+// activation (da), the conv output (y) and the normalisation's backward sums -- mis_norm_act_bwd's apply pass (read da,
+// y, write dy: 453 MB each at 96^3) and this kernel's read of dy are gone.
+struct Cin1Norm {
+    const float* y; long long y_bs;
+    const float* mean; const float* rstd; const float* gamma; const float* beta;
+    const float2* sums;          // per group (mean of dz, mean of dz*xhat): mis_norm_act_bwd_sums
+    float slope;
+    int per_sample;
+};
+
 struct Cin1Args {
     const float* x; long long x_bs;
     const float* dy; long long dy_bs;
@@ -23,7 +35,8 @@ struct Cin1Args {
     int tz, ty, tx, n_tiles;
 };
 
-__global__ __launch_bounds__(256) void wgrad_cin1_kernel(const Cin1Args a) {
+template <bool NORM>
+__global__ __launch_bounds__(256) void wgrad_cin1_kernel(const Cin1Args a, const Cin1Norm nb) {
     __shared__ float sx[HALO];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lk = lane >> 4, lj = lane & 15;
@@ -53,13 +66,31 @@ __global__ __launch_bounds__(256) void wgrad_cin1_kernel(const Cin1Args a) {
         }
         __syncthreads();
         // this wave: plane z0 + wave; 8 rows x 2 halves of 16 voxels; the lane's dy: channel lj, voxels 4 lk .. 4 lk + 3
-        const float* __restrict__ dyp = a.dy + (long long)n * a.dy_bs + (long long)lj * S +
-                                        ((long long)(z0 + wave) * a.H + y0) * a.W + x0 + 4 * lk;
+        const long long voff = (long long)lj * S + ((long long)(z0 + wave) * a.H + y0) * a.W + x0 + 4 * lk;
+        const float* __restrict__ dyp = a.dy + (long long)n * a.dy_bs + voff;
+        const float* __restrict__ yp = NORM ? nb.y + (long long)n * nb.y_bs + voff : nullptr;
+        float cm = 0.f, crs = 1.f, cga = 1.f, cbe = 0.f, s1 = 0.f, s2 = 0.f;
+        if constexpr (NORM) {      // channel lj of sample n
+            const int grp = nb.per_sample ? n * 16 + lj : lj;
+            cm = nb.mean[grp]; crs = nb.rstd[grp];
+            cga = nb.gamma ? nb.gamma[lj] : 1.f; cbe = nb.beta ? nb.beta[lj] : 0.f;
+            const float2 sm = nb.sums[grp];
+            s1 = sm.x; s2 = sm.y;
+        }
         const float* __restrict__ sb = sx + (wave * HY) * HX + 4 * lk;
 #pragma unroll 4
         for (int it = 0; it < 16; ++it) {
             const int row = it >> 1, half = it & 1;
-            const f32x4 d4 = *reinterpret_cast<const f32x4*>(dyp + (long long)row * a.W + half * 16);
+            f32x4 d4 = *reinterpret_cast<const f32x4*>(dyp + (long long)row * a.W + half * 16);
+            if constexpr (NORM) {
+                const f32x4 y4 = *reinterpret_cast<const f32x4*>(yp + (long long)row * a.W + half * 16);
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    const float xh = (y4[s] - cm) * crs;
+                    const float dz = xh * cga + cbe > 0.f ? d4[s] : d4[s] * nb.slope;
+                    d4[s] = cga * crs * (dz - s1 - xh * s2);
+                }
+            }
             const float* __restrict__ sp = sb + row * HX + half * 16;
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
@@ -110,8 +141,8 @@ long long mis_wgrad_cin1_workspace_bytes(int N, int D, int H, int W) {
     return (long long)grid_for(n_tiles) * 4 * 512 * 4;
 }
 
-int mis_wgrad_cin1(const float* x, long long x_bs, const float* dy, long long dy_bs, float* dw, float* ws,
-                   long long ws_bytes, int N, int D, int H, int W, int accumulate, hipStream_t stream) {
+static int launch_cin1(const float* x, long long x_bs, const float* dy, long long dy_bs, const Cin1Norm* nb, float* dw,
+                       float* ws, long long ws_bytes, int N, int D, int H, int W, int accumulate, hipStream_t stream) {
     if (((uintptr_t)dy & 15) || dy_bs % 4) return MIS_ERR_UNSUPPORTED;
     if (ws_bytes < mis_wgrad_cin1_workspace_bytes(N, D, H, W)) return MIS_ERR_WORKSPACE;
     Cin1Args a{};
@@ -122,7 +153,33 @@ int mis_wgrad_cin1(const float* x, long long x_bs, const float* dy, long long dy
     if (n_tiles > 0x7fffffffLL) return MIS_ERR_ARG;
     a.n_tiles = (int)n_tiles;
     const int grid = grid_for(n_tiles);
-    hipLaunchKernelGGL(wgrad_cin1_kernel, dim3(grid), dim3(256), 0, stream, a);
+    if (nb) hipLaunchKernelGGL(wgrad_cin1_kernel<true>, dim3(grid), dim3(256), 0, stream, a, *nb);
+    else hipLaunchKernelGGL(wgrad_cin1_kernel<false>, dim3(grid), dim3(256), 0, stream, a, Cin1Norm{});
     hipLaunchKernelGGL(wgrad_cin1_reduce_kernel, dim3(16 * 27), dim3(256), 0, stream, ws, dw, grid * 4, 16, accumulate);
     return mis_launch_status();
+}
+
+int mis_wgrad_cin1(const float* x, long long x_bs, const float* dy, long long dy_bs, float* dw, float* ws,
+                   long long ws_bytes, int N, int D, int H, int W, int accumulate, hipStream_t stream) {
+    return launch_cin1(x, x_bs, dy, dy_bs, nullptr, dw, ws, ws_bytes, N, D, H, W, accumulate, stream);
+}
+
+// Weight gradient of the first layer Conv3d(1 -> 16, k = 3, pad = 1) straight from the gradient at the activation that
+// follows its BatchNorm / InstanceNorm + (Leaky)ReLU: da [N][16][S] (gradient at the activation), y [N][16][S] (the
+// conv's output), sums = mis_norm_act_bwd_sums of the same layer.  Replaces mis_norm_act_bwd's apply pass +
+// mis_conv_wgrad for a conv whose input needs no gradient.  No dropout on this layer (unet_3D conv1, vnet block_one).
+extern "C" int mis_conv_wgrad_cin1_norm_eligible(int N, int Cout, int D, int H, int W) {
+    return mis_wgrad_cin1_eligible(N, 1, Cout, D, H, W, 3, 3, 3) ? 1 : 0;
+}
+
+extern "C" int mis_conv_wgrad_cin1_norm(const float* x, long long x_bs, const float* da, long long da_bs, const float* y,
+                                        long long y_bs, int N, int D, int H, int W, int per_sample, const float* mean,
+                                        const float* rstd, const float* gamma, const float* beta, const float* sums,
+                                        float slope, float* dw, float* workspace, long long workspace_bytes,
+                                        int accumulate, hipStream_t stream) {
+    if (!x || !da || !y || !mean || !rstd || !sums || !dw || !workspace || N <= 0) return MIS_ERR_ARG;
+    if (!mis_wgrad_cin1_eligible(N, 1, 16, D, H, W, 3, 3, 3) || (per_sample && (gamma || beta))) return MIS_ERR_UNSUPPORTED;
+    if (((uintptr_t)y & 15) || y_bs % 4 || ((uintptr_t)sums & 7)) return MIS_ERR_UNSUPPORTED;
+    const Cin1Norm nb{y, y_bs, mean, rstd, gamma, beta, reinterpret_cast<const float2*>(sums), slope, per_sample};
+    return launch_cin1(x, x_bs, da, da_bs, &nb, dw, workspace, workspace_bytes, N, D, H, W, accumulate, stream);
 }

@@ -528,6 +528,30 @@ extern "C" int mis_norm_act_bwd_g(const float* x, long long x_bs, const float* d
     return mis_launch_status();
 }
 
+// The reduction half of mis_norm_act_bwd alone (no dropout): sums[group] = (mean of dz, mean of dz*xhat) as two floats per
+// group (C groups, or N*C with per_sample), plus dgamma / dbeta for BatchNorm.  For consumers that form the gradient at
+// the normalisation's input themselves (mis_conv_wgrad_cin1_norm).  Workspace: mis_norm_workspace_bytes.
+extern "C" int mis_norm_act_bwd_sums(const float* x, long long x_bs, const float* da, long long da_bs, int N, int C,
+                                     long long S, int per_sample, const float* mean, const float* rstd,
+                                     const float* gamma, const float* beta, float slope, float* sums, float* dgamma,
+                                     float* dbeta, int accumulate_affine, void* workspace, long long workspace_bytes,
+                                     hipStream_t stream) {
+    int st = check_geo(x, N, C, S, x_bs);
+    if (st) return st;
+    if (!da || !mean || !rstd || !sums || !workspace || (per_sample && (gamma || beta))) return MIS_ERR_ARG;
+    if (da_bs % 4 != 0 || !aligned16(da) || ((uintptr_t)sums & 7)) return MIS_ERR_UNSUPPORTED;
+    if (da_bs < (long long)C * S) return MIS_ERR_ARG;
+    if (workspace_bytes < mis_norm_workspace_bytes(N, C, S, per_sample)) return MIS_ERR_WORKSPACE;
+    const Geo g = make_geo(N, C, S, x_bs, per_sample);
+    const DropCfg d{0.f, 0u, nullptr, nullptr};
+    float2* part = reinterpret_cast<float2*>(workspace);
+    hipLaunchKernelGGL(bwd_partial_kernel, dim3(g.P, g.nchunks, g.G), dim3(256), 0, stream, x, g, da, da_bs, mean, rstd,
+                       gamma, beta, slope, d, part);
+    hipLaunchKernelGGL(bwd_final_kernel, dim3((g.G + 3) / 4), dim3(256), 0, stream, part, g,
+                       reinterpret_cast<float2*>(sums), dgamma, dbeta, accumulate_affine);
+    return mis_launch_status();
+}
+
 extern "C" int mis_norm_act_bwd(const float* x, long long x_bs, const float* da, long long da_bs, float* dx,
                                 long long dx_bs, int N, int C, long long S, int per_sample, const float* mean,
                                 const float* rstd, const float* gamma, const float* beta, float slope,

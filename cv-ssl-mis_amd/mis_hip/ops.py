@@ -305,6 +305,39 @@ def norm_act_bwd(x, da, dx, per_sample, mean, rstd, gamma, beta, slope, drop_p=0
              "mis_norm_act_bwd_g")
 
 
+def norm_act_bwd_sums(x, da, per_sample, mean, rstd, gamma, beta, slope, sums, dgamma=None, dbeta=None,
+                      accumulate_affine=False):
+    """The reduction half of norm_act_bwd: sums[group] = (mean dz, mean dz*xhat) (+ dgamma / dbeta); no dropout."""
+    L = _l.load()
+    N, C, D, H, W, S, xbs = _geom(x)
+    _, _, _, _, _, _, dabs = _geom(da)
+    ws = scratch(L.mis_norm_workspace_bytes(N, C, S, int(per_sample)), "norm")
+    _l.check(L.mis_norm_act_bwd_sums(_l.ptr(x), xbs, _l.ptr(da), dabs, N, C, S, int(per_sample), _l.ptr(mean),
+                                     _l.ptr(rstd), _l.ptr(gamma), _l.ptr(beta), slope, _l.ptr(sums), _l.ptr(dgamma),
+                                     _l.ptr(dbeta), int(accumulate_affine), _l.ptr(ws), ws.numel(), _l.stream_ptr()),
+             "mis_norm_act_bwd_sums")
+
+
+def conv_wgrad_cin1_norm_eligible(N, Cout, D, H, W):
+    return bool(_l.load().mis_conv_wgrad_cin1_norm_eligible(N, Cout, D, H, W))
+
+
+def conv_wgrad_cin1_norm(x, da, y, per_sample, mean, rstd, gamma, beta, sums, slope, dw, accumulate=False):
+    """dw of the first layer Conv3d(1 -> 16, 3) from the gradient at the activation after its norm + (Leaky)ReLU."""
+    L = _l.load()
+    N, Cin, D, H, W, S, xbs = _geom(x)
+    _, _, _, _, _, _, dabs = _geom(da)
+    _, Cout, _, _, _, _, ybs = _geom(y)
+    nb = L.mis_conv_wgrad_workspace_bytes(N, Cin, Cout, D, H, W, 3, 3, 3)
+    if nb < 0:
+        _l.check(nb, "mis_conv_wgrad_workspace_bytes")
+    ws = scratch(nb, "wgrad")
+    _l.check(L.mis_conv_wgrad_cin1_norm(_l.ptr(x), xbs, _l.ptr(da), dabs, _l.ptr(y), ybs, N, D, H, W, int(per_sample),
+                                        _l.ptr(mean), _l.ptr(rstd), _l.ptr(gamma), _l.ptr(beta), _l.ptr(sums), slope,
+                                        _l.ptr(dw), _l.ptr(ws), ws.numel(), int(accumulate), _l.stream_ptr()),
+             "mis_conv_wgrad_cin1_norm")
+
+
 def norm_head_eligible(C, K, per_sample, gamma, beta, cg=1, no_norm=False):
     """norm + act + dropout + 1x1x1 classifier as one pass (mis_norm_head_*): C == 16, K == 2, one statistics group per
     channel, InstanceNorm only without affine."""

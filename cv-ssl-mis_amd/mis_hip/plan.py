@@ -29,6 +29,9 @@ _net_ids = itertools.count(1)
 FUSE_CONV_STATS = os.environ.get("MIS_FUSE_STATS", "1") != "0"
 # norm + act + dropout + 1x1x1 classifier of the 3-D nets as one pass over the last conv's output (norm_act.hip, mis_norm_head_*)
 FUSE_HEAD = os.environ.get("MIS_FUSE_HEAD", "1") != "0"
+# first layer (1 -> 16 channels, its input needs no gradient): the normalisation's backward apply pass on the load path of
+# the weight-gradient kernel (conv_wgrad_cin1.hip, mis_conv_wgrad_cin1_norm)
+FUSE_FIRST = os.environ.get("MIS_FUSE_FIRST", "1") != "0"
 
 
 class Act:
@@ -104,6 +107,7 @@ class ConvOp:
         self.stat_norm = None
         self._dx_tmp = None
         self.fused_into = None   # NormActOp that computes this 1x1x1 classifier in its own pass (Plan._fuse_head)
+        self.norm_bwd = None     # NormActOp whose backward apply pass runs on this (first) conv's wgrad load path
 
     def fwd(self, ctx):
         if self.fused_into is not None:
@@ -119,6 +123,12 @@ class ConvOp:
     def bwd(self, ctx):
         if self.fused_into is not None:
             return               # the NormActOp's backward writes w.grad / b.grad / its own input gradient
+        if self.norm_bwd is not None:      # need_dx False, bias gradient exactly 0: the weight gradient is all there is
+            n = self.norm_bwd
+            ops.conv_wgrad_cin1_norm(self.x.t, n.y.grad(), self.y.t, n.per_sample, n.mean, n.rstd,
+                                     None if n.gamma is None else n.gamma.data, None if n.beta is None else n.beta.data,
+                                     n.sums, n.slope, self.w.grad)
+            return
         dy = self.y.grad()
         ops.conv_wgrad(self.x.t, dy, self.w.grad, self.ksize)
         if self.b is not None and self.bias_grad:
@@ -160,6 +170,7 @@ class NormActOp:
         self.rstd = torch.ones(G, dtype=torch.float32, device="cuda")
         self._p = 0.0
         self._mask = None
+        self.sums = None         # set: backward only reduces (into this [G, 2] buffer); the producing first-layer conv applies
         self.head = None         # 1x1x1 classifier ConvOp computed in this op's pass (Plan._fuse_head); head_w / head_b:
         self.head_w = self.head_b = None     # its parameters (their gradients are written by THIS op: dist.param_progress)
 
@@ -202,6 +213,13 @@ class NormActOp:
 
     def bwd(self, ctx):
         assert not self.x.written
+        if self.sums is not None:
+            ops.norm_act_bwd_sums(self.x.t, self.y.grad(), self.per_sample, self.mean, self.rstd,
+                                  None if self.gamma is None else self.gamma.data,
+                                  None if self.beta is None else self.beta.data, self.slope, self.sums,
+                                  None if self.gamma is None else self.gamma.grad,
+                                  None if self.beta is None else self.beta.grad)
+            return
         if self.head is not None:
             h = self.head
             ops.norm_head_bwd(self.x.t, h.y.grad(), self.x.grad(), self.per_sample, self.mean, self.rstd,
@@ -376,6 +394,13 @@ class Plan:
                 prev.stat = (part, T, C * T) if per_sample else (part, N * T, T)
                 prev.stat_norm = op
                 op.fused = (part, T)
+        if (FUSE_FIRST and type(prev) is ConvOp and prev.y is x and not prev.need_dx and prev.cin == 1
+                and prev.ksize == (3, 3, 3) and drop_p == 0.0 and cg == 1 and not no_norm
+                and not (per_sample and (gamma is not None or beta is not None)) and x.parent is None
+                and ops.conv_wgrad_cin1_norm_eligible(x.shape[0], prev.cout, *x.shape[2:])):
+            op.sums = torch.empty((x.shape[0] * x.shape[1] if per_sample else x.shape[1], 2), dtype=torch.float32,
+                                  device="cuda")
+            prev.norm_bwd = op
         self.ops.append(op)
         return y
 

@@ -175,6 +175,23 @@ int mis_norm_act_bwd_g(const float* x, long long x_bs, const float* da, long lon
                        float* dbeta, int accumulate_affine, void* workspace, long long workspace_bytes,
                        mis_stream_t stream);
 
+/* First layer of the 3-D networks, Conv3d(1 -> 16, k = 3, pad = 1) -> BatchNorm / InstanceNorm -> (Leaky)ReLU
+ * (reference code/networks/unet_3D.py:28 conv1, networks/utils.py:99-107; vnet.py:123 block_one): its input needs no
+ * gradient, so the gradient at the conv output is only read by the weight gradient.  mis_norm_act_bwd_sums runs the
+ * reduction half of mis_norm_act_bwd (sums: 2 floats per group; dgamma / dbeta), mis_conv_wgrad_cin1_norm forms the
+ * gradient on its load path from da (gradient at the activation), y (conv output) and those sums: the apply pass and the
+ * re-read of its result are gone.  No dropout; InstanceNorm only without affine. */
+int mis_norm_act_bwd_sums(const float* x, long long x_bs, const float* da, long long da_bs, int N, int C, long long S,
+                          int per_sample, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                          float slope, float* sums, float* dgamma, float* dbeta, int accumulate_affine, void* workspace,
+                          long long workspace_bytes, mis_stream_t stream);
+int mis_conv_wgrad_cin1_norm_eligible(int N, int Cout, int D, int H, int W);
+int mis_conv_wgrad_cin1_norm(const float* x, long long x_bs, const float* da, long long da_bs, const float* y,
+                             long long y_bs, int N, int D, int H, int W, int per_sample, const float* mean,
+                             const float* rstd, const float* gamma, const float* beta, const float* sums, float slope,
+                             float* dw, float* workspace, long long workspace_bytes, int accumulate,
+                             mis_stream_t stream);
+
 /* Last block of the 3-D networks fused with the 1x1x1 classifier (reference code/networks/unet_3D.py: up_concat1 ->
  * dropout2 -> final = nn.Conv3d(16, n_classes, 1); vnet.py:180-181; unetr.py out): logits[N][K][S] =
  * W[K][C] . drop(act(norm(x))) + b, i.e. mis_norm_act_fwd followed by a 1x1x1 mis_conv_fwd, without storing the

@@ -1,6 +1,7 @@
-"""Last block of the 3-D networks fused with the 1x1x1 classifier (mis_norm_head_fwd / _bwd, norm_act.hip): op-level
-against torch autograd in float64 and against the un-fused kernels, and a Mean-Teacher step of unet_3D with the fusion on
-and off (reference code/networks/unet_3D.py: up_concat1 -> dropout2 -> final)."""
+"""Normalisation passes fused into their neighbours at the two ends of the 3-D networks: the last block with the 1x1x1
+classifier (mis_norm_head_fwd / _bwd, norm_act.hip; reference code/networks/unet_3D.py: up_concat1 -> dropout2 -> final)
+and the first layer's weight gradient through its norm (mis_norm_act_bwd_sums + mis_conv_wgrad_cin1_norm).  Op-level
+against torch autograd in float64 and against the un-fused kernels, and Mean-Teacher steps with the fusions on and off."""
 import pytest
 import torch
 import torch.nn.functional as F
@@ -130,7 +131,50 @@ def test_norm_head_refusals():
                           torch.ones(32, device="cuda"), None, None, 0.0, torch.zeros(2, 32, device="cuda"), None)
 
 
-@pytest.mark.parametrize("kind", ["unet3d", "vnet"])
+@pytest.mark.parametrize("per_sample,slope,N,D,H,W", [(False, 0.0, 2, 4, 8, 32), (True, 0.01, 3, 8, 16, 64), (False, 0.0, 1, 4, 8, 96)])
+def test_first_layer_weight_gradient_through_the_norm(per_sample, slope, N, D, H, W):
+    """mis_norm_act_bwd_sums + mis_conv_wgrad_cin1_norm (gradient at the conv output formed on the load path) ==
+    mis_norm_act_bwd + mis_conv_wgrad, and == torch autograd in float64 (reference unet_3D.py:28 conv1 -> norm -> ReLU)."""
+    ops = _ops()
+    C = 16
+    assert ops.conv_wgrad_cin1_norm_eligible(N, C, D, H, W)
+    x = _rand(N, 1, D, H, W, seed=41).requires_grad_(False)
+    w = _rand(C, 1, 3, 3, 3, seed=42, scale=0.5).requires_grad_(True)
+    gamma = None if per_sample else (_rand(C, seed=43) * 0.5 + 1.0).requires_grad_(True)
+    beta = None if per_sample else (_rand(C, seed=44) * 0.3).requires_grad_(True)
+    y = F.conv3d(x, w, padding=1)
+    z = F.instance_norm(y, eps=1e-5) if per_sample else F.batch_norm(y, None, None, gamma, beta, training=True, eps=1e-5)
+    a = F.leaky_relu(z, slope)
+    da = _rand(*a.shape, seed=45)
+    a.backward(da)
+
+    xd, yd, dad = x.float().cuda(), y.detach().float().cuda(), da.float().cuda()
+    G = N * C if per_sample else C
+    mean, rstd = torch.empty(G, device="cuda"), torch.empty(G, device="cuda")
+    ops.norm_stats(yd, per_sample, 1e-5, mean, rstd)
+    gd = None if gamma is None else gamma.detach().float().cuda()
+    bd = None if beta is None else beta.detach().float().cuda()
+    sums = torch.full((G, 2), float("nan"), device="cuda")
+    dg = None if gamma is None else torch.full((C,), float("nan"), device="cuda")
+    dbt = None if beta is None else torch.full((C,), float("nan"), device="cuda")
+    ops.norm_act_bwd_sums(yd, dad, per_sample, mean, rstd, gd, bd, slope, sums, dg, dbt)
+    dw = torch.full((C, 1, 3, 3, 3), float("nan"), device="cuda")
+    ops.conv_wgrad_cin1_norm(xd, dad, yd, per_sample, mean, rstd, gd, bd, sums, slope, dw)
+    _close(dw, w.grad, rtol=2e-4, atol=1e-6)
+    if gamma is not None:
+        _close(dg, gamma.grad, rtol=1e-4)
+        _close(dbt, beta.grad, rtol=1e-4)
+    # the two-pass form
+    dy = torch.empty_like(yd)
+    ops.norm_act_bwd(yd, dad, dy, per_sample, mean, rstd, gd, bd, slope)
+    dw2 = torch.empty_like(dw)
+    ops.conv_wgrad(xd, dy, dw2, (3, 3, 3))
+    _close(dw, dw2, rtol=1e-5, atol=1e-6)
+    ops.conv_wgrad_cin1_norm(xd, dad, yd, per_sample, mean, rstd, gd, bd, sums, slope, dw2, accumulate=True)
+    _close(dw2, 2 * w.grad, rtol=2e-4, atol=1e-6)
+
+
+@pytest.mark.parametrize("kind", ["unet3d", "vnet", "first:unet3d", "first:vnet"])
 def test_step_with_fused_head_equals_unfused(kind):
     """A Mean-Teacher step (dropout on, device RNG) gives the same losses, gradients and weights with the classifier
     fused into the last block's pass and without.  One step: at this 32^3 fixture the 2^3 / 4^3 levels normalise over
@@ -139,26 +183,29 @@ def test_step_with_fused_head_equals_unfused(kind):
     from mis_hip.step import MeanTeacherTrainer
     from networks.net_factory_3d import net_factory_3d
     from oracle import filler
+    attr = "FUSE_FIRST" if kind.startswith("first:") else "FUSE_HEAD"
+    kind = kind.split(":")[-1]
     key = {"unet3d": "unet_3D", "vnet": "vnet"}[kind]
     torch.manual_seed(5)
     sd0 = {k: v.clone() for k, v in net_factory_3d(key, 1, 2).state_dict().items()}
     vol = filler.image((4, 1, 32, 32, 32), "volume").cuda()
     lab = filler.labels((4, 32, 32, 32), 2, torch.int64).cuda()
     res = []
-    keep = plan_mod.FUSE_HEAD
+    keep = getattr(plan_mod, attr)
     for fuse in (True, False):
-        plan_mod.FUSE_HEAD = fuse
+        setattr(plan_mod, attr, fuse)
         try:
             m, e = net_factory_3d(key, 1, 2), net_factory_3d(key, 1, 2)
             m.load_state_dict(sd0); e.load_state_dict(sd0)
             tr = MeanTeacherTrainer(m, e, labeled_bs=2, num_classes=2, cons_start_iter=0, seed=11, iter_num=1500)
             tr.step(vol, lab)
             torch.cuda.synchronize()
-            fused = [type(op).__name__ for p in m._plans.values() for op in p.ops if getattr(op, "head", None) is not None]
+            mark = "head" if attr == "FUSE_HEAD" else "norm_bwd"
+            fused = [type(op).__name__ for p in m._plans.values() for op in p.ops if getattr(op, mark, None) is not None]
             assert bool(fused) == fuse
             res.append((tr.losses(), m.flat_grad.clone(), m.flat_param.clone(), e.flat_param.clone()))
         finally:
-            plan_mod.FUSE_HEAD = keep
+            setattr(plan_mod, attr, keep)
     (l0, g0, p0, t0), (l1, g1, p1, t1) = res
     for k in l0:
         assert abs(l0[k] - l1[k]) <= 2e-6, (k, l0[k], l1[k])
