@@ -592,12 +592,15 @@ struct HeadArgs {
     int P;
 };
 
-// Dropout of the 4 voxels of unit u in all C channels.  Philox mode: the C draws in a rolled loop (inlined C times into the
-// unrolled channel loops the generator is 160 KB of code), kept as one bit per element; explicit-mask mode reads the scale.
-template <int C>
+// Dropout of the 4 voxels of unit u in all C channels.  Philox mode (MASK = false): the C draws in a rolled loop (inlined C
+// times into the unrolled channel loops the generator is 160 KB of code), kept as one bit per element -- all ones and
+// keep = 1 when dropout is off, so the channel loops carry no branch.  MASK = true (explicit scale mask: parity tests)
+// reads the scale.
+template <int C, bool MASK>
 __device__ __forceinline__ unsigned long long head_drop_bits(const DropCfg& d, int n, long long S, long long u) {
-    unsigned long long bits = 0;
-    if (d.p > 0.f && !d.mask) {
+    unsigned long long bits = ~0ull;
+    if (!MASK && d.p > 0.f) {
+        bits = 0;
 #pragma unroll 1
         for (int c = 0; c < C; ++c) {
             float s[4];
@@ -608,14 +611,13 @@ __device__ __forceinline__ unsigned long long head_drop_bits(const DropCfg& d, i
     }
     return bits;
 }
-template <int C>
-__device__ __forceinline__ void head_drop_scale(const DropCfg& d, unsigned long long bits, int n, long long S, long long u,
-                                                int c, float (&s)[4]) {
-    if (d.mask) {
+template <int C, bool MASK>
+__device__ __forceinline__ void head_drop_scale(const DropCfg& d, unsigned long long bits, float keep, int n, long long S,
+                                                long long u, int c, float (&s)[4]) {
+    if constexpr (MASK) {
         const float4 m = *reinterpret_cast<const float4*>(d.mask + ((unsigned long long)n * C + c) * S + u * 4);
         s[0] = m.x; s[1] = m.y; s[2] = m.z; s[3] = m.w;
     } else {
-        const float keep = 1.f / (1.f - d.p);
 #pragma unroll
         for (int j = 0; j < 4; ++j) s[j] = ((bits >> (4 * c + j)) & 1ull) ? keep : 0.f;
     }
@@ -633,7 +635,7 @@ __device__ __forceinline__ void head_coeffs(const HeadArgs& a, int n, float* sc,
 }
 
 // grid = (ceil(S/4 / 256), N)
-template <int C, int K>
+template <int C, int K, bool MASK>
 __global__ __launch_bounds__(256) void head_fwd_fused_kernel(const HeadArgs a, DropCfg d) {
     __shared__ float sc[C], sh[C], sw[K * C];
     const int n = blockIdx.y;
@@ -646,8 +648,8 @@ __global__ __launch_bounds__(256) void head_fwd_fused_kernel(const HeadArgs a, D
     float4 q[C];
 #pragma unroll
     for (int c = 0; c < C; ++c) q[c] = *reinterpret_cast<const float4*>(xb + (long long)c * a.S);
-    const bool drop = d.p > 0.f;
-    const unsigned long long bits = head_drop_bits<C>(d, n, a.S, u);
+    const float keep = d.p > 0.f ? 1.f / (1.f - d.p) : 1.f;
+    const unsigned long long bits = head_drop_bits<C, MASK>(d, n, a.S, u);
     float acc[K][4];
 #pragma unroll
     for (int k = 0; k < K; ++k) {
@@ -660,9 +662,9 @@ __global__ __launch_bounds__(256) void head_fwd_fused_kernel(const HeadArgs a, D
         float v[4] = {q[c].x * sc[c] + sh[c], q[c].y * sc[c] + sh[c], q[c].z * sc[c] + sh[c], q[c].w * sc[c] + sh[c]};
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] = v[j] > 0.f ? v[j] : v[j] * a.slope;
-        if (drop) {
+        {
             float s[4];
-            head_drop_scale<C>(d, bits, n, a.S, u, c, s);
+            head_drop_scale<C, MASK>(d, bits, keep, n, a.S, u, c, s);
 #pragma unroll
             for (int j = 0; j < 4; ++j) v[j] *= s[j];
         }
@@ -679,8 +681,11 @@ __global__ __launch_bounds__(256) void head_fwd_fused_kernel(const HeadArgs a, D
 
 // grid = (P, N): block (p, n) walks its share of the sample; per channel (sum dz, sum dz*xhat) into `part` (the layout
 // bwd_final_kernel reads), the classifier's sum dl[k]*z[c] and sum dl[k] into `hpart`
-template <int C, int K>
-__global__ __launch_bounds__(256) void head_bwd_partial_kernel(const HeadArgs a, DropCfg d) {
+// 2C + KC + K accumulators per thread; the channel loop is fenced every 4 channels so that at most 4 float4 loads are
+// hoisted (128 registers, four waves per SIMD: with all 16 in flight the kernel took 512 registers, one wave per SIMD,
+// and ran at 1.4 TB/s)
+template <int C, int K, bool MASK>
+__global__ __launch_bounds__(256, 3) void head_bwd_partial_kernel(const HeadArgs a, DropCfg d) {
     __shared__ float sc[C], sh[C], sw[K * C], red[4 * (2 * C + K * C + K)];
     const int p = blockIdx.x, n = blockIdx.y;
     head_coeffs<C>(a, n, sc, sh);
@@ -689,7 +694,7 @@ __global__ __launch_bounds__(256) void head_bwd_partial_kernel(const HeadArgs a,
     const long long units = a.S >> 2;
     const long long per = (units + a.P - 1) / a.P;
     const long long u0 = p * per, u1 = (u0 + per < units) ? u0 + per : units;
-    const bool drop = d.p > 0.f;
+    const float keep = d.p > 0.f ? 1.f / (1.f - d.p) : 1.f;
     constexpr int NV = 2 * C + K * C + K;
     float v[NV];
 #pragma unroll
@@ -702,13 +707,13 @@ __global__ __launch_bounds__(256) void head_bwd_partial_kernel(const HeadArgs a,
             v[2 * C + K * C + k] += (g4[k].x + g4[k].y) + (g4[k].z + g4[k].w);
         }
         const float* __restrict__ xb = a.x + (long long)n * a.x_bs + u * 4;
-        const unsigned long long bits = head_drop_bits<C>(d, n, a.S, u);
+        const unsigned long long bits = head_drop_bits<C, MASK>(d, n, a.S, u);
 #pragma unroll
         for (int c = 0; c < C; ++c) {
             const float4 q = *reinterpret_cast<const float4*>(xb + (long long)c * a.S);
             const float xs[4] = {q.x, q.y, q.z, q.w};
-            float s[4] = {1.f, 1.f, 1.f, 1.f};
-            if (drop) head_drop_scale<C>(d, bits, n, a.S, u, c, s);
+            float s[4];
+            head_drop_scale<C, MASK>(d, bits, keep, n, a.S, u, c, s);
             // gamma * rstd = sc, so xhat = (x*sc + sh - beta) / gamma is avoided: xhat from mean / rstd directly
             const int grp = a.per_sample ? n * C + c : c;
             const float m = a.mean[grp], rs = a.rstd[grp];
@@ -729,20 +734,30 @@ __global__ __launch_bounds__(256) void head_bwd_partial_kernel(const HeadArgs a,
                 v[2 * c] += dz;
                 v[2 * c + 1] = fmaf(dz, xh, v[2 * c + 1]);
             }
+            if (c % 4 == 3) __builtin_amdgcn_sched_barrier(0);
         }
     }
-    mis_block_sum<NV>(v, red);
-    if (threadIdx.x == 0) {
-        const int nchunks = a.per_sample ? 1 : a.N;
+    // block sum: wave shuffles, then one thread per value adds the four waves' rows and stores its value
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
-        for (int c = 0; c < C; ++c) {
+    for (int i = 0; i < NV; ++i) v[i] = mis_wave_sum(v[i]);
+    if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) red[wave * NV + i] = v[i];
+    }
+    __syncthreads();
+    if (threadIdx.x < NV) {
+        const int i = threadIdx.x;
+        const float t = (red[i] + red[NV + i]) + (red[2 * NV + i] + red[3 * NV + i]);
+        if (i < 2 * C) {
+            const int c = i >> 1;
+            const int nchunks = a.per_sample ? 1 : a.N;
             const long long grp = a.per_sample ? (long long)n * C + c : c;
             const int k = a.per_sample ? 0 : n;
-            a.part[(grp * nchunks + k) * a.P + p] = make_float2(v[2 * c], v[2 * c + 1]);
+            reinterpret_cast<float*>(a.part)[((grp * nchunks + k) * a.P + p) * 2 + (i & 1)] = t;
+        } else {
+            a.hpart[((long long)n * a.P + p) * (K * C + K) + (i - 2 * C)] = t;
         }
-        float* hp = a.hpart + ((long long)n * a.P + p) * (K * C + K);
-#pragma unroll
-        for (int i = 0; i < K * C + K; ++i) hp[i] = v[2 * C + i];
     }
 }
 
@@ -760,7 +775,7 @@ __global__ __launch_bounds__(64) void head_final_kernel(const float* __restrict_
 }
 
 // grid = (ceil(S/4 / 256), N): dx = gamma*rstd * (dz - mean(dz) - xhat * mean(dz*xhat))
-template <int C, int K>
+template <int C, int K, bool MASK>
 __global__ __launch_bounds__(256) void head_bwd_apply_kernel(const HeadArgs a, DropCfg d) {
     __shared__ float sc[C], sh[C], sw[K * C];
     const int n = blockIdx.y;
@@ -775,14 +790,14 @@ __global__ __launch_bounds__(256) void head_bwd_apply_kernel(const HeadArgs a, D
         g4[k] = *reinterpret_cast<const float4*>(a.dl + (long long)n * a.dl_bs + (long long)k * a.S + u * 4);
     const float* __restrict__ xb = a.x + (long long)n * a.x_bs + u * 4;
     float* __restrict__ ob = a.dx + (long long)n * a.dx_bs + u * 4;
-    const bool drop = d.p > 0.f;
-    const unsigned long long bits = head_drop_bits<C>(d, n, a.S, u);
+    const float keep = d.p > 0.f ? 1.f / (1.f - d.p) : 1.f;
+    const unsigned long long bits = head_drop_bits<C, MASK>(d, n, a.S, u);
 #pragma unroll
     for (int c = 0; c < C; ++c) {
         const float4 q = *reinterpret_cast<const float4*>(xb + (long long)c * a.S);
         const float xs[4] = {q.x, q.y, q.z, q.w};
-        float s[4] = {1.f, 1.f, 1.f, 1.f};
-        if (drop) head_drop_scale<C>(d, bits, n, a.S, u, c, s);
+        float s[4];
+        head_drop_scale<C, MASK>(d, bits, keep, n, a.S, u, c, s);
         const int grp = a.per_sample ? n * C + c : c;
         const float m = a.mean[grp], rs = a.rstd[grp];
         const float2 sm = a.sums[grp];
@@ -805,23 +820,30 @@ __global__ __launch_bounds__(256) void head_bwd_apply_kernel(const HeadArgs a, D
 template <int C>
 int head_launch_fwd(const HeadArgs& a, const DropCfg& d, hipStream_t stream) {
     const dim3 grid((unsigned)mis_cdiv(a.S >> 2, 256), a.N);
-    hipLaunchKernelGGL((head_fwd_fused_kernel<C, 2>), grid, dim3(256), 0, stream, a, d);      // K == 2 (mis_norm_head_eligible)
+    if (d.mask) hipLaunchKernelGGL((head_fwd_fused_kernel<C, 2, true>), grid, dim3(256), 0, stream, a, d);      // K == 2 (mis_norm_head_eligible)
+    else hipLaunchKernelGGL((head_fwd_fused_kernel<C, 2, false>), grid, dim3(256), 0, stream, a, d);
     return mis_launch_status();
 }
 
 template <int C>
 void head_launch_partial(const HeadArgs& a, const DropCfg& d, hipStream_t stream) {
     const dim3 grid(a.P, a.N);
-    hipLaunchKernelGGL((head_bwd_partial_kernel<C, 2>), grid, dim3(256), 0, stream, a, d);      // K == 2 (mis_norm_head_eligible)
+    if (d.mask) hipLaunchKernelGGL((head_bwd_partial_kernel<C, 2, true>), grid, dim3(256), 0, stream, a, d);      // K == 2 (mis_norm_head_eligible)
+    else hipLaunchKernelGGL((head_bwd_partial_kernel<C, 2, false>), grid, dim3(256), 0, stream, a, d);
 }
 
 template <int C>
 void head_launch_apply(const HeadArgs& a, const DropCfg& d, hipStream_t stream) {
     const dim3 grid((unsigned)mis_cdiv(a.S >> 2, 256), a.N);
-    hipLaunchKernelGGL((head_bwd_apply_kernel<C, 2>), grid, dim3(256), 0, stream, a, d);      // K == 2 (mis_norm_head_eligible)
+    if (d.mask) hipLaunchKernelGGL((head_bwd_apply_kernel<C, 2, true>), grid, dim3(256), 0, stream, a, d);      // K == 2 (mis_norm_head_eligible)
+    else hipLaunchKernelGGL((head_bwd_apply_kernel<C, 2, false>), grid, dim3(256), 0, stream, a, d);
 }
 
 }  // namespace
+
+// partial blocks per sample = HEAD_PMUL x the plain normalisation's (the partial-sum kernel holds 66 accumulators per
+// thread: three workgroups per CU, 768 blocks for 8 volumes = one round)
+constexpr int HEAD_PMUL = 3;
 
 // The fused form covers C = 16 channels and 2 classes (the binary 3-D tasks: BraTS whole tumour, LA, Pancreas), BatchNorm /
 // InstanceNorm statistics (one group per channel).  More classes: the partial-sum kernel's 2C + KC + K accumulators per
@@ -831,7 +853,7 @@ extern "C" int mis_norm_head_eligible(int C, int K) { return C == 16 && K == 2; 
 extern "C" long long mis_norm_head_workspace_bytes(int N, int C, long long S, int per_sample, int K) {
     if (N <= 0 || C <= 0 || S <= 0 || K <= 0) return MIS_ERR_ARG;
     const long long nb = mis_norm_workspace_bytes(N, C, S, per_sample);
-    return nb + (long long)N * pick_P(S) * (K * C + K) * 4;
+    return nb * HEAD_PMUL + (long long)N * pick_P(S) * HEAD_PMUL * (K * C + K) * 4;
 }
 
 // logits[N][K][S] = W . drop(act(norm(x))) + b  (mis_norm_act_fwd followed by a 1x1x1 mis_conv_fwd, without the
@@ -871,7 +893,8 @@ extern "C" int mis_norm_head_bwd(const float* x, long long x_bs, const float* dl
     if (dl_bs < (long long)K * S || dx_bs < (long long)C * S) return MIS_ERR_ARG;
     if (drop_p < 0.f || drop_p >= 1.f || (drop_p > 0.f && !state && !drop_mask)) return MIS_ERR_ARG;
     if (workspace_bytes < mis_norm_head_workspace_bytes(N, C, S, per_sample, K)) return MIS_ERR_WORKSPACE;
-    const Geo g = make_geo(N, C, S, x_bs, per_sample);
+    Geo g = make_geo(N, C, S, x_bs, per_sample);
+    g.P *= HEAD_PMUL;
     float2* part = reinterpret_cast<float2*>(workspace);
     float2* sums = part + (long long)g.G * g.nchunks * g.P;
     HeadArgs a{};
