@@ -242,8 +242,10 @@ extern "C" int mis_conv_pack_job_bytes() { return (int)sizeof(PackJob); }
 extern "C" int mis_conv_pack_batch(const void* jobs_device, int n, long long total_floats, hipStream_t stream) {
     if (!jobs_device || n <= 0 || total_floats <= 0) return MIS_ERR_ARG;
     if (n > MAX_JOBS) return MIS_ERR_UNSUPPORTED;
-    long long blocks = mis_cdiv(total_floats, 256 * 4);
-    if (blocks > 4096) blocks = 4096;
+    // a thread writes 64 / 16 floats of a Winograd job, one of a plain one (grid-stride): every block first copies the
+    // job table into LDS, so no more blocks than the work needs
+    long long blocks = mis_cdiv(total_floats, 256 * 32);
+    if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(pack_batch_kernel, dim3((unsigned)blocks), dim3(256), 0, stream,
                        reinterpret_cast<const PackJob*>(jobs_device), n, total_floats);
     return mis_launch_status();
