@@ -79,6 +79,34 @@ __device__ __forceinline__ void drop_scale4(const DropCfg& d, unsigned long long
     for (int i = 0; i < 4; ++i) s[i] = mis_u01(r[i]) >= d.p ? keep : 0.f;
 }
 
+// Optional second source of the incoming gradient: the activation also feeds a 2x max-pool (reference unet_3D.py:35-47
+// conv_k -> maxpool_k, unet.py:56 DownBlock) whose backward scatters dpool[cell] to the argmax element of each window.
+// Instead of a separate read-modify-write pass over the full-resolution gradient (mis_maxpool2_bwd with accumulate), the
+// two passes of the normalisation backward add that term on their load path: da_total = da + (idx[cell] == local ? dpool : 0).
+struct PoolGrad {
+    const float* dp; long long dp_bs;      // dpool [N][C][So]; null: no pooled consumer
+    const unsigned char* idx;              // argmax codes dz*4 + dy*2 + dx, [N*C][So]
+    int H, W, pz;                          // fine geometry; pz = 2 (3-D) or 1 (2-D: D == 1)
+    long long So;                          // pooled elements per channel
+};
+
+// the pool's contribution to the 4 gradient elements at linear index e (multiple of 4; W % 4 == 0: one row) of (n, c)
+__device__ __forceinline__ void pool_grad4(const PoolGrad& pg, int n, int c, int C, unsigned e, float (&g)[4]) {
+    const unsigned HW = (unsigned)(pg.H * pg.W);
+    const unsigned z = e / HW, r = e - z * HW;
+    const unsigned y = r / (unsigned)pg.W, x0 = r - y * (unsigned)pg.W;
+    const unsigned zo = z / (unsigned)pg.pz;
+    const unsigned o = (zo * ((unsigned)pg.H >> 1) + (y >> 1)) * ((unsigned)pg.W >> 1) + (x0 >> 1);     // even
+    const unsigned local = (z - zo * (unsigned)pg.pz) * 4u + (y & 1u) * 2u;
+    const float2 d = *reinterpret_cast<const float2*>(pg.dp + (long long)n * pg.dp_bs + (long long)c * pg.So + o);
+    const unsigned code = *reinterpret_cast<const unsigned short*>(pg.idx + ((long long)n * C + c) * pg.So + o);
+    const unsigned c0 = code & 0xffu, c1 = code >> 8;
+    g[0] = c0 == local ? d.x : 0.f;
+    g[1] = c0 == local + 1u ? d.x : 0.f;
+    g[2] = c1 == local ? d.y : 0.f;
+    g[3] = c1 == local + 1u ? d.y : 0.f;
+}
+
 // ---------------- statistics ----------------
 // grid = (P, nchunks, G); partial[(g*nchunks + k)*P + p] = (sum, sumsq)
 __global__ __launch_bounds__(256) void stats_partial_kernel(const float* __restrict__ x, Geo g,
@@ -219,7 +247,7 @@ __global__ __launch_bounds__(256) void bwd_partial_kernel(const float* __restric
                                                           const float* __restrict__ rstd,
                                                           const float* __restrict__ gamma,
                                                           const float* __restrict__ beta, float slope, DropCfg d,
-                                                          float2* __restrict__ part) {
+                                                          float2* __restrict__ part, PoolGrad pg) {
     __shared__ float red[8];
     const int p = blockIdx.x, k = blockIdx.y, grp = blockIdx.z;
     const int n = g.per_sample ? grp / g.C : k;
@@ -228,7 +256,7 @@ __global__ __launch_bounds__(256) void bwd_partial_kernel(const float* __restric
     const float m = mean[sg], rs = rstd[sg];
     const float ga = gamma ? gamma[c] : 1.f, be = beta ? beta[c] : 0.f;
     const float* __restrict__ xb = x + (long long)n * g.x_bs + (long long)c * g.S;
-    const float* __restrict__ db = da + (long long)n * da_bs + (long long)c * g.S;
+    const float* __restrict__ db = da ? da + (long long)n * da_bs + (long long)c * g.S : nullptr;
     const unsigned long long lbase = ((unsigned long long)n * g.C + c) * g.S;
     const long long units = g.S >> 2;
     const long long per = (units + g.P - 1) / g.P;
@@ -237,9 +265,15 @@ __global__ __launch_bounds__(256) void bwd_partial_kernel(const float* __restric
     float v[2] = {0.f, 0.f};
     for (long long u = u0 + threadIdx.x; u < u1; u += 256) {
         const float4 q = *reinterpret_cast<const float4*>(xb + u * 4);
-        const float4 gq = *reinterpret_cast<const float4*>(db + u * 4);
+        const float4 gq = db ? *reinterpret_cast<const float4*>(db + u * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
         const float xs[4] = {q.x, q.y, q.z, q.w};
         float gs[4] = {gq.x, gq.y, gq.z, gq.w};
+        if (pg.dp) {
+            float pgr[4];
+            pool_grad4(pg, n, c, g.C, (unsigned)(u * 4), pgr);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) gs[j] += pgr[j];
+        }
         if (drop) {
             float s[4];
             drop_scale4(d, lbase + u * 4, (unsigned)(n * g.C + c), s);
@@ -335,7 +369,7 @@ __global__ __launch_bounds__(256) void apply_bwd_kernel(const float* __restrict_
                                                         const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, float slope, DropCfg d,
                                                         const float2* __restrict__ sums, float* __restrict__ dx,
-                                                        long long dx_bs, int kind) {
+                                                        long long dx_bs, int kind, PoolGrad pg) {
     const int c = blockIdx.y, n = blockIdx.z;
     const int grp = g.per_sample ? (n * g.C + c) / g.cg : c;
     const float m = mean[grp], rs = rstd[grp];
@@ -343,7 +377,7 @@ __global__ __launch_bounds__(256) void apply_bwd_kernel(const float* __restrict_
     const float2 sm = kind == 2 ? make_float2(0.f, 0.f) : sums[grp];
     const float k = ga * rs;
     const float* __restrict__ xb = x + (long long)n * g.x_bs + (long long)c * g.S;
-    const float* __restrict__ db = da + (long long)n * da_bs + (long long)c * g.S;
+    const float* __restrict__ db = da ? da + (long long)n * da_bs + (long long)c * g.S : nullptr;
     float* __restrict__ ob = dx + (long long)n * dx_bs + (long long)c * g.S;
     const unsigned long long lbase = ((unsigned long long)n * g.C + c) * g.S;
     const long long units = g.S >> 2;
@@ -353,9 +387,15 @@ __global__ __launch_bounds__(256) void apply_bwd_kernel(const float* __restrict_
         const long long u = ((long long)blockIdx.x * APPLY_U + i) * 256 + threadIdx.x;
         if (u >= units) break;
         const float4 q = *reinterpret_cast<const float4*>(xb + u * 4);
-        const float4 gq = *reinterpret_cast<const float4*>(db + u * 4);
+        const float4 gq = db ? *reinterpret_cast<const float4*>(db + u * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
         const float xs[4] = {q.x, q.y, q.z, q.w};
         float gs[4] = {gq.x, gq.y, gq.z, gq.w};
+        if (pg.dp) {
+            float pgr[4];
+            pool_grad4(pg, n, c, g.C, (unsigned)(u * 4), pgr);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) gs[j] += pgr[j];
+        }
         if (drop) {
             float s[4];
             drop_scale4(d, lbase + u * 4, (unsigned)(n * g.C + c), s);
@@ -487,18 +527,19 @@ extern "C" int mis_norm_act_fwd(const float* x, long long x_bs, float* y, long l
 // Backward of mis_norm_act_fwd_g.  ``no_norm`` != 0: the layer is activation (+ dropout) only -- the reference's
 // normalization='none' blocks -- mean must hold zeros, rstd ones, gamma / beta null; no reduction runs.
 // Workspace: mis_norm_workspace_bytes(N, C, S, per_sample) (covers every cg).
-extern "C" int mis_norm_act_bwd_g(const float* x, long long x_bs, const float* da, long long da_bs, float* dx,
-                                  long long dx_bs, int N, int C, long long S, int per_sample, int cg, int no_norm,
-                                  const float* mean, const float* rstd, const float* gamma, const float* beta,
-                                  float slope, float drop_p, unsigned drop_salt, const MisStepState* state,
-                                  const float* drop_mask, float* dgamma, float* dbeta, int accumulate_affine,
-                                  void* workspace, long long workspace_bytes, hipStream_t stream) {
+namespace {
+int norm_act_bwd_impl(const float* x, long long x_bs, const float* da, long long da_bs, float* dx, long long dx_bs,
+                      int N, int C, long long S, int per_sample, int cg, int no_norm, const float* mean,
+                      const float* rstd, const float* gamma, const float* beta, float slope, float drop_p,
+                      unsigned drop_salt, const MisStepState* state, const float* drop_mask, float* dgamma,
+                      float* dbeta, int accumulate_affine, void* workspace, long long workspace_bytes,
+                      const PoolGrad& pg, hipStream_t stream) {
     int st = check_geo(x, N, C, S, x_bs);
     if (st) return st;
     if (cg < 1 || C % cg != 0 || (cg > 1 && !per_sample) || (no_norm && (gamma || beta))) return MIS_ERR_ARG;
-    if (!da || !dx || !mean || !rstd || !workspace) return MIS_ERR_ARG;
-    if (da_bs % 4 != 0 || dx_bs % 4 != 0 || !aligned16(da) || !aligned16(dx)) return MIS_ERR_UNSUPPORTED;
-    if (da_bs < (long long)C * S || dx_bs < (long long)C * S) return MIS_ERR_ARG;
+    if ((!da && !pg.dp) || !dx || !mean || !rstd || !workspace) return MIS_ERR_ARG;
+    if (dx_bs % 4 != 0 || !aligned16(dx) || (da && (da_bs % 4 != 0 || !aligned16(da)))) return MIS_ERR_UNSUPPORTED;
+    if ((da && da_bs < (long long)C * S) || dx_bs < (long long)C * S) return MIS_ERR_ARG;
     if (drop_p < 0.f || drop_p >= 1.f) return MIS_ERR_ARG;
     if (drop_p > 0.f && !state && !drop_mask) return MIS_ERR_ARG;
     if (workspace_bytes < mis_norm_workspace_bytes(N, C, S, per_sample)) return MIS_ERR_WORKSPACE;
@@ -509,7 +550,7 @@ extern "C" int mis_norm_act_bwd_g(const float* x, long long x_bs, const float* d
     const bool gn = per_sample && (cg > 1 || gamma);    // per-channel affine inside a per-sample group
     if (!no_norm) {
         hipLaunchKernelGGL(bwd_partial_kernel, dim3(g.P, g.nchunks, g.G), dim3(256), 0, stream, x, g, da, da_bs, mean,
-                           rstd, gamma, beta, slope, d, part);
+                           rstd, gamma, beta, slope, d, part, pg);
         if (gn) {
             hipLaunchKernelGGL(gn_bwd_group_kernel, dim3((N * (C / cg) + 3) / 4), dim3(256), 0, stream, part, g, gamma,
                                sums);
@@ -524,8 +565,45 @@ extern "C" int mis_norm_act_bwd_g(const float* x, long long x_bs, const float* d
     const long long units = S >> 2;
     const unsigned gx = (unsigned)mis_cdiv(units, 256 * APPLY_U);
     hipLaunchKernelGGL(apply_bwd_kernel, dim3(gx, C, N), dim3(256), 0, stream, x, g, da, da_bs, mean, rstd, gamma,
-                       beta, slope, d, sums, dx, dx_bs, no_norm ? 2 : (gn ? 1 : 0));
+                       beta, slope, d, sums, dx, dx_bs, no_norm ? 2 : (gn ? 1 : 0), pg);
     return mis_launch_status();
+}
+}  // namespace
+
+extern "C" int mis_norm_act_bwd_g(const float* x, long long x_bs, const float* da, long long da_bs, float* dx,
+                                  long long dx_bs, int N, int C, long long S, int per_sample, int cg, int no_norm,
+                                  const float* mean, const float* rstd, const float* gamma, const float* beta,
+                                  float slope, float drop_p, unsigned drop_salt, const MisStepState* state,
+                                  const float* drop_mask, float* dgamma, float* dbeta, int accumulate_affine,
+                                  void* workspace, long long workspace_bytes, hipStream_t stream) {
+    if (!da) return MIS_ERR_ARG;
+    return norm_act_bwd_impl(x, x_bs, da, da_bs, dx, dx_bs, N, C, S, per_sample, cg, no_norm, mean, rstd, gamma, beta,
+                             slope, drop_p, drop_salt, state, drop_mask, dgamma, dbeta, accumulate_affine, workspace,
+                             workspace_bytes, PoolGrad{}, stream);
+}
+
+// mis_norm_act_bwd_g for an activation [N][C][D][H][W] that ALSO feeds a 2x max-pool (mis_maxpool2_fwd's idx codes):
+// the gradient arriving at the activation is da (the other consumers: skip connection; NULL: none) plus the pool's
+// backward of dpool [N][C][D/2 (D > 1)][H/2][W/2], formed on the load path of both passes -- mis_maxpool2_bwd's
+// read-modify-write of the full-resolution gradient is gone.  W % 4 == 0, H even, D even or 1.
+extern "C" int mis_norm_act_bwd_pool(const float* x, long long x_bs, const float* da, long long da_bs,
+                                     const float* dpool, long long dp_bs, const unsigned char* idx, float* dx,
+                                     long long dx_bs, int N, int C, int D, int H, int W, int per_sample, int cg,
+                                     const float* mean, const float* rstd, const float* gamma, const float* beta,
+                                     float slope, float drop_p, unsigned drop_salt, const MisStepState* state,
+                                     const float* drop_mask, float* dgamma, float* dbeta, int accumulate_affine,
+                                     void* workspace, long long workspace_bytes, hipStream_t stream) {
+    if (!dpool || !idx || D <= 0 || H <= 0 || W <= 0) return MIS_ERR_ARG;
+    if (W % 4 || H % 2 || (D > 1 && D % 2)) return MIS_ERR_UNSUPPORTED;
+    const long long S = (long long)D * H * W;
+    if (S >= (1LL << 31)) return MIS_ERR_UNSUPPORTED;
+    const int pz = D > 1 ? 2 : 1;
+    const long long So = (long long)(D / pz) * (H / 2) * (W / 2);
+    if (dp_bs < (long long)C * So || dp_bs % 2 || ((uintptr_t)dpool & 7) || ((uintptr_t)idx & 1)) return MIS_ERR_UNSUPPORTED;
+    const PoolGrad pg{dpool, dp_bs, idx, H, W, pz, So};
+    return norm_act_bwd_impl(x, x_bs, da, da_bs, dx, dx_bs, N, C, S, per_sample, cg, 0, mean, rstd, gamma, beta, slope,
+                             drop_p, drop_salt, state, drop_mask, dgamma, dbeta, accumulate_affine, workspace,
+                             workspace_bytes, pg, stream);
 }
 
 // The reduction half of mis_norm_act_bwd alone (no dropout): sums[group] = (mean of dz, mean of dz*xhat) as two floats per
@@ -546,7 +624,7 @@ extern "C" int mis_norm_act_bwd_sums(const float* x, long long x_bs, const float
     const DropCfg d{0.f, 0u, nullptr, nullptr};
     float2* part = reinterpret_cast<float2*>(workspace);
     hipLaunchKernelGGL(bwd_partial_kernel, dim3(g.P, g.nchunks, g.G), dim3(256), 0, stream, x, g, da, da_bs, mean, rstd,
-                       gamma, beta, slope, d, part);
+                       gamma, beta, slope, d, part, PoolGrad{});
     hipLaunchKernelGGL(bwd_final_kernel, dim3((g.G + 3) / 4), dim3(256), 0, stream, part, g,
                        reinterpret_cast<float2*>(sums), dgamma, dbeta, accumulate_affine);
     return mis_launch_status();

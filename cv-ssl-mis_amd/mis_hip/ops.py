@@ -305,6 +305,23 @@ def norm_act_bwd(x, da, dx, per_sample, mean, rstd, gamma, beta, slope, drop_p=0
              "mis_norm_act_bwd_g")
 
 
+def norm_act_bwd_pool(x, da, dpool, idx, dx, per_sample, mean, rstd, gamma, beta, slope, drop_p=0.0, drop_salt=0,
+                      state=None, drop_mask=None, dgamma=None, dbeta=None, accumulate_affine=False, cg=1):
+    """norm_act_bwd of an activation that also feeds a 2x max-pool: incoming gradient = da (None: no other consumer) +
+    the pool's backward of dpool through the argmax codes idx, added on the load path (no maxpool2_bwd pass)."""
+    L = _l.load()
+    N, C, D, H, W, S, xbs = _geom(x)
+    dabs = _geom(da)[6] if da is not None else 0
+    _, _, _, _, _, _, dpbs = _geom(dpool)
+    _, _, _, _, _, _, dxbs = _geom(dx)
+    ws = scratch(L.mis_norm_workspace_bytes(N, C, S, int(per_sample)), "norm")
+    _l.check(L.mis_norm_act_bwd_pool(_l.ptr(x), xbs, _l.ptr(da), dabs, _l.ptr(dpool), dpbs, _l.ptr(idx), _l.ptr(dx), dxbs,
+                                     N, C, D, H, W, int(per_sample), int(cg), _l.ptr(mean), _l.ptr(rstd), _l.ptr(gamma),
+                                     _l.ptr(beta), slope, drop_p, drop_salt, _l.ptr(state), _l.ptr(drop_mask),
+                                     _l.ptr(dgamma), _l.ptr(dbeta), int(accumulate_affine), _l.ptr(ws), ws.numel(),
+                                     _l.stream_ptr()), "mis_norm_act_bwd_pool")
+
+
 def norm_act_bwd_sums(x, da, per_sample, mean, rstd, gamma, beta, slope, sums, dgamma=None, dbeta=None,
                       accumulate_affine=False):
     """The reduction half of norm_act_bwd: sums[group] = (mean dz, mean dz*xhat) (+ dgamma / dbeta); no dropout."""

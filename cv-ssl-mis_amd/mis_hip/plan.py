@@ -32,6 +32,8 @@ FUSE_HEAD = os.environ.get("MIS_FUSE_HEAD", "1") != "0"
 # first layer (1 -> 16 channels, its input needs no gradient): the normalisation's backward apply pass on the load path of
 # the weight-gradient kernel (conv_wgrad_cin1.hip, mis_conv_wgrad_cin1_norm)
 FUSE_FIRST = os.environ.get("MIS_FUSE_FIRST", "1") != "0"
+# max-pool backward on the load path of the producing block's normalisation backward (mis_norm_act_bwd_pool)
+FUSE_POOL = os.environ.get("MIS_FUSE_POOL", "1") != "0"
 
 
 class Act:
@@ -170,6 +172,7 @@ class NormActOp:
         self.rstd = torch.ones(G, dtype=torch.float32, device="cuda")
         self._p = 0.0
         self._mask = None
+        self.pool = None         # MaxPoolOp fed by this op's output whose backward runs inside this op's (Plan.maxpool)
         self.sums = None         # set: backward only reduces (into this [G, 2] buffer); the producing first-layer conv applies
         self.head = None         # 1x1x1 classifier ConvOp computed in this op's pass (Plan._fuse_head); head_w / head_b:
         self.head_w = self.head_b = None     # its parameters (their gradients are written by THIS op: dist.param_progress)
@@ -220,6 +223,16 @@ class NormActOp:
                                   None if self.gamma is None else self.gamma.grad,
                                   None if self.beta is None else self.beta.grad)
             return
+        if self.pool is not None:
+            pl = self.pool
+            ops.norm_act_bwd_pool(self.x.t, self.y.grad() if self.y.written else None, pl.y.grad(), pl.idx, self.x.grad(),
+                                  self.per_sample, self.mean, self.rstd,
+                                  None if self.gamma is None else self.gamma.data,
+                                  None if self.beta is None else self.beta.data, self.slope, self._p, self.salt,
+                                  self._state, self._mask, None if self.gamma is None else self.gamma.grad,
+                                  None if self.beta is None else self.beta.grad, cg=self.cg)
+            self.x.mark_written()
+            return
         if self.head is not None:
             h = self.head
             ops.norm_head_bwd(self.x.t, h.y.grad(), self.x.grad(), self.per_sample, self.mean, self.rstd,
@@ -244,11 +257,14 @@ class MaxPoolOp:
     def __init__(self, x, y):
         self.x, self.y = x, y
         self.idx = torch.empty(y.t.numel(), dtype=torch.uint8, device="cuda")
+        self.fused_into = None   # NormActOp (producer of x) whose backward adds this pool's gradient on its load path
 
     def fwd(self, ctx):
         ops.maxpool2_fwd(self.x.t, self.y.t, self.idx)
 
     def bwd(self, ctx):
+        if self.fused_into is not None:
+            return
         ops.maxpool2_bwd(self.y.grad(), self.idx, self.x.grad(), accumulate=self.x.written)
         self.x.mark_written()
 
@@ -417,7 +433,15 @@ class Plan:
         return out
 
     def maxpool(self, x, y):
-        self.ops.append(MaxPoolOp(x, y))
+        op = MaxPoolOp(x, y)
+        if FUSE_POOL:
+            # x = the output of a norm/act op (possibly a view into a decoder's concat buffer: the skip connection)
+            prod = next((o for o in reversed(self.ops) if type(o) is NormActOp and o.y is x), None)
+            N, C, D, H, W = x.shape
+            if (prod is not None and prod.pool is None and prod.head is None and prod.sums is None and not prod.no_norm
+                    and W % 4 == 0 and H % 2 == 0 and (D == 1 or D % 2 == 0) and D * H * W < 2 ** 31):
+                prod.pool, op.fused_into = op, prod
+        self.ops.append(op)
         return y
 
     def upsample(self, x, y, align_corners):

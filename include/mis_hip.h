@@ -211,6 +211,18 @@ int mis_norm_head_bwd(const float* x, long long x_bs, const float* dlogits, long
                       float* dbeta, int accumulate_affine, float* dw, float* db, int accumulate_w, void* workspace,
                       long long workspace_bytes, mis_stream_t stream);
 
+/* mis_norm_act_bwd_g for an activation [N][C][D][H][W] that also feeds a 2x max-pool (reference unet_3D.py:35-47 conv_k ->
+ * maxpool_k with the skip connection to the decoder; unet.py:56 DownBlock): the incoming gradient is da (the other
+ * consumers; NULL: none) plus the backward of the pool -- dpool [N][C][D/2 (D > 1)][H/2][W/2] scattered by
+ * mis_maxpool2_fwd's argmax codes idx -- added on the load path of both passes; mis_maxpool2_bwd's read-modify-write of
+ * the full-resolution gradient is not needed.  W % 4 == 0, H even, D even or 1. */
+int mis_norm_act_bwd_pool(const float* x, long long x_bs, const float* da, long long da_bs, const float* dpool,
+                          long long dp_bs, const unsigned char* idx, float* dx, long long dx_bs, int N, int C, int D,
+                          int H, int W, int per_sample, int cg, const float* mean, const float* rstd,
+                          const float* gamma, const float* beta, float slope, float drop_p, unsigned drop_salt,
+                          const MisStepState* state, const float* drop_mask, float* dgamma, float* dbeta,
+                          int accumulate_affine, void* workspace, long long workspace_bytes, mis_stream_t stream);
+
 /* ---- 2x max-pool / 2x linear up-sampling ----------------------------------------------------------
  * reference: nn.MaxPool2d(2) unet.py:56; nn.MaxPool3d(2) unet_3D.py:35-47;
  *            nn.Upsample(bilinear, align_corners=True) unet.py:74-75;

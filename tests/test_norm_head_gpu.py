@@ -174,7 +174,48 @@ def test_first_layer_weight_gradient_through_the_norm(per_sample, slope, N, D, H
     _close(dw2, 2 * w.grad, rtol=2e-4, atol=1e-6)
 
 
-@pytest.mark.parametrize("kind", ["unet3d", "vnet", "first:unet3d", "first:vnet"])
+@pytest.mark.parametrize("shape,per_sample,with_skip,p", [((2, 8, 4, 8, 16), False, True, 0.0), ((2, 6, 8, 4, 8), True, True, 0.0),
+                                                          ((3, 16, 1, 16, 32), False, True, 0.3), ((1, 4, 6, 6, 12), False, False, 0.0),
+                                                          ((2, 32, 1, 8, 8), False, False, 0.0)])
+def test_norm_backward_with_the_pool_gradient_on_its_load_path(shape, per_sample, with_skip, p):
+    """mis_norm_act_bwd_pool == mis_maxpool2_bwd (accumulating into the skip gradient) followed by mis_norm_act_bwd
+    (reference unet_3D.py:35-47: conv_k feeds maxpool_k and the decoder's skip connection), 3-D and 2-D."""
+    ops = _ops()
+    N, C, D, H, W = shape
+    x = _rand(*shape, seed=51, scale=2.0).float().cuda()
+    G = N * C if per_sample else C
+    mean, rstd = torch.empty(G, device="cuda"), torch.empty(G, device="cuda")
+    ops.norm_stats(x, per_sample, 1e-5, mean, rstd)
+    gamma = None if per_sample else (_rand(C, seed=52) * 0.5 + 1.0).float().cuda()
+    beta = None if per_sample else (_rand(C, seed=53) * 0.3).float().cuda()
+    mask = ((torch.rand(*shape, generator=torch.Generator().manual_seed(54)) >= p).float() / (1 - p)).cuda() if p > 0 else None
+    a = torch.empty(shape, device="cuda")
+    ops.norm_act_fwd(x, a, per_sample, mean, rstd, gamma, beta, 0.01, drop_p=p, drop_mask=mask)
+    pshape = (N, C, D // 2 if D > 1 else 1, H // 2, W // 2)
+    pooled = torch.empty(pshape, device="cuda")
+    idx = torch.empty(pooled.numel(), dtype=torch.uint8, device="cuda")
+    ops.maxpool2_fwd(a, pooled, idx)
+    dpool = _rand(*pshape, seed=55).float().cuda()
+    dskip = _rand(*shape, seed=56).float().cuda() if with_skip else None
+    # two-pass form
+    da = dskip.clone() if with_skip else torch.empty(shape, device="cuda")
+    ops.maxpool2_bwd(dpool, idx, da, accumulate=with_skip)
+    dx_ref = torch.empty(shape, device="cuda")
+    dg_ref = None if gamma is None else torch.empty(C, device="cuda")
+    db_ref = None if beta is None else torch.empty(C, device="cuda")
+    ops.norm_act_bwd(x, da, dx_ref, per_sample, mean, rstd, gamma, beta, 0.01, drop_p=p, drop_mask=mask, dgamma=dg_ref,
+                     dbeta=db_ref)
+    dx = torch.full(shape, float("nan"), device="cuda")
+    dg = None if gamma is None else torch.full((C,), float("nan"), device="cuda")
+    db = None if beta is None else torch.full((C,), float("nan"), device="cuda")
+    ops.norm_act_bwd_pool(x, dskip, dpool, idx, dx, per_sample, mean, rstd, gamma, beta, 0.01, drop_p=p, drop_mask=mask,
+                          dgamma=dg, dbeta=db)
+    assert torch.equal(dx, dx_ref)
+    if gamma is not None:
+        assert torch.equal(dg, dg_ref) and torch.equal(db, db_ref)
+
+
+@pytest.mark.parametrize("kind", ["unet3d", "vnet", "first:unet3d", "first:vnet", "pool:unet3d", "pool:unet2d"])
 def test_step_with_fused_head_equals_unfused(kind):
     """A Mean-Teacher step (dropout on, device RNG) gives the same losses, gradients and weights with the classifier
     fused into the last block's pass and without.  One step: at this 32^3 fixture the 2^3 / 4^3 levels normalise over
@@ -183,24 +224,31 @@ def test_step_with_fused_head_equals_unfused(kind):
     from mis_hip.step import MeanTeacherTrainer
     from networks.net_factory_3d import net_factory_3d
     from oracle import filler
-    attr = "FUSE_FIRST" if kind.startswith("first:") else "FUSE_HEAD"
+    attr = {"first": "FUSE_FIRST", "pool": "FUSE_POOL"}.get(kind.split(":")[0], "FUSE_HEAD") if ":" in kind else "FUSE_HEAD"
     kind = kind.split(":")[-1]
-    key = {"unet3d": "unet_3D", "vnet": "vnet"}[kind]
+    if kind == "unet2d":
+        from networks.net_factory import net_factory
+        make = lambda: net_factory("unet", 1, 2)
+        vshape, lshape, ldt = (4, 1, 64, 64), (4, 64, 64), torch.uint8
+    else:
+        key = {"unet3d": "unet_3D", "vnet": "vnet"}[kind]
+        make = lambda: net_factory_3d(key, 1, 2)
+        vshape, lshape, ldt = (4, 1, 32, 32, 32), (4, 32, 32, 32), torch.int64
     torch.manual_seed(5)
-    sd0 = {k: v.clone() for k, v in net_factory_3d(key, 1, 2).state_dict().items()}
-    vol = filler.image((4, 1, 32, 32, 32), "volume").cuda()
-    lab = filler.labels((4, 32, 32, 32), 2, torch.int64).cuda()
+    sd0 = {k: v.clone() for k, v in make().state_dict().items()}
+    vol = filler.image(vshape, "volume").cuda()
+    lab = filler.labels(lshape, 2, ldt).cuda()
     res = []
     keep = getattr(plan_mod, attr)
     for fuse in (True, False):
         setattr(plan_mod, attr, fuse)
         try:
-            m, e = net_factory_3d(key, 1, 2), net_factory_3d(key, 1, 2)
+            m, e = make(), make()
             m.load_state_dict(sd0); e.load_state_dict(sd0)
             tr = MeanTeacherTrainer(m, e, labeled_bs=2, num_classes=2, cons_start_iter=0, seed=11, iter_num=1500)
             tr.step(vol, lab)
             torch.cuda.synchronize()
-            mark = "head" if attr == "FUSE_HEAD" else "norm_bwd"
+            mark = {"FUSE_HEAD": "head", "FUSE_FIRST": "norm_bwd", "FUSE_POOL": "pool"}[attr]
             fused = [type(op).__name__ for p in m._plans.values() for op in p.ops if getattr(op, mark, None) is not None]
             assert bool(fused) == fuse
             res.append((tr.losses(), m.flat_grad.clone(), m.flat_param.clone(), e.flat_param.clone()))
