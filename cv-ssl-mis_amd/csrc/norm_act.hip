@@ -238,6 +238,71 @@ __global__ __launch_bounds__(256) void apply_fwd_kernel(const float* __restrict_
     }
 }
 
+// Forward apply for an activation that feeds a 2x max-pool (reference unet_3D.py:35-47 conv_k -> maxpool_k, unet.py:56): the
+// thread that writes a 2 (z) x 2 (y) x 8 (x) block of the activation (1 x 2 x 8 in 2-D) also takes its four window maxima
+// and argmax codes (mis_maxpool2_fwd's: dz*4 + dy*2 + dx, first maximum wins, NaN propagates) -- the pooling pass's read
+// of the full-resolution activation is gone.  grid = (ceil(Ho*Wo/4 / 256), Do, N*C); W % 8 == 0.
+template <int PZ>
+__global__ __launch_bounds__(256) void apply_fwd_pool_kernel(const float* __restrict__ x, Geo g,
+                                                             const float* __restrict__ mean,
+                                                             const float* __restrict__ rstd,
+                                                             const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, float slope, DropCfg d,
+                                                             float* __restrict__ y, long long y_bs,
+                                                             float* __restrict__ pooled, long long p_bs,
+                                                             unsigned char* __restrict__ idx, int H, int W) {
+    const int Ho = H >> 1, Wo = W >> 1, Wq = Wo >> 2;
+    const int pl = blockIdx.x * 256 + threadIdx.x;
+    if (pl >= Ho * Wq) return;
+    const int zo = blockIdx.y, nc = blockIdx.z;
+    const int n = nc / g.C, c = nc - n * g.C;
+    const int yo = pl / Wq, xq = pl - yo * Wq;
+    const int grp = g.per_sample ? (n * g.C + c) / g.cg : c;
+    const float sc = (gamma ? gamma[c] : 1.f) * rstd[grp];
+    const float sh = (beta ? beta[c] : 0.f) - mean[grp] * sc;
+    const float* __restrict__ xb = x + (long long)n * g.x_bs + (long long)c * g.S;
+    float* __restrict__ yb = y + (long long)n * y_bs + (long long)c * g.S;
+    const unsigned long long lbase = ((unsigned long long)n * g.C + c) * g.S;
+    const bool drop = d.p > 0.f;
+    float best[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    unsigned bi[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int dz = 0; dz < PZ; ++dz)
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy) {
+            const unsigned e = (unsigned)(((zo * PZ + dz) * H + (yo * 2 + dy)) * W + xq * 8);
+            float v[8];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const float4 q = *reinterpret_cast<const float4*>(xb + e + 4 * h);
+                float t[4] = {q.x * sc + sh, q.y * sc + sh, q.z * sc + sh, q.w * sc + sh};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) t[j] = t[j] > 0.f ? t[j] : t[j] * slope;
+                if (drop) {
+                    float s4[4];
+                    drop_scale4(d, lbase + e + 4 * h, (unsigned)(n * g.C + c), s4);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) t[j] *= s4[j];
+                }
+                *reinterpret_cast<float4*>(yb + e + 4 * h) = make_float4(t[0], t[1], t[2], t[3]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[4 * h + j] = t[j];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int dx = 0; dx < 2; ++dx) {
+                    const float t = v[2 * j + dx];
+                    if (t > best[j] || t != t) { best[j] = t; bi[j] = dz * 4 + dy * 2 + dx; }
+                }
+        }
+    const long long So = (long long)gridDim.y * Ho * Wo;
+    const unsigned o = (unsigned)((zo * Ho + yo) * Wo + xq * 4);
+    *reinterpret_cast<float4*>(pooled + (long long)n * p_bs + (long long)c * So + o) =
+        make_float4(best[0], best[1], best[2], best[3]);
+    *reinterpret_cast<unsigned*>(idx + (long long)nc * So + o) = bi[0] | (bi[1] << 8) | (bi[2] << 16) | (bi[3] << 24);
+}
+
 // ---------------- backward ----------------
 // dz = da * dropscale * (z > 0 ? 1 : slope),  z = xhat*gamma + beta,  xhat = (x-mean)*rstd
 // partial sums per group: s1 = sum dz, s2 = sum dz*xhat
@@ -522,6 +587,38 @@ extern "C" int mis_norm_act_fwd(const float* x, long long x_bs, float* y, long l
                                 hipStream_t stream) {
     return mis_norm_act_fwd_g(x, x_bs, y, y_bs, N, C, S, per_sample, 1, mean, rstd, gamma, beta, slope, drop_p,
                               drop_salt, state, drop_mask, stream);
+}
+
+// mis_norm_act_fwd_g + mis_maxpool2_fwd in one pass: y = drop(act(norm(x))) [N][C][D][H][W], pooled = its 2x max-pool
+// [N][C][D/2 (D > 1)][H/2][W/2] with the argmax codes idx [N*C][So].  W % 8 == 0, H even, D even or 1.
+extern "C" int mis_norm_act_fwd_pool(const float* x, long long x_bs, float* y, long long y_bs, float* pooled,
+                                     long long p_bs, unsigned char* idx, int N, int C, int D, int H, int W,
+                                     int per_sample, int cg, const float* mean, const float* rstd, const float* gamma,
+                                     const float* beta, float slope, float drop_p, unsigned drop_salt,
+                                     const MisStepState* state, const float* drop_mask, hipStream_t stream) {
+    if (D <= 0 || H <= 0 || W <= 0) return MIS_ERR_ARG;
+    const long long S = (long long)D * H * W;
+    int st = check_geo(x, N, C, S, x_bs);
+    if (st) return st;
+    if (cg < 1 || C % cg != 0 || (cg > 1 && !per_sample)) return MIS_ERR_ARG;
+    if (!y || !pooled || !idx || !mean || !rstd || y_bs < (long long)C * S) return MIS_ERR_ARG;
+    if (W % 8 || H % 2 || (D > 1 && D % 2) || S >= (1LL << 31)) return MIS_ERR_UNSUPPORTED;
+    const int pz = D > 1 ? 2 : 1, Do = D / pz;
+    const long long So = (long long)Do * (H / 2) * (W / 2);
+    if (p_bs < (long long)C * So) return MIS_ERR_ARG;
+    if (y_bs % 4 || p_bs % 4 || !aligned16(y) || !aligned16(pooled) || ((uintptr_t)idx & 3)) return MIS_ERR_UNSUPPORTED;
+    if (drop_p < 0.f || drop_p >= 1.f || (drop_p > 0.f && !state && !drop_mask)) return MIS_ERR_ARG;
+    if (Do > 65535 || (long long)N * C > 65535) return MIS_ERR_UNSUPPORTED;
+    const Geo g = make_geo(N, C, S, x_bs, per_sample, cg);
+    const DropCfg d{drop_p, drop_salt, state, drop_mask};
+    const dim3 grid((unsigned)(((H / 2) * (W / 8) + 255) / 256), Do, N * C);
+    if (pz == 2)
+        hipLaunchKernelGGL(apply_fwd_pool_kernel<2>, grid, dim3(256), 0, stream, x, g, mean, rstd, gamma, beta, slope, d, y,
+                           y_bs, pooled, p_bs, idx, H, W);
+    else
+        hipLaunchKernelGGL(apply_fwd_pool_kernel<1>, grid, dim3(256), 0, stream, x, g, mean, rstd, gamma, beta, slope, d, y,
+                           y_bs, pooled, p_bs, idx, H, W);
+    return mis_launch_status();
 }
 
 // Backward of mis_norm_act_fwd_g.  ``no_norm`` != 0: the layer is activation (+ dropout) only -- the reference's

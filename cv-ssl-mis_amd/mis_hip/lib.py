@@ -75,6 +75,8 @@ PROTOTYPES = {
                                  c_p, c_p]),
     "mis_norm_act_bwd_g": (c_i, [c_p, c_ll, c_p, c_ll, c_p, c_ll, c_i, c_i, c_ll, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_f,
                                  c_f, c_u, c_p, c_p, c_p, c_p, c_i, c_p, c_ll, c_p]),
+    "mis_norm_act_fwd_pool": (c_i, [c_p, c_ll, c_p, c_ll, c_p, c_ll, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p,
+                                    c_p, c_f, c_f, c_u, c_p, c_p, c_p]),
     "mis_norm_act_bwd_pool": (c_i, [c_p, c_ll, c_p, c_ll, c_p, c_ll, c_p, c_p, c_ll, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p,
                                     c_p, c_p, c_p, c_f, c_f, c_u, c_p, c_p, c_p, c_p, c_i, c_p, c_ll, c_p]),
     "mis_norm_act_bwd_sums": (c_i, [c_p, c_ll, c_p, c_ll, c_i, c_i, c_ll, c_i, c_p, c_p, c_p, c_p, c_f, c_p, c_p, c_p, c_i,

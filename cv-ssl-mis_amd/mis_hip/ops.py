@@ -305,6 +305,19 @@ def norm_act_bwd(x, da, dx, per_sample, mean, rstd, gamma, beta, slope, drop_p=0
              "mis_norm_act_bwd_g")
 
 
+def norm_act_fwd_pool(x, y, pooled, idx, per_sample, mean, rstd, gamma, beta, slope, drop_p=0.0, drop_salt=0, state=None,
+                      drop_mask=None, cg=1):
+    """norm_act_fwd and the 2x max-pool of its output (pooled, idx as maxpool2_fwd writes them) in one pass."""
+    L = _l.load()
+    N, C, D, H, W, S, xbs = _geom(x)
+    _, _, _, _, _, _, ybs = _geom(y)
+    _, _, _, _, _, _, pbs = _geom(pooled)
+    _l.check(L.mis_norm_act_fwd_pool(_l.ptr(x), xbs, _l.ptr(y), ybs, _l.ptr(pooled), pbs, _l.ptr(idx), N, C, D, H, W,
+                                     int(per_sample), int(cg), _l.ptr(mean), _l.ptr(rstd), _l.ptr(gamma), _l.ptr(beta),
+                                     slope, drop_p, drop_salt, _l.ptr(state), _l.ptr(drop_mask), _l.stream_ptr()),
+             "mis_norm_act_fwd_pool")
+
+
 def norm_act_bwd_pool(x, da, dpool, idx, dx, per_sample, mean, rstd, gamma, beta, slope, drop_p=0.0, drop_salt=0,
                       state=None, drop_mask=None, dgamma=None, dbeta=None, accumulate_affine=False, cg=1):
     """norm_act_bwd of an activation that also feeds a 2x max-pool: incoming gradient = da (None: no other consumer) +

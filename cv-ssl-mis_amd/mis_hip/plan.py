@@ -34,6 +34,7 @@ FUSE_HEAD = os.environ.get("MIS_FUSE_HEAD", "1") != "0"
 FUSE_FIRST = os.environ.get("MIS_FUSE_FIRST", "1") != "0"
 # max-pool backward on the load path of the producing block's normalisation backward (mis_norm_act_bwd_pool)
 FUSE_POOL = os.environ.get("MIS_FUSE_POOL", "1") != "0"
+FUSE_POOL_FWD = os.environ.get("MIS_FUSE_POOL_FWD", "1") != "0"     # ... and the pool's forward inside the apply pass
 
 
 class Act:
@@ -201,6 +202,13 @@ class NormActOp:
         self._state = ctx.state
         if self._p > 0 and self._mask is None and ctx.state is None:
             raise RuntimeError("dropout is active but no device step state was supplied (Ctx.state)")
+        if self.pool is not None and self.pool.fwd_fused:
+            pl = self.pool
+            ops.norm_act_fwd_pool(self.x.t, self.y.t, pl.y.t, pl.idx, self.per_sample, self.mean, self.rstd,
+                                  None if self.gamma is None else self.gamma.data,
+                                  None if self.beta is None else self.beta.data, self.slope, self._p, self.salt,
+                                  self._state, self._mask, cg=self.cg)
+            return
         if self.head is not None:
             h = self.head
             ops.norm_head_fwd(self.x.t, h.y.t, self.per_sample, self.mean, self.rstd,
@@ -258,8 +266,11 @@ class MaxPoolOp:
         self.x, self.y = x, y
         self.idx = torch.empty(y.t.numel(), dtype=torch.uint8, device="cuda")
         self.fused_into = None   # NormActOp (producer of x) whose backward adds this pool's gradient on its load path
+        self.fwd_fused = False   # ... and whose forward also writes this pool's output and argmax codes
 
     def fwd(self, ctx):
+        if self.fwd_fused:
+            return
         ops.maxpool2_fwd(self.x.t, self.y.t, self.idx)
 
     def bwd(self, ctx):
@@ -441,6 +452,10 @@ class Plan:
             if (prod is not None and prod.pool is None and prod.head is None and prod.sums is None and not prod.no_norm
                     and W % 4 == 0 and H % 2 == 0 and (D == 1 or D % 2 == 0) and D * H * W < 2 ** 31):
                 prod.pool, op.fused_into = op, prod
+                # forward too (2-D: config 2 10.47 -> 10.41 ms; measured neutral on the 3-D volumes, where the fused
+                # kernel's four row pairs per thread cost what the saved pass gains: kept on the plain pair there)
+                # when the two ops are adjacent and the rows split into 8-float pieces
+                op.fwd_fused = FUSE_POOL_FWD and D == 1 and W % 8 == 0 and prod is self.ops[-1] and y.parent is None
         self.ops.append(op)
         return y
 

@@ -211,6 +211,14 @@ int mis_norm_head_bwd(const float* x, long long x_bs, const float* dlogits, long
                       float* dbeta, int accumulate_affine, float* dw, float* db, int accumulate_w, void* workspace,
                       long long workspace_bytes, mis_stream_t stream);
 
+/* mis_norm_act_fwd_g + mis_maxpool2_fwd in one pass (reference unet_3D.py:35-47 conv_k -> maxpool_k; unet.py:56): writes
+ * the activation y AND its 2x max-pool `pooled` [N][C][D/2 (D > 1)][H/2][W/2] with the argmax codes idx [N*C][So] (the
+ * same values mis_maxpool2_fwd produces).  W % 8 == 0, H even, D even or 1. */
+int mis_norm_act_fwd_pool(const float* x, long long x_bs, float* y, long long y_bs, float* pooled, long long p_bs,
+                          unsigned char* idx, int N, int C, int D, int H, int W, int per_sample, int cg,
+                          const float* mean, const float* rstd, const float* gamma, const float* beta, float slope,
+                          float drop_p, unsigned drop_salt, const MisStepState* state, const float* drop_mask,
+                          mis_stream_t stream);
 /* mis_norm_act_bwd_g for an activation [N][C][D][H][W] that also feeds a 2x max-pool (reference unet_3D.py:35-47 conv_k ->
  * maxpool_k with the skip connection to the decoder; unet.py:56 DownBlock): the incoming gradient is da (the other
  * consumers; NULL: none) plus the backward of the pool -- dpool [N][C][D/2 (D > 1)][H/2][W/2] scattered by

@@ -195,6 +195,11 @@ def test_norm_backward_with_the_pool_gradient_on_its_load_path(shape, per_sample
     pooled = torch.empty(pshape, device="cuda")
     idx = torch.empty(pooled.numel(), dtype=torch.uint8, device="cuda")
     ops.maxpool2_fwd(a, pooled, idx)
+    if W % 8 == 0:      # forward: the apply pass writes the pooled output and the argmax codes itself
+        a2, pooled2 = torch.full(shape, float("nan"), device="cuda"), torch.full(pshape, float("nan"), device="cuda")
+        idx2 = torch.full_like(idx, 255)
+        ops.norm_act_fwd_pool(x, a2, pooled2, idx2, per_sample, mean, rstd, gamma, beta, 0.01, drop_p=p, drop_mask=mask)
+        assert torch.equal(a2, a) and torch.equal(pooled2, pooled) and torch.equal(idx2, idx)
     dpool = _rand(*pshape, seed=55).float().cuda()
     dskip = _rand(*shape, seed=56).float().cuda() if with_skip else None
     # two-pass form
