@@ -435,12 +435,20 @@ __global__ __launch_bounds__(256) void conv_small_cout_kernel(const ConvFwdArgs 
 // Same tiles (4 x 8 x 16 voxels) and the same per-tile (sum, sumsq) epilogue as Cfg<3,3,3,4,8,16,16,4,8>, so the
 // statistics plumbing does not change.  A wave takes one z plane: 8 rows of 16 voxels.
 // ---------------------------------------------------------------------------------------------------------
-namespace cin1 {
-constexpr int TZ = 4, TY = 8, TX = 16, HZ = TZ + 2, HY = TY + 2, HX = TX + 2, HALO = HZ * HY * HX;
-}
+// KD = 3: Conv3d(1 -> 16, 3, pad 1) on tiles of 4 x 8 x 16 voxels, a wave per z plane (27 taps, 7 MFMAs per 16 voxels);
+// KD = 1: Conv2d(1 -> 16, 3, pad 1) (reference unet.py:37 in_conv of the 2-D UNet) on tiles of 32 x 16 pixels, a wave per
+// 8 rows (9 taps, 3 MFMAs per 16 pixels)
+template <int KD>
+struct Cin1 {
+    static constexpr int TZ = KD == 3 ? 4 : 1, TY = KD == 3 ? 8 : 32, TX = 16, WROWS = 8;     // rows of a wave
+    static constexpr int HZ = TZ + KD - 1, HY = TY + 2, HX = TX + 2, HALO = HZ * HY * HX;
+    static constexpr int TAPS = 9 * KD, NG = (TAPS + 3) / 4;
+};
 
+template <int KD>
 __global__ __launch_bounds__(256) void conv_fwd_cin1_kernel(const ConvFwdArgs a) {
-    __shared__ float sx[cin1::HALO];
+    using C = Cin1<KD>;
+    __shared__ float sx[C::HALO];
     __shared__ float2 red[4 * 16];
     const unsigned L = mis_xcd_remap(blockIdx.x, a.n_blocks_padded);
     if (L >= a.n_blocks) return;
@@ -449,39 +457,41 @@ __global__ __launch_bounds__(256) void conv_fwd_cin1_kernel(const ConvFwdArgs a)
     const int ty = t % a.tiles_y; t /= a.tiles_y;
     const int tz = t % a.tiles_z; t /= a.tiles_z;
     const int n = t;
-    const int z0 = tz * cin1::TZ, y0 = ty * cin1::TY, x0 = tx * cin1::TX;
+    const int z0 = tz * C::TZ, y0 = ty * C::TY, x0 = tx * C::TX;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lk = lane >> 4, lj = lane & 15;
     const long long S = (long long)a.D * a.H * a.W;
     const float* __restrict__ xn = a.x + (long long)n * a.x_bs;
-    for (int e = tid; e < cin1::HALO; e += 256) {
-        const int hz = e / (cin1::HY * cin1::HX), r2 = e - hz * (cin1::HY * cin1::HX), hy = r2 / cin1::HX, hx = r2 - hy * cin1::HX;
-        const int gz = z0 + hz - 1, gy = y0 + hy - 1, gx = x0 + hx - 1;
+    for (int e = tid; e < C::HALO; e += 256) {
+        const int hz = e / (C::HY * C::HX), r2 = e - hz * (C::HY * C::HX), hy = r2 / C::HX, hx = r2 - hy * C::HX;
+        const int gz = z0 + hz - (KD == 3 ? 1 : 0), gy = y0 + hy - 1, gx = x0 + hx - 1;
         const bool ok = (unsigned)gz < (unsigned)a.D && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
         sx[e] = ok ? xn[((long long)gz * a.H + gy) * a.W + gx] : 0.f;
     }
-    // weights (packed [1 -> 4][27][16]: wp[tap * 16 + co]) and the LDS offset of this lane's tap of every group
-    float wa[7];
-    int toff[7];
+    // weights (packed [1 -> 4][taps][16]: wp[tap * 16 + co]) and the LDS offset of this lane's tap of every group
+    float wa[C::NG];
+    int toff[C::NG];
 #pragma unroll
-    for (int g = 0; g < 7; ++g) {
+    for (int g = 0; g < C::NG; ++g) {
         const int tap = 4 * g + lk;
-        wa[g] = tap < 27 ? a.wp[tap * a.Cout_pad + lj] : 0.f;
-        const int tc = tap < 27 ? tap : 26;
-        toff[g] = ((tc / 9) * cin1::HY + (tc / 3) % 3) * cin1::HX + tc % 3;
+        wa[g] = tap < C::TAPS ? a.wp[tap * a.Cout_pad + lj] : 0.f;
+        const int tc = tap < C::TAPS ? tap : C::TAPS - 1;
+        toff[g] = ((tc / 9) * C::HY + (tc / 3) % 3) * C::HX + tc % 3;
     }
     float bv[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) bv[r] = a.bias ? a.bias[lk * 4 + r] : 0.f;
     __syncthreads();
-    const float* __restrict__ sb = sx + (wave * cin1::HY) * cin1::HX + lj;
-    float* __restrict__ yo = a.y + (long long)n * a.y_bs + ((long long)(z0 + wave) * a.H + y0) * a.W + x0 + lj;
+    // this wave's rows: plane z0 + wave (3-D) / rows y0 + 8 wave ... (2-D)
+    const int wz = KD == 3 ? wave : 0, wy = KD == 3 ? 0 : wave * C::WROWS;
+    const float* __restrict__ sb = sx + (wz * C::HY + wy) * C::HX + lj;
+    float* __restrict__ yo = a.y + (long long)n * a.y_bs + ((long long)(z0 + wz) * a.H + y0 + wy) * a.W + x0 + lj;
     float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll 2
-    for (int row = 0; row < cin1::TY; ++row) {
+    for (int row = 0; row < C::WROWS; ++row) {
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int g = 0; g < 7; ++g)
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[g], sb[row * cin1::HX + toff[g]], acc, 0, 0, 0);
+        for (int g = 0; g < C::NG; ++g)
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[g], sb[row * C::HX + toff[g]], acc, 0, 0, 0);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const float v = acc[r] + bv[r];
@@ -508,18 +518,23 @@ __global__ __launch_bounds__(256) void conv_fwd_cin1_kernel(const ConvFwdArgs a)
     }
 }
 
-bool cin1_eligible(const ConvFwdArgs& a, int kd, int kh, int kw) {
-    return kd == 3 && kh == 3 && kw == 3 && a.Cin == 1 && a.Cout == 16 && a.D % cin1::TZ == 0 && a.H % cin1::TY == 0 &&
-           a.W % cin1::TX == 0;
+// 3 (3x3x3 on a volume), 1 (3x3 on images), 0: not the first-layer form
+int cin1_kd(const ConvFwdArgs& a, int kd, int kh, int kw) {
+    if (kh != 3 || kw != 3 || a.Cin != 1 || a.Cout != 16) return 0;
+    if (kd == 3 && a.D % Cin1<3>::TZ == 0 && a.H % Cin1<3>::TY == 0 && a.W % Cin1<3>::TX == 0) return 3;
+    if (kd == 1 && a.D == 1 && a.H % Cin1<1>::TY == 0 && a.W % Cin1<1>::TX == 0) return 1;
+    return 0;
 }
 
+template <int KD>
 int launch_cin1(ConvFwdArgs a, hipStream_t stream) {
-    a.tiles_z = a.D / cin1::TZ; a.tiles_y = a.H / cin1::TY; a.tiles_x = a.W / cin1::TX;
+    using C = Cin1<KD>;
+    a.tiles_z = a.D / C::TZ; a.tiles_y = a.H / C::TY; a.tiles_x = a.W / C::TX;
     const long long nb = (long long)a.N * a.tiles_z * a.tiles_y * a.tiles_x;
     if (nb <= 0 || nb > 0x7fffffffLL) return MIS_ERR_ARG;
     a.n_blocks = (unsigned)nb;
     a.n_blocks_padded = (unsigned)(mis_cdiv(nb, MIS_NUM_XCD) * MIS_NUM_XCD);
-    hipLaunchKernelGGL(conv_fwd_cin1_kernel, dim3(a.n_blocks_padded), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL(conv_fwd_cin1_kernel<KD>, dim3(a.n_blocks_padded), dim3(256), 0, stream, a);
     return mis_launch_status();
 }
 
@@ -582,10 +597,14 @@ int dispatch_fwd(ConvFwdArgs a, int kd, int kh, int kw, hipStream_t stream, char
     // unet_3D's 48 -> 16 decoder conv): three exact 16-channel blocks beat 32 + a half-empty 32
     // (measured 2.4 ms vs 3.1 ms for 16 -> 48 at 96^3 x 8).
     const bool wide = a.Cout_pad >= 32 && a.Cout_pad % 32 == 0;
-    if (cin1_eligible(a, kd, kh, kw)) {      // first layer: the taps as the MFMA's contraction (same tiles as the generic form)
-        if (stat_tiles) { *stat_tiles = (long long)(a.D / cin1::TZ) * (a.H / cin1::TY) * (a.W / cin1::TX); return MIS_OK; }
-        if (name) { snprintf(name, name_len, "conv_fwd_cin1_kernel"); return MIS_OK; }
-        return launch_cin1(a, stream);
+    if (const int c1 = cin1_kd(a, kd, kh, kw)) {      // first layer: the taps as the MFMA's contraction
+        if (stat_tiles) {
+            *stat_tiles = c1 == 3 ? (long long)(a.D / Cin1<3>::TZ) * (a.H / Cin1<3>::TY) * (a.W / Cin1<3>::TX)
+                                  : (long long)(a.H / Cin1<1>::TY) * (a.W / Cin1<1>::TX);
+            return MIS_OK;
+        }
+        if (name) { snprintf(name, name_len, c1 == 3 ? "conv_fwd_cin1_kernel<3>" : "conv_fwd_cin1_kernel<1>"); return MIS_OK; }
+        return c1 == 3 ? launch_cin1<3>(a, stream) : launch_cin1<1>(a, stream);
     }
     if (kd == 3 && kh == 3 && kw == 3) {
         if (a.W % 16 == 0 || a.W >= 64) {

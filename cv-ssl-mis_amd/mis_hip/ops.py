@@ -358,7 +358,7 @@ def conv_wgrad_cin1_norm(x, da, y, per_sample, mean, rstd, gamma, beta, sums, sl
     N, Cin, D, H, W, S, xbs = _geom(x)
     _, _, _, _, _, _, dabs = _geom(da)
     _, Cout, _, _, _, _, ybs = _geom(y)
-    nb = L.mis_conv_wgrad_workspace_bytes(N, Cin, Cout, D, H, W, 3, 3, 3)
+    nb = L.mis_conv_wgrad_workspace_bytes(N, Cin, Cout, D, H, W, 1 if D == 1 else 3, 3, 3)
     if nb < 0:
         _l.check(nb, "mis_conv_wgrad_workspace_bytes")
     ws = scratch(nb, "wgrad")

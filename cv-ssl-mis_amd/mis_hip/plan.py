@@ -422,7 +422,7 @@ class Plan:
                 prev.stat_norm = op
                 op.fused = (part, T)
         if (FUSE_FIRST and type(prev) is ConvOp and prev.y is x and not prev.need_dx and prev.cin == 1
-                and prev.ksize == (3, 3, 3) and drop_p == 0.0 and cg == 1 and not no_norm
+                and prev.ksize in ((3, 3, 3), (1, 3, 3)) and drop_p == 0.0 and cg == 1 and not no_norm
                 and not (per_sample and (gamma is not None or beta is not None)) and x.parent is None
                 and ops.conv_wgrad_cin1_norm_eligible(x.shape[0], prev.cout, *x.shape[2:])):
             op.sums = torch.empty((x.shape[0] * x.shape[1] if per_sample else x.shape[1], 2), dtype=torch.float32,

@@ -56,11 +56,11 @@ MT_CASES = {
     # name: (kind, shape, labeled, classes, label dtype, iter_num, cons_start_iter, conv instantiations that only the
     #        full batch reaches)
     "config2_unet2d_24+24_256": ("unet2d", (48, 1, 256, 256), 24, 4, torch.uint8, 1200, 1000,
-                                 ["Cfg<1, 3, 3, 1, 16, 32, 16, 8, 8>",        # first layer (1 input channel): direct
+                                 ["name:conv_fwd_cin1_kernel<1>",             # first layer (1 input channel): taps as K
                                   "wino2d:W2Cfg<8, 8, 1, 4>",                 # 16 output channels: Winograd F(2x2, 3x3)
                                   "wino2d:W2Cfg<8, 8, 2, 3>"]),               # 32 and more
     "config3_unet3d_4+4_96": ("unet3d", (8, 1, 96, 96, 96), 4, 2, torch.int64, 1200, 0,
-                              ["name:conv_fwd_cin1_kernel",                        # first layer (1 input channel): taps as K
+                              ["name:conv_fwd_cin1_kernel<3>",                     # first layer (1 input channel): taps as K
                                "Cfg<3, 3, 3, 2, 8, 8, 16, 4, 2>",                  # 6^3 level of the teacher's 4 volumes: direct
                                "wino:WinoCfg<1, 1, 16, 2, 2, 1, 1, 4, 0>",         # 96^3: Winograd, 4 x 4 x 32 boxes
                                "wino:WinoCfg<1, 2, 8, 2, 2, 1, 1, 4, 0>",          # 48^3: 4 x 8 x 16 boxes

@@ -36,7 +36,9 @@ def _close(a, b, rtol=2e-4, atol=2e-5):
 
 CONV_CASES = [
     # N, Cin, Cout, D, H, W, k
-    (2, 1, 16, 1, 32, 32, (3, 3)),
+    (2, 1, 16, 1, 32, 32, (3, 3)),       # first layer of the 2-D UNet: conv_fwd_cin1_kernel<1>, wgrad_cin1_kernel<1>
+    (3, 1, 16, 1, 64, 96, (3, 3)),
+    (2, 1, 16, 1, 40, 32, (3, 3)),       # H not a multiple of 32: the generic kernels
     (2, 16, 16, 1, 64, 64, (3, 3)),
     (1, 32, 64, 1, 16, 16, (3, 3)),
     (2, 48, 32, 1, 32, 48, (3, 3)),
@@ -96,7 +98,8 @@ def test_conv_fwd_dgrad_wgrad(case):
 @pytest.mark.parametrize("N,Cin,Cout,D,H,W,k,per_sample", [
     (3, 16, 32, 1, 32, 64, (3, 3), False), (2, 8, 16, 1, 128, 128, (3, 3), False),
     (2, 16, 16, 8, 16, 16, (3, 3, 3), True), (2, 32, 32, 8, 16, 32, (3, 3, 3), True),
-    (2, 1, 16, 8, 16, 32, (3, 3, 3), True)])      # first layer: conv_fwd_cin1_kernel
+    (2, 1, 16, 8, 16, 32, (3, 3, 3), True),       # first layer: conv_fwd_cin1_kernel<3>
+    (3, 1, 16, 1, 64, 48, (3, 3), False)])        # ... of the 2-D UNet: conv_fwd_cin1_kernel<1>
 def test_conv_fused_statistics(N, Cin, Cout, D, H, W, k, per_sample):
     """mis_conv_fwd_stats + mis_norm_stats_finalize == conv followed by the statistics of BatchNorm / InstanceNorm."""
     ops = _ops()

@@ -226,23 +226,25 @@ def test_wino_full_size_layer_matches_direct():
     assert (d0 - d1).abs().max().item() <= 2e-5 * d0.abs().max().item()
 
 
-@pytest.mark.parametrize("N,D,H,W", [(1, 4, 8, 32), (2, 8, 16, 64), (3, 4, 8, 96)])
+@pytest.mark.parametrize("N,D,H,W", [(1, 4, 8, 32), (2, 8, 16, 64), (3, 4, 8, 96), (2, 1, 32, 32), (3, 1, 64, 96)])
 def test_first_layer_weight_gradient(N, D, H, W):
-    """Conv3d(1 -> 16) (unet_3D.py:28 conv1, vnet.py:123 block_one): the taps-as-columns MFMA kernel
-    (conv_wgrad_cin1.hip) behind mis_conv_wgrad, against torch fp64; deterministic; `accumulate` adds."""
+    """Conv3d(1 -> 16) (unet_3D.py:28 conv1, vnet.py:123 block_one) and, D == 1, Conv2d(1 -> 16) (unet.py:37): the
+    taps-as-columns MFMA kernel (conv_wgrad_cin1.hip) behind mis_conv_wgrad, against torch fp64; deterministic;
+    `accumulate` adds."""
     ops = _ops()
+    k = (3, 3, 3) if D > 1 else (3, 3)
     x = _rand(N, 1, D, H, W, seed=31)
     dy = _rand(N, 16, D, H, W, seed=32)
-    w = torch.zeros(16, 1, 3, 3, 3, dtype=torch.float64, requires_grad=True)
-    F.conv3d(x, w, padding=1).backward(dy)
+    w = torch.zeros(16, 1, *((3, 3, 3) if D > 1 else (1, 3, 3)), dtype=torch.float64, requires_grad=True)
+    F.conv3d(x, w, padding=(1, 1, 1) if D > 1 else (0, 1, 1)).backward(dy)
     xd, dyd = x.float().cuda(), dy.float().cuda()
-    dw = torch.full((16, 1, 3, 3, 3), float("nan"), device="cuda")
-    ops.conv_wgrad(xd, dyd, dw, (3, 3, 3))
+    dw = torch.full(tuple(w.shape), float("nan"), device="cuda")
+    ops.conv_wgrad(xd, dyd, dw, k)
     _close(dw, w.grad, rtol=1e-5, atol=1e-6)
     dw2 = torch.empty_like(dw)
-    ops.conv_wgrad(xd, dyd, dw2, (3, 3, 3))
+    ops.conv_wgrad(xd, dyd, dw2, k)
     assert torch.equal(dw, dw2)
-    ops.conv_wgrad(xd, dyd, dw2, (3, 3, 3), accumulate=True)
+    ops.conv_wgrad(xd, dyd, dw2, k, accumulate=True)
     _close(dw2, 2 * w.grad, rtol=1e-5, atol=1e-6)
 
 
