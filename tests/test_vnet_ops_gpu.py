@@ -34,9 +34,9 @@ def _ctx():
     return Ctx(True)
 
 
-def test_space_to_depth_round_trip_and_layout():
+@pytest.mark.parametrize("N,C,D,H,W", [(2, 3, 4, 6, 8), (2, 3, 4, 6, 12), (1, 5, 6, 4, 24)])     # W % 8 == 0: float4 form
+def test_space_to_depth_round_trip_and_layout(N, C, D, H, W):
     from mis_hip import ops
-    N, C, D, H, W = 2, 3, 4, 6, 8
     x = _rand(N, C, D, H, W, seed=1)
     xs = torch.empty(N, 8 * C, D // 2, H // 2, W // 2, device="cuda")
     ops.space_to_depth2(x.cuda(), xs, (N, C, D, H, W), True)
@@ -48,6 +48,8 @@ def test_space_to_depth_round_trip_and_layout():
     bias = _rand(C, seed=2).cuda()
     ops.space_to_depth2(xs, back, (N, C, D, H, W), False, bias=bias, accumulate=True)
     _close(back, 2 * x + bias.cpu().view(1, C, 1, 1, 1), rtol=1e-6, atol=1e-6)
+    ops.space_to_depth2(x.cuda(), xs, (N, C, D, H, W), True, accumulate=True)
+    assert torch.equal(xs.cpu(), 2 * ref)
 
 
 def test_add_copy_and_strided():
