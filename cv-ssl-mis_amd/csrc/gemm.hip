@@ -611,17 +611,40 @@ __global__ __launch_bounds__(256) void gemm_reduce_kernel(const GemmArgs a) {
 int tn_tile(int M, int N) { return (M % 96 == 0 && N % 96 == 0 && (M % 128 != 0 || N % 128 != 0)) ? 96 : 128; }
 int nt_tile_n(int N) { return (N % 96 == 0 && N % 128 != 0) ? 96 : 128; }
 
+// NT form: rows per tile (128 / 64) and K slices.  Split-K only when the tiles cannot fill the chip (deep SwinUnet stages,
+// the ViT of UNETR: 60 .. 114 tiles of 128 rows) and K is long: every slice costs a write + read of the M x N partial
+// and the reduction launch (~20 us).  One workgroup per CU is the unit: a second resident workgroup halves each one's
+// speed, so slices beyond 256 workgroups buy nothing and a partial second round doubles the time (measured: 5 slices of
+// 114 tiles 158 us).  64-row tiles double the tile count instead: UNETR's M = 1728, N = K = 768 Linears are 84 tiles x 3
+// slices + reduction (49 + 20 us) or 162 tiles unsplit -- the cost model below (workgroup time ~ rows x K / slices, +
+// a fixed share per round, + the reduction) picks between them.
+void nt_choice(int M, int N, int K, int& bm, int& ks) {
+    static const int force = getenv("MIS_GEMM_BM") ? atoi(getenv("MIS_GEMM_BM")) : 0;
+    const long long tn = mis_cdiv(N, nt_tile_n(N));
+    long long best = -1;
+    for (int rows = 128; rows >= 64; rows -= 64) {
+        if ((force == 64 || force == 128) && rows != force) continue;
+        const long long tiles = mis_cdiv(M, rows) * tn;
+        long long s = 256 / tiles;
+        const long long kmax = K / (8 * BK);      // at least 8 k-steps per slice
+        if (s > kmax) s = kmax;
+        if (s < 2) s = 1;
+        const long long rounds = mis_cdiv(tiles * s, 256);
+        // units: one row of a tile over one k; 128 rows x 768 k = 40 us measured -> 2458 units / us
+        long long cost = rounds * ((long long)rows * mis_cdiv(K, s) + 128 * 96);
+        if (s > 1) cost += 49152 + (long long)(0.0039 * (double)s * M * N);
+        if (best < 0 || cost < best) { best = cost; bm = rows; ks = (int)s; }
+    }
+}
+
+int nt_tile_m(int M, int N, int K);
+
 int pick_ks(int M, int N, int K, int trans) {
     if (!trans) {
-        // NT: only when the tiles cannot fill the chip (deep SwinUnet stages: 60..114 tiles for 512 resident
-        // workgroups) and K is long; few slices -- every slice costs a write + read of the M x N partial
-        const long long tiles = mis_cdiv(M, BM) * mis_cdiv(N, nt_tile_n(N));
-        // one workgroup per CU: a second resident workgroup halves each one's speed, so slices beyond 256
-        // workgroups buy nothing and a partial second round doubles the time (measured: 5 slices of 114 tiles 158 us)
-        long long ks = 256 / tiles;
-        const long long kmax = K / (8 * BK);      // at least 8 k-steps per slice
-        if (ks > kmax) ks = kmax;
-        return ks < 2 ? 1 : (int)ks;
+        if (nt_tile_m(M, N, K) == 64 && K <= 192) return 1;      // the short contractions: never split
+        int bm, ks;
+        nt_choice(M, N, K, bm, ks);
+        return ks;
     }
     const int bt = tn_tile(M, N);
     const long long tiles = mis_cdiv(M, bt) * mis_cdiv(N, bt);
@@ -658,9 +681,10 @@ int launch_nt_bm(const GemmArgs& a, hipStream_t stream) {
 // rows per tile of the NT form: 64 for the short contractions of the first stages (K = 96 / 192 over 10^4 .. 10^5 token
 // rows), where a tile is a prologue, 3 .. 6 k-steps and an epilogue: three resident workgroups per CU overlap them
 int nt_tile_m(int M, int N, int K) {
-    static const int force = getenv("MIS_GEMM_BM") ? atoi(getenv("MIS_GEMM_BM")) : 0;
-    if (force == 64 || force == 128) return force;
-    return (K <= 192 && mis_cdiv(M, 64) * mis_cdiv(N, nt_tile_n(N)) >= 1536) ? 64 : 128;
+    if (K <= 192 && mis_cdiv(M, 64) * mis_cdiv(N, nt_tile_n(N)) >= 1536) return 64;
+    int bm, ks;
+    nt_choice(M, N, K, bm, ks);
+    return bm;
 }
 
 // the short-contraction kernel serves: float4 epilogue, no split-K, no pixel-shuffle store, K <= 192, many tiles
@@ -700,7 +724,7 @@ int launch_nt(GemmArgs& a, hipStream_t stream) {
         a.n_blocks_padded = (unsigned)(mis_cdiv(nbs, MIS_NUM_XCD) * MIS_NUM_XCD);
         return launch_nt_short<BN>(a, stream);
     }
-    const int bm = a.KS > 1 ? BM : nt_tile_m(a.M, a.N, a.K);
+    const int bm = nt_tile_m(a.M, a.N, a.K);
     a.tiles_m = (int)mis_cdiv(a.M, bm);
     const long long nb = (long long)a.tiles_n * a.tiles_m * a.KS;
     if (nb > 0x7fffffffLL) return MIS_ERR_UNSUPPORTED;
@@ -719,7 +743,7 @@ extern "C" int mis_gemm_nt_kernel_name(int M, int N, int K, int epilogue, char* 
     a.M = M; a.N = N; a.K = K; a.vec4 = N % 4 == 0; a.KS = pick_ks(M, N, K, 0);
     const int bn = nt_tile_n(N);
     if (nt_short(a)) snprintf(name, name_len, "gemm_nt_short_kernel<%d, %d>", bn, epilogue);
-    else snprintf(name, name_len, "gemm_nt_kernel<%d, %d, %d>", a.KS > 1 ? BM : nt_tile_m(M, N, K), bn, a.KS > 1 ? 0 : epilogue);
+    else snprintf(name, name_len, "gemm_nt_kernel<%d, %d, %d>", nt_tile_m(M, N, K), bn, a.KS > 1 ? 0 : epilogue);
     return MIS_OK;
 }
 
