@@ -654,7 +654,8 @@ int pick_ks(int M, int N, int K, int trans) {
     const int bt = tn_tile(M, N);
     const long long tiles = mis_cdiv(M, bt) * mis_cdiv(N, bt);
     if (tiles >= 256) return 1;
-    long long ks = 1024 / tiles;
+    static const int slots = getenv("MIS_GEMM_TN_SLOTS") ? atoi(getenv("MIS_GEMM_TN_SLOTS")) : 768;      // slices x tiles ~ three workgroups per CU (512: 36.6, 768: 35.5, 1024: 35.8 ms per SwinUnet step)
+    long long ks = slots / tiles;
     const long long kmax = mis_cdiv(K, 4 * BK);   // at least 4 k-steps per slice
     if (ks > kmax) ks = kmax;
     if (ks < 1) ks = 1;
