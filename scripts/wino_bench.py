@@ -13,16 +13,19 @@ L = _l.load()
 c_p, c_i, c_ll = ctypes.c_void_p, ctypes.c_int, ctypes.c_longlong
 
 
-def wino(x, w, bias, variant, stat=None):
+def wino(x, w, bias, variant, stat=False):
     N, Cin, D, H, W = x.shape
     Cout = w.shape[0]
     wt = ops.conv_pack(w, 4)
     y = torch.empty(N, Cout, D, H, W, device="cuda")
     S = D * H * W
+    tiles = L.mis_conv3d_wino_stat_tiles(D, H, W, variant)
+    st = torch.zeros(Cout, N, tiles, 2, device="cuda") if stat else None
 
     def run():
         _l.check(L.mis_conv3d_wino_fwd(_l.ptr(x), Cin * S, _l.ptr(wt), _l.ptr(bias), _l.ptr(y), Cout * S, N, Cin, Cout,
-                                       D, H, W, None, 0, 0, variant, _l.stream_ptr()), "wino")
+                                       D, H, W, _l.ptr(st) if stat else None, N * tiles if stat else 0, tiles if stat else 0,
+                                       variant, _l.stream_ptr()), "wino")
     run()
     return y, run
 
@@ -114,7 +117,8 @@ def main():
             w = torch.randn(Cout, Cin, 3, 3, 3, device="cuda") * 0.05
             b = torch.randn(Cout, device="cuda")
             yw, rw = wino(x, w, b, var)
-            print(f"dbg {os.environ['MIS_WINO_DBG']} N{N} {Cin}->{Cout} {S}^3: {timeit(rw):8.1f} us", flush=True)
+            yw2, rw2 = wino(x, w, b, var, stat=True)
+            print(f"dbg {os.environ['MIS_WINO_DBG']} N{N} {Cin}->{Cout} {S}^3: {timeit(rw):8.1f} us   with stats {timeit(rw2):8.1f} us", flush=True)
         return
     for (N, Cin, Cout, D, H, W, var) in [(1, 16, 16, 4, 4, 32, 0), (2, 16, 16, 8, 12, 64, 0), (1, 24, 32, 6, 10, 20, 0),
                                          (2, 16, 32, 8, 8, 16, 1), (1, 32, 32, 6, 6, 36, 1), (3, 48, 16, 10, 6, 40, 0),
