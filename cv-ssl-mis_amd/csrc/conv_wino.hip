@@ -52,9 +52,12 @@ struct WinoArgs {
 };
 
 // group = GZ x GY x GX tiles (16) per wave; workgroup = WZ x WY x WX groups x COB blocks of 16 output channels (4 waves)
-template <int GZ_, int GY_, int GX_, int WZ_, int WY_, int WX_, int COB_, int NBUF_, int DW_ = 0>
+// FLAT = 1: the box is GZ x GY x GX tiles (<= 64, any shape) and the 4 waves take its tiles 16 at a time in (z, y, x) order
+// (lanes past the last tile idle): boxes that do not split into 4 x 16-tile groups, e.g. 3 x 3 x 6 tiles for a 12^3 volume
+// (54 of 64 lanes busy instead of the 27 of 64 that partly filled 8 x 8 x 8 boxes give)
+template <int GZ_, int GY_, int GX_, int WZ_, int WY_, int WX_, int COB_, int NBUF_, int DW_ = 0, int FLAT_ = 0>
 struct WinoCfg {
-    static constexpr int GZ = GZ_, GY = GY_, GX = GX_, WZ = WZ_, WY = WY_, WX = WX_, COB = COB_, NBUF = NBUF_;
+    static constexpr int GZ = GZ_, GY = GY_, GX = GX_, WZ = WZ_, WY = WY_, WX = WX_, COB = COB_, NBUF = NBUF_, FLAT = FLAT_;
     static constexpr int BZ = GZ * WZ, BY = GY * WY, BX = GX * WX;          // tiles per box
     static constexpr int OZ = 2 * BZ, OY = 2 * BY, OX = 2 * BX;             // output voxels per box
     static constexpr int HZ = OZ + 2, HY = OY + 2;
@@ -78,8 +81,8 @@ struct WinoCfg {
     static constexpr int LDS_BYTES = NBUF * STAGE * 4 + 512 + MAX_COUT * 4 + NCH * 256;   // + statistics scratch, bias, DMA geometry
     static constexpr int WPW = COB * 4;                                     // 1 KiB filter pieces per wave
     static constexpr int P = NCH + WPW;                                     // DMA instructions per wave and stage
-    static_assert(GZ * GY * GX == 16, "16 tiles per wave");
-    static_assert(WZ * WY * WX * COB == 4, "4 waves");
+    static_assert(FLAT ? (GZ * GY * GX <= 64 && WZ * WY * WX == 1 && COB == 1 && DW == 1) : (GZ * GY * GX == 16), "16 tiles per wave");
+    static_assert(FLAT || WZ * WY * WX * COB == 4, "4 waves");
     static_assert(NBUF == 3 || NBUF == 4, "ring depth");
     static_assert(2 * P <= 63 && P <= 21, "vmcnt range (two stages in flight), DMA slots");
     static_assert(LDS_BYTES <= 160 * 1024, "LDS");
@@ -91,7 +94,7 @@ struct WinoCfg {
 // Ablation builds (scripts/wino_variants.sh; results are WRONG with any bit set, timing only -- DESIGN.md quotes them):
 // 1 no stores, 2 no epilogue (the MFMAs become dead code), 4 no cursor recompute, 8 no DMA, 16 no transform, 32 no filter
 // reads, 64 no barrier, 128 no filter DMA, 256 no input DMA, 512 transform interleaved with the MFMA slots, 1024 no wait
-// for the DMA stage
+// for the DMA stage, 2048 every box fetches the first box's input
 constexpr int DBG = MIS_WINO_DBG_CT;
 
 extern __shared__ __attribute__((aligned(16))) float mis_wino_lds[];
@@ -179,8 +182,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lk = lane >> 4, lj = lane & 15;
     const int cb = wave % C::COB, grp = wave / C::COB;                       // this wave's channel block and group
-    const int gx = grp % C::WX, gy = (grp / C::WX) % C::WY, gz = grp / (C::WX * C::WY);
-    const int tx = gx * C::GX + lj % C::GX, ty = gy * C::GY + (lj / C::GX) % C::GY, tz = gz * C::GZ + lj / (C::GX * C::GY);
+    int tx, ty, tz;
+    bool lane_live = true;                 // FLAT: lanes past the box's last tile compute tile 0 again and store nothing
+    if constexpr (C::FLAT) {
+        int t = grp * 16 + lj;
+        lane_live = t < C::BZ * C::BY * C::BX;
+        t = lane_live ? t : 0;
+        tx = t % C::BX; ty = (t / C::BX) % C::BY; tz = t / (C::BX * C::BY);
+    } else {
+        const int gx = grp % C::WX, gy = (grp / C::WX) % C::WY, gz = grp / (C::WX * C::WY);
+        tx = gx * C::GX + lj % C::GX; ty = gy * C::GY + (lj / C::GX) % C::GY; tz = gz * C::GZ + lj / (C::GX * C::GY);
+    }
     const long long S = (long long)a.D * a.H * a.W;
     const unsigned s_bytes = (unsigned)S * 4u;
     const unsigned lds0 = lds_addr(lds);
@@ -239,7 +251,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         }
     }
     __syncthreads();
-    auto cursor_box = [&](const Box& b, bool live) {     // per-lane offsets and descriptors of box b (all OOB past the end)
+    auto cursor_box = [&](const Box& b_in, bool live) {     // per-lane offsets and descriptors of box b (all OOB past the end)
+        Box b = b_in;
+        if (DBG & 2048) { b.n = 0; b.z0 = 0; b.y0 = 0; b.x0 = 0; }      // ablation: every box reads the first box's input (L2-hot)
         icg = b.cg;
         is.rx = make_rsrc(a.x + (long long)b.n * a.x_bs, live ? (unsigned)a.Cin * s_bytes : 0u);
         unsigned geo[C::NCH];
@@ -321,6 +335,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         if (!(DBG & 64)) __syncthreads();  // ... and everyone's; everyone is done with stage gs-1
     };
 
+    // statistics: per-lane running sums over the boxes of a run (consecutive boxes of this workgroup in the same image and
+    // channel group); only the last box of a run pays the cross-lane reduction, the others store zeros in their slot
+    float run1[4] = {0.f, 0.f, 0.f, 0.f}, run2[4] = {0.f, 0.f, 0.f, 0.f};
     for (; box < box_end; box += nslot_u, bb = nb) {
         const bool nlive = box + nslot_u < box_end;
         nb = advance(bb);
@@ -339,7 +356,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         if (DBG & 2) continue;
         asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");        // the last (asm) MFMAs have left the pipe before their AGPRs are read
         const int oz = bb.z0 + 2 * tz, oy = bb.y0 + 2 * ty, ox = bb.x0 + 2 * tx;
-        const bool ok = oz < a.D && oy < a.H && ox < a.W;
+        const bool ok = lane_live && oz < a.D && oy < a.H && ox < a.W;
         const int co0 = (bb.cg * C::COB + cb) * 16;
         const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(
             (void*)(a.y + (long long)bb.n * a.y_bs + (long long)co0 * S), 0, (int)(16u * s_bytes), 0x00020000);
@@ -348,7 +365,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         // time, folded into the y and x sums as it is read.  Few live registers (the next box's first chunk is already
         // waiting in 64 of them) and no spills: a scratch reload here would wait on vmcnt(0), i.e. on the DMAs in
         // flight and on the write acknowledgements of the stores.
-        float st1[4], st2[4];
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             f32x2 o[2][2][2];
@@ -399,12 +415,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             if constexpr (C::DW) {      // this variant also runs partly filled boxes: tiles outside the volume do not count
                 if (!ok) { s1 = f32x2{0.f, 0.f}; s2 = s1; }
             }
-            st1[2 * h] = s1[0]; st1[2 * h + 1] = s1[1]; st2[2 * h] = s2[0]; st2[2 * h + 1] = s2[1];
+            run1[2 * h] += s1[0]; run1[2 * h + 1] += s1[1]; run2[2 * h] += s2[0]; run2[2 * h + 1] += s2[1];
             __builtin_amdgcn_sched_barrier(0);
         }
-        if (a.stat) {
-            // per-channel (sum, sum of squares) of the box.
+        const bool flush = !nlive || nb.n != bb.n || nb.cg != bb.cg;      // uniform
+        if (a.stat && !flush) {
+            if (tid < C::COB * 16)
+                a.stat[(long long)(bb.cg * C::COB * 16 + tid) * a.stat_sc + (long long)bb.n * a.stat_sn + bb.idx] = make_float2(0.f, 0.f);
+        } else if (a.stat) {
+            // per-channel (sum, sum of squares) of the run that ends with this box.
             // The scratch is a piece of LDS beyond the ring (the ring is live: later stages are in flight).
+            float st1[4], st2[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { st1[r] = run1[r]; st2[r] = run2[r]; run1[r] = 0.f; run2[r] = 0.f; }
 #pragma unroll
             for (int r = 0; r < 4; ++r)
 #pragma unroll
@@ -456,7 +479,8 @@ int launch_wino(WinoArgs a, hipStream_t stream) {
 
 // Which Winograd variant serves this 3x3x3 'same' convolution, or -1 (use the direct kernel, mis_conv_fwd):
 //   0: boxes of 4 x 4 x 32 outputs (W a multiple of 32: the 96^3 level),  1: 4 x 8 x 16 (W a multiple of 16: 48^3),
-//   2: 8 x 8 x 8 (24^3; halo rows as single dwords; also partly filled boxes: the 12^3 level).
+//   2: 8 x 8 x 8 (24^3; halo rows as single dwords; also partly filled boxes: the 6^3 level),
+//   3: 6 x 6 x 12 voxels = 3 x 3 x 6 tiles taken 16 at a time (W == 12: the 12^3 level, 54 of 64 tile lanes busy).
 // Needs Cin % 8 == 0 (two 4-channel chunks per loop trip), Cin >= 16 (the DMA ring runs 3 chunks ahead),
 // Cout % 16 == 0 (MFMA rows), Cout <= 384 (bias table in LDS), even D / H / W (2x2x2 tiles).
 extern "C" int mis_conv3d_wino_select(int N, int Cin, int Cout, int D, int H, int W) {
@@ -466,6 +490,9 @@ extern "C" int mis_conv3d_wino_select(int N, int Cin, int Cout, int D, int H, in
     if (W % 32 == 0 && D % 4 == 0 && H % 4 == 0) return 0;      // 16-byte halo rows: W % 4 == 0
     if (W % 16 == 0 && D % 4 == 0 && H % 8 == 0) return 1;
     if (W % 8 == 0 && D % 8 == 0 && H % 8 == 0 && Cin >= 32) return 2;      // the 24^3 level: boxes of 8 x 8 x 8
+    // the 12^3 level: 4 boxes of 54 tiles per 12^3 volume (when the launch has enough boxes for the serial walk over the
+    // input channels to pay: the direct kernel spreads a small problem over more workgroups)
+    if (W == 12 && D % 6 == 0 && H % 6 == 0 && Cin >= 32 && (long long)N * (D / 6) * (H / 6) * (Cout / 16) >= 64) return 3;
     if (Cin >= 32) {
         // partly filled 8 x 8 x 8 boxes (the 12^3 level: 42 % of the box volume is output) still beat the direct kernel
         // 1.3 - 1.8x when there are enough boxes for the 256 CUs; out-of-range tiles are not stored and not counted
@@ -489,15 +516,17 @@ extern "C" long long mis_conv3d_wino_stat_tiles(int D, int H, int W, int variant
     if (variant == 0) return boxes_per_image<WinoCfg<1, 1, 16, 2, 2, 1, 1, 4>>(D, H, W);
     if (variant == 1) return boxes_per_image<WinoCfg<1, 2, 8, 2, 2, 1, 1, 4>>(D, H, W);
     if (variant == 2) return boxes_per_image<WinoCfg<1, 4, 4, 4, 1, 1, 1, 4, 1>>(D, H, W);
+    if (variant == 3) return boxes_per_image<WinoCfg<3, 3, 6, 1, 1, 1, 1, 4, 1, 1>>(D, H, W);
     return MIS_ERR_UNSUPPORTED;
 }
 
 // kernel name as rocprofv3 prints it (minus the anonymous-namespace prefix), for bench.py's attribution
 extern "C" int mis_conv3d_wino_kernel_name(int variant, char* name, int name_len) {
     if (!name || name_len <= 0) return MIS_ERR_ARG;
-    if (variant == 0) snprintf(name, name_len, "wino_fwd_kernel<WinoCfg<1, 1, 16, 2, 2, 1, 1, 4, 0>>");
-    else if (variant == 1) snprintf(name, name_len, "wino_fwd_kernel<WinoCfg<1, 2, 8, 2, 2, 1, 1, 4, 0>>");
-    else if (variant == 2) snprintf(name, name_len, "wino_fwd_kernel<WinoCfg<1, 4, 4, 4, 1, 1, 1, 4, 1>>");
+    if (variant == 0) snprintf(name, name_len, "wino_fwd_kernel<WinoCfg<1, 1, 16, 2, 2, 1, 1, 4, 0, 0>>");
+    else if (variant == 1) snprintf(name, name_len, "wino_fwd_kernel<WinoCfg<1, 2, 8, 2, 2, 1, 1, 4, 0, 0>>");
+    else if (variant == 2) snprintf(name, name_len, "wino_fwd_kernel<WinoCfg<1, 4, 4, 4, 1, 1, 1, 4, 1, 0>>");
+    else if (variant == 3) snprintf(name, name_len, "wino_fwd_kernel<WinoCfg<3, 3, 6, 1, 1, 1, 1, 4, 1, 1>>");
     else return MIS_ERR_UNSUPPORTED;
     return MIS_OK;
 }
@@ -510,7 +539,7 @@ extern "C" int mis_conv3d_wino_fwd(const float* x, long long x_bs, const float* 
     if (!x || !wt || !y || N <= 0 || Cin <= 0 || Cout <= 0 || D <= 0 || H <= 0 || W <= 0) return MIS_ERR_ARG;
     const long long S = (long long)D * H * W;
     if (x_bs < (long long)Cin * S || y_bs < (long long)Cout * S) return MIS_ERR_ARG;
-    if (Cout % 16 || Cout > 384 || Cin % 8 || Cin < 16 || (W % 4 && variant != 2) || D % 2 || H % 2 || W % 2 || y_bs % 2 || ((uintptr_t)y & 7) || ((uintptr_t)wt & 15))
+    if (Cout % 16 || Cout > 384 || Cin % 8 || Cin < 16 || (W % 4 && variant < 2) || D % 2 || H % 2 || W % 2 || y_bs % 2 || ((uintptr_t)y & 7) || ((uintptr_t)wt & 15))
         return MIS_ERR_UNSUPPORTED;
     if (((long long)Cin + 32) * S * 4 >= (1LL << 30)) return MIS_ERR_UNSUPPORTED;
     WinoArgs a{};
@@ -521,5 +550,9 @@ extern "C" int mis_conv3d_wino_fwd(const float* x, long long x_bs, const float* 
     if (variant == 0) return launch_wino<WinoCfg<1, 1, 16, 2, 2, 1, 1, 4>>(a, stream);
     if (variant == 1) return launch_wino<WinoCfg<1, 2, 8, 2, 2, 1, 1, 4>>(a, stream);
     if (variant == 2) return launch_wino<WinoCfg<1, 4, 4, 4, 1, 1, 1, 4, 1>>(a, stream);
+    if (variant == 3) {
+        if (W != 12 || D % 6 || H % 6) return MIS_ERR_UNSUPPORTED;
+        return launch_wino<WinoCfg<3, 3, 6, 1, 1, 1, 1, 4, 1, 1>>(a, stream);
+    }
     return MIS_ERR_UNSUPPORTED;
 }

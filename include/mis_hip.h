@@ -92,8 +92,9 @@ int mis_conv_fwd_kernel_name(int N, int Cin, int Cout, int D, int H, int W, int 
  * differs from the direct form by rounding only.  The filter comes transformed (mis_conv_pack_weights / pack jobs,
  * mode 4 = forward, 5 = data gradient: the same launch on dy with Cin and Cout swapped).
  * mis_conv3d_wino_select: variant serving this geometry, or -1 (use mis_conv_fwd): 0 = boxes of 4x4x32 outputs (W % 32),
- *   1 = 4x8x16 (W % 16), 2 = 8x8x8 (also partly filled boxes -- 12^3, 6^3 -- when >= 40 % of the box volume is output
- *   and the launch has >= 128 boxes; tiles outside the volume are neither stored nor counted in the statistics).
+ *   1 = 4x8x16 (W % 16), 2 = 8x8x8 (also partly filled boxes -- 6^3 -- when >= 40 % of the box volume is output
+ *   and the launch has >= 128 boxes; tiles outside the volume are neither stored nor counted in the statistics),
+ *   3 = 6x6x12 (W == 12, D % 6 == 0, H % 6 == 0: the 12^3 level; 54 tiles per box taken 16 at a time).
  * mis_conv3d_wino_stat_tiles: partial-statistics entries per image (boxes) of that variant. */
 int mis_conv3d_wino_select(int N, int Cin, int Cout, int D, int H, int W);
 long long mis_conv3d_wino_stat_tiles(int D, int H, int W, int variant);

@@ -62,9 +62,10 @@ MT_CASES = {
     "config3_unet3d_4+4_96": ("unet3d", (8, 1, 96, 96, 96), 4, 2, torch.int64, 1200, 0,
                               ["name:conv_fwd_cin1_kernel<3>",                     # first layer (1 input channel): taps as K
                                "Cfg<3, 3, 3, 2, 8, 8, 16, 4, 2>",                  # 6^3 level of the teacher's 4 volumes: direct
-                               "wino:WinoCfg<1, 1, 16, 2, 2, 1, 1, 4, 0>",         # 96^3: Winograd, 4 x 4 x 32 boxes
-                               "wino:WinoCfg<1, 2, 8, 2, 2, 1, 1, 4, 0>",          # 48^3: 4 x 8 x 16 boxes
-                               "wino:WinoCfg<1, 4, 4, 4, 1, 1, 1, 4, 1>"]),        # 24^3, 12^3: 8 x 8 x 8 boxes
+                               "wino:WinoCfg<1, 1, 16, 2, 2, 1, 1, 4, 0, 0>",      # 96^3: Winograd, 4 x 4 x 32 boxes
+                               "wino:WinoCfg<1, 2, 8, 2, 2, 1, 1, 4, 0, 0>",       # 48^3: 4 x 8 x 16 boxes
+                               "wino:WinoCfg<1, 4, 4, 4, 1, 1, 1, 4, 1, 0>",       # 24^3, 6^3: 8 x 8 x 8 boxes
+                               "wino:WinoCfg<3, 3, 6, 1, 1, 1, 1, 4, 1, 1>"]),     # 12^3: 6 x 6 x 12 boxes, 54 tiles
     "config4_swin_24+24_224": ("swin", (48, 1, 224, 224), 24, 4, torch.uint8, 1200, 1000, []),
 }
 

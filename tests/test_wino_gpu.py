@@ -41,8 +41,10 @@ FWD_CASES = [
     (3, 96, 32, 4, 8, 16, 1),
     (1, 32, 32, 8, 8, 8, 2),        # the 24^3 level's boxes (8 x 8 x 8 voxels, dword halo rows)
     (2, 64, 48, 8, 16, 24, 2),
-    (4, 64, 128, 12, 12, 12, 2),    # the 12^3 level: partly filled boxes (tiles outside the volume are not stored)
-    (8, 32, 64, 12, 8, 20, 2),
+    (4, 64, 128, 12, 12, 12, 3),    # the 12^3 level: boxes of 3 x 3 x 6 tiles, 54 of the 64 tile lanes busy
+    (4, 32, 128, 18, 6, 12, 3),
+    (2, 128, 384, 12, 12, 12, 3),
+    (8, 32, 64, 12, 8, 20, 2),      # partly filled 8 x 8 x 8 boxes (tiles outside the volume are not stored)
     (8, 128, 256, 6, 6, 6, 2),
 ]
 
@@ -189,7 +191,7 @@ def test_wino_select_and_refusal():
     assert sel(2, 1, 16, 96, 96, 96) == -1          # first layer: 1 input channel
     assert sel(2, 16, 2, 96, 96, 96) == -1          # Cout not a multiple of 16
     assert sel(2, 64, 64, 24, 24, 24) == 2
-    assert sel(4, 128, 128, 12, 12, 12) == 2        # 12^3: partly filled boxes, when there are enough of them
+    assert sel(4, 128, 128, 12, 12, 12) == 3        # 12^3: 6 x 6 x 12 boxes, when there are enough of them
     assert sel(1, 32, 16, 12, 12, 12) == -1 and sel(8, 128, 256, 6, 6, 6) == 2 and sel(4, 128, 256, 6, 6, 6) == -1
     assert sel(2, 16, 16, 6, 6, 30) == -1
     assert ops.conv_wino_select(2, 16, 16, 1, 64, 64, (3, 3)) == ops.WINO2D          # 2-D: conv_wino2d.hip
