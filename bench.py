@@ -17,14 +17,20 @@ Default workload = BASELINE.json configs[2], the north-star target: Mean-Teacher
 scaling; value = samples of all ranks / max-over-ranks time.
 
 Prints ONE JSON line (rank 0) with the contract fields plus
-  roofline     live HIP-event timing of the dominant kernel (the MFMA conv kernel) over the timed region:
-               achieved = algorithmic FLOPs of its launches / their summed duration; ``step_flop_frac`` = the
-               algorithmic FLOPs of the WHOLE step / step time / peak
+  roofline     live HIP-event timing of the dominant kernel (the MFMA conv kernel): achieved / frac = the flops the
+               matrix pipe EXECUTES (algorithmic flops / winograd_reduction) / the launches' summed duration, against the
+               fp32 MFMA peak (<= 1); ``algorithmic_tflops`` = the direct-convolution rate of the same launches;
+               ``step_algorithmic_flop_frac`` = the algorithmic FLOPs of the WHOLE step / step time /
+               peak.  The timed region runs the product configuration (teacher forward and weight gradients on side
+               streams); the events are taken in a second region of the same run with the side streams off, where a
+               launch's duration is the kernel's own (``roofline.measured_in``, ``serial_ms_per_step``)
   others       (N=1) the other single-GPU configurations of BASELINE.json -- configs[1] 2-D UNet, configs[3]
                SwinUnet, configs[4] per-GPU cross teaching, and V-Net -- each with value, ms_per_step, step-level
                flop_frac and dominant-kernel fraction
   cpu_baseline the CPU oracle (a port of the reference arithmetic on stock torch CPU ops) timed on this host's
-               cores: thread count swept, best reported, 2 warm-up + 5 timed steps (rank 0, N=1 only)
+               cores on the SAME batch as the GPU line (config 3: 4+4 volumes): thread count swept on the reduced 1+1
+               batch, then 1 warm-up + 3 timed steps of the full batch at the best count; the 1+1 figure is reported
+               beside it (rank 0, N=1 only)
 """
 import argparse
 import json
@@ -149,7 +155,7 @@ def build_trainer(name, wl, world, stub=False):
         from mis_hip.step import UAMTTrainer
         return UAMTTrainer(model, ema, labeled_bs=L, num_classes=C, seed=1337, iter_num=1000)
     return MeanTeacherTrainer(model, ema, labeled_bs=L, num_classes=C, cons_start_iter=wl["cons_start"], seed=1337,
-                              iter_num=1000)
+                              iter_num=1000, use_graph=os.environ.get("MIS_BENCH_GRAPH", "0") == "1")
 
 
 class _StubTrainer:
@@ -164,7 +170,10 @@ class _StubTrainer:
     def step(self, vol, lab):
         from mis_hip import dist
         self.g.copy_(vol.reshape(-1)[:self.g.numel()])
-        scale = dist.sync_gradients(self.g)
+        if os.environ.get("MIS_STUB_SKIP_SYNC") == "1":      # test hook: a step whose exchange is missing must be caught
+            scale = 1.0
+        else:
+            scale = dist.sync_gradients(self.g)
         self.w.add_(self.g, alpha=-0.01 * scale)
 
     def losses(self):
@@ -190,27 +199,24 @@ def run_workload(name, args, rank, world, kernel_events=True):
         if not stub:
             torch.cuda.synchronize()
 
+    def timed(steps):
+        """`steps` steps between barrier + device sync on both sides; this rank's seconds."""
+        sync()
+        if world > 1:
+            tdist.barrier()
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            tr.step(vol, lab)
+        sync()
+        if world > 1:
+            tdist.barrier()
+        sync()
+        return time.perf_counter() - t0
+
     for _ in range(args.warmup):
         tr.step(vol, lab)
-    prof = None
-    if not stub:
-        from mis_hip import ops
-        prof = [] if kernel_events else None
-        ops.PROFILE = prof
-    sync()
-    if world > 1:
-        tdist.barrier()
-    sync()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        tr.step(vol, lab)
-    sync()
-    if world > 1:
-        tdist.barrier()
-    sync()
-    dt_local = time.perf_counter() - t0
-    if not stub:
-        ops.PROFILE = None
+    dt_local = timed(args.steps)
     dt, per_rank = dt_local, [dt_local]
     if world > 1:
         t = torch.tensor([dt_local], device=dev, dtype=torch.float64)
@@ -218,6 +224,28 @@ def run_workload(name, args, rank, world, kernel_events=True):
         tdist.all_gather(allt, t)
         per_rank = [float(x.item()) for x in allt]
         dt = max(per_rank)                         # MAX over ranks
+
+    # ---- data parallel: prove the exchange happened and price it (before any diagnostic region changes the weights)
+    dist_info = None
+    if world > 1:
+        dist_info = _distributed_checks(tr, timed, args, rank, world, dev, stub, dt_local)
+
+    # ---- roofline region: the same step with the side streams off, every MFMA launch bracketed by HIP events on its
+    # launch stream.  A launch's duration measures the kernel only when it has the chip to itself: in the timed region
+    # above the teacher forward and the weight gradients run on side streams beside the main stream's launches.
+    prof, serial_dt, serial_steps = None, None, 0
+    if not stub and kernel_events:
+        from mis_hip import ops, plan as _plan, step as _stepmod
+        keep = (_stepmod.TWO_STREAM, _plan.WGRAD_STREAM)
+        _stepmod.TWO_STREAM, _plan.WGRAD_STREAM = False, False
+        try:
+            tr.step(vol, lab)
+            ops.PROFILE = prof = []
+            serial_steps = args.steps if args.serial else max(3, min(args.steps, 10))
+            serial_dt = timed(serial_steps)
+        finally:
+            ops.PROFILE = None
+            _stepmod.TWO_STREAM, _plan.WGRAD_STREAM = keep
     losses = tr.losses()
     assert all(map(lambda v: v == v and abs(v) < 1e6, losses.values())), f"non-finite losses {losses}"
 
@@ -229,14 +257,21 @@ def run_workload(name, args, rank, world, kernel_events=True):
             d[0] += flops
             d[1] += e0.elapsed_time(e1) * 1e-3
             d[2] += 1
-        fam_flops = sum(d[0] for d in per.values())
+        def reduction(k):
+            """Winograd F(2x2x2, 3x3x3) / F(2x2, 3x3): 64 (16) multiplies per 2x2x2 (2x2) outputs instead of 216 (36)."""
+            return 3.375 if k.startswith("wino_fwd_kernel") else 2.25 if k.startswith("wino2d_fwd_kernel") else 1.0
+
+        fam_alg = sum(d[0] for d in per.values())
+        fam_exec = sum(d[0] / reduction(k) for k, d in per.items())
         fam_time = sum(d[1] for d in per.values())
         dom = max(per, key=lambda k: per[k][1])
-        achieved = per[dom][0] / per[dom][1] / 1e12
+        red = reduction(dom)
+        alg_tf = per[dom][0] / per[dom][1] / 1e12           # direct-convolution (algorithmic) flops over time
+        achieved = alg_tf / red                             # flops the matrix pipe executes over time: <= peak
         # HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this same
         # command (FETCH_SIZE / WRITE_SIZE in separate runs, scripts/pmc_traffic.py); null if not collected
         traffic, traffic_src = None, None
-        for rnd in ("r02", "r01"):
+        for rnd in ("r03", "r02", "r01"):
             tfile = os.path.join(ROOT, "profiles", f"{rnd}_{name}_pmc_traffic.json")
             if os.path.exists(tfile):
                 with open(tfile) as f:
@@ -244,38 +279,94 @@ def run_workload(name, args, rank, world, kernel_events=True):
                 if ent:
                     traffic, traffic_src = ent["hbm_bytes_per_launch"], os.path.relpath(tfile, ROOT)
                     break
+        # `achieved` / `frac` = EXECUTED matrix-pipe flops (algorithmic flops / winograd_reduction) over the kernel's
+        # summed launch durations, against the fp32 MFMA peak: a fraction of the pipe, <= 1 by construction and the
+        # quantity SQ_VALU_MFMA_BUSY_CYCLES measures (profiles/r03_*_pmc_mfma.csv).  The algorithmic rate (what a direct
+        # convolution would have to sustain for the same time) is kept beside it.
         roofline = dict(bound="mfma", kernel=dom, achieved=round(achieved, 3), peak=PEAK_FP32_MFMA_TFLOPS,
-                        unit="TFLOP/s", frac=round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), traffic=traffic,
-                        traffic_unit="HBM bytes per launch (PMC)", traffic_source=traffic_src,
+                        unit="TFLOP/s", frac=round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
+                        algorithmic_tflops=round(alg_tf, 3), winograd_reduction=red,
+                        traffic=traffic, traffic_unit="HBM bytes per launch (PMC)", traffic_source=traffic_src,
                         launches=per[dom][2], avg_launch_ms=round(per[dom][1] / per[dom][2] * 1e3, 4),
-                        flops_per_launch_avg=per[dom][0] / per[dom][2],
-                        family=dict(kernel="all event-timed MFMA launches (conv_fwd_kernel<*> forward + data-gradient; "
-                                           "gemm_nt_kernel<*> / gemm_tn_kernel<*> for SwinUnet)",
-                                    achieved=round(fam_flops / fam_time / 1e12, 3),
-                                    frac=round(fam_flops / fam_time / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
-                                    share_of_step_time=round(fam_time / dt_local, 4)))
-        wino = 3.375 if dom.startswith("wino_fwd_kernel") else 2.25 if dom.startswith("wino2d_fwd_kernel") else 0.0
-        if wino:
-            # Winograd F(2x2x2, 3x3x3) / F(2x2, 3x3): 64 (16) multiplies per 2x2x2 (2x2) outputs instead of 216 (36).
-            # `achieved` / `frac` stay the ALGORITHMIC (direct-convolution) flops over time, which may exceed the matrix
-            # pipe's peak; `mfma_*` is what the pipe actually executes (algorithmic / 3.375 or / 2.25), bounded by `peak`.
-            roofline["algorithm"] = (f"Winograd: the matrix pipe executes algorithmic/{wino:g} flops; achieved and frac "
-                                     "are algorithmic, mfma_achieved and mfma_frac are executed")
-            roofline["mfma_achieved"] = round(achieved / wino, 3)
-            roofline["mfma_frac"] = round(achieved / wino / PEAK_FP32_MFMA_TFLOPS, 4)
+                        algorithmic_flops_per_launch_avg=per[dom][0] / per[dom][2],
+                        executed_flops_per_launch_avg=per[dom][0] / per[dom][2] / red,
+                        family=dict(kernel="all event-timed MFMA launches (wino*_fwd_kernel<*> / conv_fwd_kernel<*> forward + "
+                                           "data gradient; gemm_nt_kernel<*> / gemm_tn_kernel<*> for SwinUnet)",
+                                    achieved=round(fam_exec / fam_time / 1e12, 3),
+                                    frac=round(fam_exec / fam_time / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
+                                    algorithmic_tflops=round(fam_alg / fam_time / 1e12, 3),
+                                    share_of_step_time=round(fam_time / serial_dt, 4)))
+        roofline["measured_in"] = (f"a second region of {serial_steps} steps of this run with the side streams off (teacher "
+                                   "forward and weight gradients on the main stream), HIP events on the launch stream "
+                                   "around every MFMA launch")
+        roofline["serial_ms_per_step"] = round(serial_dt / serial_steps * 1e3, 3)
     step_s = dt / args.steps
     step_frac = wl["step_gflop"] * 1e9 / step_s / (PEAK_FP32_MFMA_TFLOPS * 1e12)
     if roofline is not None:
-        roofline["step_flops"] = wl["step_gflop"] * 1e9
-        roofline["step_flop_frac"] = round(step_frac, 4)
+        roofline["step_algorithmic_flops"] = wl["step_gflop"] * 1e9
+        roofline["step_algorithmic_flop_frac"] = round(step_frac, 4)      # direct-convolution flops: may exceed 1
     res = dict(value=round(shape[0] * world * args.steps / dt, 3), unit=UNIT.get(name, "images/s"),
                ms_per_step=round(step_s * 1e3, 3), step_flop_frac=round(step_frac, 4), roofline=roofline,
                losses={k: round(v, 6) for k, v in losses.items()},
-               per_rank_ms_per_step=[round(t / args.steps * 1e3, 3) for t in per_rank])
+               per_rank_ms_per_step=[round(t / args.steps * 1e3, 3) for t in per_rank], distributed=dist_info)
     del tr
     if not stub:
         torch.cuda.empty_cache()
     return res
+
+
+def _distributed_checks(tr, timed, args, rank, world, dev, stub, dt_overlap):
+    """N > 1: (1) every rank must hold bit-identical student (and teacher) weights after the timed steps -- the
+    gradients were exchanged and the same update applied everywhere; the run FAILS otherwise.  (2) The price of the
+    exchange: the same steps with one blocking all-reduce after the backward instead of the bucketed one overlapped with
+    it (MIS_GRAD_OVERLAP=0), and with no exchange at all (what a single GPU does; run last, the ranks' weights drift
+    apart in it).  exposed = ms/step of the timed region - ms/step without exchange."""
+    import torch
+    import torch.distributed as tdist
+    from mis_hip import dist as mdist
+    seen = tdist.get_world_size()
+    if seen != world:
+        raise SystemExit(f"process group has {seen} ranks, --gpus says {world}")
+    flats = [tr.w] if stub else [m.flat_param for m in (getattr(tr, a, None) for a in
+                                                        ("model", "ema_model", "model1", "model2")) if m is not None]
+    # bit-level fingerprint: sum and xor-fold of the raw words, in int64 (exact, order-independent)
+    words = torch.cat([f.detach().reshape(-1).view(torch.int32).to(torch.int64) for f in flats])
+    fp = torch.stack([words.sum(), (words * (torch.arange(words.numel(), device=words.device) % 8191 + 1)).sum()])
+    allfp = [torch.zeros_like(fp) for _ in range(world)]
+    tdist.all_gather(allfp, fp)
+    identical = all(bool(torch.equal(allfp[0], x)) for x in allfp)
+    if not identical:
+        raise SystemExit("data-parallel check FAILED: the ranks hold different weights after the timed steps "
+                         "(the gradient exchange did not reach every parameter)")
+    n = max(3, min(args.steps, 10))
+
+    def region():
+        t = torch.tensor([timed(n)], device=dev, dtype=torch.float64)
+        tdist.all_reduce(t, op=tdist.ReduceOp.MAX)
+        return float(t.item()) / n * 1e3
+
+    out = dict(world_size_seen=seen, params_identical=True, weights_fingerprint=[int(v) for v in allfp[0].tolist()],
+               grad_bytes=sum(int(f.numel()) * 4 for f in flats if f.requires_grad or True),
+               overlapped_ms_per_step=round(dt_overlap / args.steps * 1e3, 3), regions_steps=n)
+    keep = {a: getattr(tr, a) for a in ("_bucketer", "_bucketers") if hasattr(tr, a)}
+    if keep:      # one blocking all-reduce of the whole flat gradient after the backward
+        for a, v in keep.items():
+            setattr(tr, a, None if a == "_bucketer" else (None,) * len(v))
+        out["blocking_allreduce_ms_per_step"] = round(region(), 3)
+        for a, v in keep.items():
+            setattr(tr, a, v)
+    real_sync = mdist.sync_gradients
+    try:          # no exchange at all: the single-GPU step on this rank's shard
+        mdist.sync_gradients = lambda flat_grad, group=None: 1.0 / world
+        for a, v in keep.items():
+            setattr(tr, a, None if a == "_bucketer" else (None,) * len(v))
+        out["no_exchange_ms_per_step"] = round(region(), 3)
+    finally:
+        mdist.sync_gradients = real_sync
+        for a, v in keep.items():
+            setattr(tr, a, v)
+    out["exposed_allreduce_ms_per_step"] = round(out["overlapped_ms_per_step"] - out["no_exchange_ms_per_step"], 3)
+    return out
 
 
 # ------------------------------------------------------------------------------------------------ CPU baseline
@@ -300,15 +391,14 @@ def _physical_cores():
     return os.cpu_count() or 1
 
 
-def cpu_baseline(kind, wl, timed=5, warm=2, budget_s=150.0):
-    """The oracle step (reference arithmetic on stock torch CPU ops, dropout + noise active) on this host's cores,
-    on a reduced batch of the same geometry.  ``torch.set_num_threads`` is swept over {8,16,32,64,physical cores}
-    (1 warm-up + 1 timed step each), then the best count is timed with ``warm`` + ``timed`` steps (median)."""
+def cpu_baseline(kind, wl, timed=3, warm=1, budget_s=150.0):
+    """The oracle step (reference arithmetic on stock torch CPU ops, dropout + noise active) on this host's cores.
+    ``torch.set_num_threads`` is swept over {8,16,32,64,physical cores} on the reduced batch ``wl["cpu_sample"]`` of the
+    same geometry (1 warm-up + 1 timed step each); the best count then times the reduced batch (median of 3) and the
+    FULL batch of the GPU line (``warm`` + ``timed`` steps, median) -- ``value`` is the full-batch figure."""
     import torch
     from oracle.nets import OracleUNet2D, OracleUNet3D, OracleVNet
     from oracle.step import mean_teacher_step
-    B, L = wl["cpu_sample"]
-    shape = (B,) + wl["shape"][1:]
     C = wl["classes"]
     g = torch.Generator().manual_seed(1337)
     if kind == "swin":
@@ -326,42 +416,53 @@ def cpu_baseline(kind, wl, timed=5, warm=2, budget_s=150.0):
             elif n.endswith("weight") or n.endswith("running_var"):
                 t.fill_(1.0)
     teacher = {k: v.clone() for k, v in student.items()}
-    vol = torch.rand(shape, generator=g)
-    lab = torch.randint(0, C, (B,) + shape[2:], generator=g).to(getattr(torch, wl["label"]))
     mom = {}
     it = [1000]
 
-    def one():
-        noise = torch.clamp(torch.randn((B - L,) + shape[1:], generator=g) * 0.1, -0.2, 0.2)
-        t0 = time.perf_counter()
-        mean_teacher_step(onet, student, teacher, mom, vol, lab, noise, it[0], labeled_bs=L, num_classes=C,
-                          cons_start_iter=wl["cons_start"])
-        it[0] += 1
-        return time.perf_counter() - t0
+    def make(B, L):
+        shape = (B,) + wl["shape"][1:]
+        vol = torch.rand(shape, generator=g)
+        lab = torch.randint(0, C, (B,) + shape[2:], generator=g).to(getattr(torch, wl["label"]))
 
+        def one():
+            noise = torch.clamp(torch.randn((B - L,) + shape[1:], generator=g) * 0.1, -0.2, 0.2)
+            t0 = time.perf_counter()
+            mean_teacher_step(onet, student, teacher, mom, vol, lab, noise, it[0], labeled_bs=L, num_classes=C,
+                              cons_start_iter=wl["cons_start"])
+            it[0] += 1
+            return time.perf_counter() - t0
+        return one
+
+    Bs, Ls = wl["cpu_sample"]
+    Bf, Lf = wl["shape"][0], wl["labeled"]
+    small, full = make(Bs, Ls), make(Bf, Lf)
     logical, physical = os.cpu_count() or 1, _physical_cores()
     default_threads = torch.get_num_threads()
     cands = sorted({n for n in (8, 16, 32, 64, physical) if 1 <= n <= logical})
     sweep, t_start = {}, time.perf_counter()
     for n in cands:
         torch.set_num_threads(n)
-        one()
-        sweep[n] = one()
-        if time.perf_counter() - t_start > budget_s * 0.5:
+        small()
+        sweep[n] = small()
+        if time.perf_counter() - t_start > budget_s * 0.4:
             break
     best = min(sweep, key=sweep.get)
     torch.set_num_threads(best)
+    ts = sorted(small() for _ in range(3))[1]
     for _ in range(warm):
-        one()
-    times = sorted(one() for _ in range(timed))
+        full()
+    times = sorted(full() for _ in range(timed))
     t = times[len(times) // 2]
     torch.set_num_threads(default_threads)
-    return dict(value=B / t, unit=UNIT.get(kind, "images/s"), cores=best, kind="port",
+    sp = "x".join(map(str, wl["shape"][2:]))
+    return dict(value=Bf / t, unit=UNIT.get(kind, "images/s"), cores=best, kind="port",
                 host=dict(logical_cpus=logical, physical_cores=physical),
                 thread_sweep_s_per_step={str(k): round(v, 3) for k, v in sweep.items()},
-                sample=f"oracle.step.mean_teacher_step, batch {L}+{B - L} of {'x'.join(map(str, shape[2:]))}, "
-                       f"torch.set_num_threads swept over {sorted(sweep)} -> best {best}; {warm} warm-up + {timed} "
-                       f"timed steps, median {t:.3f} s/step, torch {torch.__version__} CPU")
+                reduced_batch=dict(batch=f"{Ls}+{Bs - Ls}", value=Bs / ts, s_per_step=round(ts, 3)),
+                sample=f"oracle.step.mean_teacher_step on the GPU line's batch {Lf}+{Bf - Lf} of {sp}: {warm} warm-up + "
+                       f"{timed} timed steps, median {t:.3f} s/step, at {best} threads (torch.set_num_threads swept over "
+                       f"{sorted(sweep)} on the reduced batch {Ls}+{Bs - Ls}: {ts:.3f} s/step there), torch "
+                       f"{torch.__version__} CPU")
 
 
 # ------------------------------------------------------------------------------------------------ main
@@ -374,11 +475,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-others", action="store_true", help="skip the 'others' block (the other single-GPU configs)")
     ap.add_argument("--no-kernel-events", action="store_true", help="skip the per-launch HIP events")
-    ap.add_argument("--overlap-teacher", action="store_true",
-                    help="run the teacher forward on a side stream, concurrently with the student forward "
-                         "(MeanTeacherTrainer, MIS_TWO_STREAM=1): higher throughput, but per-launch durations then "
-                         "include time shared with the other stream's kernels, so the roofline object understates "
-                         "the kernels -- off by default to keep it meaningful")
+    ap.add_argument("--serial", action="store_true",
+                    help="side streams off in the timed region too (MIS_TWO_STREAM=0 MIS_WGRAD_STREAM=0): every kernel has "
+                         "the chip to itself -- what the rocprofv3 kernel statistics under profiles/ are collected with")
     ap.add_argument("--stub", action="store_true", help=argparse.SUPPRESS)   # CPU/gloo launcher test only
     args = ap.parse_args()
 
@@ -404,12 +503,12 @@ def main():
             backend = "nccl (RCCL)"
             torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
-    two_stream = False
+    two_stream = wgrad_stream = False
     if not args.stub:
-        from mis_hip import step as _step
-        if args.overlap_teacher:
-            _step.TWO_STREAM = True
-        two_stream = _step.TWO_STREAM
+        from mis_hip import plan as _plan, step as _step
+        if args.serial:
+            _step.TWO_STREAM = _plan.WGRAD_STREAM = False
+        two_stream, wgrad_stream = _step.TWO_STREAM, _plan.WGRAD_STREAM
 
     wl = WORKLOADS[args.workload]
     res = run_workload(args.workload, args, rank, world, kernel_events=not args.no_kernel_events)
@@ -425,10 +524,10 @@ def main():
             "config": {"workload": wl["config"], "per_gpu_batch": f"{wl['labeled']}+{wl['shape'][0] - wl['labeled']}",
                        "global_batch": wl["shape"][0] * world, "parallelism": f"dp{world}",
                        "dropout": "on (Philox)", "teacher_noise": "on", "iter_num_start": 1000,
-                       "teacher_forward": "side stream (overlapped)" if two_stream else "same stream"},
-            "distributed": {"world_size_seen": torch.distributed.get_world_size() if world > 1 else 1,
-                            "backend": backend, "per_rank_ms_per_step": res["per_rank_ms_per_step"],
-                            "max_ms_per_step": res["ms_per_step"]},
+                       "teacher_forward": "side stream (beside the student forward)" if two_stream else "same stream",
+                       "weight_gradients": "side stream (beside the data-gradient chain)" if wgrad_stream else "same stream"},
+            "distributed": dict(res["distributed"] or {"world_size_seen": 1}, backend=backend,
+                                per_rank_ms_per_step=res["per_rank_ms_per_step"], max_ms_per_step=res["ms_per_step"]),
             "losses_last_step": res["losses"],
             "roofline": res["roofline"],
         }
@@ -445,7 +544,8 @@ def main():
             rf = r["roofline"] or {}
             others[name] = dict(workload=WORKLOADS[name]["config"], value=r["value"], unit=r["unit"],
                                 ms_per_step=r["ms_per_step"], steps=oargs.steps, flop_frac=r["step_flop_frac"],
-                                dominant_kernel=rf.get("kernel"), dominant_kernel_frac=rf.get("frac"))
+                                dominant_kernel=rf.get("kernel"), dominant_kernel_frac=rf.get("frac"),
+                                dominant_kernel_algorithmic_tflops=rf.get("algorithmic_tflops"))
         out["others"] = others
     if rank == 0:
         if world == 1 and not args.stub and not args.no_cpu_baseline and wl["cpu_sample"] is not None:

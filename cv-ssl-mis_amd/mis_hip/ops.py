@@ -32,12 +32,19 @@ def _geom(t):
     return N, C, D, H, W, S, bs
 
 
+_scratch_retired = []
+
+
 def scratch(nbytes, key="default"):
     """Grow-only device scratch buffer (bytes) for kernel workspaces, per device, key and stream."""
     # keyed by stream too: student and teacher forwards may run concurrently on two streams (step.py)
     k = (torch.cuda.current_device(), key, torch.cuda.current_stream().cuda_stream)
     buf = _scratch.get(k)
     if buf is None or buf.numel() < nbytes:
+        if buf is not None:
+            # a captured hipGraph may hold raw pointers into the buffer being outgrown (an eager validation forward
+            # between replays can need more workspace than the training step did): never hand it back to the allocator
+            _scratch_retired.append(buf)
         buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device="cuda")
         _scratch[k] = buf
     return buf

@@ -35,6 +35,9 @@ FUSE_FIRST = os.environ.get("MIS_FUSE_FIRST", "1") != "0"
 # max-pool backward on the load path of the producing block's normalisation backward (mis_norm_act_bwd_pool)
 FUSE_POOL = os.environ.get("MIS_FUSE_POOL", "1") != "0"
 FUSE_POOL_FWD = os.environ.get("MIS_FUSE_POOL_FWD", "1") != "0"     # ... and the pool's forward inside the apply pass
+# weight gradients on a side stream: dW of a layer needs only (x, dy) and nothing of the backward needs dW, so it runs
+# beside the data gradient / normalisation backward of the layers below and fills the CUs their launch tails leave idle
+WGRAD_STREAM = os.environ.get("MIS_WGRAD_STREAM", "1") != "0"
 
 
 class Act:
@@ -133,9 +136,17 @@ class ConvOp:
                                      n.sums, n.slope, self.w.grad)
             return
         dy = self.y.grad()
-        ops.conv_wgrad(self.x.t, dy, self.w.grad, self.ksize)
-        if self.b is not None and self.bias_grad:
-            ops.channel_sum(dy, self.b.grad)
+        side = getattr(ctx, "wgrad_stream", None) if self.need_dx else None
+        if side is not None:
+            side.wait_stream(torch.cuda.current_stream())     # dy is final
+            with torch.cuda.stream(side):
+                ops.conv_wgrad(self.x.t, dy, self.w.grad, self.ksize)
+                if self.b is not None and self.bias_grad:
+                    ops.channel_sum(dy, self.b.grad)
+        else:
+            ops.conv_wgrad(self.x.t, dy, self.w.grad, self.ksize)
+            if self.b is not None and self.bias_grad:
+                ops.channel_sum(dy, self.b.grad)
         # bias_grad False: the conv feeds a normalisation, its bias gradient is exactly 0
         # (sum over a normalisation group of dL/dx vanishes); the flat grad buffer keeps its zeros.
         if self.need_dx:
@@ -385,6 +396,7 @@ class Plan:
         self.acts = []
         self.inp = Act(tensor=torch.empty(0, device="cuda"))
         self.acts.append(self.inp)
+        self._wgrad_stream = None
         self._salt = itertools.count(0)
         self.out = None
         self._packs = None
@@ -527,9 +539,18 @@ class Plan:
         if dlogits5 is not None:
             self.out.g = dlogits5
         self._pack(1)
+        main = torch.cuda.current_stream()
+        side = None
+        if WGRAD_STREAM:
+            if self._wgrad_stream is None:
+                self._wgrad_stream = torch.cuda.Stream()
+            side = self._wgrad_stream
+        ctx.wgrad_stream = side
         if on_progress is None:
             for op in reversed(self.ops):
                 op.bwd(ctx)
+            if side is not None:
+                main.wait_stream(side)      # every weight gradient is in the flat buffer before the optimizer reads it
             return
         if self._progress is None:
             from .dist import param_progress
@@ -537,6 +558,8 @@ class Plan:
         for i in range(len(self.ops) - 1, -1, -1):
             self.ops[i].bwd(ctx)
             if i == 0 or self._progress[i] != self._progress[i - 1] or i == len(self.ops) - 1:
+                if side is not None:
+                    main.wait_stream(side)  # the reported suffix includes weight gradients issued on the side stream
                 on_progress(self._progress[i])
 
     def drop_sites(self):

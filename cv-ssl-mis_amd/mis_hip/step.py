@@ -20,7 +20,9 @@ import torch
 
 from . import dist, ops
 
-TWO_STREAM = os.environ.get("MIS_TWO_STREAM", "0") == "1"   # teacher forward on a side stream (see _run)
+# teacher forward (cross teaching: the second student) on a side stream, see _run: bit-identical training, the second
+# network's launches fill the CUs the first one's launch tails and small deep layers leave idle (MIS_TWO_STREAM=0: off)
+TWO_STREAM = os.environ.get("MIS_TWO_STREAM", "1") != "0"
 # data parallel: issue the all-reduce of finished gradient buckets while the backward is still running
 # (dist.GradBucketer); MIS_GRAD_OVERLAP=0 falls back to one blocking all-reduce after the backward
 GRAD_OVERLAP = os.environ.get("MIS_GRAD_OVERLAP", "1") != "0"
@@ -268,7 +270,7 @@ class CrossTeachingTrainer:
                                 pseudo_ce=self.pseudo_ce)
         ops.cross_teaching_tail(o2, o1, lab, L, self.out2, dlogits=self.model2.logits_grad_buffer(), state=self.state,
                                 pseudo_ce=self.pseudo_ce)
-        if TWO_STREAM:
+        if TWO_STREAM and self._bucketers[0] is None:
             self._side.wait_stream(main)
             with torch.cuda.stream(self._side):
                 self.model2.backward_raw()

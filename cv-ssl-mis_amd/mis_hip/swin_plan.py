@@ -376,16 +376,21 @@ class SwinPlan:
             res = [op for op in self.ops if isinstance(op, ResidualOp)]
             n, B = len(res), self.in_shape[0]
             key = ctx.rng_stream
-            if self._dp_const is None or self._dp_const[0] != key:
+            # one (p, salt, table) set per Philox sub-stream: UA-MT cycles the teacher through several streams per step
+            # on the same plan, and rebuilding the constants means two pageable host-to-device copies in the hot loop
+            if self._dp_const is None:
+                self._dp_const = {}
+            if key not in self._dp_const:
                 p = torch.tensor([op.drop_p for op in res], dtype=torch.float32).cuda()
                 salt = torch.tensor([(((ctx.rng_stream & 0xFFFF) << 16) | op.site) for op in res],
                                     dtype=torch.int64).to(torch.int32).cuda()       # bit pattern of the unsigned salt
                 assert [op.site for op in res] == list(range(n))
-                self._dp_const = (key, p, salt, torch.empty((n, B), dtype=torch.float32, device="cuda"))
-            _, p, salt, table = self._dp_const
+                self._dp_const[key] = (p, salt, torch.empty((n, B), dtype=torch.float32, device="cuda"))
+            p, salt, table = self._dp_const[key]
             tops.droppath_table(table, p, salt, n, B, ctx.state)
             self._dp_gen = self.generation
-        return self._dp_const[3]
+            self._dp_table = table
+        return self._dp_table
 
     def next_site(self):
         return next(self._site)

@@ -173,13 +173,17 @@ class Validator:
     the model goes to eval mode and is scored on the validation split -- 2-D: ``val_2D.test_single_volume`` over
     ``BaseDataSets(split='val')`` (train_mean_teacher_2D.py:262-294), 3-D: ``val_3D.test_all_case(...,
     test_list='val.txt', stride_xy=64, stride_z=64)`` (train_mean_teacher_3D.py:201-222) -- and a new best mean Dice
-    writes ``<prefix>iter_{n}_dice_{d}.pth`` and ``{model}_best_<name>.pth``.  Runs on rank 0 only (every rank holds
-    identical weights; BatchNorm running statistics are rank 0's).  When the validation list file is missing (the
-    synthetic runs) nothing is scored and ``finish`` writes the final weights under the best-model name, so that the
-    inference CLIs always find their checkpoint."""
+    writes ``<prefix>iter_{n}_dice_{d}.pth`` and ``{model}_best_<name>.pth``.  Data-parallel runs (the reference is
+    single-GPU) shard the validation cases over the ranks (``cases[rank::world]``) and all-reduce the metric sums: no
+    rank waits in the next step's gradient all-reduce for a whole validation pass on rank 0 (RCCL's watchdog would
+    abort a long 3-D one).  Every rank holds identical weights; the BatchNorm running statistics -- per-rank, there is
+    no SyncBN -- are taken from rank 0 for the scoring, as the checkpoint is.  Scalars, logs and checkpoints are
+    rank 0's.  When the validation list file is missing (the synthetic runs) nothing is scored and ``finish`` writes
+    the final weights under the best-model name, so that the inference CLIs always find their checkpoint."""
 
-    def __init__(self, args, snapshot_path, scalars=None):
+    def __init__(self, args, snapshot_path, scalars=None, rank=0, world=1):
         self.args, self.snapshot_path, self.scalars = args, snapshot_path, scalars
+        self.rank, self.world = rank, world
         self.three_d = len(args.patch_size) == 3
         self.best = {}
         self.db_val = None
@@ -192,21 +196,36 @@ class Validator:
     def score(self, model):
         """(mean Dice, mean HD95, per-class [[dice, hd95], ...]) of ``model`` on the validation split."""
         args = self.args
+        if self.world > 1:      # score with rank 0's BatchNorm running statistics on every rank
+            for b in model.buffers():
+                torch.distributed.broadcast(b, 0)
         if self.three_d:
             from val_3D import test_all_case
-            m = test_all_case(model, args.root_path, test_list="val.txt", num_classes=args.num_classes,
-                              patch_size=args.patch_size, stride_xy=64, stride_z=64)
-            return float(m[:, 0].mean()), float(m[:, 1].mean()), m
-        from val_2D import test_single_volume
-        total = 0.0
-        for i in range(len(self.db_val)):
-            s = self.db_val[i]
-            image = torch.from_numpy(np.asarray(s["image"])).unsqueeze(0)
-            label = torch.from_numpy(np.asarray(s["label"])).unsqueeze(0)
-            total = total + np.array(test_single_volume(image, label, model, classes=args.num_classes,
-                                                        patch_size=args.patch_size), dtype=np.float64)
-        m = total / len(self.db_val)
+            total, count = test_all_case(model, args.root_path, test_list="val.txt", num_classes=args.num_classes,
+                                         patch_size=args.patch_size, stride_xy=64, stride_z=64,
+                                         shard=(self.rank, self.world))
+        else:
+            from val_2D import test_single_volume
+            total, count = np.zeros((args.num_classes - 1, 2)), 0
+            for i in range(self.rank, len(self.db_val), self.world):
+                s = self.db_val[i]
+                image = torch.from_numpy(np.asarray(s["image"])).unsqueeze(0)
+                label = torch.from_numpy(np.asarray(s["label"])).unsqueeze(0)
+                total = total + np.array(test_single_volume(image, label, model, classes=args.num_classes,
+                                                            patch_size=args.patch_size), dtype=np.float64)
+                count += 1
+        m = self._reduce(total, count)
         return float(np.mean(m, axis=0)[0]), float(np.mean(m, axis=0)[1]), m
+
+    def _reduce(self, total, count):
+        """Mean over all ranks' cases: all-reduce (sum) of the metric sums and the case count."""
+        if self.world > 1:
+            t = torch.tensor(np.append(np.asarray(total, dtype=np.float64).ravel(), float(count)), dtype=torch.float64,
+                             device="cuda" if torch.distributed.get_backend() == "nccl" else "cpu")
+            torch.distributed.all_reduce(t)
+            t = t.cpu().numpy()
+            total, count = t[:-1].reshape(np.shape(total)), t[-1]
+        return np.asarray(total, dtype=np.float64) / max(count, 1)
 
     def __call__(self, iter_num, models):
         """``models``: list of (tag, file prefix, best-file suffix, module), e.g. ('', '', 'best_model', model) or
@@ -218,6 +237,8 @@ class Validator:
             model.eval()
             perf, hd95, m = self.score(model)
             model.train(was_training)
+            if self.rank != 0:
+                continue
             if self.scalars is not None:
                 for c in range(m.shape[0]):
                     self.scalars.add_scalar('info/%sval_%d_dice' % (tag, c + 1), m[c, 0], iter_num)
@@ -236,6 +257,8 @@ class Validator:
                 logging.info('iteration %d : %smean_dice : %f %smean_hd95 : %f' % (iter_num, tag, perf, tag, hd95))
 
     def finish(self, models):
+        if self.rank != 0:
+            return
         for tag, prefix, best_name, model in models:
             path = os.path.join(self.snapshot_path, '%s_%s.pth' % (self.args.model, best_name))
             if not os.path.exists(path):
@@ -298,7 +321,7 @@ def run_cross_teaching(args, make_model1, make_model2, log_every=1, label_dtype=
     if rank == 0:
         logging.info("{} iterations per epoch ({})".format(len(loader), source))
     scalars = ScalarLog(snapshot_path, enabled=(rank == 0))
-    validator = Validator(args, snapshot_path, scalars) if rank == 0 else None
+    validator = Validator(args, snapshot_path, scalars, rank, world)
     val_models = [('model1_', 'model1_', 'best_model1', model1), ('model2_', 'model2_', 'best_model2', model2)]
     if ema_model is not None:     # train_cnn_meet_vit_2D.py:441-468
         val_models.append(('ema_model_', 'ema_model_', 'best_ema_model', ema_model))
@@ -315,8 +338,7 @@ def run_cross_teaching(args, make_model1, make_model2, log_every=1, label_dtype=
                                        iter_num)
                 logging.info('iteration %d : model1 loss : %f model2 loss : %f' %
                              (iter_num, s["model1_loss"], s["model2_loss"]))
-            if rank == 0:
-                validator(iter_num, val_models)
+            validator(iter_num, val_models)      # every rank: the validation cases are sharded over the ranks
             if rank == 0 and iter_num % 3000 == 0:
                 for i, m in ((1, model1), (2, model2)):
                     path = os.path.join(snapshot_path, 'model%d_iter_%d.pth' % (i, iter_num))
@@ -372,7 +394,7 @@ def run_training(args, make_model, *, label_dtype, cons_start_iter, save_ema, lo
     if rank == 0:
         logging.info("{} iterations per epoch ({})".format(len(loader), source))
     scalars = ScalarLog(snapshot_path, enabled=(rank == 0))
-    validator = Validator(args, snapshot_path, scalars) if rank == 0 else None
+    validator = Validator(args, snapshot_path, scalars, rank, world)
     val_models = [('', '', 'best_model', model)]
     iter_num = 0
     max_epoch = args.max_iterations // len(loader) + 1
@@ -383,8 +405,9 @@ def run_training(args, make_model, *, label_dtype, cons_start_iter, save_ema, lo
             iter_num += 1
             if rank == 0 and iter_num % log_every == 0:
                 s = trainer.losses()          # the only device->host read of the step: ONE copy of trainer.out
-                # all scalars of train_mean_teacher_2D.py:239-245 (lr = the rate the NEXT step will use, as there)
-                lr_ = args.base_lr * (1.0 - min(iter_num, args.max_iterations) / args.max_iterations) ** 0.9
+                # all scalars of train_mean_teacher_2D.py:239-245.  lr_ is computed there (:234) BEFORE iter_num += 1
+                # and logged under the incremented iter_num: base_lr * (1 - (n - 1) / max) ** 0.9 at tag n
+                lr_ = args.base_lr * (1.0 - min(iter_num - 1, args.max_iterations) / args.max_iterations) ** 0.9
                 scalars.add_scalar('info/lr', lr_, iter_num)
                 scalars.add_scalar('info/total_loss', s["loss"], iter_num)
                 scalars.add_scalar('info/loss_ce', s["loss_ce"], iter_num)
@@ -393,8 +416,7 @@ def run_training(args, make_model, *, label_dtype, cons_start_iter, save_ema, lo
                 scalars.add_scalar('info/consistency_weight', s["consistency_weight"], iter_num)
                 logging.info('iteration %d : loss : %f, loss_ce: %f, loss_dice: %f' %
                              (iter_num, s["loss"], s["loss_ce"], s["loss_dice"]))
-            if rank == 0:
-                validator(iter_num, val_models)
+            validator(iter_num, val_models)      # every rank: the validation cases are sharded over the ranks
             if rank == 0 and iter_num % 3000 == 0:
                 path = os.path.join(snapshot_path, 'iter_' + str(iter_num) + '.pth')
                 torch.save(model.state_dict(), path)

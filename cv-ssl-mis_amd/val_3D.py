@@ -84,14 +84,20 @@ def cal_metric(gt, pred):
 
 
 def test_all_case(net, base_dir, test_list="full_test.list", num_classes=4, patch_size=(48, 160, 160), stride_xy=32,
-                  stride_z=24):
+                  stride_z=24, shard=None):
+    """``shard=(rank, world)``: score only the cases ``rank::world`` and return ``(metric sums, cases scored)`` instead
+    of the mean -- the data-parallel training loop shards its in-training validation over the ranks and sums the
+    shards (mis_hip.train_common.Validator); the default is the reference's whole-list mean."""
     from dataloaders.dataset import read_case
     with open("{}/{}".format(base_dir, test_list)) as f:
         cases = [ln.replace('\n', '').split(",")[0] for ln in f.readlines()]
+    mine = cases if shard is None else cases[shard[0]::shard[1]]
     total = np.zeros((num_classes - 1, 2))
-    for case in cases:
+    for case in mine:
         image, label = read_case("{}/data/{}".format(base_dir, case))
         prediction = test_single_case(net, image, stride_xy, stride_z, patch_size, num_classes=num_classes)
         for c in range(1, num_classes):
             total[c - 1] += cal_metric(label == c, prediction == c)
+    if shard is not None:
+        return total, len(mine)
     return total / len(cases)

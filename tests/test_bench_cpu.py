@@ -31,6 +31,19 @@ def test_self_launch_world2_gloo():
     assert out["scaling"] == "weak" and out["higher_is_better"] is True
     assert out["config"]["global_batch"] == 2 * 8 and out["config"]["parallelism"] == "dp2"
     assert "configs[2]" in out["config"]["workload"]                        # default = the north-star workload
+    # the run proves its own exchange: identical weights on every rank, and what the exchange costs
+    d = out["distributed"]
+    assert d["params_identical"] is True and len(d["weights_fingerprint"]) == 2
+    assert d["no_exchange_ms_per_step"] > 0 and "exposed_allreduce_ms_per_step" in d
+
+
+@pytest.mark.timeout(900)
+def test_missing_gradient_exchange_fails_the_run():
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["MIS_STUB_SKIP_SYNC"] = "1"
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--stub", "--steps", "3", "--warmup", "1",
+                        "--gpus", "2"], capture_output=True, text=True, timeout=600, env=env)
+    assert p.returncode != 0 and "data-parallel check FAILED" in (p.stderr + p.stdout)
 
 
 @pytest.mark.timeout(600)

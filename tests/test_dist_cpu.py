@@ -197,3 +197,68 @@ def test_bucketed_overlapped_allreduce_equals_single_allreduce(tmp_path):
     mp.spawn(_bucket_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
     a, b = (torch.load(os.path.join(tmp_path, f"g{r}.pt")) for r in range(world))
     assert torch.equal(a, b)
+
+
+# ---- the real plans' gradient ordering, recorded on the GPU (scripts/record_grad_ranges.py), through the real
+# ---- param_progress + GradBucketer over gloo
+class _RecordedOp:
+    """An op of a recorded plan: ``owns`` = the parameter-gradient views it holds as attributes (what param_progress
+    scans), ``writes`` = the ranges of the flat gradient buffer its backward actually wrote on the GPU."""
+
+    def __init__(self, flat_p, flat_g, true, owns, writes):
+        for i, (lo, hi) in enumerate(owns):
+            setattr(self, f"p{i}", _Ref(flat_p[lo:hi], flat_g[lo:hi], None))
+        self.flat_g, self.true, self.writes = flat_g, true, writes
+
+    def bwd(self):
+        for lo, hi in self.writes:
+            self.flat_g[lo:hi] = self.true[lo:hi]
+
+
+def _recorded_worker(rank, world, port, out_dir):
+    import json
+    for p in (os.path.join(ROOT, "cv-ssl-mis_amd"), ROOT):
+        sys.path.insert(0, p)
+    import torch.distributed as dist
+    from mis_hip import dist as mdist
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    with open(os.path.join(ROOT, "tests", "golden", "plan_grad_ranges.json")) as f:
+        rec = json.load(f)
+    for kind, r in sorted(rec.items()):
+        total = r["total"]
+        g = torch.Generator().manual_seed(1000 + rank)
+        flat_p, flat_g = torch.zeros(total), torch.zeros(total)
+        true = torch.randn(total, generator=g)
+        ops = [_RecordedOp(flat_p, flat_g, true, o["owns"], o["writes"]) for o in r["ops"]]
+        done = mdist.param_progress(ops, flat_g)
+        assert done == sorted(done) and done[0] == 0, kind
+        b = mdist.GradBucketer(flat_g, bucket_bytes=1 << 20)        # 1 MiB: many buckets even for the small nets
+        b.begin()
+        shipped_at = []
+        for i in range(len(ops) - 1, -1, -1):                       # Plan.backward(on_progress=b.advance)
+            ops[i].bwd()
+            if i == 0 or done[i] != done[i - 1] or i == len(ops) - 1:
+                b.advance(done[i])
+            shipped_at.append(b._next)
+        b.finish()
+        written = torch.zeros(total, dtype=torch.bool)
+        for o in r["ops"]:
+            for lo, hi in o["writes"]:
+                written[lo:hi] = True
+        ref = torch.where(written, true, torch.zeros(()))
+        dist.all_reduce(ref)                                        # the single blocking all-reduce of the final buffer
+        assert torch.equal(flat_g, ref), f"{kind}: a bucket left before one of its gradients was written"
+        assert shipped_at[len(shipped_at) // 2] > 0, f"{kind}: nothing was exchanged during the backward"
+        if rank == 0:
+            with open(os.path.join(out_dir, f"{kind}.ok"), "w") as f:
+                f.write(f"{len(ops)} ops, {len(b.buckets)} buckets\n")
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_recorded_plan_backward_order_through_bucketer(tmp_path):
+    """Every op's owned and actually written gradient ranges of the real unet / unet_3D / V-Net (GroupNorm) / SwinUnet
+    plans: the bucketed, overlapped exchange equals the blocking all-reduce of the finished buffer."""
+    world = 2
+    mp.spawn(_recorded_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    assert sorted(os.listdir(tmp_path)) == ["swin.ok", "unet2d.ok", "unet3d.ok", "vnet_groupnorm.ok"]
