@@ -18,6 +18,7 @@
 // A "group" is what one mean/variance is taken over: per channel over (N, S)
 // for BatchNorm (per_sample = 0), per (n, c) over S for InstanceNorm (per_sample = 1).
 #include "common.h"
+#include <type_traits>
 
 namespace {
 
@@ -107,11 +108,26 @@ __device__ __forceinline__ void pool_grad4(const PoolGrad& pg, int n, int c, int
     g[3] = c1 == local + 1u ? d.y : 0.f;
 }
 
+// block-wide sum of two doubles (256 threads), result in thread 0; fixed tree
+__device__ __forceinline__ void block_sum2_d(double (&v)[2], double* red) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    v[0] = mis_wave_sum_d(v[0]); v[1] = mis_wave_sum_d(v[1]);
+    __syncthreads();
+    if (lane == 0) { red[wave * 2] = v[0]; red[wave * 2 + 1] = v[1]; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        v[0] = ((red[0] + red[2]) + red[4]) + red[6];
+        v[1] = ((red[1] + red[3]) + red[5]) + red[7];
+    }
+}
+
 // ---------------- statistics ----------------
 // grid = (P, nchunks, G); partial[(g*nchunks + k)*P + p] = (sum, sumsq)
+// The stand-alone pass (layers whose producer is not a conv with fused statistics, and every GroupNorm) accumulates in
+// double, as torch's CPU kernels do (at::acc_type<float>): the pass is HBM-bound, the fp64 adds are free
 __global__ __launch_bounds__(256) void stats_partial_kernel(const float* __restrict__ x, Geo g,
                                                             float2* __restrict__ part) {
-    __shared__ float red[8];
+    __shared__ double red[8];
     const int p = blockIdx.x, k = blockIdx.y, grp = blockIdx.z;
     const int n = g.per_sample ? grp / g.C : k;
     const int c = g.per_sample ? grp % g.C : grp;
@@ -119,14 +135,14 @@ __global__ __launch_bounds__(256) void stats_partial_kernel(const float* __restr
     const long long units = g.S >> 2;
     const long long per = (units + g.P - 1) / g.P;
     const long long u0 = p * per, u1 = (u0 + per < units) ? u0 + per : units;
-    float v[2] = {0.f, 0.f};
+    double v[2] = {0.0, 0.0};
     for (long long u = u0 + threadIdx.x; u < u1; u += 256) {
         const float4 q = *reinterpret_cast<const float4*>(base + u * 4);
-        v[0] += (q.x + q.y) + (q.z + q.w);
-        v[1] += (q.x * q.x + q.y * q.y) + (q.z * q.z + q.w * q.w);
+        v[0] += ((double)q.x + (double)q.y) + ((double)q.z + (double)q.w);
+        v[1] += ((double)q.x * q.x + (double)q.y * q.y) + ((double)q.z * q.z + (double)q.w * q.w);
     }
-    mis_block_sum<2>(v, red);
-    if (threadIdx.x == 0) part[((long long)grp * g.nchunks + k) * g.P + p] = make_float2(v[0], v[1]);
+    block_sum2_d(v, red);
+    if (threadIdx.x == 0) part[((long long)grp * g.nchunks + k) * g.P + p] = make_float2((float)v[0], (float)v[1]);
 }
 
 // one 256-thread block per group (the fused conv statistics leave thousands of partials per channel)
@@ -306,6 +322,9 @@ __global__ __launch_bounds__(256) void apply_fwd_pool_kernel(const float* __rest
 // ---------------- backward ----------------
 // dz = da * dropscale * (z > 0 ? 1 : slope),  z = xhat*gamma + beta,  xhat = (x-mean)*rstd
 // partial sums per group: s1 = sum dz, s2 = sum dz*xhat
+// DACC: per-thread accumulation in double (GroupNorm: the reference's CPU kernels accumulate in double there, and its
+// gradient noise is what the parity gates are measured against)
+template <bool DACC>
 __global__ __launch_bounds__(256) void bwd_partial_kernel(const float* __restrict__ x, Geo g,
                                                           const float* __restrict__ da, long long da_bs,
                                                           const float* __restrict__ mean,
@@ -313,7 +332,7 @@ __global__ __launch_bounds__(256) void bwd_partial_kernel(const float* __restric
                                                           const float* __restrict__ gamma,
                                                           const float* __restrict__ beta, float slope, DropCfg d,
                                                           float2* __restrict__ part, PoolGrad pg) {
-    __shared__ float red[8];
+    __shared__ double red[8];
     const int p = blockIdx.x, k = blockIdx.y, grp = blockIdx.z;
     const int n = g.per_sample ? grp / g.C : k;
     const int c = g.per_sample ? grp % g.C : grp;
@@ -327,7 +346,8 @@ __global__ __launch_bounds__(256) void bwd_partial_kernel(const float* __restric
     const long long per = (units + g.P - 1) / g.P;
     const long long u0 = p * per, u1 = (u0 + per < units) ? u0 + per : units;
     const bool drop = d.p > 0.f;
-    float v[2] = {0.f, 0.f};
+    typedef typename std::conditional<DACC, double, float>::type acc_t;
+    acc_t v[2] = {0, 0};
     for (long long u = u0 + threadIdx.x; u < u1; u += 256) {
         const float4 q = *reinterpret_cast<const float4*>(xb + u * 4);
         const float4 gq = db ? *reinterpret_cast<const float4*>(db + u * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -351,11 +371,15 @@ __global__ __launch_bounds__(256) void bwd_partial_kernel(const float* __restric
             const float z = xh * ga + be;
             const float dz = z > 0.f ? gs[j] : gs[j] * slope;
             v[0] += dz;
-            v[1] += dz * xh;
+            v[1] += (acc_t)dz * (acc_t)xh;
         }
     }
-    mis_block_sum<2>(v, red);
-    if (threadIdx.x == 0) part[((long long)grp * g.nchunks + k) * g.P + p] = make_float2(v[0], v[1]);
+    if constexpr (DACC) {
+        block_sum2_d(v, red);
+    } else {
+        mis_block_sum<2>(v, reinterpret_cast<float*>(red));
+    }
+    if (threadIdx.x == 0) part[((long long)grp * g.nchunks + k) * g.P + p] = make_float2((float)v[0], (float)v[1]);
 }
 
 // one wave per group: sums[g] = (s1/E, s2/E); affine grads for batch norm
@@ -646,8 +670,12 @@ int norm_act_bwd_impl(const float* x, long long x_bs, const float* da, long long
     float2* sums = part + (long long)g.G * g.nchunks * g.P;
     const bool gn = per_sample && (cg > 1 || gamma);    // per-channel affine inside a per-sample group
     if (!no_norm) {
-        hipLaunchKernelGGL(bwd_partial_kernel, dim3(g.P, g.nchunks, g.G), dim3(256), 0, stream, x, g, da, da_bs, mean,
-                           rstd, gamma, beta, slope, d, part, pg);
+        if (cg > 1)
+            hipLaunchKernelGGL(bwd_partial_kernel<true>, dim3(g.P, g.nchunks, g.G), dim3(256), 0, stream, x, g, da, da_bs,
+                               mean, rstd, gamma, beta, slope, d, part, pg);
+        else
+            hipLaunchKernelGGL(bwd_partial_kernel<false>, dim3(g.P, g.nchunks, g.G), dim3(256), 0, stream, x, g, da, da_bs,
+                               mean, rstd, gamma, beta, slope, d, part, pg);
         if (gn) {
             hipLaunchKernelGGL(gn_bwd_group_kernel, dim3((N * (C / cg) + 3) / 4), dim3(256), 0, stream, part, g, gamma,
                                sums);
@@ -720,7 +748,7 @@ extern "C" int mis_norm_act_bwd_sums(const float* x, long long x_bs, const float
     const Geo g = make_geo(N, C, S, x_bs, per_sample);
     const DropCfg d{0.f, 0u, nullptr, nullptr};
     float2* part = reinterpret_cast<float2*>(workspace);
-    hipLaunchKernelGGL(bwd_partial_kernel, dim3(g.P, g.nchunks, g.G), dim3(256), 0, stream, x, g, da, da_bs, mean, rstd,
+    hipLaunchKernelGGL(bwd_partial_kernel<false>, dim3(g.P, g.nchunks, g.G), dim3(256), 0, stream, x, g, da, da_bs, mean, rstd,
                        gamma, beta, slope, d, part, PoolGrad{});
     hipLaunchKernelGGL(bwd_final_kernel, dim3((g.G + 3) / 4), dim3(256), 0, stream, part, g,
                        reinterpret_cast<float2*>(sums), dgamma, dbeta, accumulate_affine);

@@ -291,9 +291,12 @@ F64_LOGIT = 5e-4
 F64_MEDIAN_RATIO = 2.0
 # GroupNorm nets: torch's CPU GroupNorm kernels accumulate their sums in double (at::acc_type<float> on the CPU), so the
 # reference's own fp32 noise e32 is ~3x lower there (1.8e-2 at the worst tensors) than for its BatchNorm / InstanceNorm
-# nets (5e-2), while the HIP path (fp32 block partials, double final stage) has the same absolute noise for both
-# (5e-2 BatchNorm, 8e-2 GroupNorm at the worst tensors; measured medians of HIP / e32: 0.15-0.75 vs 2.1-2.7).
-F64_GN = dict(K=30.0, median=4.0)
+# nets (5e-2).  Round 3: the HIP GroupNorm path accumulates in double too (statistics pass and backward partial sums,
+# norm_act.hip) -- medians of HIP / e32 went from 2.1-2.7 to 1.2-1.9 (BatchNorm / InstanceNorm nets: 0.1-0.8).  What is
+# left is the fp32 rounding of everything else on an ill-conditioned fixture: single tensors land anywhere between 0.1x
+# and 22x the reference's own error (block_five.conv.3.weight, the 4^3 level, with the Winograd kernels; with MIS_WINO=0
+# the same tensor is at 2.7x and another case's median moves from 1.2 to 2.1), so the per-tensor factor stays wide.
+F64_GN = dict(K=30.0, median=2.5)
 
 
 @pytest.mark.parametrize("name,it", F64_CASES)
@@ -366,6 +369,9 @@ def test_step_gradients_match_float64_oracle(name, it):
         if gmax > 1e-4 * gscale:
             ratios.append((err / gmax) / max(float(ref32[i]), 1e-3))
     worst = max(rows)
+    if os.environ.get("MIS_PRINT_GRAD_ROWS"):
+        for r in sorted(rows, reverse=True)[:12]:
+            print(f"   {r[1]:50s} err/tol {r[0]:.3f} err {r[2]:.2e} |g|max {r[3]:.2e} rel {r[2] / max(r[3], 1e-30):.2e}")
     ratios = np.sort(np.array(ratios))
     print(f"\n{name}: logits max err {logit_err:.2e}, losses max err {loss_err:.2e}; worst gradient error / tolerance = "
           f"{worst[0]:.3f} at {worst[1]} (err {worst[2]:.2e}, |g|max {worst[3]:.2e}); HIP error / reference-fp32 error "
