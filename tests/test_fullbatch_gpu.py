@@ -19,7 +19,12 @@ import torch
 pytestmark = pytest.mark.gpu
 
 TOL_LOGIT, TOL_LOSS = 1e-3, 2e-4          # the north-star bar on logits; scalar losses tighter
-GRAD_REL, GRAD_ABS = 0.25, 2e-3           # per tensor: |dg|_max <= GRAD_REL * |g|_max + GRAD_ABS * (largest |g| of the net)
+# per tensor: |dg|_max <= grad_rel * |g|_max + GRAD_ABS * (largest |g| of the net).  grad_rel per case = ~5x the largest
+# value measured at the full batch (round 3: config 2 5.8e-3, config 3 2.4e-3, config 4 inside the absolute term,
+# cross teaching 2.0e-2 on the CNN / inside the absolute term on the Transformer) -- the fixture-size envelope of
+# test_parity_gpu.py (6 x the reference's own fp32 noise + 2e-3), not a dispatch-only bound
+GRAD_REL, GRAD_ABS = 0.1, 2e-3
+GRAD_REL_CASE = {"config2_unet2d_24+24_256": 0.03, "config3_unet3d_4+4_96": 0.015, "config4_swin_24+24_224": 0.01}
 
 
 def _states(onet, tag=""):
@@ -40,16 +45,20 @@ def _record_kernels(fn):
         ops.PROFILE = None
 
 
-def _check_grads_and_params(model, grads, student_after, lr, what):
+def _check_grads_and_params(model, grads, student_after, lr, what, grad_rel=GRAD_REL):
     gscale = max(float(g.abs().max()) for g in grads.values())
+    worst = (0.0, "")
     for n, g in model.named_flat(model.flat_grad):
         ref = grads[n]
         err = (g.cpu() - ref).abs().max().item()
-        tol = GRAD_REL * float(ref.abs().max()) + GRAD_ABS * gscale
+        tol = grad_rel * float(ref.abs().max()) + GRAD_ABS * gscale
+        worst = max(worst, ((err - GRAD_ABS * gscale) / max(float(ref.abs().max()), 1e-30), n))
         assert err <= tol, (what, n, err, tol)
+    print(f"\n{what}: largest per-tensor gradient error beyond the absolute term, relative to the tensor's max: "
+          f"{worst[0]:.3e} at {worst[1]} (bound {grad_rel})")
     for n, v in model.named_flat(model.flat_param):
         err = (v.cpu() - student_after[n]).abs().max().item()
-        assert err <= 1e-6 + lr * (GRAD_REL + GRAD_ABS) * gscale, (what, n, err)
+        assert err <= 1e-6 + lr * (grad_rel + GRAD_ABS) * gscale, (what, n, err)
 
 
 MT_CASES = {
@@ -113,7 +122,7 @@ def test_mean_teacher_step_at_full_batch(name):
     for k in ("loss", "loss_ce", "loss_dice", "consistency_loss"):
         assert abs(got[k] - orc[k]) <= TOL_LOSS, (k, got[k], orc[k])
     assert abs(got["consistency_weight"] - orc["consistency_weight"]) <= 1e-6
-    _check_grads_and_params(model, orc["grads"], student, orc["lr"], name)
+    _check_grads_and_params(model, orc["grads"], student, orc["lr"], name, GRAD_REL_CASE[name])
     alpha = orc["ema_alpha"]
     gscale = max(float(g.abs().max()) for g in orc["grads"].values())
     for n, v in ema.named_flat(ema.flat_param):
@@ -121,8 +130,11 @@ def test_mean_teacher_step_at_full_batch(name):
 
 
 @pytest.mark.timeout(1500)
-def test_cross_teaching_step_at_full_batch():
-    """config 5 per GPU: UNet <-> SwinUnet, 16 labeled + 16 unlabeled images of 224^2."""
+@pytest.mark.parametrize("size,window", [(224, 7), (256, 8)], ids=["224_w7", "256_w8"])
+def test_cross_teaching_step_at_full_batch(size, window):
+    """config 5 per GPU: UNet <-> SwinUnet, 16 labeled + 16 unlabeled images -- at the reference yaml's 224^2 / window 7
+    and at BASELINE's 256^2 with DATA.IMG_SIZE 256 + MODEL.SWIN.WINDOW_SIZE 8 (reference config.py:194-195), the
+    geometry bench.py's `cross` workload times."""
     from config import lite_config
     from mis_hip.step import CrossTeachingTrainer
     from networks.net_factory import net_factory
@@ -132,11 +144,13 @@ def test_cross_teaching_step_at_full_batch():
     from oracle.step import cross_teaching_step
     from oracle.swin import OracleSwinUnet
     C, L, B, it = 4, 16, 32, 1300
-    nets = [OracleUNet2D(1, C), OracleSwinUnet(C)]
+    nets = [OracleUNet2D(1, C), OracleSwinUnet(C) if size == 224 else OracleSwinUnet(C, img_size=size, window=window)]
     sds = [_states(nets[0], "m0."), _states(nets[1], "m1.")]
-    volume = filler.image((B, 1, 224, 224), "volume")
-    label = filler.labels((B, 224, 224), C, torch.uint8)
-    models = [net_factory("unet", 1, C), SwinUnet(lite_config(), img_size=224, num_classes=C)]
+    volume = filler.image((B, 1, size, size), "volume")
+    label = filler.labels((B, size, size), C, torch.uint8)
+    cfg = lite_config()
+    cfg.DATA.IMG_SIZE, cfg.MODEL.SWIN.WINDOW_SIZE = size, window
+    models = [net_factory("unet", 1, C), SwinUnet(cfg, img_size=size, num_classes=C)]
     for m in range(2):
         models[m].load_state_dict(sds[m])
         models[m].train()
@@ -152,7 +166,10 @@ def test_cross_teaching_step_at_full_batch():
         moms.append(mm)
     vol_d, lab_d = volume.cuda(), label.cuda()
     names = _record_kernels(lambda: tr.step(vol_d, lab_d))
-    assert "conv_fwd_kernel<Cfg<1, 3, 3, 1, 16, 32, 16, 8, 8>>" in names, sorted(names)
+    if size == 224:
+        assert "conv_fwd_kernel<Cfg<1, 3, 3, 1, 16, 32, 16, 8, 8>>" in names, sorted(names)
+    else:       # 256^2 divides into the Winograd boxes
+        assert "wino2d_fwd_kernel<W2Cfg<8, 8, 2, 3>>" in names, sorted(names)
     got = tr.losses()
     osd = [{k: v.clone() for k, v in sd.items()} for sd in sds]
     r = cross_teaching_step(nets[0], nets[1], osd[0], osd[1], moms[0], moms[1], volume, label, it, labeled_bs=L,
@@ -165,4 +182,4 @@ def test_cross_teaching_step_at_full_batch():
         assert abs(got[f"pseudo_supervision{m + 1}"] - ps) <= TOL_LOSS
         lg = models[m]._last[0].out.t.cpu().reshape(r[f"logits{m + 1}"].shape)
         assert (lg - r[f"logits{m + 1}"]).abs().max().item() <= TOL_LOGIT
-        _check_grads_and_params(models[m], r["grads"][m], osd[m], r["lr"], f"model{m + 1}")
+        _check_grads_and_params(models[m], r["grads"][m], osd[m], r["lr"], f"model{m + 1}", 0.08 if m == 0 else 0.01)
