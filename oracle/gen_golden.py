@@ -351,16 +351,18 @@ def run_case(name, kind, cfg, iters, drop_mode, eval_logits=False):
     print(f"{name}: oracle vs reference worst rel err {worst:.2e}; wrote {name}.npz")
 
 
-def run_cross_case(name, cfg, it):
+def run_cross_case(name, cfg, it, kinds=("unet2d", "swin")):
     """Cross teaching UNet <-> SwinUnet (config 5 geometry, 224x224): reference modules in the restated loop of
-    train_cross_teaching_between_cnn_transformer_2D.py:216-263 vs oracle.step.cross_teaching_step."""
+    train_cross_teaching_between_cnn_transformer_2D.py:216-263 vs oracle.step.cross_teaching_step.
+    ``kinds=("swin", "swin")``: train_cross_pseudo_supervision_2D_ViT.py:213-241 -- two SwinUnet students, the same loop
+    body (Dice on the other student's arg-max pseudo labels)."""
     from oracle.step import cross_teaching_step
     from oracle.swin import OracleSwinUnet
     from utils import losses as ref_losses, ramps as ref_ramps
     torch.manual_seed(0)
     C, L = cfg["num_classes"], cfg["labeled_bs"]
-    nets = [OracleUNet2D(1, C), OracleSwinUnet(C)]
-    models = [build_reference("unet2d", 1, C), build_reference("swin", 1, C)]
+    nets = [OracleUNet2D(1, C) if k == "unet2d" else OracleSwinUnet(C) for k in kinds]
+    models = [build_reference(k, 1, C) for k in kinds]
     sds = []
     for m, (onet, model) in enumerate(zip(nets, models)):
         sd = filler.fill_state_dict({f"m{m}." + k: v.clone() for k, v in model.state_dict().items()})
@@ -369,8 +371,8 @@ def run_cross_case(name, cfg, it):
         model.load_state_dict(sd)
         model.train()
         sds.append(sd)
-    set_reference_dropout(models[0], "unet2d", "off", None)
-    set_reference_dropout(models[1], "swin", "off", None)
+    set_reference_dropout(models[0], kinds[0], "off", None)
+    set_reference_dropout(models[1], kinds[1], "off", None)
     volume, label, _ = make_inputs("swin", cfg)
     # ---- reference loop body ----
     opts = [torch.optim.SGD(m.parameters(), lr=cfg["base_lr"], momentum=0.9, weight_decay=0.0001) for m in models]
@@ -415,12 +417,12 @@ def run_cross_case(name, cfg, it):
             rel_close(r["grads"][m][n], g, 2e-4, f"{name} grad m{m} {n}")
             rel_close(osd[m][n], ref_sd[n], 1e-5, f"{name} post-SGD m{m} {n}")
     # fp64 reference for the gradient envelope
-    m64 = [build_reference("unet2d", 1, C).double(), build_reference("swin", 1, C).double()]
+    m64 = [build_reference(k, 1, C).double() for k in kinds]
     for m in range(2):
         m64[m].load_state_dict({k: (v.double() if v.is_floating_point() else v) for k, v in sds[m].items()})
         m64[m].train()
-    set_reference_dropout(m64[0], "unet2d", "off", None)
-    set_reference_dropout(m64[1], "swin", "off", None)
+    set_reference_dropout(m64[0], kinds[0], "off", None)
+    set_reference_dropout(m64[1], kinds[1], "off", None)
     q1, q2 = m64[0](volume.double()), m64[1](volume.double())
     t1, t2 = torch.softmax(q1, 1), torch.softmax(q2, 1)
     l1 = 0.5 * (ce(q1[:L], label[:L].long()) + dice(t1[:L], label[:L].unsqueeze(1))) + \
@@ -428,7 +430,7 @@ def run_cross_case(name, cfg, it):
     l2 = 0.5 * (ce(q2[:L], label[:L].long()) + dice(t2[:L], label[:L].unsqueeze(1))) + \
         w * dice(t2[L:], torch.argmax(t1[L:].detach(), 1).unsqueeze(1))
     (l1 + l2).backward()
-    out = dict(meta=json.dumps(dict(name=name, kind="cross", cfg=cfg, iters=[it], drop_mode="off")))
+    out = dict(meta=json.dumps(dict(name=name, kind="cross", cfg=cfg, iters=[it], drop_mode="off", kinds=list(kinds))))
     pre = f"it{it}_"
     out[pre + "model1_loss"], out[pre + "model2_loss"] = np.float64(float(m1)), np.float64(float(m2))
     out[pre + "loss1_ce_dice"] = np.float64(float(loss1))
@@ -729,7 +731,11 @@ def run_uamt_case(name, kind, cfg, it):
     from oracle.step import uamt_step
     torch.manual_seed(0)
     C, L = cfg["num_classes"], cfg["labeled_bs"]
-    onet = OracleUNet2D(1, C) if kind == "unet2d" else OracleUNet3D(C, 1)
+    if kind == "swin":       # train_uncertainty_aware_mean_teacher_ViT_2D.py:183-245 == the 2-D loop on two SwinUnets
+        from oracle.swin import OracleSwinUnet
+        onet = OracleSwinUnet(C)
+    else:
+        onet = OracleUNet2D(1, C) if kind == "unet2d" else OracleUNet3D(C, 1)
     model, ema_model = build_reference(kind, 1, C), build_reference(kind, 1, C)
     for p in ema_model.parameters():
         p.detach_()
@@ -738,7 +744,7 @@ def run_uamt_case(name, kind, cfg, it):
     tsd0 = {k[2:]: v for k, v in tsd0.items()}
     # the filler teacher predicts near-uniform probabilities (entropy > ln 2 everywhere = empty mask): sharpen its
     # output layer so that the entropy threshold splits the voxels.  Recorded in the fixture's cfg.
-    head = "decoder.out_conv.weight" if kind == "unet2d" else "final.weight"
+    head = {"unet2d": "decoder.out_conv.weight", "swin": "swin_unet.output.weight"}.get(kind, "final.weight")
     tsd0[head] = tsd0[head] * cfg["teacher_head_scale"]
     model.load_state_dict(sd0)
     ema_model.load_state_dict(tsd0)
@@ -872,6 +878,18 @@ def main():
         if not only or uname in only:
             sys.path.insert(0, REF)
             run_uamt_case(uname, ukind, ucfg, uit)
+    # the ViT variant of UA-MT (train_uncertainty_aware_mean_teacher_ViT_2D.py): two SwinUnets at 224 x 224, batch 1+1
+    if not only or "uamt_swin_224" in only:
+        _install_timm_shim()
+        sys.path.insert(0, REF)
+        run_uamt_case("uamt_swin_224", "swin", dict(CFG2D, batch_size=2, labeled_bs=1, spatial=[224, 224],
+                                                    max_iterations=3000, teacher_head_scale=40.0), 2500)
+    # ... and of cross pseudo supervision (train_cross_pseudo_supervision_2D_ViT.py): two SwinUnet students
+    if not only or "cps_vit_224" in only:
+        _install_timm_shim()
+        sys.path.insert(0, REF)
+        run_cross_case("cps_vit_224", dict(CFG2D, batch_size=2, labeled_bs=1, spatial=[224, 224]), 1300,
+                       kinds=("swin", "swin"))
     # cross pseudo supervision (SURVEY s.8 row n2), CNN scripts: CE pseudo-supervision between two students
     for cname, ckind, ccfg, cit in (("cps_unet2d_64", "unet2d", small2d, 1300), ("cps_unet3d_64", "unet3d", small3d, 460)):
         if not only or cname in only:

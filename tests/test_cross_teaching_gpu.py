@@ -15,7 +15,10 @@ def _sample_idx(numel):
     return np.unique(np.linspace(0, numel - 1, 64).astype(np.int64))
 
 
-def test_cross_teaching_step_matches_reference_and_oracle():
+@pytest.mark.parametrize("gold", ["cross_224", "cps_vit_224"])
+def test_cross_teaching_step_matches_reference_and_oracle(gold):
+    """cross_224: UNet <-> SwinUnet (train_cross_teaching_between_cnn_transformer_2D.py); cps_vit_224: two SwinUnet
+    students (train_cross_pseudo_supervision_2D_ViT.py:213-241, the same loop body)."""
     from config import lite_config
     from mis_hip.step import CrossTeachingTrainer
     from networks.net_factory import net_factory
@@ -25,11 +28,12 @@ def test_cross_teaching_step_matches_reference_and_oracle():
     from oracle.step import cross_teaching_step
     from oracle.swin import OracleSwinUnet
 
-    z = np.load(os.path.join(GOLD, "cross_224.npz"))
+    z = np.load(os.path.join(GOLD, gold + ".npz"))
     meta = json.loads(str(z["meta"]))
     cfg, it = meta["cfg"], meta["iters"][0]
+    kinds = meta.get("kinds", ["unet2d", "swin"])
     C, L = cfg["num_classes"], cfg["labeled_bs"]
-    nets = [OracleUNet2D(1, C), OracleSwinUnet(C)]
+    nets = [OracleUNet2D(1, C) if k == "unet2d" else OracleSwinUnet(C) for k in kinds]
     sds = []
     for m, onet in enumerate(nets):
         sd = filler.fill_state_dict({f"m{m}." + k: v.clone() for k, v in onet.new_state().items()})
@@ -37,7 +41,8 @@ def test_cross_teaching_step_matches_reference_and_oracle():
     B, sp = cfg["batch_size"], tuple(cfg["spatial"])
     volume = filler.image((B, 1) + sp, "volume")
     label = filler.labels((B,) + sp, C, torch.uint8)
-    models = [net_factory("unet", 1, C), SwinUnet(lite_config(), img_size=224, num_classes=C)]
+    models = [net_factory("unet", 1, C) if k == "unet2d" else SwinUnet(lite_config(), img_size=224, num_classes=C)
+              for k in kinds]
     for m in range(2):
         models[m].load_state_dict(sds[m])
         models[m].train()

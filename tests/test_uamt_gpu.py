@@ -1,5 +1,5 @@
 """UA-MT (SURVEY s.8 row n1): the HIP path through UAMTTrainer against the golden vectors of the real reference
-(oracle/gen_golden.py::run_uamt_case, code/train_uncertainty_aware_mean_teacher_{2D,3D}.py) and the CPU oracle.
+(oracle/gen_golden.py::run_uamt_case, code/train_uncertainty_aware_mean_teacher_{2D,3D,ViT_2D}.py) and the CPU oracle.
 Tolerances as in test_parity_gpu.py: 1e-3 on logits / losses, the measured fp32 envelope on gradients."""
 import json
 import os
@@ -20,7 +20,7 @@ def _sample_idx(numel):
     return np.unique(np.linspace(0, numel - 1, 64).astype(np.int64))
 
 
-@pytest.mark.parametrize("name", ["uamt_unet2d_64", "uamt_unet3d_64"])
+@pytest.mark.parametrize("name", ["uamt_unet2d_64", "uamt_unet3d_64", "uamt_swin_224"])
 def test_uamt_step_matches_reference_golden_and_oracle(name):
     from oracle import filler
     from oracle.nets import OracleUNet2D, OracleUNet3D
@@ -32,7 +32,12 @@ def test_uamt_step_matches_reference_golden_and_oracle(name):
     kind, cfg, it = meta["kind"], meta["cfg"], meta["iters"][0]
     C, L, B = cfg["num_classes"], cfg["labeled_bs"], cfg["batch_size"]
     U, sp = B - L, tuple(cfg["spatial"])
-    if kind == "unet2d":
+    if kind == "swin":       # train_uncertainty_aware_mean_teacher_ViT_2D.py: the 2-D loop on two SwinUnets
+        from networks.net_factory import net_factory
+        from oracle.swin import OracleSwinUnet
+        onet, make, head = OracleSwinUnet(C), (lambda: net_factory("ViT_Seg", 1, C)), "swin_unet.output.weight"
+        ldt = torch.uint8
+    elif kind == "unet2d":
         from networks.net_factory import net_factory
         onet, make, head = OracleUNet2D(1, C), (lambda: net_factory("unet", 1, C)), "decoder.out_conv.weight"
         ldt = torch.uint8
