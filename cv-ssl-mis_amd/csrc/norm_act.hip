@@ -888,7 +888,7 @@ __global__ __launch_bounds__(256) void head_fwd_fused_kernel(const HeadArgs a, D
 // hoisted (128 registers, four waves per SIMD: with all 16 in flight the kernel took 512 registers, one wave per SIMD,
 // and ran at 1.4 TB/s)
 template <int C, int K, bool MASK>
-__global__ __launch_bounds__(256, 3) void head_bwd_partial_kernel(const HeadArgs a, DropCfg d) {
+__global__ __launch_bounds__(256, K <= 2 ? 3 : 2) void head_bwd_partial_kernel(const HeadArgs a, DropCfg d) {
     __shared__ float sc[C], sh[C], sw[K * C], red[4 * (2 * C + K * C + K)];
     const int p = blockIdx.x, n = blockIdx.y;
     head_coeffs<C>(a, n, sc, sh);
@@ -1023,23 +1023,32 @@ __global__ __launch_bounds__(256) void head_bwd_apply_kernel(const HeadArgs a, D
 template <int C>
 int head_launch_fwd(const HeadArgs& a, const DropCfg& d, hipStream_t stream) {
     const dim3 grid((unsigned)mis_cdiv(a.S >> 2, 256), a.N);
-    if (d.mask) hipLaunchKernelGGL((head_fwd_fused_kernel<C, 2, true>), grid, dim3(256), 0, stream, a, d);      // K == 2 (mis_norm_head_eligible)
-    else hipLaunchKernelGGL((head_fwd_fused_kernel<C, 2, false>), grid, dim3(256), 0, stream, a, d);
+    // K in 2 .. 4 (mis_norm_head_eligible)
+#define MIS_HEAD_LAUNCH(KK) do { if (d.mask) hipLaunchKernelGGL((head_fwd_fused_kernel<C, KK, true>), grid, dim3(256), 0, stream, a, d); \
+        else hipLaunchKernelGGL((head_fwd_fused_kernel<C, KK, false>), grid, dim3(256), 0, stream, a, d); } while (0)
+    if (a.K == 2) MIS_HEAD_LAUNCH(2); else if (a.K == 3) MIS_HEAD_LAUNCH(3); else MIS_HEAD_LAUNCH(4);
+#undef MIS_HEAD_LAUNCH
     return mis_launch_status();
 }
 
 template <int C>
 void head_launch_partial(const HeadArgs& a, const DropCfg& d, hipStream_t stream) {
     const dim3 grid(a.P, a.N);
-    if (d.mask) hipLaunchKernelGGL((head_bwd_partial_kernel<C, 2, true>), grid, dim3(256), 0, stream, a, d);      // K == 2 (mis_norm_head_eligible)
-    else hipLaunchKernelGGL((head_bwd_partial_kernel<C, 2, false>), grid, dim3(256), 0, stream, a, d);
+    // K in 2 .. 4 (mis_norm_head_eligible)
+#define MIS_HEAD_LAUNCH(KK) do { if (d.mask) hipLaunchKernelGGL((head_bwd_partial_kernel<C, KK, true>), grid, dim3(256), 0, stream, a, d); \
+        else hipLaunchKernelGGL((head_bwd_partial_kernel<C, KK, false>), grid, dim3(256), 0, stream, a, d); } while (0)
+    if (a.K == 2) MIS_HEAD_LAUNCH(2); else if (a.K == 3) MIS_HEAD_LAUNCH(3); else MIS_HEAD_LAUNCH(4);
+#undef MIS_HEAD_LAUNCH
 }
 
 template <int C>
 void head_launch_apply(const HeadArgs& a, const DropCfg& d, hipStream_t stream) {
     const dim3 grid((unsigned)mis_cdiv(a.S >> 2, 256), a.N);
-    if (d.mask) hipLaunchKernelGGL((head_bwd_apply_kernel<C, 2, true>), grid, dim3(256), 0, stream, a, d);      // K == 2 (mis_norm_head_eligible)
-    else hipLaunchKernelGGL((head_bwd_apply_kernel<C, 2, false>), grid, dim3(256), 0, stream, a, d);
+    // K in 2 .. 4 (mis_norm_head_eligible)
+#define MIS_HEAD_LAUNCH(KK) do { if (d.mask) hipLaunchKernelGGL((head_bwd_apply_kernel<C, KK, true>), grid, dim3(256), 0, stream, a, d); \
+        else hipLaunchKernelGGL((head_bwd_apply_kernel<C, KK, false>), grid, dim3(256), 0, stream, a, d); } while (0)
+    if (a.K == 2) MIS_HEAD_LAUNCH(2); else if (a.K == 3) MIS_HEAD_LAUNCH(3); else MIS_HEAD_LAUNCH(4);
+#undef MIS_HEAD_LAUNCH
 }
 
 }  // namespace
@@ -1048,10 +1057,11 @@ void head_launch_apply(const HeadArgs& a, const DropCfg& d, hipStream_t stream) 
 // thread: three workgroups per CU, 768 blocks for 8 volumes = one round)
 constexpr int HEAD_PMUL = 3;
 
-// The fused form covers C = 16 channels and 2 classes (the binary 3-D tasks: BraTS whole tumour, LA, Pancreas), BatchNorm /
-// InstanceNorm statistics (one group per channel).  More classes: the partial-sum kernel's 2C + KC + K accumulators per
-// thread no longer fit the register file (K = 3: 2.3 KB of scratch).
-extern "C" int mis_norm_head_eligible(int C, int K) { return C == 16 && K == 2; }
+// The fused form covers C = 16 channels and 2 .. 4 classes (the binary 3-D tasks -- BraTS whole tumour, LA, Pancreas -- and
+// the 3- / 4-class label sets), BatchNorm / InstanceNorm statistics (one group per channel).  The partial-sum kernel
+// holds 2C + KC + K accumulators per thread: three workgroups per CU for K = 2 (66 accumulators), two for K = 3, 4
+// (83 / 100: at three per CU they spill 2.3 KB of scratch per thread).
+extern "C" int mis_norm_head_eligible(int C, int K) { return C == 16 && K >= 2 && K <= 4; }
 
 extern "C" long long mis_norm_head_workspace_bytes(int N, int C, long long S, int per_sample, int K) {
     if (N <= 0 || C <= 0 || S <= 0 || K <= 0) return MIS_ERR_ARG;

@@ -376,7 +376,7 @@ def conv_wgrad_cin1_norm(x, da, y, per_sample, mean, rstd, gamma, beta, sums, sl
 
 
 def norm_head_eligible(C, K, per_sample, gamma, beta, cg=1, no_norm=False):
-    """norm + act + dropout + 1x1x1 classifier as one pass (mis_norm_head_*): C == 16, K == 2, one statistics group per
+    """norm + act + dropout + 1x1x1 classifier as one pass (mis_norm_head_*): C == 16, K in 2..4, one statistics group per
     channel, InstanceNorm only without affine."""
     return bool(_l.load().mis_norm_head_eligible(C, K)) and cg == 1 and not no_norm and not (
         per_sample and (gamma is not None or beta is not None))

@@ -25,12 +25,12 @@ def _close(a, b, rtol=2e-5, atol=2e-6):
     assert err <= atol + rtol * b.abs().max().item(), f"max err {err:.3e} vs scale {b.abs().max().item():.3e}"
 
 
+@pytest.mark.parametrize("K", [2, 3, 4])
 @pytest.mark.parametrize("per_sample,slope,shape,p", [(False, 0.0, (3, 16, 4, 8, 16), 0.3), (False, 0.01, (2, 16, 8, 8, 8), 0.0),
                                                       (True, 0.0, (2, 16, 4, 4, 32), 0.5), (False, 0.0, (1, 16, 2, 6, 10), 0.3)])
-def test_norm_head_forward_backward(per_sample, slope, shape, p):
+def test_norm_head_forward_backward(per_sample, slope, shape, p, K):
     ops = _ops()
     N, C, D, H, W = shape
-    K = 2
     assert ops.norm_head_eligible(C, K, per_sample, None, None)
     x = _rand(*shape, seed=1, scale=2.0).requires_grad_(True)
     gamma = None if per_sample else (_rand(C, seed=2) * 0.5 + 1.0).requires_grad_(True)
@@ -87,7 +87,17 @@ def test_norm_head_philox_matches_unfused_kernels():
     """Device-RNG dropout (element-wise and nn.Dropout3d channel mode): the fused pass draws the same masks as
     mis_norm_act_fwd / _bwd followed by the 1x1x1 conv kernels."""
     ops = _ops()
-    shape, K, p = (2, 16, 4, 8, 32), 2, 0.3
+    _philox_case(2)
+
+
+@pytest.mark.parametrize("K", [3, 4])
+def test_norm_head_philox_more_classes(K):
+    _philox_case(K)
+
+
+def _philox_case(K):
+    ops = _ops()
+    shape, p = (2, 16, 4, 8, 32), 0.3
     N, C = shape[:2]
     x = _rand(*shape, seed=21, scale=2.0).float().cuda()
     w = _rand(K, C, 1, 1, 1, seed=22, scale=0.5).float().cuda()
@@ -122,7 +132,7 @@ def test_norm_head_philox_matches_unfused_kernels():
 def test_norm_head_refusals():
     ops = _ops()
     assert not ops.norm_head_eligible(32, 2, False, None, None)
-    assert not ops.norm_head_eligible(16, 4, False, None, None)
+    assert ops.norm_head_eligible(16, 4, False, None, None) and not ops.norm_head_eligible(16, 5, False, None, None)
     assert not ops.norm_head_eligible(16, 2, True, torch.ones(16), None)      # InstanceNorm with affine: GroupNorm kernels
     assert not ops.norm_head_eligible(16, 2, False, None, None, no_norm=True)
     x = torch.zeros(1, 32, 2, 4, 8, device="cuda")
