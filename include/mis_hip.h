@@ -199,7 +199,7 @@ int mis_conv_wgrad_cin1_norm(const float* x, long long x_bs, const float* da, lo
  * dropout2 -> final = nn.Conv3d(16, n_classes, 1); vnet.py:180-181; unetr.py out): logits[N][K][S] =
  * W[K][C] . drop(act(norm(x))) + b, i.e. mis_norm_act_fwd followed by a 1x1x1 mis_conv_fwd, without storing the
  * activation; the backward recomputes it from x and yields dx, dgamma / dbeta (BatchNorm) and the classifier's
- * dw[K][C], db[K] (NULL: none) from dlogits in two passes.  mis_norm_head_eligible: C == 16, K == 2; per_sample != 0
+ * dw[K][C], db[K] (NULL: none) from dlogits in two passes.  mis_norm_head_eligible: C == 16, 2 <= K <= 4; per_sample != 0
  * (InstanceNorm) only without affine.  Workspace: mis_norm_head_workspace_bytes. */
 int mis_norm_head_eligible(int C, int K);
 long long mis_norm_head_workspace_bytes(int N, int C, long long S, int per_sample, int K);
