@@ -13,6 +13,7 @@
 // Rows may live inside wider buffers (row stride `ld` > C), so the decoder's torch.cat([x, skip], -1)
 // (:767) is realised by writing the two halves into one buffer.  Reductions use fixed-order trees.
 #include "common.h"
+#include <string.h>
 
 namespace {
 
@@ -640,6 +641,44 @@ __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict_
     }
 }
 
+// every Linear weight of a network in one launch: a device table of jobs ordered by `first` (prefix sum of their 32x32
+// tiles); a workgroup finds the job of its tile by binary search (66 separate launches of ~5 us per SwinUnet backward before)
+struct TransposeJob {
+    const float* in; float* out;
+    int rows, cols, tiles_c, first;
+};
+
+__global__ __launch_bounds__(256) void transpose_batch_kernel(const TransposeJob* __restrict__ jobs, int n) {
+    __shared__ float tile[32][33];
+    __shared__ TransposeJob job;
+    __shared__ int local;
+    if (threadIdx.x == 0) {
+        int lo = 0, hi = n - 1;
+        const int t = (int)blockIdx.x;
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (jobs[mid].first <= t) lo = mid; else hi = mid - 1;
+        }
+        job = jobs[lo];
+        local = t - jobs[lo].first;
+    }
+    __syncthreads();
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int r0 = (local / job.tiles_c) * 32, c0 = (local % job.tiles_c) * 32;
+    const int rows = job.rows, cols = job.cols;
+#pragma unroll
+    for (int i = 0; i < 32; i += 8) {
+        const int r = r0 + ty + i, c = c0 + tx;
+        tile[ty + i][tx] = (r < rows && c < cols) ? job.in[(long long)r * cols + c] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 32; i += 8) {
+        const int c = c0 + ty + i, r = r0 + tx;
+        if (c < cols && r < rows) job.out[(long long)c * rows + r] = tile[tx][ty + i];
+    }
+}
+
 unsigned sgrid(long long units) {
     long long b = mis_cdiv(units, 256);
     if (b > 4096) b = 4096;
@@ -666,6 +705,28 @@ extern "C" int mis_transpose(const float* in, long long ldi, float* out, long lo
     if (!in || !out || rows <= 0 || cols <= 0 || ldi < cols || ldo < rows) return MIS_ERR_ARG;
     hipLaunchKernelGGL(transpose_kernel, dim3((cols + 31) / 32, (rows + 31) / 32), dim3(256), 0, stream, in, ldi, out,
                        ldo, rows, cols);
+    return mis_launch_status();
+}
+
+// Batched form: `jobs` = device array of n job records built by mis_transpose_job (dense row-major matrices:
+// out[cols][rows] = in[rows][cols]), `tiles` = the sum of their 32x32 tiles.
+extern "C" long long mis_transpose_job_bytes(void) { return (long long)sizeof(TransposeJob); }
+
+// fills one record on the HOST; returns the job's number of tiles (the next job's `first` = first + that), < 0: error
+extern "C" long long mis_transpose_job(void* job, const float* in, float* out, int rows, int cols, long long first) {
+    if (!job || !in || !out || rows <= 0 || cols <= 0 || first < 0) return MIS_ERR_ARG;
+    TransposeJob j;
+    j.in = in; j.out = out; j.rows = rows; j.cols = cols; j.tiles_c = (cols + 31) / 32; j.first = (int)first;
+    const long long tiles = (long long)j.tiles_c * ((rows + 31) / 32);
+    if (first + tiles > 0x7fffffffLL) return MIS_ERR_ARG;
+    memcpy(job, &j, sizeof(j));
+    return tiles;
+}
+
+extern "C" int mis_transpose_batch(const void* jobs, int n, long long tiles, hipStream_t stream) {
+    if (!jobs || n <= 0 || tiles <= 0 || tiles > 0x7fffffffLL) return MIS_ERR_ARG;
+    hipLaunchKernelGGL(transpose_batch_kernel, dim3((unsigned)tiles), dim3(256), 0, stream,
+                       reinterpret_cast<const TransposeJob*>(jobs), n);
     return mis_launch_status();
 }
 

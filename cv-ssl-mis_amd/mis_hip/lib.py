@@ -129,6 +129,9 @@ PROTOTYPES = {
                           c_ll, c_p]),
     "mis_droppath_table": (c_i, [c_p, c_p, c_p, c_i, c_i, c_p, c_p]),
     "mis_transpose": (c_i, [c_p, c_ll, c_p, c_ll, c_i, c_i, c_p]),
+    "mis_transpose_job_bytes": (c_ll, []),
+    "mis_transpose_job": (c_ll, [c_p, c_p, c_p, c_i, c_i, c_ll]),
+    "mis_transpose_batch": (c_i, [c_p, c_i, c_ll, c_p]),
     "mis_layernorm_fwd": (c_i, [c_p, c_ll, c_p, c_ll, c_p, c_p, c_p, c_p, c_ll, c_i, c_f, c_p]),
     "mis_colreduce_workspace_bytes": (c_ll, [c_ll, c_i]),
     "mis_layernorm_bwd": (c_i, [c_p, c_ll, c_p, c_ll, c_p, c_ll, c_p, c_p, c_p, c_p, c_p, c_ll, c_i, c_i, c_i, c_p,

@@ -82,6 +82,7 @@ class LinearOp:
         self.w2 = w.data.view(w.data.shape[0], -1)
         self.gw2 = w.grad.view(w.grad.shape[0], -1)
         self.wT = None
+        self.wT_batched = False      # True: the plan transposes every Linear weight in one launch (SwinPlan.backward)
         self.gelu = self.res = self.dx_gelu = None
 
     def fwd(self, ctx):
@@ -101,13 +102,24 @@ class LinearOp:
 
     def bwd(self, ctx):
         dy = self.y.grad()
-        tops.gemm(dy, self.x.t, self.gw2, trans=True)
-        if self.b is not None:
-            tops.colsum(dy, self.b.grad)
+        # dW / db need only (x, dy) and nothing downstream needs them: on the plan's side stream they run beside the
+        # dX chain (mis_hip.plan.WGRAD_STREAM)
+        side = getattr(ctx, "wgrad_stream", None) if self.need_dx else None
+        if side is not None:
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                tops.gemm(dy, self.x.t, self.gw2, trans=True)
+                if self.b is not None:
+                    tops.colsum(dy, self.b.grad)
+        else:
+            tops.gemm(dy, self.x.t, self.gw2, trans=True)
+            if self.b is not None:
+                tops.colsum(dy, self.b.grad)
         if self.need_dx:
-            if self.wT is None:
-                self.wT = torch.empty((self.w2.shape[1], self.w2.shape[0]), dtype=torch.float32, device="cuda")
-            tops.transpose(self.w2, self.wT)
+            if not self.wT_batched:
+                if self.wT is None:
+                    self.wT = torch.empty((self.w2.shape[1], self.w2.shape[0]), dtype=torch.float32, device="cuda")
+                tops.transpose(self.w2, self.wT)
             g = self.dx_gelu
             if (FUSE & 2) and g is not None and not g.x.written and \
                     tops.gemm_ex(dy, self.wT, g.x.grad(), tops.EP_GELU_BWD, E1=g.x.t):
@@ -351,6 +363,8 @@ class SwinPlan:
         self.out = None
         self.generation = 0      # forwards run on this plan (see mis_hip.plan.Plan / _NetFn.backward)
         self._progress = None
+        self._wgrad_stream = None
+        self._tbatch = None
         self._dp_gen, self._dp_const = -1, None
 
     def new(self, rows, C):
@@ -395,6 +409,19 @@ class SwinPlan:
     def next_site(self):
         return next(self._site)
 
+    def transpose_weights(self, ops_list=None):
+        """W^T of every Linear that needs a data gradient, one launch (the weights changed with the last SGD update)."""
+        if self._tbatch is None:
+            jobs = []
+            for op in (self.ops if ops_list is None else ops_list):
+                if isinstance(op, LinearOp) and op.need_dx and op.w2.is_contiguous():
+                    op.wT = torch.empty((op.w2.shape[1], op.w2.shape[0]), dtype=torch.float32, device="cuda")
+                    op.wT_batched = True
+                    jobs.append((op.w2, op.wT))
+            self._tbatch = tops.TransposeBatch(jobs) if jobs else False
+        if self._tbatch:
+            self._tbatch.run()
+
     def forward(self, x5, ctx):
         assert tuple(x5.shape) == self.in_shape, (tuple(x5.shape), self.in_shape)
         self.generation += 1
@@ -409,9 +436,19 @@ class SwinPlan:
         self.out.reset()
         if dlogits5 is not None:
             self.out.g = dlogits5
+        self.transpose_weights()
+        from . import plan as _plan
+        main, side = torch.cuda.current_stream(), None
+        if _plan.WGRAD_STREAM:
+            if self._wgrad_stream is None:
+                self._wgrad_stream = torch.cuda.Stream()
+            side = self._wgrad_stream
+        ctx.wgrad_stream = side
         if on_progress is None:
             for op in reversed(self.ops):
                 op.bwd(ctx)
+            if side is not None:
+                main.wait_stream(side)
             return
         if self._progress is None:
             from .dist import param_progress
@@ -419,6 +456,8 @@ class SwinPlan:
         for i in range(len(self.ops) - 1, -1, -1):      # see mis_hip.plan.Plan.backward
             self.ops[i].bwd(ctx)
             if i == 0 or self._progress[i] != self._progress[i - 1] or i == len(self.ops) - 1:
+                if side is not None:
+                    main.wait_stream(side)
                 on_progress(self._progress[i])
 
     def drop_sites(self):

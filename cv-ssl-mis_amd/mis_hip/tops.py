@@ -126,6 +126,31 @@ def transpose(src, dst):
     _l.check(L.mis_transpose(_l.ptr(src), lds, _l.ptr(dst), ldd, R, Cc, _l.stream_ptr()), "mis_transpose")
 
 
+class TransposeBatch:
+    """All weight transposes of a network's backward in one launch (``mis_transpose_batch``).  ``jobs``: list of
+    (src [R, C] dense, dst [C, R] dense); the device job table is built once (it holds raw pointers into the tensors)."""
+
+    def __init__(self, jobs):
+        import ctypes
+        L = _l.load()
+        nb = L.mis_transpose_job_bytes()
+        host = (ctypes.c_char * (nb * len(jobs)))()
+        first = 0
+        for i, (src, dst) in enumerate(jobs):
+            R, Cc = src.shape
+            assert src.is_contiguous() and dst.is_contiguous() and tuple(dst.shape) == (Cc, R)
+            n = L.mis_transpose_job(ctypes.byref(host, i * nb), _l.ptr(src), _l.ptr(dst), R, Cc, first)
+            if n < 0:
+                _l.check(n, "mis_transpose_job")
+            first += n
+        self.n, self.tiles, self.keep = len(jobs), first, jobs
+        self.table = torch.frombuffer(bytearray(bytes(host)), dtype=torch.uint8).cuda()
+
+    def run(self):
+        _l.check(_l.load().mis_transpose_batch(_l.ptr(self.table), self.n, self.tiles, _l.stream_ptr()),
+                 "mis_transpose_batch")
+
+
 def layernorm_fwd(x, y, gamma, beta, mean, rstd, eps=1e-5):
     L = _l.load()
     M, C, ldx = _mat(x)

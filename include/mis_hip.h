@@ -383,6 +383,13 @@ int mis_droppath_table(float* table, const float* p, const unsigned* salt, int n
                        const MisStepState* state, mis_stream_t stream);
 /* out[c][r] = in[r][c]: weight^T for the input-gradient GEMM (packed once per step) */
 int mis_transpose(const float* in, long long ldi, float* out, long long ldo, int rows, int cols, mis_stream_t stream);
+/* every Linear weight of a network in ONE launch (the dX GEMM of nn.Linear wants W^T; reference: autograd of nn.Linear in
+ * swin_transformer_unet_skip_expand_decoder_sys.py:17-31,115-150): mis_transpose_job fills one record of a HOST table
+ * (mis_transpose_job_bytes each; dense row-major in[rows][cols] -> out[cols][rows]; `first` = tiles of the jobs before it)
+ * and returns the job's tile count; mis_transpose_batch runs a DEVICE copy of the table. */
+long long mis_transpose_job_bytes(void);
+long long mis_transpose_job(void* job, const float* in, float* out, int rows, int cols, long long first);
+int mis_transpose_batch(const void* jobs, int n, long long tiles, mis_stream_t stream);
 /* nn.LayerNorm over the last dim (:204,211,323,365,393,716-717); mean/rstd: M floats saved for backward */
 int mis_layernorm_fwd(const float* x, long long ldx, float* y, long long ldy, const float* gamma, const float* beta,
                       float* mean, float* rstd, long long M, int C, float eps, mis_stream_t stream);
