@@ -49,6 +49,11 @@ struct WinoArgs {
     int boxes_z, boxes_y, boxes_x, co_groups;
     unsigned n_blocks, n_blocks_padded;
     float2* stat; long long stat_sc, stat_sn;
+    // NB instantiation (data gradient feeding the backward of a ReLU'd InstanceNorm): the norm's input, its per-(n, c)
+    // means = the activation thresholds, the activation's negative slope; `stat` then receives (sum dz, sum dz * x)
+    const float* xn; long long xn_bs;
+    const float* thr;
+    float slope;
 };
 
 // group = GZ x GY x GX tiles (16) per wave; workgroup = WZ x WY x WX groups x COB blocks of 16 output channels (4 waves)
@@ -167,7 +172,16 @@ __device__ __forceinline__ void slots(const f32x4* __restrict__ wl, const f32x4*
     }
 }
 
-template <class C>
+// NB = true: the launch is the data gradient dL/da of a convolution whose input a = ReLU(InstanceNorm(xn)) has no other
+// consumer.  The epilogue then also forms the two sums the normalisation's backward needs per (n, channel),
+//   s1 = sum dz,  t2 = sum dz * xn,   dz = da * (xn > mean ? 1 : slope)
+// (the backward's second stage turns t2 into sum dz * xhat = rstd * (t2 - mean * s1)), and writes them per run of boxes
+// into `stat` exactly as the forward writes its (sum, sum of squares): mis_norm_act_bwd's partial-sum pass over da and
+// xn -- 906 MB at 96^3 -- is not run.  The 16 float2 loads of xn a lane needs are issued in front of the LAST chunk's
+// DMAs, so that chunk's closing vmcnt wait covers them (vmcnt retires in order: loads issued in the epilogue itself
+// would wait for every DMA in flight).  The thresholds of all (n, c) sit in the LDS bias table (a data gradient has
+// no bias): N * Cout <= MAX_COUT.
+template <class C, bool NB = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void wino_fwd_kernel(const WinoArgs a) {
     float* const lds = mis_wino_lds;
     // persistent: XCD x owns the boxes [x * per, (x + 1) * per); its workgroups walk them 32 apart, so the 32 resident
@@ -284,7 +298,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     };
 
     float* const s_bias = lds + C::NBUF * C::STAGE + 128;
-    for (int i = tid; i < a.Cout; i += 256) s_bias[i] = a.bias ? a.bias[i] : 0.f;      // published by the barrier below
+    if constexpr (NB) {
+        for (int i = tid; i < a.N * a.Cout; i += 256) s_bias[i] = a.thr[i];             // thresholds [n][c]
+    } else {
+        for (int i = tid; i < a.Cout; i += 256) s_bias[i] = a.bias ? a.bias[i] : 0.f;      // published by the barrier below
+    }
     constexpr int A = C::NBUF - 1;
     const unsigned nslot_u = (unsigned)nslot;
     Box bb = decode(box), nb = bb;       // the box being computed, the box under the DMA cursor
@@ -315,7 +333,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // On entry stage gs+1 has landed for every wave and everyone is done with stage gs-1 (the barrier at the end of the
     // previous iteration).  The wait for stage gs+2 sits at the END of the iteration, in front of the epilogue's stores
     // (vmcnt counts stores too: a wait behind them would wait for their write acknowledgements).
-    auto iter = [&](auto first, f32x2 (&cur)[32], f32x2 (&nxt)[32], int s) {
+    auto iter = [&](auto first, f32x2 (&cur)[32], f32x2 (&nxt)[32], int s, bool relaxed) {
         cursor_set(gs + A, s + A < nst ? s + A : s + A - nst);
         RawPlanes rp;
         {
@@ -331,27 +349,62 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         // (scripts/ubench/mfma_overlap.hip), and in one block it costs 4 % less than spread over the slots
         if (!(DBG & 16) && !(DBG & 512)) in_units<0, 24>(nxt);
         ++gs;
-        vmwait<(DBG & 1024) ? 2 * C::P : C::P>::go();   // stage gs+1 landed (mine) ...  (1024: ablation, do not wait for it)
+        // stage gs+1 landed (mine) ...  (1024: ablation, do not wait for it).  `extra`: younger plain loads that may stay
+        // in flight (NB: the norm input issued in front of this chunk's DMAs; vmcnt retires in order, so everything
+        // older than them -- the stage this wait is for -- has landed all the same)
+        // (a uniform branch around the wait only: two copies of the MFMA run behind a branch make hipcc move the
+        // accumulators through VGPRs -- 593 spills)
+        if (NB && relaxed) vmwait<C::P + 16>::go();
+        else vmwait<(DBG & 1024) ? 2 * C::P : C::P>::go();
         if (!(DBG & 64)) __syncthreads();  // ... and everyone's; everyone is done with stage gs-1
     };
 
     // statistics: per-lane running sums over the boxes of a run (consecutive boxes of this workgroup in the same image and
     // channel group); only the last box of a run pays the cross-lane reduction, the others store zeros in their slot
     float run1[4] = {0.f, 0.f, 0.f, 0.f}, run2[4] = {0.f, 0.f, 0.f, 0.f};
+    f32x2 xv[NB ? 16 : 1];             // NB: the norm input at this lane's 4 channels x 2 x 2 (z, y) x-pairs
     for (; box < box_end; box += nslot_u, bb = nb) {
         const bool nlive = box + nslot_u < box_end;
         nb = advance(bb);
         if (sw == 0 && !(DBG & 4)) cursor_box(nb, nlive);
-        iter(std::true_type{}, ua, ub, 0);
+        iter(std::true_type{}, ua, ub, 0, false);
         if (sw == 1 && !(DBG & 4)) cursor_box(nb, nlive);
-        iter(std::false_type{}, ub, ua, 1);
+        iter(std::false_type{}, ub, ua, 1, false);
         for (int s = 2; s < nst; s += 2) {      // nst is even (Cin % 8 == 0)
             if (sw == s && !(DBG & 4)) cursor_box(nb, nlive);
-            iter(std::false_type{}, ua, ub, s);
+            if constexpr (NB) {
+                // in front of the DMAs of the second-to-last chunk: that chunk's closing wait lets these 16 loads fly
+                // (vmcnt(P + 16)), the last chunk's vmcnt(P) retires them -- two chunks of latency, as the DMAs have
+                if (s + 2 >= nst && !(DBG & 4096)) {
+                    const int oz = bb.z0 + 2 * tz, oy = bb.y0 + 2 * ty, ox = bb.x0 + 2 * tx;
+                    const bool okx = lane_live && oz < a.D && oy < a.H && ox < a.W;
+                    const int c0 = (bb.cg * C::COB + cb) * 16;
+                    // inline asm: hipcc's own waitcnt insertion does not see the asm DMAs and would guard a builtin
+                    // load with vmcnt(0) at its first use -- a wait for every DMA in flight (+1.5 us per box measured)
+                    const i32x4 rxn = make_rsrc(a.xn + (long long)bb.n * a.xn_bs + (long long)c0 * S, 16u * s_bytes);
+                    const unsigned vx = okx ? (unsigned)(lk * 4) * s_bytes + (unsigned)((oz * a.H + oy) * a.W + ox) * 4u : OOB;
+                    unsigned vzy[4];
+#pragma unroll
+                    for (int zy = 0; zy < 4; ++zy) vzy[zy] = vx + (unsigned)(((zy >> 1) * a.H + (zy & 1)) * a.W) * 4u;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const unsigned so = (unsigned)r * s_bytes;
+#pragma unroll
+                        for (int zy = 0; zy < 4; ++zy)
+                            asm volatile("buffer_load_dwordx2 %0, %1, %2, %3 offen"
+                                         : "=v"(xv[r * 4 + zy]) : "v"(vzy[zy]), "s"(rxn), "s"(so) : "memory");
+                    }
+                }
+            }
+            iter(std::false_type{}, ua, ub, s, NB && s + 2 >= nst);
             if (sw == s + 1 && !(DBG & 4)) cursor_box(nb, nlive);
-            iter(std::false_type{}, ub, ua, s + 1);
+            iter(std::false_type{}, ub, ua, s + 1, false);
         }
 
+        if constexpr (NB) {     // the last chunk's vmcnt(P) retired the xn loads: from here on their registers hold data
+#pragma unroll
+            for (int i = 0; i < 16; ++i) asm volatile("" : "+v"(xv[i]));
+        }
         // ---- epilogue: inverse transform (64 -> 2x2x2 per (channel, tile)), bias, store, optional statistics ----
         if (DBG & 2) continue;
         asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");        // the last (asm) MFMAs have left the pipe before their AGPRs are read
@@ -394,15 +447,28 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                     }
                 __builtin_amdgcn_sched_barrier(0);
             }
-            const f32x2 bv = *reinterpret_cast<const f32x2*>(s_bias + co0 + lk * 4 + 2 * h);     // LDS: lgkmcnt, not vmcnt
+            f32x2 bv = *reinterpret_cast<const f32x2*>(s_bias + (NB ? bb.n * a.Cout : 0) + co0 + lk * 4 + 2 * h);     // LDS: lgkmcnt, not vmcnt
+            const f32x2 th = bv;                 // NB: the two channels' thresholds (a data gradient has no bias)
+            if constexpr (NB) bv = f32x2{0.f, 0.f};
             f32x2 s1 = {0.f, 0.f}, s2 = s1;
 #pragma unroll
             for (int zz = 0; zz < 2; ++zz)
 #pragma unroll
                 for (int yy = 0; yy < 2; ++yy) {
                     const f32x2 v0 = o[zz][yy][0] + bv, v1 = o[zz][yy][1] + bv;
-                    s1 += v0 + v1;
-                    s2 += v0 * v0 + v1 * v1;
+                    if constexpr (NB && !(DBG & 8192)) {
+#pragma unroll
+                        for (int rr = 0; rr < 2; ++rr) {
+                            const f32x2 x = xv[(2 * h + rr) * 4 + zz * 2 + yy];      // (x, x + 1) of channel 2h + rr
+                            const float d0 = x[0] > th[rr] ? v0[rr] : v0[rr] * a.slope;
+                            const float d1 = x[1] > th[rr] ? v1[rr] : v1[rr] * a.slope;
+                            s1[rr] += d0 + d1;
+                            s2[rr] = fmaf(d0, x[0], fmaf(d1, x[1], s2[rr]));
+                        }
+                    } else {
+                        s1 += v0 + v1;
+                        s2 += v0 * v0 + v1 * v1;
+                    }
 #pragma unroll
                     for (int rr = 0; rr < 2; ++rr) {
                         typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
@@ -457,7 +523,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     }
 }
 
-template <class C>
+template <class C, bool NB = false>
 int launch_wino(WinoArgs a, hipStream_t stream) {
     a.boxes_z = (int)mis_cdiv(a.D, C::OZ);
     a.boxes_y = (int)mis_cdiv(a.H, C::OY);
@@ -468,10 +534,10 @@ int launch_wino(WinoArgs a, hipStream_t stream) {
     a.n_blocks = (unsigned)nb;
     a.n_blocks_padded = (unsigned)(mis_cdiv(nb, MIS_NUM_XCD) * MIS_NUM_XCD);
     static std::atomic<unsigned long long> attr_done{0};
-    if (mis_set_lds_attr(reinterpret_cast<const void*>(&wino_fwd_kernel<C>), C::LDS_BYTES, attr_done) != MIS_OK)
+    if (mis_set_lds_attr(reinterpret_cast<const void*>(&wino_fwd_kernel<C, NB>), C::LDS_BYTES, attr_done) != MIS_OK)
         return MIS_ERR_LAUNCH;
     const unsigned grid = a.n_blocks_padded < 256u ? a.n_blocks_padded : 256u;      // persistent: one workgroup per CU
-    hipLaunchKernelGGL(wino_fwd_kernel<C>, dim3(grid), dim3(256), C::LDS_BYTES, stream, a);
+    hipLaunchKernelGGL((wino_fwd_kernel<C, NB>), dim3(grid), dim3(256), C::LDS_BYTES, stream, a);
     return mis_launch_status();
 }
 
@@ -523,10 +589,10 @@ extern "C" long long mis_conv3d_wino_stat_tiles(int D, int H, int W, int variant
 // kernel name as rocprofv3 prints it (minus the anonymous-namespace prefix), for bench.py's attribution
 extern "C" int mis_conv3d_wino_kernel_name(int variant, char* name, int name_len) {
     if (!name || name_len <= 0) return MIS_ERR_ARG;
-    if (variant == 0) snprintf(name, name_len, "wino_fwd_kernel<WinoCfg<1, 1, 16, 2, 2, 1, 1, 4, 0, 0>>");
-    else if (variant == 1) snprintf(name, name_len, "wino_fwd_kernel<WinoCfg<1, 2, 8, 2, 2, 1, 1, 4, 0, 0>>");
-    else if (variant == 2) snprintf(name, name_len, "wino_fwd_kernel<WinoCfg<1, 4, 4, 4, 1, 1, 1, 4, 1, 0>>");
-    else if (variant == 3) snprintf(name, name_len, "wino_fwd_kernel<WinoCfg<3, 3, 6, 1, 1, 1, 1, 4, 1, 1>>");
+    if (variant == 0) snprintf(name, name_len, "wino_fwd_kernel<WinoCfg<1, 1, 16, 2, 2, 1, 1, 4, 0, 0>, false>");
+    else if (variant == 1) snprintf(name, name_len, "wino_fwd_kernel<WinoCfg<1, 2, 8, 2, 2, 1, 1, 4, 0, 0>, false>");
+    else if (variant == 2) snprintf(name, name_len, "wino_fwd_kernel<WinoCfg<1, 4, 4, 4, 1, 1, 1, 4, 1, 0>, false>");
+    else if (variant == 3) snprintf(name, name_len, "wino_fwd_kernel<WinoCfg<3, 3, 6, 1, 1, 1, 1, 4, 1, 1>, false>");
     else return MIS_ERR_UNSUPPORTED;
     return MIS_OK;
 }
@@ -555,4 +621,35 @@ extern "C" int mis_conv3d_wino_fwd(const float* x, long long x_bs, const float* 
         return launch_wino<WinoCfg<3, 3, 6, 1, 1, 1, 1, 4, 1, 1>>(a, stream);
     }
     return MIS_ERR_UNSUPPORTED;
+}
+
+// The data gradient of mis_conv3d_wino_fwd (dy -> da, transformed filter of pack mode 5) for a convolution whose input
+// a = act(InstanceNorm(xn)) (no affine, negative slope `slope`, no dropout) is read by nothing else: besides da the launch
+// leaves, per (n, channel) and run of boxes, part = (sum dz, sum dz * xn) with dz = da * (xn > mean ? 1 : slope) -- the
+// first stage of that normalisation's backward (reference: autograd of nn.InstanceNorm3d + nn.ReLU in UnetConv3,
+// code/networks/utils.py:105-109) -- in the layout of the forward's statistics partials (part_sc / part_sn strides in
+// float2, mis_conv3d_wino_stat_tiles entries per image).  mis_norm_act_bwd_tiles finishes the backward from them.
+// `mean`: [N][Cin_of_the_forward] = [N][Cout here]; N * Cout <= 384.  Variants 0 and 1 (the 96^3 and 48^3 levels).
+extern "C" int mis_conv3d_wino_dgrad_norm(const float* dy, long long dy_bs, const float* wt, float* da, long long da_bs,
+                                          int N, int Cin, int Cout, int D, int H, int W, const float* xn, long long xn_bs,
+                                          const float* mean, float slope, float* part, long long part_sc,
+                                          long long part_sn, int variant, hipStream_t stream) {
+    if (!dy || !wt || !da || !xn || !mean || !part || N <= 0 || Cin <= 0 || Cout <= 0 || D <= 0 || H <= 0 || W <= 0)
+        return MIS_ERR_ARG;
+    const long long S = (long long)D * H * W;
+    if (dy_bs < (long long)Cin * S || da_bs < (long long)Cout * S || xn_bs < (long long)Cout * S) return MIS_ERR_ARG;
+    if (variant < 0 || variant > 1 || (long long)N * Cout > 384) return MIS_ERR_UNSUPPORTED;
+    if (Cout % 16 || Cin % 8 || Cin < 16 || W % 4 || D % 2 || H % 2 || da_bs % 2 || xn_bs % 2 || ((uintptr_t)da & 7) ||
+        ((uintptr_t)xn & 7) || ((uintptr_t)wt & 15))
+        return MIS_ERR_UNSUPPORTED;
+    if (mis_conv3d_wino_select(N, Cin, Cout, D, H, W) != variant) return MIS_ERR_UNSUPPORTED;
+    if (((long long)Cin + 32) * S * 4 >= (1LL << 30) || 16 * S * 4 >= (1LL << 31)) return MIS_ERR_UNSUPPORTED;
+    WinoArgs a{};
+    a.x = dy; a.x_bs = dy_bs; a.wt = wt; a.bias = nullptr; a.y = da; a.y_bs = da_bs;
+    a.N = N; a.Cin = Cin; a.Cout = Cout; a.D = D; a.H = H; a.W = W;
+    a.nci4 = (Cin + 3) / 4;
+    a.stat = reinterpret_cast<float2*>(part); a.stat_sc = part_sc; a.stat_sn = part_sn;
+    a.xn = xn; a.xn_bs = xn_bs; a.thr = mean; a.slope = slope;
+    if (variant == 0) return launch_wino<WinoCfg<1, 1, 16, 2, 2, 1, 1, 4>, true>(a, stream);
+    return launch_wino<WinoCfg<1, 2, 8, 2, 2, 1, 1, 4>, true>(a, stream);
 }

@@ -405,6 +405,27 @@ __global__ __launch_bounds__(256) void bwd_final_kernel(const float2* __restrict
     }
 }
 
+// Second stage from the partials a Winograd data-gradient launch left (mis_conv3d_wino_dgrad_norm): per (n, c) and tile
+// (sum dz, sum dz * x) with the RAW x; sum dz * xhat = rstd * (t2 - mean * s1).  InstanceNorm without affine: one wave
+// per (n, c), sums[g] = (s1 / S, s2 / S).
+__global__ __launch_bounds__(256) void bwd_final_raw_kernel(const float2* __restrict__ part, int G, int tiles, long long S,
+                                                            const float* __restrict__ mean,
+                                                            const float* __restrict__ rstd, float2* __restrict__ sums) {
+    const int grp = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (grp >= G) return;
+    double s1 = 0.0, t2 = 0.0;
+    for (int i = lane; i < tiles; i += 64) {
+        const float2 q = part[(long long)grp * tiles + i];
+        s1 += q.x; t2 += q.y;
+    }
+    s1 = mis_wave_sum_d(s1); t2 = mis_wave_sum_d(t2);
+    if (lane == 0) {
+        const double E = (double)S;
+        const double s2 = (double)rstd[grp] * (t2 - (double)mean[grp] * s1);
+        sums[grp] = make_float2((float)(s1 / E), (float)(s2 / E));
+    }
+}
+
 // GroupNorm backward, second stage.  part[(n*C + c)*P + p] = (sum dz, sum dz*xhat) of one channel of one sample
 // (dz = gradient at the affine output).  With dxhat = gamma_c * dz:
 //   sums[n*G + grp] = (sum_{c in grp} gamma_c * a_nc, sum gamma_c * b_nc) / (cg * S)      one wave per (n, grp)
@@ -752,6 +773,32 @@ extern "C" int mis_norm_act_bwd_sums(const float* x, long long x_bs, const float
                        gamma, beta, slope, d, part, PoolGrad{});
     hipLaunchKernelGGL(bwd_final_kernel, dim3((g.G + 3) / 4), dim3(256), 0, stream, part, g,
                        reinterpret_cast<float2*>(sums), dgamma, dbeta, accumulate_affine);
+    return mis_launch_status();
+}
+
+// The backward of InstanceNorm (no affine) + (Leaky)ReLU whose first stage ran inside the data-gradient launch that
+// produced da (mis_conv3d_wino_dgrad_norm): part[(n * C + c) * tiles + t] = (sum dz, sum dz * x).  Writes
+// sums[n * C + c] = (mean dz, mean dz * xhat) and, when dx != NULL, the gradient at the normalisation's input (dx NULL:
+// the consumer forms it itself from the sums -- mis_conv_wgrad_cin1_norm).  No dropout on this path.
+extern "C" int mis_norm_act_bwd_tiles(const float* x, long long x_bs, const float* da, long long da_bs, float* dx,
+                                      long long dx_bs, int N, int C, long long S, const float* mean, const float* rstd,
+                                      float slope, const float* part, int tiles, float* sums, hipStream_t stream) {
+    int st = check_geo(x, N, C, S, x_bs);
+    if (st) return st;
+    if (!da || !mean || !rstd || !part || !sums || tiles <= 0) return MIS_ERR_ARG;
+    if (da_bs % 4 != 0 || !aligned16(da) || da_bs < (long long)C * S || ((uintptr_t)sums & 7) || ((uintptr_t)part & 7))
+        return MIS_ERR_UNSUPPORTED;
+    if (dx && (dx_bs % 4 != 0 || !aligned16(dx) || dx_bs < (long long)C * S)) return MIS_ERR_UNSUPPORTED;
+    const Geo g = make_geo(N, C, S, x_bs, 1);
+    hipLaunchKernelGGL(bwd_final_raw_kernel, dim3((g.G + 3) / 4), dim3(256), 0, stream,
+                       reinterpret_cast<const float2*>(part), g.G, tiles, S, mean, rstd, reinterpret_cast<float2*>(sums));
+    if (dx) {
+        const DropCfg d{0.f, 0u, nullptr, nullptr};
+        const unsigned gx = (unsigned)mis_cdiv(S >> 2, 256 * APPLY_U);
+        hipLaunchKernelGGL(apply_bwd_kernel, dim3(gx, C, N), dim3(256), 0, stream, x, g, da, da_bs, mean, rstd,
+                           (const float*)nullptr, (const float*)nullptr, slope, d, reinterpret_cast<const float2*>(sums),
+                           dx, dx_bs, 0, PoolGrad{});
+    }
     return mis_launch_status();
 }
 

@@ -223,6 +223,45 @@ def conv_fwd(x, wp, bias, y, Cin, Cout, ksize, stat=None, wino=-1):
 PROFILE = None
 
 
+def conv_dgrad_norm(dy, wpd, da, Cin, Cout, xn, mean, slope, part, wino):
+    """The Winograd data gradient ``da = dgrad(dy)`` (``wpd``: pack mode 5) with the first stage of the backward of the
+    InstanceNorm + (Leaky)ReLU that produced the conv's input from ``xn`` in its epilogue (mis_conv3d_wino_dgrad_norm):
+    ``part [N*Cout*tiles, 2]`` receives (sum dz, sum dz * xn) per (n, channel, tile).  ``Cin`` / ``Cout``: channels of
+    dy / da.  Returns the number of tiles per image."""
+    L = _l.load()
+    N, C, D, H, W, S, dbs = _geom(dy)
+    _, _, _, _, _, _, abs_ = _geom(da)
+    _, _, _, _, _, _, xbs = _geom(xn)
+    assert C == Cin and da.shape[1] == Cout and xn.shape[1] == Cout
+    tiles = int(L.mis_conv3d_wino_stat_tiles(D, H, W, wino))
+    assert part.numel() >= N * Cout * tiles * 2
+    prof = PROFILE
+    if prof is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    _l.check(L.mis_conv3d_wino_dgrad_norm(_l.ptr(dy), dbs, _l.ptr(wpd), _l.ptr(da), abs_, N, Cin, Cout, D, H, W,
+                                          _l.ptr(xn), xbs, _l.ptr(mean), float(slope), _l.ptr(part), tiles, Cout * tiles,
+                                          wino, _l.stream_ptr()), "mis_conv3d_wino_dgrad_norm")
+    if prof is not None:
+        e1.record()
+        buf = _ctypes.create_string_buffer(128)
+        L.mis_conv3d_wino_kernel_name(wino, buf, 128)
+        prof.append((buf.value.decode().replace(", false>", ", true>"), 2.0 * N * Cout * Cin * 27 * S, e0, e1))
+    return tiles
+
+
+def norm_act_bwd_tiles(x, da, dx, mean, rstd, slope, part, tiles, sums):
+    """Second stage + apply pass of the InstanceNorm + (Leaky)ReLU backward from conv_dgrad_norm's partials; ``dx`` may
+    be None (only ``sums`` is wanted: the first layer's weight gradient forms dx itself)."""
+    L = _l.load()
+    N, C, D, H, W, S, xbs = _geom(x)
+    _, _, _, _, _, _, dabs = _geom(da)
+    dxbs = _geom(dx)[6] if dx is not None else 0
+    _l.check(L.mis_norm_act_bwd_tiles(_l.ptr(x), xbs, _l.ptr(da), dabs, _l.ptr(dx), dxbs, N, C, S, _l.ptr(mean),
+                                      _l.ptr(rstd), float(slope), _l.ptr(part), int(tiles), _l.ptr(sums),
+                                      _l.stream_ptr()), "mis_norm_act_bwd_tiles")
+
+
 def conv_wgrad(x, dy, dw, ksize, accumulate=False):
     """dw[Cout,Cin,*k] (+)= sum_n,p dy * shifted x."""
     L = _l.load()

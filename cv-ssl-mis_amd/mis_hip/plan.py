@@ -38,6 +38,9 @@ FUSE_POOL_FWD = os.environ.get("MIS_FUSE_POOL_FWD", "1") != "0"     # ... and th
 # weight gradients on a side stream: dW of a layer needs only (x, dy) and nothing of the backward needs dW, so it runs
 # beside the data gradient / normalisation backward of the layers below and fills the CUs their launch tails leave idle
 WGRAD_STREAM = os.environ.get("MIS_WGRAD_STREAM", "1") != "0"
+# first stage of the InstanceNorm + ReLU backward (sum dz, sum dz * x) in the epilogue of the Winograd data-gradient launch
+# that produces the gradient at the activation (mis_conv3d_wino_dgrad_norm): the partial-sum pass over da and x is not run
+FUSE_DGRAD_NORM = os.environ.get("MIS_FUSE_DGRAD_NORM", "1") != "0"
 
 
 class Act:
@@ -114,6 +117,7 @@ class ConvOp:
         self._dx_tmp = None
         self.fused_into = None   # NormActOp that computes this 1x1x1 classifier in its own pass (Plan._fuse_head)
         self.norm_bwd = None     # NormActOp whose backward apply pass runs on this (first) conv's wgrad load path
+        self.dgrad_norm = None   # NormActOp producing x whose backward partial sums this conv's data gradient forms
 
     def fwd(self, ctx):
         if self.fused_into is not None:
@@ -160,6 +164,11 @@ class ConvOp:
                     self._dx_tmp = torch.empty(self.x.shape, dtype=torch.float32, device="cuda")
                 ops.conv_fwd(dy, self.wpd, None, self._dx_tmp, self.cout, self.cin, self.ksize, wino=self.wino_b)
                 ops.add(self.x.grad(), self._dx_tmp, self.x.grad())
+            elif self.dgrad_norm is not None:
+                n = self.dgrad_norm
+                ops.conv_dgrad_norm(dy, self.wpd, self.x.grad(), self.cout, self.cin, n.x.t, n.mean, n.slope, n.ext_part,
+                                    self.wino_b)
+                n.ext_ready = True
             else:
                 ops.conv_fwd(dy, self.wpd, None, self.x.grad(), self.cout, self.cin, self.ksize, wino=self.wino_b)
             self.x.mark_written()
@@ -186,6 +195,8 @@ class NormActOp:
         self._mask = None
         self.pool = None         # MaxPoolOp fed by this op's output whose backward runs inside this op's (Plan.maxpool)
         self.sums = None         # set: backward only reduces (into this [G, 2] buffer); the producing first-layer conv applies
+        self.ext_part = None     # [N*C*tiles, 2] partial sums of the backward written by the consuming conv's data-gradient
+        self.ext_tiles, self.ext_ready, self.ext_sums = 0, False, None     # launch (Plan._fuse_dgrad_norm)
         self.head = None         # 1x1x1 classifier ConvOp computed in this op's pass (Plan._fuse_head); head_w / head_b:
         self.head_w = self.head_b = None     # its parameters (their gradients are written by THIS op: dist.param_progress)
 
@@ -235,6 +246,14 @@ class NormActOp:
 
     def bwd(self, ctx):
         assert not self.x.written
+        if self.ext_ready:       # the data gradient that produced y.grad() already formed the partial sums
+            self.ext_ready = False
+            to_sums = self.sums is not None      # first layer: its weight gradient applies the backward itself
+            ops.norm_act_bwd_tiles(self.x.t, self.y.grad(), None if to_sums else self.x.grad(), self.mean, self.rstd,
+                                   self.slope, self.ext_part, self.ext_tiles, self.sums if to_sums else self.ext_sums)
+            if not to_sums:
+                self.x.mark_written()
+            return
         if self.sums is not None:
             ops.norm_act_bwd_sums(self.x.t, self.y.grad(), self.per_sample, self.mean, self.rstd,
                                   None if self.gamma is None else self.gamma.data,
@@ -499,6 +518,42 @@ class Plan:
         if self._packs[mode] is not None:
             self._packs[mode].run()
 
+    def _fuse_dgrad_norm(self):
+        """conv_a -> InstanceNorm -> ReLU -> conv_b (reference UnetConv3, utils.py:99-123): when the activation between
+        the two convolutions has no other reader, conv_b's Winograd data gradient also forms the partial sums of the
+        normalisation's backward (ops.conv_dgrad_norm)."""
+        if not FUSE_DGRAD_NORM:
+            return
+        L = ops._l.load()
+        for conv in self.ops:
+            if type(conv) is not ConvOp or not conv.need_dx or conv.wino_b not in (0, 1) or conv.ksize != (3, 3, 3):
+                continue
+            if conv.fused_into is not None or conv.x.parent is not None:
+                continue
+            norm = next((o for o in self.ops if type(o) is NormActOp and o.y is conv.x), None)
+            if norm is None or not norm.per_sample or norm.gamma is not None or norm.beta is not None or norm.cg != 1:
+                continue
+            if norm.no_norm or norm.drop_p > 0 or norm.pool is not None or norm.head is not None:
+                continue
+            N, C = norm.x.shape[0], norm.x.shape[1]
+            if N * C > 384:
+                continue
+            readers = 0
+            for op in self.ops:
+                if op is norm:
+                    continue
+                for v in vars(op).values():
+                    if isinstance(v, Act) and v._root() is norm.y:
+                        readers += 1
+            if readers != 1:
+                continue
+            _, _, D, H, W = norm.x.shape
+            tiles = int(L.mis_conv3d_wino_stat_tiles(D, H, W, conv.wino_b))
+            norm.ext_part = torch.zeros(N * C * tiles, 2, dtype=torch.float32, device="cuda")
+            norm.ext_tiles = tiles
+            norm.ext_sums = torch.zeros(N * C, 2, dtype=torch.float32, device="cuda")
+            conv.dgrad_norm = norm
+
     def _fuse_head(self):
         """Last two ops = norm/act(/dropout) -> 1x1x1 classifier, the activation in between read by nobody else: one op."""
         self._head_checked = True
@@ -524,6 +579,7 @@ class Plan:
         assert tuple(x5.shape) == self.in_shape, (tuple(x5.shape), self.in_shape)
         if not self._head_checked:
             self._fuse_head()
+            self._fuse_dgrad_norm()
         self.generation += 1
         self.inp.t = x5
         self._pack(0)

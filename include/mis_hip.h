@@ -102,6 +102,16 @@ int mis_conv3d_wino_kernel_name(int variant, char* name, int name_len);
 int mis_conv3d_wino_fwd(const float* x, long long x_bs, const float* wt, const float* bias, float* y, long long y_bs,
                         int N, int Cin, int Cout, int D, int H, int W, float* stat, long long stat_sc,
                         long long stat_sn, int variant, mis_stream_t stream);
+/* The data gradient (dy -> da, filter of pack mode 5) of a conv whose input a = act(InstanceNorm(xn)) -- no affine, no
+ * dropout, read by nothing else -- with the first stage of that normalisation's backward in its epilogue: per (n, channel)
+ * and run of boxes part = (sum dz, sum dz * xn), dz = da * (xn > mean ? 1 : slope), in the layout of the forward's
+ * statistics partials (mis_conv3d_wino_stat_tiles entries per image).  Replaces the partial-sum pass of autograd's
+ * nn.InstanceNorm3d + nn.ReLU backward in UnetConv3 (code/networks/utils.py:105-109); mis_norm_act_bwd_tiles finishes
+ * it.  Variants 0 / 1 only, N * Cout <= 384 (Cout = channels of da). */
+int mis_conv3d_wino_dgrad_norm(const float* dy, long long dy_bs, const float* wt, float* da, long long da_bs, int N,
+                               int Cin, int Cout, int D, int H, int W, const float* xn, long long xn_bs,
+                               const float* mean, float slope, float* part, long long part_sc, long long part_sn,
+                               int variant, mis_stream_t stream);
 /* ---- Winograd F(2x2, 3x3) form of the stride-1 'same' 3x3 convolution of the 2-D UNet (csrc/conv_wino2d.hip) ----
  * reference: nn.Conv2d(k=3, padding=1) of ConvBlock (code/networks/unet.py:30-45).  Same contract as the 3-D entry
  * points above with D = 1; filter transformed by pack modes 6 (forward) / 7 (data gradient). */
@@ -188,6 +198,11 @@ int mis_norm_act_bwd_sums(const float* x, long long x_bs, const float* da, long 
                           int per_sample, const float* mean, const float* rstd, const float* gamma, const float* beta,
                           float slope, float* sums, float* dgamma, float* dbeta, int accumulate_affine, void* workspace,
                           long long workspace_bytes, mis_stream_t stream);
+/* ... from the partials of mis_conv3d_wino_dgrad_norm: sums[n * C + c] = (mean dz, mean dz * xhat), and dx (may be NULL:
+ * the consumer forms it from the sums) = the gradient at the normalisation's input.  InstanceNorm without affine. */
+int mis_norm_act_bwd_tiles(const float* x, long long x_bs, const float* da, long long da_bs, float* dx, long long dx_bs,
+                           int N, int C, long long S, const float* mean, const float* rstd, float slope,
+                           const float* part, int tiles, float* sums, mis_stream_t stream);
 int mis_conv_wgrad_cin1_norm_eligible(int N, int Cout, int D, int H, int W);
 int mis_conv_wgrad_cin1_norm(const float* x, long long x_bs, const float* da, long long da_bs, const float* y,
                              long long y_bs, int N, int D, int H, int W, int per_sample, const float* mean,

@@ -118,7 +118,18 @@ def main():
             b = torch.randn(Cout, device="cuda")
             yw, rw = wino(x, w, b, var)
             yw2, rw2 = wino(x, w, b, var, stat=True)
-            print(f"dbg {os.environ['MIS_WINO_DBG']} N{N} {Cin}->{Cout} {S}^3: {timeit(rw):8.1f} us   with stats {timeit(rw2):8.1f} us", flush=True)
+            line = f"dbg {os.environ['MIS_WINO_DBG']} N{N} {Cin}->{Cout} {S}^3: {timeit(rw):8.1f} us   with stats {timeit(rw2):8.1f} us"
+            if Cin == Cout:      # the data gradient with the norm backward's partial sums in its epilogue
+                xn = torch.randn(N, Cout, S, S, S, device="cuda")
+                mean = xn.mean(dim=(2, 3, 4)).flatten().contiguous()
+                T = L.mis_conv3d_wino_stat_tiles(S, S, S, var)
+                part = torch.zeros(N * Cout * T, 2, device="cuda")
+                da = torch.empty_like(xn)
+                wpd = ops.conv_pack(w, 5)
+                rn = lambda: ops.conv_dgrad_norm(x, wpd, da, Cin, Cout, xn, mean, 0.0, part, var)
+                rn()
+                line += f"   dgrad+norm partials {timeit(rn):8.1f} us"
+            print(line, flush=True)
         return
     for (N, Cin, Cout, D, H, W, var) in [(1, 16, 16, 4, 4, 32, 0), (2, 16, 16, 8, 12, 64, 0), (1, 24, 32, 6, 10, 20, 0),
                                          (2, 16, 32, 8, 8, 16, 1), (1, 32, 32, 6, 6, 36, 1), (3, 48, 16, 10, 6, 40, 0),

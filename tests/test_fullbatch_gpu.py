@@ -106,7 +106,7 @@ def test_mean_teacher_step_at_full_batch(name):
     vol_d, lab_d, noise_d = volume.cuda(), label.cuda(), noise.cuda()
     names = _record_kernels(lambda: tr.step(vol_d, lab_d, noise=noise_d))
     for e in expect:
-        kname = (e[5:] if e.startswith("name:") else f"wino_fwd_kernel<{e[5:]}>" if e.startswith("wino:") else
+        kname = (e[5:] if e.startswith("name:") else f"wino_fwd_kernel<{e[5:]}, false>" if e.startswith("wino:") else
                  f"wino2d_fwd_kernel<{e[7:]}>" if e.startswith("wino2d:") else f"conv_fwd_kernel<{e}>")
         assert kname in names, (e, sorted(names))
     got = tr.losses()

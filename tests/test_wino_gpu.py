@@ -324,3 +324,48 @@ def test_wino2d_weight_gradient(N, Cin, Cout, H, W):
         ops.WINO = keep
     _close(dw, dwd, rtol=1e-5, atol=1e-6)
     assert lib.load().mis_conv2d_wino_wgrad_select(2, 16, 16, 28, 28) == -1      # 28 x 28: direct kernel
+
+
+@pytest.mark.parametrize("N,Cdy,Cda,D,H,W,slope", [(2, 16, 16, 8, 8, 32, 0.0), (3, 32, 32, 8, 8, 16, 0.0), (2, 48, 16, 4, 8, 32, 0.01),
+                                                   (8, 16, 16, 4, 4, 96, 0.0), (2, 32, 32, 4, 8, 48, 0.0)])
+def test_wino_data_gradient_with_norm_backward_partials(N, Cdy, Cda, D, H, W, slope):
+    """mis_conv3d_wino_dgrad_norm: the data gradient is the plain Winograd launch's, and its (sum dz, sum dz * x) partials
+    + mis_norm_act_bwd_tiles give the InstanceNorm + (Leaky)ReLU backward of mis_norm_act_bwd (reference: autograd of
+    nn.InstanceNorm3d -> nn.ReLU between the two convs of UnetConv3, utils.py:105-109)."""
+    ops = _ops()
+    v = ops.conv_wino_select(N, Cdy, Cda, D, H, W, (3, 3, 3))
+    assert v in (0, 1)
+    xn = (_rand(N, Cda, D, H, W, seed=31) * 2 + _rand(N, Cda, 1, 1, 1, seed=32)).float().cuda()     # per-(n, c) offsets
+    dy = _rand(N, Cdy, D, H, W, seed=33).float().cuda()
+    w = _rand(Cdy, Cda, 3, 3, 3, seed=34, scale=0.2).float().cuda()      # forward conv: Cda -> Cdy channels
+    wpd = ops.conv_pack(w, 5)
+    mean, rstd = torch.empty(N * Cda, device="cuda"), torch.empty(N * Cda, device="cuda")
+    ops.norm_stats(xn, True, 1e-5, mean, rstd)
+    # reference: plain data gradient, then the three-pass normalisation backward
+    da_ref = torch.empty(N, Cda, D, H, W, device="cuda")
+    ops.conv_fwd(dy, wpd, None, da_ref, Cdy, Cda, (3, 3, 3), wino=v)
+    dx_ref = torch.empty_like(da_ref)
+    ops.norm_act_bwd(xn, da_ref, dx_ref, True, mean, rstd, None, None, slope)
+    # fused
+    T = ops.conv_stat_tiles(N, Cdy, Cda, D, H, W, (3, 3, 3), wino=v)
+    part = torch.full((N * Cda * T, 2), float("nan"), device="cuda")
+    da = torch.full((N, Cda, D, H, W), float("nan"), device="cuda")
+    assert ops.conv_dgrad_norm(dy, wpd, da, Cdy, Cda, xn, mean, slope, part, v) == T
+    assert torch.equal(da, da_ref)
+    assert torch.isfinite(part).all()
+    sums = torch.empty(N * Cda, 2, device="cuda")
+    dx = torch.full_like(da, float("nan"))
+    ops.norm_act_bwd_tiles(xn, da, dx, mean, rstd, slope, part, T, sums)
+    # the sums against torch fp64
+    xh = (xn.double() - mean.double().view(N, Cda, 1, 1, 1)) * rstd.double().view(N, Cda, 1, 1, 1)
+    dz = torch.where(xh > 0, da.double(), da.double() * slope)
+    S = D * H * W
+    s1 = dz.sum(dim=(2, 3, 4)).flatten() / S
+    s2 = (dz * xh).sum(dim=(2, 3, 4)).flatten() / S
+    _close(sums[:, 0], s1, rtol=2e-5, atol=1e-6)
+    _close(sums[:, 1], s2, rtol=2e-5, atol=1e-6)
+    _close(dx, dx_ref, rtol=2e-5, atol=2e-6)
+    # only the sums (first layer: the consumer applies the backward itself)
+    sums2 = torch.empty_like(sums)
+    ops.norm_act_bwd_tiles(xn, da, None, mean, rstd, slope, part, T, sums2)
+    assert torch.equal(sums, sums2)
