@@ -132,6 +132,13 @@ PROTOTYPES = {
                           c_ll, c_p]),
     "mis_droppath_table": (c_i, [c_p, c_p, c_p, c_i, c_i, c_p, c_p]),
     "mis_transpose": (c_i, [c_p, c_ll, c_p, c_ll, c_i, c_i, c_p]),
+    "mis_win3d_gather": (c_i, [c_p, c_p] + [c_i] * 12 + [c_p]),
+    "mis_win3d_windows": (c_ll, [c_i] * 7),
+    "mis_merge3d": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
+    "mis_win3d_attn_fwd": (c_i, [c_p, c_ll, c_p, c_ll, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p]),
+    "mis_win3d_attn_workspace_bytes": (c_ll, [c_i, c_i, c_i]),
+    "mis_win3d_attn_bwd": (c_i, [c_p, c_ll, c_p, c_p, c_ll, c_p, c_ll, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p,
+                                 c_ll, c_p]),
     "mis_transpose_job_bytes": (c_ll, []),
     "mis_transpose_job": (c_ll, [c_p, c_p, c_p, c_i, c_i, c_ll]),
     "mis_transpose_batch": (c_i, [c_p, c_i, c_ll, c_p]),

@@ -126,6 +126,43 @@ def transpose(src, dst):
     _l.check(L.mis_transpose(_l.ptr(src), lds, _l.ptr(dst), ldd, R, Cc, _l.stream_ptr()), "mis_transpose")
 
 
+# ---------------------------------------------------------------- SwinUNETR encoder (csrc/swin3d.hip)
+def win3d_gather(src, dst, B, dims, C, win, shift, inverse=False):
+    """windows [B*nW, n, C] <- tokens [B*D*H*W, C] (zero padding to multiples of the window, cyclic shift); ``inverse``:
+    tokens <- windows.  Each direction is the other's gradient."""
+    L = _l.load()
+    D, H, W = dims
+    _l.check(L.mis_win3d_gather(_l.ptr(src), _l.ptr(dst), B, D, H, W, C, win[0], win[1], win[2], shift[0], shift[1],
+                                shift[2], int(inverse), _l.stream_ptr()), "mis_win3d_gather")
+
+
+def win3d_windows(B, dims, win):
+    return int(_l.load().mis_win3d_windows(B, dims[0], dims[1], dims[2], win[0], win[1], win[2]))
+
+
+def merge3d(src, dst, B, dims, C, inverse=False):
+    """merged [B*D/2*H/2*W/2, 8C] <- tokens [B*D*H*W, C] in MONAI's v0.9 "merging" order; ``inverse``: token gradient."""
+    L = _l.load()
+    _l.check(L.mis_merge3d(_l.ptr(src), _l.ptr(dst), B, dims[0], dims[1], dims[2], C, int(inverse), _l.stream_ptr()),
+             "mis_merge3d")
+
+
+def win3d_attn_fwd(qkv, out, stats, table, region, BW, nW, n, nH):
+    L = _l.load()
+    _l.check(L.mis_win3d_attn_fwd(_l.ptr(qkv), qkv.stride(0), _l.ptr(out), out.stride(0), _l.ptr(stats), _l.ptr(table),
+                                  _l.ptr(region), BW, nW, n, nH, _l.stream_ptr()), "mis_win3d_attn_fwd")
+
+
+def win3d_attn_bwd(qkv, out, dout, dqkv, stats, table, region, dtable, BW, nW, n, nH, accumulate_table=False):
+    L = _l.load()
+    nb = L.mis_win3d_attn_workspace_bytes(BW, n, nH)
+    ws = scratch(nb, "attn3d")
+    _l.check(L.mis_win3d_attn_bwd(_l.ptr(qkv), qkv.stride(0), _l.ptr(out), _l.ptr(dout), dout.stride(0), _l.ptr(dqkv),
+                                  dqkv.stride(0), _l.ptr(stats), _l.ptr(table), _l.ptr(region), _l.ptr(dtable),
+                                  int(accumulate_table), BW, nW, n, nH, _l.ptr(ws), ws.numel(), _l.stream_ptr()),
+             "mis_win3d_attn_bwd")
+
+
 class TransposeBatch:
     """All weight transposes of a network's backward in one launch (``mis_transpose_batch``).  ``jobs``: list of
     (src [R, C] dense, dst [C, R] dense); the device job table is built once (it holds raw pointers into the tensors)."""

@@ -510,6 +510,28 @@ typedef struct MisCrop3D {       /* code/dataloaders/brats2019.py RandomRotFlip 
 int mis_crop_rotflip3d(const float* img_pool, const unsigned char* lab_pool, const void* params_device, int B, int p0,
                        int p1, int p2, float* image_out, void* label_out, int label_bytes, mis_stream_t stream);
 
+/* ---- SwinUNETR encoder (csrc/swin3d.hip): 3-D shifted-window attention and patch merging ------------------------
+ * reference: net_factory_3d('swinunetr') = monai.networks.nets.SwinUNETR(img_size=(64,64,64), in_channels, out_channels,
+ * feature_size=48) (code/networks/net_factory_3d.py:7,37-38).  MONAI is an un-vendored dependency: PARITY UNPINNED, the
+ * published algorithm (SwinTransformerBlock.forward_part1, WindowAttention, PatchMerging "merging") is restated in
+ * oracle/swinunetr.py.  Token-major activations [B][D][H][W][C], C % 4 == 0; heads of 16 channels.
+ * mis_win3d_gather: windows [B*nW][n][C] <- tokens after zero padding to multiples of the window and the cyclic shift
+ *   torch.roll(x, (-sd,-sh,-sw)) (inverse != 0: tokens <- windows; each is the other's gradient).
+ * mis_merge3d: merged [B][D/2][H/2][W/2][8C] <- tokens in MONAI's v0.9 slot order (inverse: gradient of the tokens).
+ * mis_win3d_attn_fwd / _bwd: softmax(q k^T / 4 + table[index[:n,:n]] + shift mask) v per (window, head) from qkv
+ *   [BW*n][3*nH*16]; region [nW][n] int32 shift-region ids or NULL; dtable [2197][nH] deterministic. */
+int mis_win3d_gather(const float* src, float* dst, int B, int D, int H, int W, int C, int wd, int wh, int ww, int sd,
+                     int sh, int sw, int inverse, mis_stream_t stream);
+long long mis_win3d_windows(int B, int D, int H, int W, int wd, int wh, int ww);
+int mis_merge3d(const float* src, float* dst, int B, int D, int H, int W, int C, int inverse, mis_stream_t stream);
+int mis_win3d_attn_fwd(const float* qkv, long long ldq, float* out, long long ldo, float* stats, const float* table,
+                       const int* region, int BW, int nW, int n, int nH, mis_stream_t stream);
+long long mis_win3d_attn_workspace_bytes(int BW, int n, int nH);
+int mis_win3d_attn_bwd(const float* qkv, long long ldq, const float* out, const float* dout, long long ldo, float* dqkv,
+                       long long lddq, const float* stats, const float* table, const int* region, float* dtable,
+                       int accumulate_table, int BW, int nW, int n, int nH, void* workspace, long long workspace_bytes,
+                       mis_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
