@@ -325,16 +325,17 @@ class UpsampleOp:
 class DownConvOp:
     """nn.Conv3d(Cin, Cout, 2, stride=2) (reference vnet.py:73) = space_to_depth + 1x1x1 MFMA conv."""
 
-    def __init__(self, x, y, w, b, bias_grad=False):
-        self.x, self.y, self.w, self.b, self.bias_grad = x, y, w, b, bias_grad
-        N, Cin, D, H, W = x.shape
+    def __init__(self, x, y, w, b, bias_grad=False, need_dx=True, in_shape=None):
+        self.x, self.y, self.w, self.b, self.bias_grad, self.need_dx = x, y, w, b, bias_grad, need_dx
+        N, Cin, D, H, W = in_shape if in_shape is not None else x.shape      # in_shape: x is the plan's (late-bound) input
+        self.in_shape = (N, Cin, D, H, W)
         self.cin8, self.cout = 8 * Cin, w.data.shape[0]
         self.xs = torch.empty((N, self.cin8, D // 2, H // 2, W // 2), dtype=torch.float32, device="cuda")
         self.dxs = None
         self.wp = self.wpd = None
 
     def fwd(self, ctx):
-        ops.space_to_depth2(self.x.t, self.xs, self.x.shape, True)
+        ops.space_to_depth2(self.x.t, self.xs, self.in_shape, True)
         self.wp = ops.conv_pack_raw(self.w.data, self.cout, self.cin8, 1, 0, out=self.wp)
         ops.conv_fwd(self.xs, self.wp, self.b.data, self.y.t, self.cin8, self.cout, (1, 1, 1))
 
@@ -344,11 +345,13 @@ class DownConvOp:
         # bias gradient exactly 0 when the conv feeds a normalisation (see ConvOp)
         if self.bias_grad:
             ops.channel_sum(dy, self.b.grad)
+        if not self.need_dx:
+            return
         if self.dxs is None:
             self.dxs = torch.empty_like(self.xs)
         self.wpd = ops.conv_pack_raw(self.w.data, self.cout, self.cin8, 1, 1, out=self.wpd)
         ops.conv_fwd(dy, self.wpd, None, self.dxs, self.cout, self.cin8, (1, 1, 1))
-        ops.space_to_depth2(self.dxs, self.x.grad(), self.x.shape, False, accumulate=self.x.written)
+        ops.space_to_depth2(self.dxs, self.x.grad(), self.in_shape, False, accumulate=self.x.written)
         self.x.mark_written()
 
 

@@ -351,6 +351,85 @@ class TokToVolOp:
         self.tok.mark_written()
 
 
+# ---------------------------------------------------------------- SwinUNETR ops (token part of networks/swinunetr.py)
+class ConstRef:
+    """Stand-in for a parameter reference with constant data (the affine-free F.layer_norm of SwinUNETR's proj_out: gamma
+    = 1, beta = 0); its gradient buffer is private, so dist.param_progress does not see it."""
+
+    def __init__(self, data):
+        self.data, self.grad = data, torch.zeros_like(data)
+
+
+class VolToTokOp:
+    """volume [B, C, d, h, w] -> tokens [B*L, C] (a transpose per sample): the inverse of TokToVolOp."""
+
+    def __init__(self, vol, tok, B, L):
+        self.vol, self.tok, self.B, self.L = vol, tok, B, L
+
+    def fwd(self, ctx):
+        C = self.tok.C
+        for b in range(self.B):
+            tops.transpose(self.vol.t[b].reshape(C, self.L), self.tok.t[b * self.L:(b + 1) * self.L])
+
+    def bwd(self, ctx):
+        assert not self.vol.written
+        C = self.tok.C
+        g, gv = self.tok.grad(), self.vol.grad()
+        for b in range(self.B):
+            tops.transpose(g[b * self.L:(b + 1) * self.L], gv[b].reshape(C, self.L))
+        self.vol.mark_written()
+
+
+class Win3dOp:
+    """MONAI SwinTransformerBlock.forward_part1's data movement: ``to_windows`` = F.pad + torch.roll + window_partition
+    (tokens [B*L, C] -> windows [B*nW*n, C]); otherwise window_reverse + roll back + un-pad.  Each direction is the
+    other's gradient (padding slots receive zero)."""
+
+    def __init__(self, src, dst, B, dims, win, shift, to_windows):
+        self.src, self.dst, self.args, self.to_windows = src, dst, (B, dims, src.C, win, shift), to_windows
+
+    def fwd(self, ctx):
+        tops.win3d_gather(self.src.t, self.dst.t, *self.args, inverse=not self.to_windows)
+
+    def bwd(self, ctx):
+        assert not self.src.written
+        tops.win3d_gather(self.dst.grad(), self.src.grad(), *self.args, inverse=self.to_windows)
+        self.src.mark_written()
+
+
+class Win3dAttnOp:
+    """MONAI WindowAttention core on 7^3 (or clipped) windows, heads of 16 channels (csrc/swin3d.hip)."""
+
+    def __init__(self, qkv, out, table, region, BW, nW, n, nH):
+        self.qkv, self.out, self.table, self.region = qkv, out, table, region
+        self.geo = (BW, nW, n, nH)
+        self.stats = torch.empty(BW * nH * n * 2, dtype=torch.float32, device="cuda")
+
+    def fwd(self, ctx):
+        tops.win3d_attn_fwd(self.qkv.t, self.out.t, self.stats, self.table.data, self.region, *self.geo)
+
+    def bwd(self, ctx):
+        assert not self.qkv.written
+        tops.win3d_attn_bwd(self.qkv.t, self.out.t, self.out.grad(), self.qkv.grad(), self.stats, self.table.data,
+                            self.region, self.table.grad, *self.geo)
+        self.qkv.mark_written()
+
+
+class Merge3dOp:
+    """MONAI PatchMerging ("merging", v0.9 slot order) gather: tokens [B*L, C] -> [B*L/8, 8C]."""
+
+    def __init__(self, src, dst, B, dims):
+        self.src, self.dst, self.args = src, dst, (B, dims, src.C)
+
+    def fwd(self, ctx):
+        tops.merge3d(self.src.t, self.dst.t, *self.args)
+
+    def bwd(self, ctx):
+        assert not self.src.written      # the blocks' output has no other reader (proj_out reads the MERGED tokens)
+        tops.merge3d(self.dst.grad(), self.src.grad(), *self.args, inverse=True)
+        self.src.mark_written()
+
+
 class SwinPlan:
     """Op list + buffers of one SwinUnet for one input geometry; same interface as ``plan.Plan``."""
 
