@@ -71,6 +71,12 @@ WORKLOADS = {
                          "n4; BASELINE configs[2] geometry; parity unpinned: MONAI-based in the reference)",
                   shape=(8, 1, 96, 96, 96), labeled=4, classes=2, cons_start=0, label="int64",
                   cpu_sample=None, step_gflop=145.6 * 28),
+    # SwinUNETR forward per 96^3 volume: UnetResBlock / UnetrUpBlock convolutions 581 GFLOP (the 96^3 level alone 454), Swin
+    # encoder (Linear layers 30, 343-token window attention 20) ~50 -> ~630 GFLOP
+    "swinunetr": dict(config="Mean-Teacher SwinUNETR (--model swinunetr), synthetic BraTS 96x96x96 2-class, bs=4+4 (SURVEY "
+                             "s.8 rows n4 / f; BASELINE configs[2] geometry; parity unpinned: MONAI's network in the reference)",
+                      shape=(8, 1, 96, 96, 96), labeled=4, classes=2, cons_start=0, label="int64",
+                      cpu_sample=None, step_gflop=630.0 * 28),
     "swin": dict(config="Mean-Teacher ViT (SwinUNet 2D), synthetic ACDC 224x224 4-class, bs=24+24 "
                         "(BASELINE configs[3])",
                  shape=(48, 1, 224, 224), labeled=24, classes=4, cons_start=1000, label="uint8",
@@ -91,7 +97,7 @@ WORKLOADS = {
                    cpu_sample=None, step_gflop=(4.52 + 12.17) * 48 + 12.17 * 8),
 }
 OTHERS = ("unet2d", "swin", "cross", "vnet")     # reported under "others" beside the default workload (N=1)
-UNIT = {"unet3d": "volumes/s", "vnet": "volumes/s", "uamt3d": "volumes/s", "unetr": "volumes/s"}
+UNIT = {"unet3d": "volumes/s", "vnet": "volumes/s", "uamt3d": "volumes/s", "unetr": "volumes/s", "swinunetr": "volumes/s"}
 
 
 # ------------------------------------------------------------------------------------------------ launcher
@@ -140,7 +146,7 @@ def build_trainer(name, wl, world, stub=False):
         ema.load_state_dict(model.state_dict())
     else:
         from networks.net_factory_3d import net_factory_3d
-        key = {"vnet": "vnet", "unetr": "unetr"}.get(name, "unet_3D")
+        key = {"vnet": "vnet", "unetr": "unetr", "swinunetr": "swinunetr"}.get(name, "unet_3D")
         model, ema = net_factory_3d(key, 1, C), net_factory_3d(key, 1, C)
         ema.load_state_dict(model.state_dict())
     if world > 1:   # identical initial weights on every rank

@@ -526,6 +526,113 @@ __global__ __launch_bounds__(256) void apply_bwd_kernel(const float* __restrict_
 
 bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
+// ---------------- volumes whose voxel count is not a multiple of 4 (3 x 3 x 3: the deepest level of SwinUNETR at 96^3) ----
+// The float4 kernels above want S % 4 == 0.  These scalar forms serve the few-voxel levels: one 256-thread workgroup per
+// statistics group (channel for BatchNorm: N * S elements; (n, c) for InstanceNorm: S elements), sums in double.
+// No dropout, no GroupNorm, no fused pooling on this path.
+__device__ __forceinline__ void small_group(const Geo& g, int grp, int& n0, int& nn, int& c) {
+    if (g.per_sample) { n0 = grp / g.C; nn = 1; c = grp % g.C; } else { n0 = 0; nn = g.N; c = grp; }
+}
+
+__global__ __launch_bounds__(256) void stats_small_kernel(const float* __restrict__ x, Geo g, float eps,
+                                                          float* __restrict__ mean, float* __restrict__ rstd,
+                                                          float* running_mean, float* running_var,
+                                                          long long* num_batches, float momentum) {
+    __shared__ double red[8];
+    int n0, nn, c;
+    small_group(g, blockIdx.x, n0, nn, c);
+    double v[2] = {0.0, 0.0};
+    for (long long i = threadIdx.x; i < (long long)nn * g.S; i += 256) {
+        const float q = x[(long long)(n0 + i / g.S) * g.x_bs + (long long)c * g.S + i % g.S];
+        v[0] += q; v[1] += (double)q * q;
+    }
+    block_sum2_d(v, red);
+    if (threadIdx.x == 0) {
+        const double E = (double)nn * (double)g.S, m = v[0] / E;
+        double var = v[1] / E - m * m;
+        if (var < 0.0) var = 0.0;
+        mean[blockIdx.x] = (float)m;
+        rstd[blockIdx.x] = (float)(1.0 / sqrt(var + (double)eps));
+        if (running_mean && !g.per_sample) {
+            const double unb = E > 1.0 ? var * E / (E - 1.0) : var;
+            running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * m);
+            running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unb);
+            if (num_batches && c == 0) *num_batches += 1;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void apply_fwd_small_kernel(const float* __restrict__ x, Geo g,
+                                                              const float* __restrict__ mean,
+                                                              const float* __restrict__ rstd,
+                                                              const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta, float slope,
+                                                              float* __restrict__ y, long long y_bs) {
+    const long long total = (long long)g.N * g.C * g.S;
+    for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long s = i % g.S;
+        const int c = (int)((i / g.S) % g.C), n = (int)(i / (g.S * g.C));
+        const int grp = g.per_sample ? n * g.C + c : c;
+        const float sc = (gamma ? gamma[c] : 1.f) * rstd[grp];
+        const float sh = (beta ? beta[c] : 0.f) - mean[grp] * sc;
+        const float v = x[(long long)n * g.x_bs + (long long)c * g.S + s] * sc + sh;
+        y[(long long)n * y_bs + (long long)c * g.S + s] = v > 0.f ? v : v * slope;
+    }
+}
+
+// backward of one statistics group in one workgroup: sums (double), then dx; kind as apply_bwd_kernel (0 norm, 2 none)
+__global__ __launch_bounds__(256) void bwd_small_kernel(const float* __restrict__ x, Geo g,
+                                                        const float* __restrict__ da, long long da_bs,
+                                                        const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                        float slope, float* __restrict__ dx, long long dx_bs,
+                                                        float* dgamma, float* dbeta, int accumulate, int kind) {
+    __shared__ double red[8];
+    __shared__ float sm[2];
+    int n0, nn, c;
+    small_group(g, blockIdx.x, n0, nn, c);
+    const float m = kind == 2 ? 0.f : mean[blockIdx.x], rs = kind == 2 ? 1.f : rstd[blockIdx.x];      // kind 2: mean / rstd are [C] of (0, 1)
+    const float ga = gamma ? gamma[c] : 1.f, be = beta ? beta[c] : 0.f;
+    const long long cnt = (long long)nn * g.S;
+    double v[2] = {0.0, 0.0};
+    if (kind != 2) {
+        for (long long i = threadIdx.x; i < cnt; i += 256) {
+            const long long o = (long long)c * g.S + i % g.S;
+            const int n = n0 + (int)(i / g.S);
+            const float xh = (x[(long long)n * g.x_bs + o] - m) * rs;
+            const float gq = da[(long long)n * da_bs + o];
+            const float dz = (xh * ga + be) > 0.f ? gq : gq * slope;
+            v[0] += dz; v[1] += (double)dz * xh;
+        }
+        block_sum2_d(v, red);
+        if (threadIdx.x == 0) {
+            sm[0] = (float)(v[0] / (double)cnt); sm[1] = (float)(v[1] / (double)cnt);
+            if (dgamma && !g.per_sample) {
+                dgamma[c] = accumulate ? dgamma[c] + (float)v[1] : (float)v[1];
+                dbeta[c] = accumulate ? dbeta[c] + (float)v[0] : (float)v[0];
+            }
+        }
+        __syncthreads();
+    }
+    const float k = ga * rs;
+    for (long long i = threadIdx.x; i < cnt; i += 256) {
+        const long long o = (long long)c * g.S + i % g.S;
+        const int n = n0 + (int)(i / g.S);
+        const float xh = (x[(long long)n * g.x_bs + o] - m) * rs;
+        const float gq = da[(long long)n * da_bs + o];
+        const float dz = (xh * ga + be) > 0.f ? gq : gq * slope;
+        dx[(long long)n * dx_bs + o] = kind == 2 ? dz : k * (dz - sm[0] - xh * sm[1]);
+    }
+}
+
+// geometry check of the scalar path
+int check_geo_small(const void* x, int N, int C, long long S, long long x_bs) {
+    if (!x || N <= 0 || C <= 0 || S <= 0) return MIS_ERR_ARG;
+    if (x_bs < (long long)C * S) return MIS_ERR_ARG;
+    if ((long long)N * C > 0x7fffffffLL / 4) return MIS_ERR_UNSUPPORTED;
+    return MIS_OK;
+}
+
 int check_geo(const void* x, int N, int C, long long S, long long x_bs) {
     if (!x || N <= 0 || C <= 0 || S <= 0) return MIS_ERR_ARG;
     if (S % 4 != 0 || x_bs % 4 != 0 || !aligned16(x)) return MIS_ERR_UNSUPPORTED;
@@ -548,6 +655,15 @@ extern "C" int mis_norm_stats(const float* x, long long x_bs, int N, int C, long
                               float* mean, float* rstd, float* running_mean, float* running_var,
                               long long* num_batches_tracked, float momentum, void* workspace,
                               long long workspace_bytes, hipStream_t stream) {
+    if (S % 4 != 0) {      // few-voxel volumes: scalar kernels
+        int st = check_geo_small(x, N, C, S, x_bs);
+        if (st) return st;
+        if (!mean || !rstd) return MIS_ERR_ARG;
+        const Geo g = make_geo(N, C, S, x_bs, per_sample);
+        hipLaunchKernelGGL(stats_small_kernel, dim3(g.G), dim3(256), 0, stream, x, g, eps, mean, rstd, running_mean,
+                           running_var, num_batches_tracked, momentum);
+        return mis_launch_status();
+    }
     int st = check_geo(x, N, C, S, x_bs);
     if (st) return st;
     if (!mean || !rstd || !workspace) return MIS_ERR_ARG;
@@ -610,6 +726,17 @@ extern "C" int mis_norm_act_fwd_g(const float* x, long long x_bs, float* y, long
                                   const float* gamma, const float* beta, float slope, float drop_p,
                                   unsigned drop_salt, const MisStepState* state, const float* drop_mask,
                                   hipStream_t stream) {
+    if (S % 4 != 0) {      // few-voxel volumes: scalar kernel (no dropout, no GroupNorm)
+        int st = check_geo_small(x, N, C, S, x_bs);
+        if (st) return st;
+        if (!y || !mean || !rstd || y_bs < (long long)C * S) return MIS_ERR_ARG;
+        if (cg != 1 || drop_p != 0.f) return MIS_ERR_UNSUPPORTED;
+        const Geo g = make_geo(N, C, S, x_bs, per_sample, 1);
+        long long b = mis_cdiv((long long)N * C * S, 256);
+        hipLaunchKernelGGL(apply_fwd_small_kernel, dim3((unsigned)(b > 4096 ? 4096 : b)), dim3(256), 0, stream, x, g, mean,
+                           rstd, gamma, beta, slope, y, y_bs);
+        return mis_launch_status();
+    }
     int st = check_geo(x, N, C, S, x_bs);
     if (st) return st;
     if (cg < 1 || C % cg != 0 || (cg > 1 && !per_sample)) return MIS_ERR_ARG;
@@ -676,6 +803,17 @@ int norm_act_bwd_impl(const float* x, long long x_bs, const float* da, long long
                       unsigned drop_salt, const MisStepState* state, const float* drop_mask, float* dgamma,
                       float* dbeta, int accumulate_affine, void* workspace, long long workspace_bytes,
                       const PoolGrad& pg, hipStream_t stream) {
+    if (S % 4 != 0) {      // few-voxel volumes: one workgroup per statistics group (no dropout, GroupNorm, pooling)
+        int st = check_geo_small(x, N, C, S, x_bs);
+        if (st) return st;
+        if (!da || !dx || !mean || !rstd || da_bs < (long long)C * S || dx_bs < (long long)C * S) return MIS_ERR_ARG;
+        if (cg != 1 || drop_p != 0.f || pg.dp || (per_sample && (gamma || beta))) return MIS_ERR_UNSUPPORTED;
+        // no normalisation: every (n, c) is its own group of the element-wise pass
+        const Geo g = make_geo(N, C, S, x_bs, no_norm ? 1 : per_sample, 1);
+        hipLaunchKernelGGL(bwd_small_kernel, dim3(g.G), dim3(256), 0, stream, x, g, da, da_bs, mean, rstd, gamma, beta,
+                           slope, dx, dx_bs, dgamma, dbeta, accumulate_affine, no_norm ? 2 : 0);
+        return mis_launch_status();
+    }
     int st = check_geo(x, N, C, S, x_bs);
     if (st) return st;
     if (cg < 1 || C % cg != 0 || (cg > 1 && !per_sample) || (no_norm && (gamma || beta))) return MIS_ERR_ARG;

@@ -25,13 +25,14 @@ CASES = [
     ("swin", (2, 1, 224, 224), 4),
     ("swin_w8", (2, 1, 256, 256), 4),
     ("unetr", (1, 1, 96, 96, 96), 2),
+    ("swinunetr", (1, 1, 64, 64, 64), 2),
 ]
 
 
 def _make(kind, C):
-    if kind == "unetr":
+    if kind in ("unetr", "swinunetr"):
         from networks.net_factory_3d import net_factory_3d
-        return net_factory_3d("unetr", 1, C)
+        return net_factory_3d(kind, 1, C)
     from test_parity_gpu import _build
     return _build(kind, C)[1]()
 

@@ -443,3 +443,35 @@ def test_teacher_noise_and_argmax():
     out = torch.empty(3 * 256, dtype=torch.uint8, device="cuda")
     ops.argmax_channels(lg, out)
     assert torch.equal(out.cpu().view(3, 1, 16, 16).long(), lg.cpu().argmax(dim=1))
+
+
+@pytest.mark.parametrize("per_sample,slope,no_norm", [(True, 0.01, False), (False, 0.0, False), (False, 0.01, True)])
+def test_norm_act_on_a_volume_of_27_voxels(per_sample, slope, no_norm):
+    """Volumes whose voxel count is not a multiple of 4 (3 x 3 x 3: SwinUNETR's deepest level at 96^3) run the scalar
+    kernels of norm_act.hip: statistics, apply and backward against torch fp64 (nn.InstanceNorm3d / nn.BatchNorm3d +
+    nn.LeakyReLU, MONAI UnetResBlock)."""
+    import torch.nn.functional as F
+    from mis_hip import ops
+    N, C, shape = 3, 8, (3, 3, 3)
+    g = torch.Generator().manual_seed(0)
+    x = (torch.rand(N, C, *shape, generator=g, dtype=torch.float64) * 2 - 1).requires_grad_(True)
+    da = torch.rand(N, C, *shape, generator=g, dtype=torch.float64) * 2 - 1
+    if no_norm:
+        z = x
+    elif per_sample:
+        z = F.instance_norm(x, eps=1e-5)
+    else:
+        z = F.batch_norm(x, None, None, None, None, training=True, eps=1e-5)
+    y = F.leaky_relu(z, slope)
+    y.backward(da)
+    xd = x.detach().float().cuda()
+    G = C if (no_norm or not per_sample) else N * C
+    mean, rstd = torch.zeros(G, device="cuda"), torch.ones(G, device="cuda")
+    if not no_norm:
+        ops.norm_stats(xd, per_sample, 1e-5, mean, rstd)
+    yd = torch.full((N, C) + shape, float("nan"), device="cuda")
+    ops.norm_act_fwd(xd, yd, per_sample and not no_norm, mean, rstd, None, None, slope)
+    assert (yd.cpu().double() - y.detach()).abs().max().item() <= 2e-5
+    dx = torch.full((N, C) + shape, float("nan"), device="cuda")
+    ops.norm_act_bwd(xd, da.float().cuda(), dx, per_sample and not no_norm, mean, rstd, None, None, slope, no_norm=no_norm)
+    assert (dx.cpu().double() - x.grad).abs().max().item() <= 5e-5 * max(1.0, x.grad.abs().max().item())

@@ -318,6 +318,40 @@ def test_unetr_oracle_runs_and_has_the_documented_keys():
     assert sum(v.numel() for v in OracleUNETR(2).new_state().values()) > 90e6     # the 96^3 network: ~92.8 M parameters
 
 
+def test_swinunetr_oracle_runs_and_has_the_documented_properties():
+    """oracle/swinunetr.py (parity unpinned: MONAI is not vendored in the reference) on CPU: MONAI's parameter names and
+    count (62.19 M for feature_size 48), the published structural facts of the restated algorithm (relative-position index,
+    27 shift regions, window clipping, the v0.9 merging order with its two duplicated slices), a finite forward."""
+    from oracle.swinunetr import (MERGE_OFFSETS, OracleSwinUNETR, region_ids, relative_position_index, window_geometry,
+                                  window_partition, window_reverse)
+    o = OracleSwinUNETR(2)
+    sd = o.new_state()
+    keys = list(sd)
+    assert keys[0] == "swinViT.patch_embed.proj.weight" and keys[-1] == "out.conv.conv.bias"
+    assert "swinViT.layers4.0.blocks.1.attn.relative_position_bias_table" in sd
+    assert "swinViT.layers1.0.downsample.reduction.weight" in sd and "encoder10.layer.conv2.conv.weight" in sd
+    assert "decoder1.conv_block.conv3.conv.weight" in sd and "encoder2.layer.conv3.conv.weight" not in sd
+    assert sum(v.numel() for v in sd.values()) == 62186708
+    idx = relative_position_index()
+    assert idx.shape == (343, 343) and int(idx.min()) == 0 and int(idx.max()) == 13 ** 3 - 1
+    assert int(idx[0, 0]) == int(idx[342, 342]) == (13 ** 3 - 1) // 2        # zero offset = the table's centre
+    assert window_geometry((4, 4, 4)) == ((4, 4, 4), (0, 0, 0)) and window_geometry((32, 16, 8)) == ((7, 7, 7), (3, 3, 3))
+    r = region_ids((14, 14, 14), (7, 7, 7), (3, 3, 3))
+    assert r.shape == (8, 343) and r.unique().numel() == 27
+    x = torch.arange(2 * 14 * 14 * 14 * 3, dtype=torch.float32).view(2, 14, 14, 14, 3)
+    assert torch.equal(window_reverse(window_partition(x, (7, 7, 7)), (7, 7, 7), (2, 14, 14, 14)), x)
+    assert MERGE_OFFSETS[2] == MERGE_OFFSETS[5] and MERGE_OFFSETS[3] == MERGE_OFFSETS[6]      # the v0.9 duplicates
+    assert (1, 1, 0) not in MERGE_OFFSETS and (0, 1, 1) not in MERGE_OFFSETS
+    g = torch.Generator().manual_seed(0)
+    for k, v in sd.items():
+        if v.dim() >= 2:
+            v.copy_(torch.randn(v.shape, generator=g) * 0.05)
+    y = o.forward(sd, torch.rand(1, 1, 32, 32, 64, generator=g), training=False)
+    assert y.shape == (1, 2, 32, 32, 64) and torch.isfinite(y).all()
+    with pytest.raises(ValueError):
+        o.forward(sd, torch.rand(1, 1, 48, 64, 64), training=False)
+
+
 def _brute_surface(mask):
     """Surface voxels by definition: object voxels with at least one face neighbour outside the object (or the volume)."""
     m = np.pad(mask, 1)

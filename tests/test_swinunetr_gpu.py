@@ -47,6 +47,26 @@ def test_swinunetr_forward_matches_oracle():
 
 
 @pytest.mark.timeout(1800)
+def test_swinunetr_forward_at_96_matches_oracle():
+    """The BraTS patch of the training scripts (96^3): 48^3 tokens padded to 49^3 (343 windows), a 3^3-voxel deepest conv level
+    (27 voxels: the scalar normalisation kernels), the 6^3 level in one clipped window of 216 tokens."""
+    from networks.net_factory_3d import net_factory_3d
+    from oracle import filler
+    from oracle.swinunetr import OracleSwinUNETR
+    onet = OracleSwinUNETR(2)
+    sd0 = _filled(onet)
+    net = net_factory_3d("swinunetr", 1, 2)
+    net.load_state_dict(sd0)
+    net.eval()
+    x = filler.image((1, 1, 96, 96, 96), "volume")
+    with torch.no_grad():
+        y = net(x.cuda())
+    ref = onet.forward(sd0, x, training=False)
+    err = (y.cpu() - ref).abs().max().item()
+    assert err <= 1e-3, err
+
+
+@pytest.mark.timeout(1800)
 def test_swinunetr_mean_teacher_step_matches_oracle():
     """One Mean-Teacher step (1 labeled + 1 unlabeled volume of 64^3) against oracle.step on the oracle network: logits,
     losses, gradients, updated weights."""
