@@ -1,0 +1,77 @@
+"""The data-parallel step on real GPU kernels with a real collective: two processes share the one GPU of the test box
+and exchange gradients over gloo (RCCL needs one device per rank; the collective API, the asynchronous work handles and
+the stream hand-over of ``mis_hip.dist.GradBucketer`` are the same).  Checks: both ranks end with bit-identical weights;
+the bucketed exchange overlapped with the backward (and with the weight gradients on their side stream) gives bit for
+bit the weights of one blocking all-reduce after the backward.
+
+Reference: single-GPU; this is the standard DDP contract of SURVEY s.8 row e."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, out_dir, overlap, kind):
+    os.environ["MIS_GRAD_OVERLAP"] = "1" if overlap else "0"
+    for p in (os.path.join(ROOT, "cv-ssl-mis_amd"), ROOT, os.path.join(ROOT, "tests")):
+        sys.path.insert(0, p)
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    from mis_hip import step as mstep
+    from mis_hip.step import MeanTeacherTrainer
+    from test_grad_progress_gpu import _make
+    assert mstep.GRAD_OVERLAP == bool(overlap)
+    torch.manual_seed(5)                                   # identical initial weights on both ranks
+    C = 4 if kind == "unet2d" else 2
+    model, ema = _make(kind, C), _make(kind, C)
+    ema.load_state_dict(model.state_dict())
+    model.train(); ema.train()
+    tr = MeanTeacherTrainer(model, ema, labeled_bs=1, num_classes=C, cons_start_iter=0, iter_num=1000, seed=7)
+    assert (tr._bucketer is not None) == bool(overlap)
+    if tr._bucketer is not None:
+        # small buckets: several collectives per backward even for the small test networks
+        from mis_hip.dist import GradBucketer
+        tr._bucketer = GradBucketer(model.flat_grad, None, bucket_bytes=1 << 20)
+        assert len(tr._bucketer.buckets) >= 3
+    g = torch.Generator(device="cuda").manual_seed(100 + rank)          # a different shard per rank
+    shape = (2, 1, 64, 64) if kind == "unet2d" else (2, 1, 32, 32, 32)
+    vol = torch.rand(shape, generator=g, device="cuda")
+    lab = torch.randint(0, C, (shape[0],) + shape[2:], generator=g, device="cuda").to(torch.uint8 if kind == "unet2d" else torch.int64)
+    noise = torch.zeros((1,) + shape[1:], device="cuda")                 # injected: no device RNG in the comparison
+    model.dropout_enabled = ema.dropout_enabled = False
+    for _ in range(3):
+        tr.step(vol, lab, noise=noise)
+    torch.cuda.synchronize()
+    torch.save(dict(student=model.flat_param.cpu(), teacher=ema.flat_param.cpu(), loss=tr.losses()["loss"]),
+               os.path.join(out_dir, f"{kind}_{int(overlap)}_{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("kind", ["unet3d", "unet2d"])
+def test_two_ranks_on_one_gpu_exchange_gradients(tmp_path, kind):
+    world = 2
+    for overlap in (0, 1):
+        mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), overlap, kind), nprocs=world, join=True)
+    r = {(o, k): torch.load(os.path.join(tmp_path, f"{kind}_{o}_{k}.pt")) for o in (0, 1) for k in (0, 1)}
+    for o in (0, 1):
+        assert torch.equal(r[(o, 0)]["student"], r[(o, 1)]["student"]), "ranks diverged"
+        assert torch.equal(r[(o, 0)]["teacher"], r[(o, 1)]["teacher"])
+        assert r[(o, 0)]["loss"] != r[(o, 1)]["loss"]                    # the shards really differ
+    # overlapped, bucketed exchange == one blocking all-reduce
+    assert torch.equal(r[(0, 0)]["student"], r[(1, 0)]["student"])
+    assert torch.equal(r[(0, 0)]["teacher"], r[(1, 0)]["teacher"])
