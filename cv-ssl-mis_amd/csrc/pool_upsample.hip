@@ -393,6 +393,65 @@ __global__ __launch_bounds__(256) void upsample_tri2_fwd_kernel(const UpArgs a) 
         }
 }
 
+// The same arithmetic (bit-identical), marching along z: a thread owns one (y, x) input column segment of ZR cells and
+// keeps E(p)[dy][dx] = the (y, x)-interpolated 2 x 2 block of input plane p for three consecutive planes; every new plane
+// costs 9 loads and feeds two output planes: out(2z) = 0.25 E(z-1) + 0.75 E(z), out(2z+1) = 0.75 E(z) + 0.25 E(z+1).
+// 1.7 loads and ~5 VALU instructions per output instead of 3.4 and ~11 (the one-cell kernel is instruction-bound:
+// 3.4 TB/s of the 906 MB it writes at 96^3; this form 4.3).
+template <int ZR>
+__global__ __launch_bounds__(256) void upsample_tri2_fwd_z_kernel(const UpArgs a) {
+    const int pl = blockIdx.x * 256 + threadIdx.x;
+    if (pl >= a.H * a.W) return;
+    const int z0 = blockIdx.y * ZR, nc = blockIdx.z;
+    const int n = nc / a.C, c = nc - n * a.C;
+    const int y = pl / a.W, x = pl - y * a.W;
+    const int S = a.D * a.H * a.W;
+    const float* __restrict__ xb = a.x + (long long)n * a.x_bs + (long long)c * S;
+    const int yo[3] = {(y > 0 ? y - 1 : 0) * a.W, y * a.W, (y < a.H - 1 ? y + 1 : y) * a.W};
+    const int xi[3] = {x > 0 ? x - 1 : 0, x, x < a.W - 1 ? x + 1 : x};
+    auto plane = [&](int p, float (&E)[2][2]) {
+        const float* __restrict__ r = xb + (long long)p * a.H * a.W;
+        float ex[3][2];
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const float v0 = r[yo[ky] + xi[0]], v1 = r[yo[ky] + xi[1]], v2 = r[yo[ky] + xi[2]];
+            ex[ky][0] = 0.25f * v0 + 0.75f * v1;
+            ex[ky][1] = 0.75f * v1 + 0.25f * v2;
+        }
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 2; ++dx) {
+                const float hy = dy ? 0.75f : 0.25f, ly = 1.f - hy;
+                E[dy][dx] = hy * ex[dy][dx] + ly * ex[dy + 1][dx];
+            }
+    };
+    const long long So = (long long)a.Do * a.Ho * a.Wo;
+    float* __restrict__ yb = a.y + (long long)n * a.y_bs + (long long)c * So + (long long)(2 * y) * a.Wo + 2 * x;
+    float Ep[2][2], Ec[2][2], En[2][2];
+    plane(z0 > 0 ? z0 - 1 : 0, Ep);
+    plane(z0, Ec);
+    const int z1 = z0 + ZR < a.D ? z0 + ZR : a.D;
+#pragma unroll
+    for (int zz = 0; zz < ZR; ++zz) {
+        const int z = z0 + zz;
+        if (z >= z1) break;
+        plane(z < a.D - 1 ? z + 1 : z, En);
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy) {
+            float* d0 = yb + ((long long)(2 * z) * a.Ho + dy) * a.Wo;
+            // dz = 0: hz = 0.25 on plane z-1, lz = 0.75 on plane z;  dz = 1: hz = 0.75 on plane z, lz = 0.25 on plane z+1
+            *reinterpret_cast<float2*>(d0) = make_float2(0.25f * Ep[dy][0] + 0.75f * Ec[dy][0], 0.25f * Ep[dy][1] + 0.75f * Ec[dy][1]);
+            *reinterpret_cast<float2*>(d0 + (long long)a.Ho * a.Wo) =
+                make_float2(0.75f * Ec[dy][0] + 0.25f * En[dy][0], 0.75f * Ec[dy][1] + 0.25f * En[dy][1]);
+        }
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 2; ++dx) { Ep[dy][dx] = Ec[dy][dx]; Ec[dy][dx] = En[dy][dx]; }
+    }
+}
+
 // Backward of the same: dx[i] collects outputs 2i-1 .. 2i+2 with weights (0.25, 0.75, 0.75, 0.25) (1.0 at the
 // two border outputs, 0 outside).  One thread owns an x-pair of input cells and ZR consecutive z: every
 // dy plane is reduced over (y, x) once (24 loads for the pair) and feeds two dx planes, i.e. ~30 loads per
@@ -682,7 +741,14 @@ extern "C" int mis_upsample2_fwd(const float* x, long long x_bs, float* y, long 
     if (x_bs < (long long)C * D * H * W || y_bs < (long long)C * So) return MIS_ERR_ARG;
     if ((y_bs & 1) || ((uintptr_t)y & 7)) return MIS_ERR_UNSUPPORTED;   // float2 stores (Wo = 2W is even)
     if (!grid_ok(a.Do, (long long)N * C)) return MIS_ERR_UNSUPPORTED;
-    if (!a.align && D > 1 && So < (1LL << 31))
+    // z-marching form, 4 input planes per thread (measured 300 -> 237 us at 48^3 -> 96^3 x 32 channels x 8; 8 planes per
+    // thread and an x-pair per thread with float4 stores are slower: 242 / 276 us); MIS_TRI2_FWD_Z=0: the one-cell kernel
+    static const int zmarch = getenv("MIS_TRI2_FWD_Z") ? atoi(getenv("MIS_TRI2_FWD_Z")) : 4;
+    if (!a.align && D > 1 && So < (1LL << 31) && zmarch >= 8 && D >= 8 && (long long)H * W * N * C >= 256 * 512)
+        hipLaunchKernelGGL(upsample_tri2_fwd_z_kernel<8>, dim3((H * W + 255) / 256, (D + 7) / 8, N * C), dim3(256), 0, stream, a);
+    else if (!a.align && D > 1 && So < (1LL << 31) && zmarch >= 4 && D >= 4 && (long long)H * W * N * C >= 256 * 256)
+        hipLaunchKernelGGL(upsample_tri2_fwd_z_kernel<4>, dim3((H * W + 255) / 256, (D + 3) / 4, N * C), dim3(256), 0, stream, a);
+    else if (!a.align && D > 1 && So < (1LL << 31))
         hipLaunchKernelGGL(upsample_tri2_fwd_kernel, dim3((H * W + 255) / 256, D, N * C), dim3(256), 0, stream, a);
     else if (a.align && D == 1 && a.Wo % 4 == 0 && H > 1 && W > 1 && !(y_bs & 3) && !((uintptr_t)y & 15))
         hipLaunchKernelGGL(upsample_bi2_fwd_kernel, dim3(((a.Ho / 2) * (a.Wo / 4) + 255) / 256, 1, N * C), dim3(256), 0,
