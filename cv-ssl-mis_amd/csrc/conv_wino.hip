@@ -96,6 +96,12 @@ struct WinoCfg {
 #ifndef MIS_WINO_DBG_CT
 #define MIS_WINO_DBG_CT 0
 #endif
+#ifndef MIS_WINO_NV
+#define MIS_WINO_NV 16      // transform points whose accumulators live in VGPRs (the MFMA takes either): 64 fewer v_accvgpr_read per
+                            // box; 16 is what fits beside the patch registers without the allocator parking VGPRs in AGPRs (24) or
+                            // spilling (32); serial config-3 step 19.94 -> 19.84 ms
+#endif
+constexpr int NVP = MIS_WINO_NV;
 // Ablation builds (scripts/wino_variants.sh; results are WRONG with any bit set, timing only -- DESIGN.md quotes them):
 // 1 no stores, 2 no epilogue (the MFMAs become dead code), 4 no cursor recompute, 8 no DMA, 16 no transform, 32 no filter
 // reads, 64 no barrier, 128 no filter DMA, 256 no input DMA, 512 transform interleaved with the MFMA slots, 1024 no wait
@@ -154,8 +160,13 @@ __device__ __forceinline__ void slots(const f32x4* __restrict__ wl, const f32x4*
             // asm with the accumulator tied to an AGPR tuple: through the builtin hipcc placed 14 of the first chunk's
             // (C = 0) results in VGPRs and copied them into AGPRs in the second chunk (112 v_accvgpr moves per box)
             const float av = ar[G % 4][K % 4], bv = cur[K / 2][K % 2];
-            if constexpr (FIRST) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, 0" : "=a"(acc[K]) : "v"(av), "v"(bv));
-            else asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+a"(acc[K]) : "v"(av), "v"(bv));
+            if constexpr (K < NVP) {
+                if constexpr (FIRST) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, 0" : "=v"(acc[K]) : "v"(av), "v"(bv));
+                else asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc[K]) : "v"(av), "v"(bv));
+            } else {
+                if constexpr (FIRST) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, 0" : "=a"(acc[K]) : "v"(av), "v"(bv));
+                else asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+a"(acc[K]) : "v"(av), "v"(bv));
+            }
         }
         if constexpr (K < 16 && !(DBG & 16)) {
 #pragma unroll
@@ -427,7 +438,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
                 for (int y = 0; y < 4; ++y) {
                     // read in place, here: left to itself hipcc copies all 256 accumulators to VGPRs first
-                    const f32x2 m0 = acc_pair(acc[y * 4 + x], h), m1 = acc_pair(acc[16 + y * 4 + x], h),
+                    const f32x2 m0 = (y * 4 + x < NVP) ? f32x2{acc[y * 4 + x][2 * h], acc[y * 4 + x][2 * h + 1]} : acc_pair(acc[y * 4 + x], h),
+                                m1 = acc_pair(acc[16 + y * 4 + x], h),
                                 m2 = acc_pair(acc[32 + y * 4 + x], h), m3 = acc_pair(acc[48 + y * 4 + x], h);
                     const f32x2 pz0 = m0 + m1 + m2, pz1 = m1 - m2 - m3;
                     if (y == 0) { py[0][0] = pz0; py[1][0] = pz1; }
