@@ -16,7 +16,7 @@
 // position bias of the head (2197 floats) and the window's shift-region ids in LDS.  head_dim is 16 (feature_size 48 with
 // 3 / 6 / 12 / 24 heads): a 343 x 343 x 16 product per workgroup is 7.5 MFLOP -- the whole encoder's attention is two
 // orders of magnitude below the convolutions of the decoder.  Deterministic: no atomics; the bias-table gradient is one
-// partial table per (window, head) summed in a fixed order.
+// partial table per (window, head) -- accumulated per wave in LDS inside the dQ kernel -- summed in a fixed order.
 #include "common.h"
 
 namespace {
@@ -212,12 +212,17 @@ __global__ __launch_bounds__(NT) void attn3d_fwd_kernel(const AttnArgs a) {
     reinterpret_cast<float2*>(a.stats)[((long long)blockIdx.x) * n + t] = make_float2(m, l);
 }
 
-// backward, queries: delta_t = dO_t . O_t, dQ_t = scale * sum_j dS_tj K_j,  dS = P (dP - delta)
+// backward, queries: delta_t = dO_t . O_t, dQ_t = scale * sum_j dS_tj K_j,  dS = P (dP - delta); and the bias-table
+// gradient of this (window, head): tpart[r] = sum of dS_tj over the pairs with relative index r.  At a given j the lanes
+// of a wave (distinct t) hit distinct table entries, so every wave adds into its OWN LDS copy of the table with plain
+// read-modify-writes in program order (deterministic); the six copies are summed in a fixed order at the end.
 __global__ __launch_bounds__(NT) void attn3d_bwd_q_kernel(const AttnArgs a) {
     float* const sk = swin3d_lds;
     float* const sv = sk + NMAX * HD;
     float* const sb = sv + NMAX * HD;
     int* const sr = reinterpret_cast<int*>(sb + TBL);
+    float* const stab = reinterpret_cast<float*>(sr + NMAX);       // [NT / 64][TBL]
+    for (int i = threadIdx.x; i < (NT / 64) * TBL; i += NT) stab[i] = 0.f;
     const int bw = blockIdx.x / a.nH, h = blockIdx.x % a.nH, n = a.n, C = a.nH * HD;
     const float* __restrict__ qb = a.qkv + (long long)bw * n * a.ldq + h * HD;
     stage_rows(sk, qb + C, a.ldq, n);
@@ -226,38 +231,49 @@ __global__ __launch_bounds__(NT) void attn3d_bwd_q_kernel(const AttnArgs a) {
     if (a.region) for (int i = threadIdx.x; i < n; i += NT) sr[i] = a.region[(long long)(bw % a.nW) * n + i];
     __syncthreads();
     const int t = threadIdx.x;
-    if (t >= n) return;
-    float q[HD], dO[HD], o[HD];
-    load16(qb + (long long)t * a.ldq, q);
-    load16(a.dout + ((long long)bw * n + t) * a.ldo + h * HD, dO);
-    load16(a.o + ((long long)bw * n + t) * a.ldo + h * HD, o);
-    float delta = 0.f;
+    if (t < n) {
+        float q[HD], dO[HD], o[HD];
+        load16(qb + (long long)t * a.ldq, q);
+        load16(a.dout + ((long long)bw * n + t) * a.ldo + h * HD, dO);
+        load16(a.o + ((long long)bw * n + t) * a.ldo + h * HD, o);
+        float delta = 0.f;
 #pragma unroll
-    for (int i = 0; i < HD; ++i) { q[i] *= a.scale; delta = fmaf(dO[i], o[i], delta); }
-    const float2 st = reinterpret_cast<const float2*>(a.stats)[(long long)blockIdx.x * n + t];
-    const float inv = 1.f / st.y;
-    const int rt = a.region ? sr[t] : 0;
-    float dq[HD];
+        for (int i = 0; i < HD; ++i) { q[i] *= a.scale; delta = fmaf(dO[i], o[i], delta); }
+        const float2 st = reinterpret_cast<const float2*>(a.stats)[(long long)blockIdx.x * n + t];
+        const float inv = 1.f / st.y;
+        const int rt = a.region ? sr[t] : 0;
+        float* const mytab = stab + (threadIdx.x >> 6) * TBL;
+        float dq[HD];
 #pragma unroll
-    for (int i = 0; i < HD; ++i) dq[i] = 0.f;
-    for (int j = 0; j < n; ++j) {
-        float s = dot16(q, sk + j * HD) + sb[rel_index(t, j)];
-        if (a.region && sr[j] != rt) s -= 100.f;
-        const float p = __expf(s - st.x) * inv;
-        const float ds = p * (dot16(dO, sv + j * HD) - delta);
+        for (int i = 0; i < HD; ++i) dq[i] = 0.f;
+        for (int j = 0; j < n; ++j) {
+            const int r = rel_index(t, j);
+            float s = dot16(q, sk + j * HD) + sb[r];
+            if (a.region && sr[j] != rt) s -= 100.f;
+            const float p = __expf(s - st.x) * inv;
+            const float ds = p * (dot16(dO, sv + j * HD) - delta);
+            mytab[r] += ds;
 #pragma unroll
-        for (int i = 0; i < HD / 4; ++i) {
-            const float4 k = reinterpret_cast<const float4*>(sk + j * HD)[i];
-            dq[4 * i] = fmaf(ds, k.x, dq[4 * i]); dq[4 * i + 1] = fmaf(ds, k.y, dq[4 * i + 1]);
-            dq[4 * i + 2] = fmaf(ds, k.z, dq[4 * i + 2]); dq[4 * i + 3] = fmaf(ds, k.w, dq[4 * i + 3]);
+            for (int i = 0; i < HD / 4; ++i) {
+                const float4 k = reinterpret_cast<const float4*>(sk + j * HD)[i];
+                dq[4 * i] = fmaf(ds, k.x, dq[4 * i]); dq[4 * i + 1] = fmaf(ds, k.y, dq[4 * i + 1]);
+                dq[4 * i + 2] = fmaf(ds, k.z, dq[4 * i + 2]); dq[4 * i + 3] = fmaf(ds, k.w, dq[4 * i + 3]);
+            }
         }
-    }
-    float* __restrict__ db = a.dqkv + ((long long)bw * n + t) * a.lddq + h * HD;
+        float* __restrict__ db = a.dqkv + ((long long)bw * n + t) * a.lddq + h * HD;
 #pragma unroll
-    for (int i = 0; i < HD / 4; ++i)
-        reinterpret_cast<float4*>(db)[i] = make_float4(dq[4 * i] * a.scale, dq[4 * i + 1] * a.scale, dq[4 * i + 2] * a.scale,
-                                                       dq[4 * i + 3] * a.scale);
-    a.delta[(long long)blockIdx.x * n + t] = delta;
+        for (int i = 0; i < HD / 4; ++i)
+            reinterpret_cast<float4*>(db)[i] = make_float4(dq[4 * i] * a.scale, dq[4 * i + 1] * a.scale, dq[4 * i + 2] * a.scale,
+                                                           dq[4 * i + 3] * a.scale);
+        a.delta[(long long)blockIdx.x * n + t] = delta;
+    }
+    __syncthreads();
+    for (int r = threadIdx.x; r < TBL; r += NT) {
+        float acc = 0.f;
+#pragma unroll
+        for (int w = 0; w < NT / 64; ++w) acc += stab[w * TBL + r];
+        a.tpart[(long long)blockIdx.x * TBL + r] = acc;
+    }
 }
 
 // backward, keys: dK_j = scale * sum_t dS_tj Q_t,  dV_j = sum_t P_tj dO_t    (one key row per thread; Q, dO in LDS)
@@ -315,60 +331,6 @@ __global__ __launch_bounds__(NT) void attn3d_bwd_kv_kernel(const AttnArgs a) {
     }
 }
 
-// backward, bias table: tpart[(bw, h)][r] = sum over the (t, j) pairs of this window with relative index r of dS_tj
-// (one relative offset per thread and pass; only the pairs that exist are walked)
-__global__ __launch_bounds__(NT) void attn3d_bwd_table_kernel(const AttnArgs a) {
-    constexpr int LR = HD + 4;                              // padded rows: the threads read different rows
-    float* const sq = swin3d_lds;                           // [n][LR] q * scale
-    float* const sk = sq + NMAX * LR;
-    float* const sv = sk + NMAX * LR;
-    float* const sdo = sv + NMAX * LR;
-    int* const sr = reinterpret_cast<int*>(sdo + NMAX * LR);
-    float* const sm = reinterpret_cast<float*>(sr + NMAX);
-    float* const sl = sm + NMAX;
-    float* const sdl = sl + NMAX;
-    float* const sbias = sdl + NMAX;                        // [TBL]
-    const int bw = blockIdx.x / a.nH, h = blockIdx.x % a.nH, n = a.n, C = a.nH * HD;
-    const float* __restrict__ qb = a.qkv + (long long)bw * n * a.ldq + h * HD;
-    for (int i = threadIdx.x; i < n * (HD / 4); i += NT) {
-        const int r = i / (HD / 4), q4 = i % (HD / 4);
-        float4 q = reinterpret_cast<const float4*>(qb + (long long)r * a.ldq)[q4];
-        q.x *= a.scale; q.y *= a.scale; q.z *= a.scale; q.w *= a.scale;
-        *reinterpret_cast<float4*>(sq + r * LR + 4 * q4) = q;
-        *reinterpret_cast<float4*>(sk + r * LR + 4 * q4) = reinterpret_cast<const float4*>(qb + C + (long long)r * a.ldq)[q4];
-        *reinterpret_cast<float4*>(sv + r * LR + 4 * q4) = reinterpret_cast<const float4*>(qb + 2 * C + (long long)r * a.ldq)[q4];
-        *reinterpret_cast<float4*>(sdo + r * LR + 4 * q4) =
-            reinterpret_cast<const float4*>(a.dout + ((long long)bw * n + r) * a.ldo + h * HD)[q4];
-    }
-    for (int i = threadIdx.x; i < TBL; i += NT) sbias[i] = a.table[(long long)i * a.nH + h];
-    for (int i = threadIdx.x; i < n; i += NT) {
-        if (a.region) sr[i] = a.region[(long long)(bw % a.nW) * n + i];
-        const float2 st = reinterpret_cast<const float2*>(a.stats)[(long long)blockIdx.x * n + i];
-        sm[i] = st.x; sl[i] = 1.f / st.y;
-        sdl[i] = a.delta[(long long)blockIdx.x * n + i];
-    }
-    __syncthreads();
-    for (int r = threadIdx.x; r < TBL; r += NT) {
-        const int dz = r / 169 - 6, dy = (r / 13) % 13 - 6, dx = r % 13 - 6;       // t - j per axis
-        float acc = 0.f;
-        for (int tz = dz > 0 ? dz : 0; tz < (dz < 0 ? 7 + dz : 7); ++tz)
-            for (int ty = dy > 0 ? dy : 0; ty < (dy < 0 ? 7 + dy : 7); ++ty)
-                for (int tx = dx > 0 ? dx : 0; tx < (dx < 0 ? 7 + dx : 7); ++tx) {
-                    const int t = tz * 49 + ty * 7 + tx, j = (tz - dz) * 49 + (ty - dy) * 7 + (tx - dx);
-                    if (t >= n || j >= n) continue;
-                    float s = sbias[r], dp = 0.f;
-#pragma unroll
-                    for (int i = 0; i < HD; ++i) {
-                        s = fmaf(sq[t * LR + i], sk[j * LR + i], s);
-                        dp = fmaf(sdo[t * LR + i], sv[j * LR + i], dp);
-                    }
-                    if (a.region && sr[t] != sr[j]) s -= 100.f;
-                    acc += __expf(s - sm[t]) * sl[t] * (dp - sdl[t]);
-                }
-        a.tpart[(long long)blockIdx.x * TBL + r] = acc;
-    }
-}
-
 // dtable[r][h] (+)= sum over the windows of tpart[(bw, h)][r], fixed order, in double
 __global__ __launch_bounds__(256) void attn3d_table_reduce_kernel(const float* __restrict__ tpart, float* __restrict__ dtable,
                                                                   int BW, int nH, int accumulate) {
@@ -396,7 +358,7 @@ unsigned grid_for(long long total) {
 
 constexpr int FWD_LDS = (2 * NMAX * HD + TBL + NMAX) * 4;
 constexpr int KV_LDS = (2 * NMAX * HD + TBL + 4 * NMAX) * 4;
-constexpr int TAB_LDS = (4 * NMAX * (HD + 4) + 4 * NMAX + TBL) * 4;
+constexpr int BQ_LDS = FWD_LDS + (NT / 64) * TBL * 4;
 
 int check_attn(const float* qkv, long long ldq, int BW, int nW, int n, int nH) {
     if (!qkv || BW <= 0 || nW <= 0 || n <= 0 || nH <= 0 || BW % nW) return MIS_ERR_ARG;
@@ -477,14 +439,12 @@ extern "C" int mis_win3d_attn_bwd(const float* qkv, long long ldq, const float* 
     a.stats = const_cast<float*>(stats); a.table = table; a.region = region;
     a.delta = reinterpret_cast<float*>(workspace); a.tpart = a.delta + (long long)BW * nH * n;
     a.BW = BW; a.nW = nW; a.n = n; a.nH = nH; a.scale = 0.25f;
-    static std::atomic<unsigned long long> d0{0}, d1{0}, d2{0};
-    if (mis_set_lds_attr(reinterpret_cast<const void*>(&attn3d_bwd_q_kernel), FWD_LDS, d0) != MIS_OK ||
-        mis_set_lds_attr(reinterpret_cast<const void*>(&attn3d_bwd_kv_kernel), KV_LDS, d1) != MIS_OK ||
-        mis_set_lds_attr(reinterpret_cast<const void*>(&attn3d_bwd_table_kernel), TAB_LDS, d2) != MIS_OK)
+    static std::atomic<unsigned long long> d0{0}, d1{0};
+    if (mis_set_lds_attr(reinterpret_cast<const void*>(&attn3d_bwd_q_kernel), BQ_LDS, d0) != MIS_OK ||
+        mis_set_lds_attr(reinterpret_cast<const void*>(&attn3d_bwd_kv_kernel), KV_LDS, d1) != MIS_OK)
         return MIS_ERR_LAUNCH;
-    hipLaunchKernelGGL(attn3d_bwd_q_kernel, dim3(BW * nH), dim3(NT), FWD_LDS, stream, a);
+    hipLaunchKernelGGL(attn3d_bwd_q_kernel, dim3(BW * nH), dim3(NT), BQ_LDS, stream, a);       // dQ, delta, table partials
     hipLaunchKernelGGL(attn3d_bwd_kv_kernel, dim3(BW * nH), dim3(NT), KV_LDS, stream, a);
-    hipLaunchKernelGGL(attn3d_bwd_table_kernel, dim3(BW * nH), dim3(NT), TAB_LDS, stream, a);
     hipLaunchKernelGGL(attn3d_table_reduce_kernel, dim3((TBL * nH + 255) / 256), dim3(256), 0, stream, a.tpart, dtable, BW,
                        nH, accumulate_table);
     return mis_launch_status();
