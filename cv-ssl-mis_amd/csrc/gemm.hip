@@ -55,6 +55,9 @@ struct GemmArgs {
     const float* E1; long long lde1;
     float* C2; long long ldc2;
     const float* rowscale; long long rps;
+    // TN only, optional (mis_gemm_dw): dbias[m] (+)= sum_k A[k][m] -- the bias gradient of nn.Linear rides on the weight
+    // gradient's read of dy.  Split-K: per-slice sums in wsb [KS][M] (behind the M x N partials), summed by the reduction
+    float* dbias; float* wsb; int dbias_acc;
 };
 
 enum { EP_NONE = 0, EP_GELU_FWD = 1, EP_GELU_BWD = 2, EP_RESIDUAL = 3 };
@@ -503,6 +506,10 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const GemmArgs a) {
     for (int i = 0; i < NI; ++i)
 #pragma unroll
         for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // column sums of A (the bias gradient): the workgroups of the first tile column, thread = (column, half of the k-step)
+    const bool colsum = a.dbias != nullptr && tn == 0;
+    const int bc = tid % BT, bh = tid / BT;
+    float bsum = 0.f;
 
     for (int k0 = kbeg; k0 < kend; k0 += BK) {
         __syncthreads();
@@ -529,6 +536,10 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const GemmArgs a) {
             }
         }
         __syncthreads();
+        if (colsum && bh < 2) {
+#pragma unroll
+            for (int r = 0; r < BK / 2; ++r) bsum += sA[(bh * (BK / 2) + r) * LD + bc];
+        }
 #pragma unroll
         for (int s = 0; s < BK / 4; ++s) {
             float af[NI], bf[NI];
@@ -545,6 +556,16 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const GemmArgs a) {
     }
 
     const bool direct = a.KS == 1;
+    if (colsum) {      // workgroup-uniform
+        __syncthreads();
+        if (bh < 2) sB[bh * BT + bc] = bsum;
+        __syncthreads();
+        if (tid < BT && m0 + tid < a.M) {
+            const float v = sB[tid] + sB[BT + tid];
+            if (direct) a.dbias[m0 + tid] = a.dbias_acc ? a.dbias[m0 + tid] + v : v;
+            else a.wsb[(long long)kz * a.M + m0 + tid] = v;
+        }
+    }
     float* __restrict__ out = direct ? a.C : a.ws + (long long)kz * a.M * a.N;
     const long long ldo = direct ? a.ldc : a.N;
 #pragma unroll
@@ -576,6 +597,21 @@ __global__ __launch_bounds__(256) void gemm_reduce_kernel(const GemmArgs a) {
     __shared__ float red[256];
     const long long total = (long long)a.M * a.N;
     const int el = threadIdx.x & 31, kl = threadIdx.x >> 5;
+    const long long main_blocks = (total + 31) / 32;
+    if (blockIdx.x >= main_blocks) {      // mis_gemm_dw: the per-slice column sums of A, same lane pattern
+        const long long m = (blockIdx.x - main_blocks) * 32LL + el;
+        float s = 0.f;
+        if (m < a.M)
+            for (int k = kl; k < a.KS; k += 8) s += a.wsb[(long long)k * a.M + m];
+        red[threadIdx.x] = s;
+        __syncthreads();
+        if (kl == 0 && m < a.M) {
+#pragma unroll
+            for (int j = 1; j < 8; ++j) s += red[j * 32 + el];
+            a.dbias[m] = a.dbias_acc ? a.dbias[m] + s : s;
+        }
+        return;
+    }
     const long long e = blockIdx.x * 32LL + el;
     float s = 0.f;
     if (e < total) {
@@ -847,6 +883,53 @@ extern "C" int mis_gemm(const float* A, long long lda, const float* B, long long
     if (a.KS > 1) {
         hipLaunchKernelGGL(gemm_reduce_kernel, dim3((unsigned)mis_cdiv((long long)M * N, 32)), dim3(256), 0, stream, a);
     }
+    return mis_launch_status();
+}
+
+// Weight and bias gradient of nn.Linear in one pass over dy (reference swin_transformer_unet_skip_expand_decoder_sys.py
+// :14,16,107,109 through autograd): dW[M,N] (+)= dy[K,M]^T . x[K,N], db[M] (+)= sum_k dy[k][m] -- mis_gemm's TN form
+// whose first tile column also sums the dy tile it staged (mis_colsum's partial + final launches are gone).
+// Deterministic: fixed slices, fixed-order sums.  workspace >= mis_gemm_dw_workspace_bytes(M, N, K).
+extern "C" long long mis_gemm_dw_workspace_bytes(int M, int N, int K) {
+    if (M <= 0 || N <= 0 || K <= 0) return MIS_ERR_ARG;
+    const int ks = pick_ks(M, N, K, 1);
+    return ks > 1 ? (long long)ks * M * (N + 1) * 4 : 0;
+}
+
+extern "C" int mis_gemm_dw(const float* dy, long long lddy, const float* x, long long ldx, float* dW, long long lddw,
+                           float* db, int M, int N, int K, int accumulate, float* workspace, long long workspace_bytes,
+                           hipStream_t stream) {
+    if (!dy || !x || !dW || !db || M <= 0 || N <= 0 || K <= 0) return MIS_ERR_ARG;
+    if (!a16(dy) || !a16(x) || lddy % 4 || ldx % 4 || M % 4 || N % 4) return MIS_ERR_UNSUPPORTED;
+    GemmArgs a{dy, lddy, x, ldx, dW, lddw, nullptr, workspace, M, N, K, 1, K, accumulate};
+    a.ex_P = 0;
+    a.ep = EP_NONE;
+    a.vec4 = 0;
+    a.dbias = db;
+    a.dbias_acc = accumulate;
+    a.KS = pick_ks(M, N, K, 1);
+    if (a.KS > 1) {
+        if (!workspace || workspace_bytes < (long long)a.KS * M * (N + 1) * 4) return MIS_ERR_WORKSPACE;
+        a.kchunk = (int)(mis_cdiv(mis_cdiv(K, a.KS), BK) * BK);
+        a.KS = (int)mis_cdiv(K, a.kchunk);
+        a.wsb = workspace + (long long)a.KS * M * N;
+    }
+    const int bt = tn_tile(M, N);
+    a.tiles_n = (int)mis_cdiv(N, bt);
+    a.tiles_m = (int)mis_cdiv(M, bt);
+    const long long nb = (long long)a.tiles_n * a.tiles_m * a.KS;
+    if (nb > 0x7fffffffLL) return MIS_ERR_UNSUPPORTED;
+    a.n_blocks = (unsigned)nb;
+    a.n_blocks_padded = (unsigned)(mis_cdiv(nb, MIS_NUM_XCD) * MIS_NUM_XCD);
+    if (bt == 96)
+        hipLaunchKernelGGL(gemm_tn_kernel<96>, dim3(a.n_blocks_padded), dim3(256), 0, stream, a);
+    else
+        hipLaunchKernelGGL(gemm_tn_kernel<128>, dim3(a.n_blocks_padded), dim3(256), 0, stream, a);
+    const int st = mis_launch_status();
+    if (st) return st;
+    if (a.KS > 1)
+        hipLaunchKernelGGL(gemm_reduce_kernel, dim3((unsigned)(mis_cdiv((long long)M * N, 32) + mis_cdiv(M, 32))), dim3(256),
+                           0, stream, a);
     return mis_launch_status();
 }
 

@@ -100,6 +100,12 @@ class LinearOp:
                 return
         tops.gemm(self.x.t, self.w2, self.y.t, bias=bias)
 
+    def _wgrad(self, dy):
+        if self.b is not None:
+            tops.gemm_dw(dy, self.x.t, self.gw2, self.b.grad)      # db rides on the dW GEMM's read of dy
+        else:
+            tops.gemm(dy, self.x.t, self.gw2, trans=True)
+
     def bwd(self, ctx):
         dy = self.y.grad()
         # dW / db need only (x, dy) and nothing downstream needs them: on the plan's side stream they run beside the
@@ -108,13 +114,9 @@ class LinearOp:
         if side is not None:
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
-                tops.gemm(dy, self.x.t, self.gw2, trans=True)
-                if self.b is not None:
-                    tops.colsum(dy, self.b.grad)
+                self._wgrad(dy)
         else:
-            tops.gemm(dy, self.x.t, self.gw2, trans=True)
-            if self.b is not None:
-                tops.colsum(dy, self.b.grad)
+            self._wgrad(dy)
         if self.need_dx:
             if not self.wT_batched:
                 if self.wT is None:

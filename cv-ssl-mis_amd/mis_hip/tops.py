@@ -58,6 +58,27 @@ def gemm(A, B, C, bias=None, trans=False, accumulate=False):
         prof.append((name, 2.0 * M * N * K, e0, e1))
 
 
+def gemm_dw(dy, x, dW, db, accumulate=False):
+    """dW[M,N] (+)= dy[K,M]^T @ x[K,N] and db[M] (+)= dy.sum(0) in one pass over dy (mis_gemm_dw)."""
+    L = _l.load()
+    K, M, lddy = _mat(dy)
+    K2, N, ldx = _mat(x)
+    Mc, Nc, ldw = _mat(dW)
+    assert K == K2 and (Mc, Nc) == (M, N) and db.numel() == M and db.is_contiguous(), (dy.shape, x.shape, dW.shape)
+    nb = L.mis_gemm_dw_workspace_bytes(M, N, K)
+    ws = scratch(nb, "gemm") if nb > 0 else None
+    prof = _ops.PROFILE
+    if prof is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    _l.check(L.mis_gemm_dw(_l.ptr(dy), lddy, _l.ptr(x), ldx, _l.ptr(dW), ldw, _l.ptr(db), M, N, K, int(accumulate),
+                           _l.ptr(ws), ws.numel() if ws is not None else 0, _l.stream_ptr()), "mis_gemm_dw")
+    if prof is not None:
+        e1.record()
+        name = "gemm_tn_kernel<96>" if (M % 96 == 0 and N % 96 == 0 and (M % 128 or N % 128)) else "gemm_tn_kernel<128>"
+        prof.append((name, 2.0 * M * N * K, e0, e1))
+
+
 EP_GELU_FWD, EP_GELU_BWD, EP_RESIDUAL = 1, 2, 3
 
 

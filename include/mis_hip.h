@@ -371,6 +371,16 @@ int mis_add(const float* a, long long a_bs, const float* b, long long b_bs, floa
  *           (:14,16,107,109,320,361,390,690) and, with B = weight^T, its input gradient;
  *           trans = 1: C[M,N] (+)= A[K,M]^T . B[K,N]  -- weight gradient dY^T . X (split over K, deterministic). */
 long long mis_gemm_workspace_bytes(int M, int N, int K, int trans);
+
+/* Weight AND bias gradient of nn.Linear in one pass over dy (replaces autograd of nn.Linear at
+ * code/networks/swin_transformer_unet_skip_expand_decoder_sys.py:14,16,107,109; code/networks/unetr.py's ViT Linears):
+ *   dW[M,N] (+)= dy[K,M]^T . x[K,N]     db[M] (+)= sum_k dy[k][m]
+ * mis_gemm's trans = 1 form; the workgroups of the first tile column also sum the dy tile they staged, so the separate
+ * mis_colsum launches are not needed.  Deterministic (fixed k slices, fixed-order sums).  M % 4 == N % 4 == 0, 16-byte
+ * aligned operands; workspace >= mis_gemm_dw_workspace_bytes(M, N, K) (0: none needed). */
+long long mis_gemm_dw_workspace_bytes(int M, int N, int K);
+int mis_gemm_dw(const float* dy, long long lddy, const float* x, long long ldx, float* dW, long long lddw, float* db, int M,
+                int N, int K, int accumulate, float* workspace, long long workspace_bytes, hipStream_t stream);
 /* the NT kernel instantiation mis_gemm / mis_gemm_ex run this shape with (aligned operands), as a profiler names it */
 int mis_gemm_nt_kernel_name(int M, int N, int K, int epilogue, char* name, int name_len);
 /* nn.Linear of PatchExpand / FinalPatchExpand_X4 fused with their pixel shuffle

@@ -72,6 +72,29 @@ def test_gemm_tn_split_k_large():
     assert torch.equal(dW, dW2)        # deterministic
 
 
+@pytest.mark.parametrize("T,Cout,Cin", [(20000, 96, 288), (150528, 288, 96), (2352, 768, 3072), (49, 1536, 768),
+                                        (3137, 100, 36), (9408, 1536, 384)])
+def test_gemm_dw_weight_and_bias_gradient_in_one_pass(T, Cout, Cin):
+    """mis_gemm_dw: dW = dy^T x and db = dy.sum(0) from one read of dy (nn.Linear backward), split-K and direct forms,
+    ragged tiles, accumulate; bit-identical dW to the plain TN form and deterministic."""
+    tops = _t()
+    X, dY = _rand(T, Cin, seed=15).cuda(), (_rand(T, Cout, seed=16) + 0.25).cuda()
+    dW, db = torch.full((Cout, Cin), float("nan"), device="cuda"), torch.full((Cout,), float("nan"), device="cuda")
+    tops.gemm_dw(dY, X, dW, db)
+    _close(dW, dY.double().t() @ X.double(), rtol=3e-4)
+    refb = dY.double().sum(0)
+    assert (db.double() - refb).abs().max().item() <= 2e-5 * max(1.0, refb.abs().max().item())
+    plain = torch.empty_like(dW)
+    tops.gemm(dY, X, plain, trans=True)
+    assert torch.equal(dW, plain)
+    dW2, db2 = dW.clone(), db.clone()
+    tops.gemm_dw(dY, X, dW2, db2, accumulate=True)
+    assert torch.allclose(dW2, 2 * dW, rtol=1e-6, atol=1e-6) and torch.allclose(db2, 2 * db, rtol=1e-6, atol=1e-6)
+    dW3, db3 = torch.empty_like(dW), torch.empty_like(db)
+    tops.gemm_dw(dY, X, dW3, db3)
+    assert torch.equal(dW, dW3) and torch.equal(db, db3)
+
+
 @pytest.mark.parametrize("M,C", [(784, 96), (50, 1536), (3137, 384)])
 def test_layernorm(M, C):
     tops = _t()
