@@ -48,6 +48,13 @@ Geo make_geo(int N, int C, long long S, long long x_bs, int per_sample, int cg =
     return g;
 }
 
+// residual branch of y = act(norm(x) + r) (MONAI UnetResBlock: conv-IN (+ shortcut) -> LeakyReLU): r read on the load path
+// of all three passes, its gradient dr (+)= dz written by the backward apply
+struct ResArgs {
+    const float* r; long long r_bs;
+    float* dr; long long dr_bs; int dr_acc;
+};
+
 struct DropCfg {
     float p;                   // drop probability (0 = off)
     unsigned salt;             // per-layer stream id
@@ -221,12 +228,13 @@ __global__ void running_to_stats_kernel(const float* __restrict__ rm, const floa
 // grid = (ceil(S/4 / (256*U)), C, N)
 constexpr int APPLY_U = 4;
 
+template <bool RES>
 __global__ __launch_bounds__(256) void apply_fwd_kernel(const float* __restrict__ x, Geo g,
                                                         const float* __restrict__ mean,
                                                         const float* __restrict__ rstd,
                                                         const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, float slope, DropCfg d,
-                                                        float* __restrict__ y, long long y_bs) {
+                                                        float* __restrict__ y, long long y_bs, ResArgs ra) {
     const int c = blockIdx.y, n = blockIdx.z;
     const int grp = g.per_sample ? (n * g.C + c) / g.cg : c;
     const float sc = (gamma ? gamma[c] : 1.f) * rstd[grp];
@@ -242,6 +250,10 @@ __global__ __launch_bounds__(256) void apply_fwd_kernel(const float* __restrict_
         if (u >= units) break;
         const float4 q = *reinterpret_cast<const float4*>(xb + u * 4);
         float v[4] = {q.x * sc + sh, q.y * sc + sh, q.z * sc + sh, q.w * sc + sh};
+        if constexpr (RES) {
+            const float4 rq = *reinterpret_cast<const float4*>(ra.r + (long long)n * ra.r_bs + (long long)c * g.S + u * 4);
+            v[0] += rq.x; v[1] += rq.y; v[2] += rq.z; v[3] += rq.w;
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] = v[j] > 0.f ? v[j] : v[j] * slope;
         if (drop) {
@@ -324,14 +336,14 @@ __global__ __launch_bounds__(256) void apply_fwd_pool_kernel(const float* __rest
 // partial sums per group: s1 = sum dz, s2 = sum dz*xhat
 // DACC: per-thread accumulation in double (GroupNorm: the reference's CPU kernels accumulate in double there, and its
 // gradient noise is what the parity gates are measured against)
-template <bool DACC>
+template <bool DACC, bool RES = false>
 __global__ __launch_bounds__(256) void bwd_partial_kernel(const float* __restrict__ x, Geo g,
                                                           const float* __restrict__ da, long long da_bs,
                                                           const float* __restrict__ mean,
                                                           const float* __restrict__ rstd,
                                                           const float* __restrict__ gamma,
                                                           const float* __restrict__ beta, float slope, DropCfg d,
-                                                          float2* __restrict__ part, PoolGrad pg) {
+                                                          float2* __restrict__ part, PoolGrad pg, ResArgs ra) {
     __shared__ double red[8];
     const int p = blockIdx.x, k = blockIdx.y, grp = blockIdx.z;
     const int n = g.per_sample ? grp / g.C : k;
@@ -353,6 +365,11 @@ __global__ __launch_bounds__(256) void bwd_partial_kernel(const float* __restric
         const float4 gq = db ? *reinterpret_cast<const float4*>(db + u * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
         const float xs[4] = {q.x, q.y, q.z, q.w};
         float gs[4] = {gq.x, gq.y, gq.z, gq.w};
+        float rv[4] = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (RES) {
+            const float4 rq = *reinterpret_cast<const float4*>(ra.r + (long long)n * ra.r_bs + (long long)c * g.S + u * 4);
+            rv[0] = rq.x; rv[1] = rq.y; rv[2] = rq.z; rv[3] = rq.w;
+        }
         if (pg.dp) {
             float pgr[4];
             pool_grad4(pg, n, c, g.C, (unsigned)(u * 4), pgr);
@@ -368,7 +385,7 @@ __global__ __launch_bounds__(256) void bwd_partial_kernel(const float* __restric
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const float xh = (xs[j] - m) * rs;
-            const float z = xh * ga + be;
+            const float z = xh * ga + be + rv[j];
             const float dz = z > 0.f ? gs[j] : gs[j] * slope;
             v[0] += dz;
             v[1] += (acc_t)dz * (acc_t)xh;
@@ -472,6 +489,7 @@ __global__ __launch_bounds__(256) void gn_bwd_affine_kernel(const float2* __rest
 // kind 0: BatchNorm / InstanceNorm (sums = means of dz, dz*xhat; gamma is constant over the group and factors out)
 // kind 1: GroupNorm (sums = means of gamma*dz, gamma*dz*xhat over the channel group)
 // kind 2: no normalisation (mean = 0, rstd = 1, gamma = null): dx = dz
+template <bool RES>
 __global__ __launch_bounds__(256) void apply_bwd_kernel(const float* __restrict__ x, Geo g,
                                                         const float* __restrict__ da, long long da_bs,
                                                         const float* __restrict__ mean,
@@ -479,7 +497,7 @@ __global__ __launch_bounds__(256) void apply_bwd_kernel(const float* __restrict_
                                                         const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, float slope, DropCfg d,
                                                         const float2* __restrict__ sums, float* __restrict__ dx,
-                                                        long long dx_bs, int kind, PoolGrad pg) {
+                                                        long long dx_bs, int kind, PoolGrad pg, ResArgs ra) {
     const int c = blockIdx.y, n = blockIdx.z;
     const int grp = g.per_sample ? (n * g.C + c) / g.cg : c;
     const float m = mean[grp], rs = rstd[grp];
@@ -512,15 +530,29 @@ __global__ __launch_bounds__(256) void apply_bwd_kernel(const float* __restrict_
 #pragma unroll
             for (int j = 0; j < 4; ++j) gs[j] *= s[j];
         }
-        float o[4];
+        float o[4], rv[4] = {0.f, 0.f, 0.f, 0.f}, dzs[4];
+        if constexpr (RES) {
+            const float4 rq = *reinterpret_cast<const float4*>(ra.r + (long long)n * ra.r_bs + (long long)c * g.S + u * 4);
+            rv[0] = rq.x; rv[1] = rq.y; rv[2] = rq.z; rv[3] = rq.w;
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const float xh = (xs[j] - m) * rs;
-            const float z = xh * ga + be;
+            const float z = xh * ga + be + rv[j];
             const float dz = z > 0.f ? gs[j] : gs[j] * slope;
+            dzs[j] = dz;
             o[j] = kind == 1 ? rs * (ga * dz - sm.x - xh * sm.y) : k * (dz - sm.x - xh * sm.y);
         }
         *reinterpret_cast<float4*>(ob + u * 4) = make_float4(o[0], o[1], o[2], o[3]);
+        if constexpr (RES) {
+            float* const dp = ra.dr + (long long)n * ra.dr_bs + (long long)c * g.S + u * 4;
+            float4 w = make_float4(dzs[0], dzs[1], dzs[2], dzs[3]);
+            if (ra.dr_acc) {
+                const float4 old = *reinterpret_cast<const float4*>(dp);
+                w.x += old.x; w.y += old.y; w.z += old.z; w.w += old.w;
+            }
+            *reinterpret_cast<float4*>(dp) = w;
+        }
     }
 }
 
@@ -747,8 +779,8 @@ extern "C" int mis_norm_act_fwd_g(const float* x, long long x_bs, float* y, long
     DropCfg d{drop_p, drop_salt, state, drop_mask};
     const long long units = S >> 2;
     const unsigned gx = (unsigned)mis_cdiv(units, 256 * APPLY_U);
-    hipLaunchKernelGGL(apply_fwd_kernel, dim3(gx, C, N), dim3(256), 0, stream, x, g, mean, rstd, gamma, beta,
-                       slope, d, y, y_bs);
+    hipLaunchKernelGGL(apply_fwd_kernel<false>, dim3(gx, C, N), dim3(256), 0, stream, x, g, mean, rstd, gamma, beta,
+                       slope, d, y, y_bs, ResArgs{});
     return mis_launch_status();
 }
 
@@ -802,8 +834,9 @@ int norm_act_bwd_impl(const float* x, long long x_bs, const float* da, long long
                       const float* rstd, const float* gamma, const float* beta, float slope, float drop_p,
                       unsigned drop_salt, const MisStepState* state, const float* drop_mask, float* dgamma,
                       float* dbeta, int accumulate_affine, void* workspace, long long workspace_bytes,
-                      const PoolGrad& pg, hipStream_t stream) {
-    if (S % 4 != 0) {      // few-voxel volumes: one workgroup per statistics group (no dropout, GroupNorm, pooling)
+                      const PoolGrad& pg, hipStream_t stream, const ResArgs& ra = ResArgs{}) {
+    if (S % 4 != 0) {
+        if (ra.r) return MIS_ERR_UNSUPPORTED;      // few-voxel volumes: one workgroup per statistics group (no dropout, GroupNorm, pooling)
         int st = check_geo_small(x, N, C, S, x_bs);
         if (st) return st;
         if (!da || !dx || !mean || !rstd || da_bs < (long long)C * S || dx_bs < (long long)C * S) return MIS_ERR_ARG;
@@ -831,10 +864,13 @@ int norm_act_bwd_impl(const float* x, long long x_bs, const float* da, long long
     if (!no_norm) {
         if (cg > 1)
             hipLaunchKernelGGL(bwd_partial_kernel<true>, dim3(g.P, g.nchunks, g.G), dim3(256), 0, stream, x, g, da, da_bs,
-                               mean, rstd, gamma, beta, slope, d, part, pg);
+                               mean, rstd, gamma, beta, slope, d, part, pg, ResArgs{});
+        else if (ra.r)
+            hipLaunchKernelGGL((bwd_partial_kernel<false, true>), dim3(g.P, g.nchunks, g.G), dim3(256), 0, stream, x, g, da,
+                               da_bs, mean, rstd, gamma, beta, slope, d, part, pg, ra);
         else
             hipLaunchKernelGGL(bwd_partial_kernel<false>, dim3(g.P, g.nchunks, g.G), dim3(256), 0, stream, x, g, da, da_bs,
-                               mean, rstd, gamma, beta, slope, d, part, pg);
+                               mean, rstd, gamma, beta, slope, d, part, pg, ResArgs{});
         if (gn) {
             hipLaunchKernelGGL(gn_bwd_group_kernel, dim3((N * (C / cg) + 3) / 4), dim3(256), 0, stream, part, g, gamma,
                                sums);
@@ -848,8 +884,12 @@ int norm_act_bwd_impl(const float* x, long long x_bs, const float* da, long long
     }
     const long long units = S >> 2;
     const unsigned gx = (unsigned)mis_cdiv(units, 256 * APPLY_U);
-    hipLaunchKernelGGL(apply_bwd_kernel, dim3(gx, C, N), dim3(256), 0, stream, x, g, da, da_bs, mean, rstd, gamma,
-                       beta, slope, d, sums, dx, dx_bs, no_norm ? 2 : (gn ? 1 : 0), pg);
+    if (ra.r)
+        hipLaunchKernelGGL(apply_bwd_kernel<true>, dim3(gx, C, N), dim3(256), 0, stream, x, g, da, da_bs, mean, rstd, gamma,
+                           beta, slope, d, sums, dx, dx_bs, no_norm ? 2 : (gn ? 1 : 0), pg, ra);
+    else
+        hipLaunchKernelGGL(apply_bwd_kernel<false>, dim3(gx, C, N), dim3(256), 0, stream, x, g, da, da_bs, mean, rstd, gamma,
+                           beta, slope, d, sums, dx, dx_bs, no_norm ? 2 : (gn ? 1 : 0), pg, ResArgs{});
     return mis_launch_status();
 }
 }  // namespace
@@ -908,7 +948,7 @@ extern "C" int mis_norm_act_bwd_sums(const float* x, long long x_bs, const float
     const DropCfg d{0.f, 0u, nullptr, nullptr};
     float2* part = reinterpret_cast<float2*>(workspace);
     hipLaunchKernelGGL(bwd_partial_kernel<false>, dim3(g.P, g.nchunks, g.G), dim3(256), 0, stream, x, g, da, da_bs, mean, rstd,
-                       gamma, beta, slope, d, part, PoolGrad{});
+                       gamma, beta, slope, d, part, PoolGrad{}, ResArgs{});
     hipLaunchKernelGGL(bwd_final_kernel, dim3((g.G + 3) / 4), dim3(256), 0, stream, part, g,
                        reinterpret_cast<float2*>(sums), dgamma, dbeta, accumulate_affine);
     return mis_launch_status();
@@ -933,11 +973,48 @@ extern "C" int mis_norm_act_bwd_tiles(const float* x, long long x_bs, const floa
     if (dx) {
         const DropCfg d{0.f, 0u, nullptr, nullptr};
         const unsigned gx = (unsigned)mis_cdiv(S >> 2, 256 * APPLY_U);
-        hipLaunchKernelGGL(apply_bwd_kernel, dim3(gx, C, N), dim3(256), 0, stream, x, g, da, da_bs, mean, rstd,
+        hipLaunchKernelGGL(apply_bwd_kernel<false>, dim3(gx, C, N), dim3(256), 0, stream, x, g, da, da_bs, mean, rstd,
                            (const float*)nullptr, (const float*)nullptr, slope, d, reinterpret_cast<const float2*>(sums),
-                           dx, dx_bs, 0, PoolGrad{});
+                           dx, dx_bs, 0, PoolGrad{}, ResArgs{});
     }
     return mis_launch_status();
+}
+
+// y = act(norm(x) + res): the tail of MONAI's UnetResBlock (UNETR / SwinUNETR: conv - IN - lrelu - conv - IN, + shortcut,
+// lrelu; reference code/networks/unetr.py's UnetrBasicBlock(res_block=True) / net_factory_3d.py:37-38) in one pass
+// instead of normalise, add, activate.  BatchNorm / InstanceNorm with optional affine; no dropout, no GroupNorm; S % 4 == 0.
+extern "C" int mis_norm_res_act_fwd(const float* x, long long x_bs, const float* res, long long res_bs, float* y,
+                                    long long y_bs, int N, int C, long long S, int per_sample, const float* mean,
+                                    const float* rstd, const float* gamma, const float* beta, float slope,
+                                    hipStream_t stream) {
+    int st = check_geo(x, N, C, S, x_bs);
+    if (st) return st;
+    if (!res || !y || !mean || !rstd || y_bs < (long long)C * S || res_bs < (long long)C * S) return MIS_ERR_ARG;
+    if (y_bs % 4 != 0 || !aligned16(y) || res_bs % 4 != 0 || !aligned16(res)) return MIS_ERR_UNSUPPORTED;
+    const Geo g = make_geo(N, C, S, x_bs, per_sample, 1);
+    const DropCfg d{0.f, 0u, nullptr, nullptr};
+    const unsigned gx = (unsigned)mis_cdiv(S >> 2, 256 * APPLY_U);
+    hipLaunchKernelGGL(apply_fwd_kernel<true>, dim3(gx, C, N), dim3(256), 0, stream, x, g, mean, rstd, gamma, beta, slope,
+                       d, y, y_bs, ResArgs{res, res_bs, nullptr, 0, 0});
+    return mis_launch_status();
+}
+
+// Backward of mis_norm_res_act_fwd: dz = dy * act'(norm(x) + res);  dres (+)= dz;  dx = the normalisation's backward of
+// dz.  accumulate_dres != 0 adds to dres (the shortcut has other consumers whose gradient is already there).
+// Workspace: mis_norm_workspace_bytes(N, C, S, per_sample).
+extern "C" int mis_norm_res_act_bwd(const float* x, long long x_bs, const float* res, long long res_bs, const float* dy,
+                                    long long dy_bs, float* dx, long long dx_bs, float* dres, long long dres_bs,
+                                    int accumulate_dres, int N, int C, long long S, int per_sample, const float* mean,
+                                    const float* rstd, const float* gamma, const float* beta, float slope,
+                                    float* dgamma, float* dbeta, int accumulate_affine, void* workspace,
+                                    long long workspace_bytes, hipStream_t stream) {
+    if (!dy || !res || !dres || S % 4 != 0) return !dy || !res || !dres ? MIS_ERR_ARG : MIS_ERR_UNSUPPORTED;
+    if (res_bs % 4 != 0 || !aligned16(res) || dres_bs % 4 != 0 || !aligned16(dres)) return MIS_ERR_UNSUPPORTED;
+    if (res_bs < (long long)C * S || dres_bs < (long long)C * S) return MIS_ERR_ARG;
+    if (per_sample && (gamma || beta)) return MIS_ERR_UNSUPPORTED;
+    return norm_act_bwd_impl(x, x_bs, dy, dy_bs, dx, dx_bs, N, C, S, per_sample, 1, 0, mean, rstd, gamma, beta, slope, 0.f,
+                             0u, nullptr, nullptr, dgamma, dbeta, accumulate_affine, workspace, workspace_bytes, PoolGrad{},
+                             stream, ResArgs{res, res_bs, dres, dres_bs, accumulate_dres});
 }
 
 extern "C" int mis_norm_act_bwd(const float* x, long long x_bs, const float* da, long long da_bs, float* dx,

@@ -41,6 +41,8 @@ WGRAD_STREAM = os.environ.get("MIS_WGRAD_STREAM", "1") != "0"
 # first stage of the InstanceNorm + ReLU backward (sum dz, sum dz * x) in the epilogue of the Winograd data-gradient launch
 # that produces the gradient at the activation (mis_conv3d_wino_dgrad_norm): the partial-sum pass over da and x is not run
 FUSE_DGRAD_NORM = os.environ.get("MIS_FUSE_DGRAD_NORM", "1") != "0"
+# residual blocks (UNETR / SwinUNETR): normalise + add the shortcut + activate in one pass, forward and backward
+NORM_RES = os.environ.get("MIS_NORM_RES", "1") != "0"
 
 
 class Act:
@@ -197,6 +199,7 @@ class NormActOp:
         self.sums = None         # set: backward only reduces (into this [G, 2] buffer); the producing first-layer conv applies
         self.ext_part = None     # [N*C*tiles, 2] partial sums of the backward written by the consuming conv's data-gradient
         self.ext_tiles, self.ext_ready, self.ext_sums = 0, False, None     # launch (Plan._fuse_dgrad_norm)
+        self.res = None          # Act added to the normalised value in front of the activation (Plan.norm_res_act)
         self.head = None         # 1x1x1 classifier ConvOp computed in this op's pass (Plan._fuse_head); head_w / head_b:
         self.head_w = self.head_b = None     # its parameters (their gradients are written by THIS op: dist.param_progress)
 
@@ -224,6 +227,11 @@ class NormActOp:
         self._state = ctx.state
         if self._p > 0 and self._mask is None and ctx.state is None:
             raise RuntimeError("dropout is active but no device step state was supplied (Ctx.state)")
+        if self.res is not None:
+            ops.norm_res_act_fwd(self.x.t, self.res.t, self.y.t, self.per_sample, self.mean, self.rstd,
+                                 None if self.gamma is None else self.gamma.data,
+                                 None if self.beta is None else self.beta.data, self.slope)
+            return
         if self.pool is not None and self.pool.fwd_fused:
             pl = self.pool
             ops.norm_act_fwd_pool(self.x.t, self.y.t, pl.y.t, pl.idx, self.per_sample, self.mean, self.rstd,
@@ -246,6 +254,16 @@ class NormActOp:
 
     def bwd(self, ctx):
         assert not self.x.written
+        if self.res is not None:
+            r = self.res
+            ops.norm_res_act_bwd(self.x.t, r.t, self.y.grad(), self.x.grad(), r.grad(), r.written, self.per_sample,
+                                 self.mean, self.rstd, None if self.gamma is None else self.gamma.data,
+                                 None if self.beta is None else self.beta.data, self.slope,
+                                 None if self.gamma is None else self.gamma.grad,
+                                 None if self.beta is None else self.beta.grad)
+            r.mark_written()
+            self.x.mark_written()
+            return
         if self.ext_ready:       # the data gradient that produced y.grad() already formed the partial sums
             self.ext_ready = False
             to_sums = self.sums is not None      # first layer: its weight gradient applies the backward itself
@@ -465,6 +483,19 @@ class Plan:
         self.ops.append(op)
         return y
 
+    @staticmethod
+    def can_norm_res_act(x):
+        """Geometry the one-pass form serves (the float4 kernels): voxel count a multiple of 4."""
+        return NORM_RES and (x.shape[2] * x.shape[3] * x.shape[4]) % 4 == 0
+
+    def norm_res_act(self, x, res, y, per_sample, gamma=None, beta=None, running=None, slope=0.0):
+        """y = act(norm(x) + res): the tail of a residual block in one pass (ops.norm_res_act_fwd); no dropout."""
+        assert self.can_norm_res_act(x) and tuple(res.shape) == tuple(x.shape)
+        assert not (per_sample and (gamma is not None or beta is not None))
+        self.norm_act(x, y, per_sample, gamma, beta, running, slope)
+        self.ops[-1].res = res
+        return y
+
     def down_conv(self, x, y, w, b, bias_grad=False):
         self.ops.append(DownConvOp(x, y, w, b, bias_grad))
         return y
@@ -536,7 +567,7 @@ class Plan:
             norm = next((o for o in self.ops if type(o) is NormActOp and o.y is conv.x), None)
             if norm is None or not norm.per_sample or norm.gamma is not None or norm.beta is not None or norm.cg != 1:
                 continue
-            if norm.no_norm or norm.drop_p > 0 or norm.pool is not None or norm.head is not None:
+            if norm.no_norm or norm.drop_p > 0 or norm.pool is not None or norm.head is not None or norm.res is not None:
                 continue
             N, C = norm.x.shape[0], norm.x.shape[1]
             if N * C > 384:
@@ -565,7 +596,7 @@ class Plan:
         norm, conv = self.ops[-2], self.ops[-1]
         if type(norm) is not NormActOp or type(conv) is not ConvOp or conv.ksize != (1, 1, 1) or conv.x is not norm.y:
             return
-        if norm.y.parent is not None or conv.y is not self.out or not conv.need_dx:
+        if norm.y.parent is not None or conv.y is not self.out or not conv.need_dx or norm.res is not None:
             return
         for op in self.ops[:-1]:
             for v in vars(op).values():

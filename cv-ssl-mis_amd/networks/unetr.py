@@ -106,17 +106,19 @@ class UNETR(HipNet):
     def _resblock(self, plan, p, x, cin, cout, spatial, out, need_dx=True):
         """MONAI UnetResBlock: conv3-IN-lrelu-conv3-IN (+ conv1-IN shortcut when cin != cout) -> add -> lrelu."""
         P = self.P
+        res = x
+        if cin != cout:      # the shortcut first: conv2 stays adjacent to its normalisation (statistics from its epilogue)
+            t3 = plan.new(cout, spatial)
+            plan.conv(x, t3, P(p + ".conv3.conv.weight"), None, (1, 1, 1), need_dx=need_dx, bias_grad=False)
+            res = plan.norm_act(t3, plan.new(cout, spatial), per_sample=True, slope=1.0)
         t1 = plan.new(cout, spatial)
         plan.conv(x, t1, P(p + ".conv1.conv.weight"), None, (3, 3, 3), need_dx=need_dx, bias_grad=False)
         n1 = plan.norm_act(t1, plan.new(cout, spatial), per_sample=True, slope=0.01)
         t2 = plan.new(cout, spatial)
         plan.conv(n1, t2, P(p + ".conv2.conv.weight"), None, (3, 3, 3), bias_grad=False)
+        if plan.can_norm_res_act(t2):       # IN(t2) + shortcut -> LeakyReLU in one pass over t2 and the shortcut
+            return plan.norm_res_act(t2, res, out, per_sample=True, slope=0.01)
         n2 = plan.norm_act(t2, plan.new(cout, spatial), per_sample=True, slope=1.0)      # IN only (slope 1 = identity)
-        res = x
-        if cin != cout:
-            t3 = plan.new(cout, spatial)
-            plan.conv(x, t3, P(p + ".conv3.conv.weight"), None, (1, 1, 1), need_dx=need_dx, bias_grad=False)
-            res = plan.norm_act(t3, plan.new(cout, spatial), per_sample=True, slope=1.0)
         s = plan.add(n2, res, plan.new(cout, spatial))
         return plan.norm_act(s, out, per_sample=False, slope=0.01, no_norm=True)          # LeakyReLU only
 

@@ -199,6 +199,50 @@ def test_norm_act_fwd_bwd(per_sample, slope, shape):
         _close(db, beta.grad, rtol=5e-4, atol=1e-4)
 
 
+@pytest.mark.parametrize("per_sample,shape", [(True, (2, 16, 8, 8, 8)), (True, (3, 8, 6, 6, 6)), (False, (4, 16, 1, 32, 32))])
+def test_norm_residual_act_fwd_bwd(per_sample, shape):
+    """mis_norm_res_act_{fwd,bwd}: lrelu(norm(x) + res) -- MONAI's UnetResBlock tail (UNETR / SwinUNETR) -- in one pass,
+    against torch autograd; the shortcut is a channel slice of a wider buffer (batch-strided view) and its gradient is
+    written or accumulated."""
+    ops = _ops()
+    N, C = shape[0], shape[1]
+    x = (_rand(*shape, seed=17, scale=2.0) + 0.3).requires_grad_(True)
+    wide = _rand(N, C + 8, *shape[2:], seed=18)
+    r = wide[:, 8:].clone().requires_grad_(True)
+    gamma = (1 + 0.1 * _rand(C, seed=8)).requires_grad_(not per_sample)
+    beta = (0.1 * _rand(C, seed=9)).requires_grad_(not per_sample)
+    z = F.instance_norm(x, eps=1e-5) if per_sample else \
+        F.batch_norm(x, torch.zeros(C), torch.ones(C), gamma, beta, training=True, momentum=0.1, eps=1e-5)
+    ref = F.leaky_relu(z + r, 0.01)
+    dy = _rand(*shape, seed=19)
+    ref.backward(dy)
+
+    xd, wd = x.detach().cuda(), wide.cuda()
+    rd = wd[:, 8:]
+    G = N * C if per_sample else C
+    mean, rstd = torch.empty(G, device="cuda"), torch.empty(G, device="cuda")
+    ops.norm_stats(xd, per_sample, 1e-5, mean, rstd, None, None, None)
+    g = None if per_sample else gamma.detach().cuda()
+    bt = None if per_sample else beta.detach().cuda()
+    y = torch.full(shape, float("nan"), device="cuda")
+    ops.norm_res_act_fwd(xd, rd, y, per_sample, mean, rstd, g, bt, 0.01)
+    _close(y, ref)
+    dx = torch.full(shape, float("nan"), device="cuda")
+    dwide = torch.full(tuple(wide.shape), float("nan"), device="cuda")
+    dr = dwide[:, 8:]
+    dg = None if per_sample else torch.empty(C, device="cuda")
+    db = None if per_sample else torch.empty(C, device="cuda")
+    ops.norm_res_act_bwd(xd, rd, dy.cuda(), dx, dr, False, per_sample, mean, rstd, g, bt, 0.01, dgamma=dg, dbeta=db)
+    _close(dx, x.grad, rtol=5e-4, atol=1e-5)
+    _close(dr, r.grad, rtol=1e-6, atol=1e-7)
+    assert torch.isnan(dwide[:, :8]).all()          # nothing outside the slice is touched
+    if not per_sample:
+        _close(dg, gamma.grad, rtol=5e-4, atol=1e-4)
+        _close(db, beta.grad, rtol=5e-4, atol=1e-4)
+    ops.norm_res_act_bwd(xd, rd, dy.cuda(), dx, dr, True, per_sample, mean, rstd, g, bt, 0.01, dgamma=dg, dbeta=db)
+    _close(dr, 2 * r.grad, rtol=1e-6, atol=1e-7)
+
+
 @pytest.mark.parametrize("shape,cg", [((2, 32, 4, 8, 8), 2), ((2, 64, 2, 8, 8), 4), ((3, 16, 4, 4, 8), 1)])
 def test_group_norm_act_fwd_bwd(shape, cg):
     """nn.GroupNorm(16, C) + ReLU (reference code/networks/vnet.py:19-20) against torch CPU: statistics per
