@@ -115,6 +115,31 @@ def space_to_depth2(src, dst, fine_shape, to_depth, bias=None, accumulate=False)
                                    int(accumulate), _l.stream_ptr()), "mis_space_to_depth2")
 
 
+def conv_k2s2_eligible(cin, cout, coarse, up):
+    """(cin, cout) and the COARSE (Do, Ho, Wo) the in-place kernel-2 / stride-2 kernels serve (conv_k2s2.hip)."""
+    return K2S2 and bool(_l.load().mis_conv_k2s2_eligible(int(cin), int(cout), *[int(v) for v in coarse], int(up)))
+
+
+def conv_k2s2_down(x, w, bias, y, accumulate=False):
+    """y (coarse) (+)= bias + sum w[co][ci*8 + tap] x[ci][2v + tap]: Conv3d(k2s2) forward / ConvTranspose3d(k2s2) dX."""
+    L = _l.load()
+    N, Cin, _, _, _, _, xbs = _geom(x)
+    _, Cout, Do, Ho, Wo, _, ybs = _geom(y)
+    assert w.is_contiguous() and w.numel() == Cin * Cout * 8
+    _l.check(L.mis_conv_k2s2_down(_l.ptr(x), xbs, _l.ptr(w), _l.ptr(bias), _l.ptr(y), ybs, N, Cin, Cout, Do, Ho, Wo,
+                                  int(accumulate), _l.stream_ptr()), "mis_conv_k2s2_down")
+
+
+def conv_k2s2_up(x, w, bias, y, accumulate=False):
+    """y (fine) (+)= bias + sum w[ci][co*8 + tap] x[ci][v]: ConvTranspose3d(k2s2) forward / Conv3d(k2s2) dX."""
+    L = _l.load()
+    N, Cin, Do, Ho, Wo, _, xbs = _geom(x)
+    _, Cout, _, _, _, _, ybs = _geom(y)
+    assert w.is_contiguous() and w.numel() == Cin * Cout * 8
+    _l.check(L.mis_conv_k2s2_up(_l.ptr(x), xbs, _l.ptr(w), _l.ptr(bias), _l.ptr(y), ybs, N, Cin, Cout, Do, Ho, Wo,
+                                int(accumulate), _l.stream_ptr()), "mis_conv_k2s2_up")
+
+
 def add(a, b, out):
     """out = a (+ b if b is not None) on [N,C,D,H,W] views."""
     L = _l.load()
@@ -130,6 +155,7 @@ def _ksize(k):
     return tuple(k)
 
 
+K2S2 = _os.environ.get("MIS_K2S2", "1") != "0"      # kernel-2 / stride-2 (de)convolutions in place (conv_k2s2.hip)
 WINO = int(_os.environ.get("MIS_WINO", "3"))      # bit 0: Winograd form of the 3x3x3 convolutions, bit 1: of the 3x3 ones
 
 

@@ -341,32 +341,55 @@ class UpsampleOp:
 
 
 class DownConvOp:
-    """nn.Conv3d(Cin, Cout, 2, stride=2) (reference vnet.py:73) = space_to_depth + 1x1x1 MFMA conv."""
+    """nn.Conv3d(Cin, Cout, 2, stride=2) (reference vnet.py:73): on V-Net's large levels read in place from the fine volume
+    (conv_k2s2.hip); otherwise space_to_depth + 1x1x1 MFMA conv.  The weight gradient always takes the space-to-depth
+    view of x (formed in the backward when the forward ran in place: the teacher never needs it)."""
 
     def __init__(self, x, y, w, b, bias_grad=False, need_dx=True, in_shape=None):
         self.x, self.y, self.w, self.b, self.bias_grad, self.need_dx = x, y, w, b, bias_grad, need_dx
         N, Cin, D, H, W = in_shape if in_shape is not None else x.shape      # in_shape: x is the plan's (late-bound) input
         self.in_shape = (N, Cin, D, H, W)
         self.cin8, self.cout = 8 * Cin, w.data.shape[0]
-        self.xs = torch.empty((N, self.cin8, D // 2, H // 2, W // 2), dtype=torch.float32, device="cuda")
+        coarse = (D // 2, H // 2, W // 2)
+        self.direct = ops.conv_k2s2_eligible(Cin, self.cout, coarse, False)
+        self.direct_dx = ops.conv_k2s2_eligible(self.cout, Cin, coarse, True)
+        self._xs = None if self.direct else self._new_xs()
+        self._xs_valid = False
         self.dxs = None
         self.wp = self.wpd = None
 
+    def _new_xs(self):
+        N, Cin, D, H, W = self.in_shape
+        return torch.empty((N, self.cin8, D // 2, H // 2, W // 2), dtype=torch.float32, device="cuda")
+
     def fwd(self, ctx):
-        ops.space_to_depth2(self.x.t, self.xs, self.in_shape, True)
+        if self.direct:
+            self._xs_valid = False
+            ops.conv_k2s2_down(self.x.t, self.w.data, self.b.data, self.y.t)
+            return
+        ops.space_to_depth2(self.x.t, self._xs, self.in_shape, True)
+        self._xs_valid = True
         self.wp = ops.conv_pack_raw(self.w.data, self.cout, self.cin8, 1, 0, out=self.wp)
-        ops.conv_fwd(self.xs, self.wp, self.b.data, self.y.t, self.cin8, self.cout, (1, 1, 1))
+        ops.conv_fwd(self._xs, self.wp, self.b.data, self.y.t, self.cin8, self.cout, (1, 1, 1))
 
     def bwd(self, ctx):
         dy = self.y.grad()
-        ops.conv_wgrad(self.xs, dy, self.w.grad, (1, 1, 1))      # [Cout][8Cin] == [Cout][Cin][2][2][2] in memory
+        if not self._xs_valid:
+            if self._xs is None:
+                self._xs = self._new_xs()
+            ops.space_to_depth2(self.x.t, self._xs, self.in_shape, True)
+        ops.conv_wgrad(self._xs, dy, self.w.grad, (1, 1, 1))      # [Cout][8Cin] == [Cout][Cin][2][2][2] in memory
         # bias gradient exactly 0 when the conv feeds a normalisation (see ConvOp)
         if self.bias_grad:
             ops.channel_sum(dy, self.b.grad)
         if not self.need_dx:
             return
+        if self.direct_dx:       # dX = ConvTranspose3d(dy) with the parameter read as [K = Cout][M = 8 Cin]
+            ops.conv_k2s2_up(dy, self.w.data, None, self.x.grad(), accumulate=self.x.written)
+            self.x.mark_written()
+            return
         if self.dxs is None:
-            self.dxs = torch.empty_like(self.xs)
+            self.dxs = self._new_xs()
         self.wpd = ops.conv_pack_raw(self.w.data, self.cout, self.cin8, 1, 1, out=self.wpd)
         ops.conv_fwd(dy, self.wpd, None, self.dxs, self.cout, self.cin8, (1, 1, 1))
         ops.space_to_depth2(self.dxs, self.x.grad(), self.in_shape, False, accumulate=self.x.written)
@@ -374,19 +397,29 @@ class DownConvOp:
 
 
 class UpConvOp:
-    """nn.ConvTranspose3d(Cin, Cout, 2, stride=2) (reference vnet.py:100) = 1x1x1 MFMA conv to 8*Cout
-    channels (weight stored input-major [Cin][Cout*8]) + depth_to_space (+ bias)."""
+    """nn.ConvTranspose3d(Cin, Cout, 2, stride=2) (reference vnet.py:100): on V-Net's large levels written in place into
+    the fine volume (conv_k2s2.hip); otherwise 1x1x1 MFMA conv to 8*Cout channels (weight stored input-major
+    [Cin][Cout*8]) + depth_to_space (+ bias)."""
 
     def __init__(self, x, y, w, b, bias_grad=False):
         self.x, self.y, self.w, self.b, self.bias_grad = x, y, w, b, bias_grad
         N, Cin, d, h, wd = x.shape
         self.cin, self.cout8 = Cin, 8 * w.data.shape[1]
-        self.y8 = torch.empty((N, self.cout8, d, h, wd), dtype=torch.float32, device="cuda")
+        self.direct = ops.conv_k2s2_eligible(Cin, w.data.shape[1], (d, h, wd), True)
+        self.direct_dx = ops.conv_k2s2_eligible(w.data.shape[1], Cin, (d, h, wd), False)
+        self.y8 = None if self.direct else self._new_y8()
         self.dy8 = None
         self.dw8 = None
         self.wp = self.wpd = None
 
+    def _new_y8(self):
+        N, _, d, h, wd = self.x.shape
+        return torch.empty((N, self.cout8, d, h, wd), dtype=torch.float32, device="cuda")
+
     def fwd(self, ctx):
+        if self.direct:
+            ops.conv_k2s2_up(self.x.t, self.w.data, None if self.b is None else self.b.data, self.y.t)
+            return
         self.wp = ops.conv_pack_raw(self.w.data, self.cout8, self.cin, 1, 2, out=self.wp)
         ops.conv_fwd(self.x.t, self.wp, None, self.y8, self.cin, self.cout8, (1, 1, 1))
         ops.space_to_depth2(self.y8, self.y.t, self.y.shape, False, bias=None if self.b is None else self.b.data)
@@ -394,7 +427,7 @@ class UpConvOp:
     def bwd(self, ctx):
         from . import tops
         if self.dy8 is None:
-            self.dy8 = torch.empty_like(self.y8)
+            self.dy8 = self._new_y8()
             self.dw8 = torch.empty((self.cout8, self.cin), dtype=torch.float32, device="cuda")
         if self.bias_grad and self.b is not None:
             ops.channel_sum(self.y.grad(), self.b.grad)
@@ -402,6 +435,10 @@ class UpConvOp:
         ops.conv_wgrad(self.x.t, self.dy8, self.dw8, (1, 1, 1))                  # [8Cout][Cin]
         tops.transpose(self.dw8, self.w.grad.view(self.cin, self.cout8))         # parameter is [Cin][8Cout]
         assert not self.x.written
+        if self.direct_dx:       # dX = Conv3d(k2s2)(dy) with the parameter read as [M = Cin][K = 8 Cout]
+            ops.conv_k2s2_down(self.y.grad(), self.w.data, None, self.x.grad())
+            self.x.mark_written()
+            return
         self.wpd = ops.conv_pack_raw(self.w.data, self.cout8, self.cin, 1, 3, out=self.wpd)
         ops.conv_fwd(self.dy8, self.wpd, None, self.x.grad(), self.cout8, self.cin, (1, 1, 1))
         self.x.mark_written()

@@ -368,6 +368,19 @@ int mis_step_advance(MisStepState* state, double base_lr, double max_iterations,
 int mis_argmax_channels(const float* x, long long x_bs, unsigned char* out, int B, int C, long long S,
                         mis_stream_t stream);
 
+/* Conv3d(k = 2, stride = 2) and ConvTranspose3d(k = 2, stride = 2) of V-Net (reference code/networks/vnet.py:73, :100)
+ * read / written in place on the fine volume -- no space_to_depth re-layout -- for the channel pairs
+ * mis_conv_k2s2_eligible names (V-Net's two largest levels); forward and data gradient:
+ *   mis_conv_k2s2_down: y[N][Cout][Do][Ho][Wo] (+)= bias + sum w[co][ci*8 + tap] x[ci][2v + tap]      x fine, w [Cout][Cin*8]
+ *                       (= dX of ConvTranspose3d with w = its parameter [Cin_t][Cout_t*8], Cout = Cin_t, Cin = Cout_t)
+ *   mis_conv_k2s2_up:   y[N][Cout][2Do][2Ho][2Wo] (+)= bias + sum w[ci][co*8 + tap] x[ci][v]          x coarse, w [Cin][Cout*8]
+ *                       (= dX of Conv3d(k2s2) with w = its parameter [Cout_c][Cin_c*8], Cin = Cout_c, Cout = Cin_c)
+ * Do x Ho x Wo is always the COARSE geometry; tap = dz*4 + dy*2 + dx; bias may be NULL; accumulate != 0 adds to y. */
+int mis_conv_k2s2_eligible(int Cin, int Cout, int Do, int Ho, int Wo, int up);
+int mis_conv_k2s2_down(const float* x, long long x_bs, const float* w, const float* bias, float* y, long long y_bs, int N,
+                       int Cin, int Cout, int Do, int Ho, int Wo, int accumulate, mis_stream_t stream);
+int mis_conv_k2s2_up(const float* x, long long x_bs, const float* w, const float* bias, float* y, long long y_bs, int N,
+                     int Cin, int Cout, int Do, int Ho, int Wo, int accumulate, mis_stream_t stream);
 /* ---- V-Net data movement (code/networks/vnet.py) -------------------------------------------------------
  * A kernel-2/stride-2 Conv3d (:73) is space_to_depth + the 1x1x1 MFMA conv with the weight viewed as
  * [Cout][8*Cin]; ConvTranspose3d k2 s2 (:100) is the 1x1x1 conv to 8*Cout channels (weight stored input-major,

@@ -64,7 +64,52 @@ def test_add_copy_and_strided():
     assert torch.equal(out, a + a)
 
 
-@pytest.mark.parametrize("N,Cin,Cout,d", [(2, 16, 32, 8), (1, 32, 64, 4), (2, 128, 256, 2), (1, 20, 24, 6)])
+@pytest.mark.parametrize("N,Cin,Cout,dims", [(2, 16, 32, (4, 16, 16)), (1, 32, 64, (3, 18, 18)), (2, 16, 32, (2, 20, 14))])
+def test_k2s2_in_place_kernels(N, Cin, Cout, dims):
+    """conv_k2s2.hip through the C-ABI: Conv3d(k2s2) forward on the fine volume and its data gradient (= the transposed
+    convolution) against torch, channel-slice views, ragged 16-voxel tiles (18 x 18, 20 x 14 planes), accumulate."""
+    from mis_hip import ops
+    Do, Ho, Wo = dims
+    assert ops.conv_k2s2_eligible(Cin, Cout, dims, False) and ops.conv_k2s2_eligible(Cout, Cin, dims, True)
+    wide = _rand(N, Cin + 4, 2 * Do, 2 * Ho, 2 * Wo, seed=21)
+    x = wide[:, 4:].clone().requires_grad_(True)
+    w = _rand(Cout, Cin, 2, 2, 2, seed=22, scale=0.2)
+    b = _rand(Cout, seed=23)
+    y_ref = F.conv3d(x, w, b, stride=2)
+    dy = _rand(*y_ref.shape, seed=24)
+    y_ref.backward(dy)
+    wd_, xd = wide.cuda(), None
+    xd = wd_[:, 4:]
+    y = torch.full(tuple(y_ref.shape), float("nan"), device="cuda")
+    ops.conv_k2s2_down(xd, w.cuda().contiguous(), b.cuda(), y)
+    _close(y, y_ref)
+    y2 = y.clone()
+    ops.conv_k2s2_down(xd, w.cuda().contiguous(), None, y2, accumulate=True)
+    _close(y2, 2 * y_ref - b.view(1, -1, 1, 1, 1))
+    dwide = torch.full(tuple(wide.shape), float("nan"), device="cuda")
+    dx = dwide[:, 4:]
+    ops.conv_k2s2_up(dy.cuda(), w.cuda().contiguous(), None, dx)
+    _close(dx, x.grad)
+    assert torch.isnan(dwide[:, :4]).all()
+    ops.conv_k2s2_up(dy.cuda(), w.cuda().contiguous(), None, dx, accumulate=True)
+    _close(dx, 2 * x.grad)
+    # the same pair as ConvTranspose3d forward (+ bias) and its data gradient
+    wt = _rand(Cout, Cin, 2, 2, 2, seed=25, scale=0.2)          # ConvTranspose3d(Cout -> Cin) parameter [in][out][2][2][2]
+    bt = _rand(Cin, seed=26)
+    xc = _rand(N, Cout, Do, Ho, Wo, seed=27).requires_grad_(True)
+    yt_ref = F.conv_transpose3d(xc, wt, bt, stride=2)
+    g = _rand(*yt_ref.shape, seed=28)
+    yt_ref.backward(g)
+    yt = torch.full(tuple(yt_ref.shape), float("nan"), device="cuda")
+    ops.conv_k2s2_up(xc.detach().cuda(), wt.cuda().contiguous(), bt.cuda(), yt)
+    _close(yt, yt_ref)
+    dxc = torch.full(tuple(xc.shape), float("nan"), device="cuda")
+    ops.conv_k2s2_down(g.cuda(), wt.cuda().contiguous(), None, dxc)
+    _close(dxc, xc.grad)
+
+
+@pytest.mark.parametrize("N,Cin,Cout,d", [(2, 16, 32, 8), (1, 32, 64, 4), (2, 128, 256, 2), (1, 20, 24, 6), (2, 16, 32, 16),
+                                          (1, 32, 64, 18)])
 def test_down_conv_op(N, Cin, Cout, d):
     from mis_hip.plan import DownConvOp
     x = _rand(N, Cin, 2 * d, 2 * d, 2 * d, seed=5).requires_grad_(True)
@@ -76,6 +121,7 @@ def test_down_conv_op(N, Cin, Cout, d):
     xa, ya = _act(x.detach()), _act(torch.empty_like(y_ref))
     wp, bp = _pref(w.detach()), _pref(b)
     op = DownConvOp(xa, ya, wp, bp)
+    assert op.direct == op.direct_dx == (d >= 16)          # the in-place kernels serve V-Net's two largest levels
     op.fwd(_ctx())
     _close(ya.t, y_ref)
     ya.g = dy.cuda()
@@ -87,7 +133,8 @@ def test_down_conv_op(N, Cin, Cout, d):
     _close(xa.grad(), 2 * x.grad)
 
 
-@pytest.mark.parametrize("N,Cin,Cout,d", [(2, 32, 16, 8), (1, 64, 32, 4), (2, 256, 128, 2), (1, 24, 20, 6)])
+@pytest.mark.parametrize("N,Cin,Cout,d", [(2, 32, 16, 8), (1, 64, 32, 4), (2, 256, 128, 2), (1, 24, 20, 6), (2, 32, 16, 16),
+                                          (1, 64, 32, 18)])
 def test_up_conv_op(N, Cin, Cout, d):
     from mis_hip.plan import UpConvOp
     x = _rand(N, Cin, d, d, d, seed=9).requires_grad_(True)
@@ -99,6 +146,7 @@ def test_up_conv_op(N, Cin, Cout, d):
     xa, ya = _act(x.detach()), _act(torch.empty_like(y_ref))
     wp, bp = _pref(w.detach()), _pref(b)
     op = UpConvOp(xa, ya, wp, bp)
+    assert op.direct == op.direct_dx == (d >= 16)
     op.fwd(_ctx())
     _close(ya.t, y_ref)
     ya.g = dy.cuda()
