@@ -50,9 +50,11 @@ Geo make_geo(int N, int C, long long S, long long x_bs, int per_sample, int cg =
 
 // residual branch of y = act(norm(x) + r) (MONAI UnetResBlock: conv-IN (+ shortcut) -> LeakyReLU): r read on the load path
 // of all three passes, its gradient dr (+)= dz written by the backward apply
+// post != 0: y = act(norm(x)) + r instead (V-Net's x_up + skip, vnet.py:210-222): the activation's sign does not involve r
 struct ResArgs {
     const float* r; long long r_bs;
     float* dr; long long dr_bs; int dr_acc;
+    int post;
 };
 
 struct DropCfg {
@@ -250,12 +252,16 @@ __global__ __launch_bounds__(256) void apply_fwd_kernel(const float* __restrict_
         if (u >= units) break;
         const float4 q = *reinterpret_cast<const float4*>(xb + u * 4);
         float v[4] = {q.x * sc + sh, q.y * sc + sh, q.z * sc + sh, q.w * sc + sh};
+        float4 rq = make_float4(0.f, 0.f, 0.f, 0.f);
         if constexpr (RES) {
-            const float4 rq = *reinterpret_cast<const float4*>(ra.r + (long long)n * ra.r_bs + (long long)c * g.S + u * 4);
-            v[0] += rq.x; v[1] += rq.y; v[2] += rq.z; v[3] += rq.w;
+            rq = *reinterpret_cast<const float4*>(ra.r + (long long)n * ra.r_bs + (long long)c * g.S + u * 4);
+            if (!ra.post) { v[0] += rq.x; v[1] += rq.y; v[2] += rq.z; v[3] += rq.w; }
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] = v[j] > 0.f ? v[j] : v[j] * slope;
+        if constexpr (RES) {
+            if (ra.post) { v[0] += rq.x; v[1] += rq.y; v[2] += rq.z; v[3] += rq.w; }
+        }
         if (drop) {
             float s[4];
             drop_scale4(d, lbase + u * 4, (unsigned)(n * g.C + c), s);
@@ -532,15 +538,17 @@ __global__ __launch_bounds__(256) void apply_bwd_kernel(const float* __restrict_
         }
         float o[4], rv[4] = {0.f, 0.f, 0.f, 0.f}, dzs[4];
         if constexpr (RES) {
-            const float4 rq = *reinterpret_cast<const float4*>(ra.r + (long long)n * ra.r_bs + (long long)c * g.S + u * 4);
-            rv[0] = rq.x; rv[1] = rq.y; rv[2] = rq.z; rv[3] = rq.w;
+            if (!ra.post) {
+                const float4 rq = *reinterpret_cast<const float4*>(ra.r + (long long)n * ra.r_bs + (long long)c * g.S + u * 4);
+                rv[0] = rq.x; rv[1] = rq.y; rv[2] = rq.z; rv[3] = rq.w;
+            }
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const float xh = (xs[j] - m) * rs;
             const float z = xh * ga + be + rv[j];
             const float dz = z > 0.f ? gs[j] : gs[j] * slope;
-            dzs[j] = dz;
+            dzs[j] = (RES && ra.post) ? gs[j] : dz;
             o[j] = kind == 1 ? rs * (ga * dz - sm.x - xh * sm.y) : k * (dz - sm.x - xh * sm.y);
         }
         *reinterpret_cast<float4*>(ob + u * 4) = make_float4(o[0], o[1], o[2], o[3]);
@@ -865,7 +873,7 @@ int norm_act_bwd_impl(const float* x, long long x_bs, const float* da, long long
         if (cg > 1)
             hipLaunchKernelGGL(bwd_partial_kernel<true>, dim3(g.P, g.nchunks, g.G), dim3(256), 0, stream, x, g, da, da_bs,
                                mean, rstd, gamma, beta, slope, d, part, pg, ResArgs{});
-        else if (ra.r)
+        else if (ra.r && !ra.post)
             hipLaunchKernelGGL((bwd_partial_kernel<false, true>), dim3(g.P, g.nchunks, g.G), dim3(256), 0, stream, x, g, da,
                                da_bs, mean, rstd, gamma, beta, slope, d, part, pg, ra);
         else
@@ -982,11 +990,11 @@ extern "C" int mis_norm_act_bwd_tiles(const float* x, long long x_bs, const floa
 
 // y = act(norm(x) + res): the tail of MONAI's UnetResBlock (UNETR / SwinUNETR: conv - IN - lrelu - conv - IN, + shortcut,
 // lrelu; reference code/networks/unetr.py's UnetrBasicBlock(res_block=True) / net_factory_3d.py:37-38) in one pass
-// instead of normalise, add, activate.  BatchNorm / InstanceNorm with optional affine; no dropout, no GroupNorm; S % 4 == 0.
+// instead of normalise, add, activate.  add_after_act != 0: y = act(norm(x)) + res -- V-Net's x_up + skip (vnet.py:210-222).  BatchNorm / InstanceNorm with optional affine; no dropout, no GroupNorm; S % 4 == 0.
 extern "C" int mis_norm_res_act_fwd(const float* x, long long x_bs, const float* res, long long res_bs, float* y,
                                     long long y_bs, int N, int C, long long S, int per_sample, const float* mean,
                                     const float* rstd, const float* gamma, const float* beta, float slope,
-                                    hipStream_t stream) {
+                                    int add_after_act, hipStream_t stream) {
     int st = check_geo(x, N, C, S, x_bs);
     if (st) return st;
     if (!res || !y || !mean || !rstd || y_bs < (long long)C * S || res_bs < (long long)C * S) return MIS_ERR_ARG;
@@ -995,7 +1003,7 @@ extern "C" int mis_norm_res_act_fwd(const float* x, long long x_bs, const float*
     const DropCfg d{0.f, 0u, nullptr, nullptr};
     const unsigned gx = (unsigned)mis_cdiv(S >> 2, 256 * APPLY_U);
     hipLaunchKernelGGL(apply_fwd_kernel<true>, dim3(gx, C, N), dim3(256), 0, stream, x, g, mean, rstd, gamma, beta, slope,
-                       d, y, y_bs, ResArgs{res, res_bs, nullptr, 0, 0});
+                       d, y, y_bs, ResArgs{res, res_bs, nullptr, 0, 0, add_after_act});
     return mis_launch_status();
 }
 
@@ -1006,15 +1014,15 @@ extern "C" int mis_norm_res_act_bwd(const float* x, long long x_bs, const float*
                                     long long dy_bs, float* dx, long long dx_bs, float* dres, long long dres_bs,
                                     int accumulate_dres, int N, int C, long long S, int per_sample, const float* mean,
                                     const float* rstd, const float* gamma, const float* beta, float slope,
-                                    float* dgamma, float* dbeta, int accumulate_affine, void* workspace,
-                                    long long workspace_bytes, hipStream_t stream) {
+                                    float* dgamma, float* dbeta, int accumulate_affine, int add_after_act,
+                                    void* workspace, long long workspace_bytes, hipStream_t stream) {
     if (!dy || !res || !dres || S % 4 != 0) return !dy || !res || !dres ? MIS_ERR_ARG : MIS_ERR_UNSUPPORTED;
     if (res_bs % 4 != 0 || !aligned16(res) || dres_bs % 4 != 0 || !aligned16(dres)) return MIS_ERR_UNSUPPORTED;
     if (res_bs < (long long)C * S || dres_bs < (long long)C * S) return MIS_ERR_ARG;
     if (per_sample && (gamma || beta)) return MIS_ERR_UNSUPPORTED;
     return norm_act_bwd_impl(x, x_bs, dy, dy_bs, dx, dx_bs, N, C, S, per_sample, 1, 0, mean, rstd, gamma, beta, slope, 0.f,
                              0u, nullptr, nullptr, dgamma, dbeta, accumulate_affine, workspace, workspace_bytes, PoolGrad{},
-                             stream, ResArgs{res, res_bs, dres, dres_bs, accumulate_dres});
+                             stream, ResArgs{res, res_bs, dres, dres_bs, accumulate_dres, add_after_act});
 }
 
 extern "C" int mis_norm_act_bwd(const float* x, long long x_bs, const float* da, long long da_bs, float* dx,

@@ -52,9 +52,9 @@ PROTOTYPES = {
     "mis_conv3d_wino_fwd": (c_i, [c_p, c_ll, c_p, c_p, c_p, c_ll, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_ll, c_ll, c_i, c_p]),
     "mis_conv3d_wino_dgrad_norm": (c_i, [c_p, c_ll, c_p, c_p, c_ll, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_ll, c_p, c_f, c_p,
                                          c_ll, c_ll, c_i, c_p]),
-    "mis_norm_res_act_fwd": (c_i, [c_p, c_ll, c_p, c_ll, c_p, c_ll, c_i, c_i, c_ll, c_i, c_p, c_p, c_p, c_p, c_f, c_p]),
+    "mis_norm_res_act_fwd": (c_i, [c_p, c_ll, c_p, c_ll, c_p, c_ll, c_i, c_i, c_ll, c_i, c_p, c_p, c_p, c_p, c_f, c_i, c_p]),
     "mis_norm_res_act_bwd": (c_i, [c_p, c_ll, c_p, c_ll, c_p, c_ll, c_p, c_ll, c_p, c_ll, c_i, c_i, c_i, c_ll, c_i, c_p, c_p,
-                                   c_p, c_p, c_f, c_p, c_p, c_i, c_p, c_ll, c_p]),
+                                   c_p, c_p, c_f, c_p, c_p, c_i, c_i, c_p, c_ll, c_p]),
     "mis_norm_act_bwd_tiles": (c_i, [c_p, c_ll, c_p, c_ll, c_p, c_ll, c_i, c_i, c_ll, c_p, c_p, c_f, c_p, c_i, c_p, c_p]),
     "mis_conv2d_wino_select": (c_i, [c_i, c_i, c_i, c_i, c_i]),
     "mis_conv2d_wino_stat_tiles": (c_ll, [c_i, c_i, c_i]),

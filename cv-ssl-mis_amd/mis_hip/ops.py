@@ -377,18 +377,18 @@ def norm_act_bwd(x, da, dx, per_sample, mean, rstd, gamma, beta, slope, drop_p=0
              "mis_norm_act_bwd_g")
 
 
-def norm_res_act_fwd(x, res, y, per_sample, mean, rstd, gamma, beta, slope):
-    """y = act(norm(x) + res) in one pass (mis_norm_res_act_fwd)."""
+def norm_res_act_fwd(x, res, y, per_sample, mean, rstd, gamma, beta, slope, post=False):
+    """y = act(norm(x) + res) in one pass (mis_norm_res_act_fwd); ``post``: y = act(norm(x)) + res."""
     L = _l.load()
     N, C, D, H, W, S, xbs = _geom(x)
     rbs, ybs = _geom(res)[6], _geom(y)[6]
     _l.check(L.mis_norm_res_act_fwd(_l.ptr(x), xbs, _l.ptr(res), rbs, _l.ptr(y), ybs, N, C, S, int(per_sample),
-                                    _l.ptr(mean), _l.ptr(rstd), _l.ptr(gamma), _l.ptr(beta), slope, _l.stream_ptr()),
-             "mis_norm_res_act_fwd")
+                                    _l.ptr(mean), _l.ptr(rstd), _l.ptr(gamma), _l.ptr(beta), slope, int(post),
+                                    _l.stream_ptr()), "mis_norm_res_act_fwd")
 
 
 def norm_res_act_bwd(x, res, dy, dx, dres, accumulate_dres, per_sample, mean, rstd, gamma, beta, slope, dgamma=None,
-                     dbeta=None, accumulate_affine=False):
+                     dbeta=None, accumulate_affine=False, post=False):
     """Backward of norm_res_act_fwd: dres (+)= dz, dx = norm backward of dz, dz = dy * act'(norm(x) + res)."""
     L = _l.load()
     N, C, D, H, W, S, xbs = _geom(x)
@@ -397,7 +397,7 @@ def norm_res_act_bwd(x, res, dy, dx, dres, accumulate_dres, per_sample, mean, rs
     _l.check(L.mis_norm_res_act_bwd(_l.ptr(x), xbs, _l.ptr(res), rbs, _l.ptr(dy), dybs, _l.ptr(dx), dxbs, _l.ptr(dres),
                                     drbs, int(accumulate_dres), N, C, S, int(per_sample), _l.ptr(mean), _l.ptr(rstd),
                                     _l.ptr(gamma), _l.ptr(beta), slope, _l.ptr(dgamma), _l.ptr(dbeta),
-                                    int(accumulate_affine), _l.ptr(ws), ws.numel(), _l.stream_ptr()),
+                                    int(accumulate_affine), int(post), _l.ptr(ws), ws.numel(), _l.stream_ptr()),
              "mis_norm_res_act_bwd")
 
 

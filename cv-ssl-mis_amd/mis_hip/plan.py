@@ -200,6 +200,7 @@ class NormActOp:
         self.ext_part = None     # [N*C*tiles, 2] partial sums of the backward written by the consuming conv's data-gradient
         self.ext_tiles, self.ext_ready, self.ext_sums = 0, False, None     # launch (Plan._fuse_dgrad_norm)
         self.res = None          # Act added to the normalised value in front of the activation (Plan.norm_res_act)
+        self.res_post = False    # True: added behind the activation instead (Plan.add's fusion of V-Net's x_up + skip)
         self.head = None         # 1x1x1 classifier ConvOp computed in this op's pass (Plan._fuse_head); head_w / head_b:
         self.head_w = self.head_b = None     # its parameters (their gradients are written by THIS op: dist.param_progress)
 
@@ -230,7 +231,7 @@ class NormActOp:
         if self.res is not None:
             ops.norm_res_act_fwd(self.x.t, self.res.t, self.y.t, self.per_sample, self.mean, self.rstd,
                                  None if self.gamma is None else self.gamma.data,
-                                 None if self.beta is None else self.beta.data, self.slope)
+                                 None if self.beta is None else self.beta.data, self.slope, post=self.res_post)
             return
         if self.pool is not None and self.pool.fwd_fused:
             pl = self.pool
@@ -260,7 +261,7 @@ class NormActOp:
                                  self.mean, self.rstd, None if self.gamma is None else self.gamma.data,
                                  None if self.beta is None else self.beta.data, self.slope,
                                  None if self.gamma is None else self.gamma.grad,
-                                 None if self.beta is None else self.beta.grad)
+                                 None if self.beta is None else self.beta.grad, post=self.res_post)
             r.mark_written()
             self.x.mark_written()
             return
@@ -541,7 +542,18 @@ class Plan:
         self.ops.append(UpConvOp(x, y, w, b, bias_grad))
         return y
 
-    def add(self, a, b, out):
+    def add(self, a, b, out, fuse=False):
+        """out = a + b.  ``fuse``: the caller guarantees that ``a`` -- the output of the norm/activation op just appended --
+        has no other reader; that op then writes act(norm(x)) + b itself (one pass, forward and backward) and ``a`` is returned."""
+        prev = self.ops[-1] if self.ops else None
+        if (fuse and NORM_RES and type(prev) is NormActOp and prev.y is a and a.parent is None and prev.res is None
+                and prev.pool is None and prev.sums is None and not prev.no_norm and prev.drop_p == 0.0 and prev.cg == 1
+                and not (prev.per_sample and (prev.gamma is not None or prev.beta is not None))
+                and self.can_norm_res_act(a)):
+            prev.res, prev.res_post = b, True        # the sum lands in ``a``; ``out`` is not needed
+            if out in self.acts:
+                self.acts.remove(out)
+            return a
         self.ops.append(AddOp(a, b, out))
         return out
 

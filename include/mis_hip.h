@@ -207,15 +207,18 @@ int mis_norm_act_bwd_tiles(const float* x, long long x_bs, const float* da, long
  * + shortcut, lrelu; reference code/networks/unetr.py UnetrBasicBlock(res_block=True), net_factory_3d.py:37-38) in one
  * pass over x and res instead of normalise / add / activate.  Backward: dz = dy * act'(.), dres (+)= dz, dx = the
  * normalisation's backward of dz (res is re-read on the load path of both passes).  BatchNorm (optional affine) or
- * InstanceNorm without affine; no dropout; S % 4 == 0.  Workspace: mis_norm_workspace_bytes. */
+ * InstanceNorm without affine; no dropout; S % 4 == 0.  Workspace: mis_norm_workspace_bytes.
+ * add_after_act != 0: y = act(norm(x)) + res instead -- V-Net's x_up + skip (code/networks/vnet.py:210-222); then
+ * dres (+)= dy and the activation's derivative does not involve res. */
 int mis_norm_res_act_fwd(const float* x, long long x_bs, const float* res, long long res_bs, float* y, long long y_bs,
                          int N, int C, long long S, int per_sample, const float* mean, const float* rstd,
-                         const float* gamma, const float* beta, float slope, mis_stream_t stream);
+                         const float* gamma, const float* beta, float slope, int add_after_act, mis_stream_t stream);
 int mis_norm_res_act_bwd(const float* x, long long x_bs, const float* res, long long res_bs, const float* dy,
                          long long dy_bs, float* dx, long long dx_bs, float* dres, long long dres_bs, int accumulate_dres,
                          int N, int C, long long S, int per_sample, const float* mean, const float* rstd,
                          const float* gamma, const float* beta, float slope, float* dgamma, float* dbeta,
-                         int accumulate_affine, void* workspace, long long workspace_bytes, mis_stream_t stream);
+                         int accumulate_affine, int add_after_act, void* workspace, long long workspace_bytes,
+                         mis_stream_t stream);
 int mis_conv_wgrad_cin1_norm_eligible(int N, int Cout, int D, int H, int W);
 int mis_conv_wgrad_cin1_norm(const float* x, long long x_bs, const float* da, long long da_bs, const float* y,
                              long long y_bs, int N, int D, int H, int W, int per_sample, const float* mean,

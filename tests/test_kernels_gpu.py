@@ -199,8 +199,9 @@ def test_norm_act_fwd_bwd(per_sample, slope, shape):
         _close(db, beta.grad, rtol=5e-4, atol=1e-4)
 
 
+@pytest.mark.parametrize("post", [False, True])
 @pytest.mark.parametrize("per_sample,shape", [(True, (2, 16, 8, 8, 8)), (True, (3, 8, 6, 6, 6)), (False, (4, 16, 1, 32, 32))])
-def test_norm_residual_act_fwd_bwd(per_sample, shape):
+def test_norm_residual_act_fwd_bwd(per_sample, shape, post):
     """mis_norm_res_act_{fwd,bwd}: lrelu(norm(x) + res) -- MONAI's UnetResBlock tail (UNETR / SwinUNETR) -- in one pass,
     against torch autograd; the shortcut is a channel slice of a wider buffer (batch-strided view) and its gradient is
     written or accumulated."""
@@ -213,7 +214,7 @@ def test_norm_residual_act_fwd_bwd(per_sample, shape):
     beta = (0.1 * _rand(C, seed=9)).requires_grad_(not per_sample)
     z = F.instance_norm(x, eps=1e-5) if per_sample else \
         F.batch_norm(x, torch.zeros(C), torch.ones(C), gamma, beta, training=True, momentum=0.1, eps=1e-5)
-    ref = F.leaky_relu(z + r, 0.01)
+    ref = F.leaky_relu(z, 0.01) + r if post else F.leaky_relu(z + r, 0.01)      # post: V-Net's x_up + skip
     dy = _rand(*shape, seed=19)
     ref.backward(dy)
 
@@ -225,21 +226,23 @@ def test_norm_residual_act_fwd_bwd(per_sample, shape):
     g = None if per_sample else gamma.detach().cuda()
     bt = None if per_sample else beta.detach().cuda()
     y = torch.full(shape, float("nan"), device="cuda")
-    ops.norm_res_act_fwd(xd, rd, y, per_sample, mean, rstd, g, bt, 0.01)
+    ops.norm_res_act_fwd(xd, rd, y, per_sample, mean, rstd, g, bt, 0.01, post=post)
     _close(y, ref)
     dx = torch.full(shape, float("nan"), device="cuda")
     dwide = torch.full(tuple(wide.shape), float("nan"), device="cuda")
     dr = dwide[:, 8:]
     dg = None if per_sample else torch.empty(C, device="cuda")
     db = None if per_sample else torch.empty(C, device="cuda")
-    ops.norm_res_act_bwd(xd, rd, dy.cuda(), dx, dr, False, per_sample, mean, rstd, g, bt, 0.01, dgamma=dg, dbeta=db)
+    ops.norm_res_act_bwd(xd, rd, dy.cuda(), dx, dr, False, per_sample, mean, rstd, g, bt, 0.01, dgamma=dg, dbeta=db,
+                         post=post)
     _close(dx, x.grad, rtol=5e-4, atol=1e-5)
     _close(dr, r.grad, rtol=1e-6, atol=1e-7)
     assert torch.isnan(dwide[:, :8]).all()          # nothing outside the slice is touched
     if not per_sample:
         _close(dg, gamma.grad, rtol=5e-4, atol=1e-4)
         _close(db, beta.grad, rtol=5e-4, atol=1e-4)
-    ops.norm_res_act_bwd(xd, rd, dy.cuda(), dx, dr, True, per_sample, mean, rstd, g, bt, 0.01, dgamma=dg, dbeta=db)
+    ops.norm_res_act_bwd(xd, rd, dy.cuda(), dx, dr, True, per_sample, mean, rstd, g, bt, 0.01, dgamma=dg, dbeta=db,
+                         post=post)
     _close(dr, 2 * r.grad, rtol=1e-6, atol=1e-7)
 
 
