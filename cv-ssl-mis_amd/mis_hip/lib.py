@@ -127,6 +127,9 @@ PROTOTYPES = {
     "mis_conv_k2s2_eligible": (c_i, [c_i, c_i, c_i, c_i, c_i, c_i]),
     "mis_conv_k2s2_down": (c_i, [c_p, c_ll, c_p, c_p, c_p, c_ll, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
     "mis_conv_k2s2_up": (c_i, [c_p, c_ll, c_p, c_p, c_p, c_ll, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
+    "mis_conv_k2s2_wgrad_eligible": (c_i, [c_i, c_i, c_i, c_i, c_i]),
+    "mis_conv_k2s2_wgrad_workspace_bytes": (c_ll, [c_i, c_i]),
+    "mis_conv_k2s2_wgrad": (c_i, [c_p, c_ll, c_p, c_ll, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_ll, c_p]),
     "mis_space_to_depth2": (c_i, [c_p, c_ll, c_p, c_ll, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
     "mis_add": (c_i, [c_p, c_ll, c_p, c_ll, c_p, c_ll, c_i, c_i, c_ll, c_p]),
     # token-major (SwinUnet) kernels

@@ -120,6 +120,22 @@ def conv_k2s2_eligible(cin, cout, coarse, up):
     return K2S2 and bool(_l.load().mis_conv_k2s2_eligible(int(cin), int(cout), *[int(v) for v in coarse], int(up)))
 
 
+def conv_k2s2_wgrad_eligible(cf, cc, coarse):
+    return K2S2 and bool(_l.load().mis_conv_k2s2_wgrad_eligible(int(cf), int(cc), *[int(v) for v in coarse]))
+
+
+def conv_k2s2_wgrad(coarse, fine, dw, accumulate=False):
+    """dw[cc][cf*8 + tap] (+)= sum coarse[n][cc][v] * fine[n][cf][2v + tap] (mis_conv_k2s2_wgrad): the parameter gradient of
+    Conv3d(k2s2) (coarse = dy, fine = x) and of ConvTranspose3d(k2s2) (coarse = x, fine = dy), in the parameter's layout."""
+    L = _l.load()
+    N, CC, Do, Ho, Wo, _, cbs = _geom(coarse)
+    _, CF, _, _, _, _, fbs = _geom(fine)
+    assert dw.is_contiguous() and dw.numel() == CC * CF * 8
+    ws = scratch(L.mis_conv_k2s2_wgrad_workspace_bytes(CF, CC), "wgrad")
+    _l.check(L.mis_conv_k2s2_wgrad(_l.ptr(coarse), cbs, _l.ptr(fine), fbs, _l.ptr(dw), N, CF, CC, Do, Ho, Wo,
+                                   int(accumulate), _l.ptr(ws), ws.numel(), _l.stream_ptr()), "mis_conv_k2s2_wgrad")
+
+
 def conv_k2s2_down(x, w, bias, y, accumulate=False):
     """y (coarse) (+)= bias + sum w[co][ci*8 + tap] x[ci][2v + tap]: Conv3d(k2s2) forward / ConvTranspose3d(k2s2) dX."""
     L = _l.load()

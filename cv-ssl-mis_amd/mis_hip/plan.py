@@ -354,6 +354,7 @@ class DownConvOp:
         coarse = (D // 2, H // 2, W // 2)
         self.direct = ops.conv_k2s2_eligible(Cin, self.cout, coarse, False)
         self.direct_dx = ops.conv_k2s2_eligible(self.cout, Cin, coarse, True)
+        self.direct_wg = ops.conv_k2s2_wgrad_eligible(Cin, self.cout, coarse)
         self._xs = None if self.direct else self._new_xs()
         self._xs_valid = False
         self.dxs = None
@@ -375,11 +376,14 @@ class DownConvOp:
 
     def bwd(self, ctx):
         dy = self.y.grad()
-        if not self._xs_valid:
-            if self._xs is None:
-                self._xs = self._new_xs()
-            ops.space_to_depth2(self.x.t, self._xs, self.in_shape, True)
-        ops.conv_wgrad(self._xs, dy, self.w.grad, (1, 1, 1))      # [Cout][8Cin] == [Cout][Cin][2][2][2] in memory
+        if self.direct_wg and self.x.t.data_ptr() % 16 == 0 and dy.data_ptr() % 16 == 0:
+            ops.conv_k2s2_wgrad(dy, self.x.t, self.w.grad.view(-1))
+        else:
+            if not self._xs_valid:
+                if self._xs is None:
+                    self._xs = self._new_xs()
+                ops.space_to_depth2(self.x.t, self._xs, self.in_shape, True)
+            ops.conv_wgrad(self._xs, dy, self.w.grad, (1, 1, 1))      # [Cout][8Cin] == [Cout][Cin][2][2][2] in memory
         # bias gradient exactly 0 when the conv feeds a normalisation (see ConvOp)
         if self.bias_grad:
             ops.channel_sum(dy, self.b.grad)
@@ -408,6 +412,7 @@ class UpConvOp:
         self.cin, self.cout8 = Cin, 8 * w.data.shape[1]
         self.direct = ops.conv_k2s2_eligible(Cin, w.data.shape[1], (d, h, wd), True)
         self.direct_dx = ops.conv_k2s2_eligible(w.data.shape[1], Cin, (d, h, wd), False)
+        self.direct_wg = ops.conv_k2s2_wgrad_eligible(w.data.shape[1], Cin, (d, h, wd))
         self.y8 = None if self.direct else self._new_y8()
         self.dy8 = None
         self.dw8 = None
@@ -427,14 +432,18 @@ class UpConvOp:
 
     def bwd(self, ctx):
         from . import tops
-        if self.dy8 is None:
-            self.dy8 = self._new_y8()
-            self.dw8 = torch.empty((self.cout8, self.cin), dtype=torch.float32, device="cuda")
         if self.bias_grad and self.b is not None:
             ops.channel_sum(self.y.grad(), self.b.grad)
-        ops.space_to_depth2(self.y.grad(), self.dy8, self.y.shape, True)
-        ops.conv_wgrad(self.x.t, self.dy8, self.dw8, (1, 1, 1))                  # [8Cout][Cin]
-        tops.transpose(self.dw8, self.w.grad.view(self.cin, self.cout8))         # parameter is [Cin][8Cout]
+        dyf = self.y.grad()
+        if self.direct_wg and self.direct_dx and self.x.t.data_ptr() % 16 == 0 and dyf.data_ptr() % 16 == 0:
+            ops.conv_k2s2_wgrad(self.x.t, dyf, self.w.grad.view(-1))             # the parameter's own [Cin][8Cout] layout
+        else:
+            if self.dy8 is None:
+                self.dy8 = self._new_y8()
+                self.dw8 = torch.empty((self.cout8, self.cin), dtype=torch.float32, device="cuda")
+            ops.space_to_depth2(dyf, self.dy8, self.y.shape, True)
+            ops.conv_wgrad(self.x.t, self.dy8, self.dw8, (1, 1, 1))                  # [8Cout][Cin]
+            tops.transpose(self.dw8, self.w.grad.view(self.cin, self.cout8))         # parameter is [Cin][8Cout]
         assert not self.x.written
         if self.direct_dx:       # dX = Conv3d(k2s2)(dy) with the parameter read as [M = Cin][K = 8 Cout]
             ops.conv_k2s2_down(self.y.grad(), self.w.data, None, self.x.grad())

@@ -384,6 +384,16 @@ int mis_conv_k2s2_down(const float* x, long long x_bs, const float* w, const flo
                        int Cin, int Cout, int Do, int Ho, int Wo, int accumulate, mis_stream_t stream);
 int mis_conv_k2s2_up(const float* x, long long x_bs, const float* w, const float* bias, float* y, long long y_bs, int N,
                      int Cin, int Cout, int Do, int Ho, int Wo, int accumulate, mis_stream_t stream);
+/* ... and their weight gradient from the tensors as they lie (no space_to_depth view, no transpose of the result):
+ *   dw[cc][cf*8 + tap] (+)= sum_{n, v} coarse[n][cc][v] * fine[n][cf][2v + tap]
+ * Conv3d(k2s2): coarse = dy (CC = Cout), fine = x (CF = Cin); ConvTranspose3d(k2s2): coarse = x (CC = Cin), fine = dy
+ * (CF = Cout) -- dw is the parameter's own layout in both cases.  Deterministic (one partial per workgroup, summed in
+ * order).  workspace >= mis_conv_k2s2_wgrad_workspace_bytes(CF, CC). */
+int mis_conv_k2s2_wgrad_eligible(int CF, int CC, int Do, int Ho, int Wo);
+long long mis_conv_k2s2_wgrad_workspace_bytes(int CF, int CC);
+int mis_conv_k2s2_wgrad(const float* coarse, long long c_bs, const float* fine, long long f_bs, float* dw, int N, int CF,
+                        int CC, int Do, int Ho, int Wo, int accumulate, float* workspace, long long workspace_bytes,
+                        mis_stream_t stream);
 /* ---- V-Net data movement (code/networks/vnet.py) -------------------------------------------------------
  * A kernel-2/stride-2 Conv3d (:73) is space_to_depth + the 1x1x1 MFMA conv with the weight viewed as
  * [Cout][8*Cin]; ConvTranspose3d k2 s2 (:100) is the 1x1x1 conv to 8*Cout channels (weight stored input-major,

@@ -108,8 +108,43 @@ def test_k2s2_in_place_kernels(N, Cin, Cout, dims):
     _close(dxc, xc.grad)
 
 
+@pytest.mark.parametrize("N,CF,CC,dims", [(2, 16, 32, (4, 16, 16)), (1, 32, 64, (3, 18, 24)), (3, 16, 32, (2, 20, 16))])
+def test_k2s2_weight_gradient_in_place(N, CF, CC, dims):
+    """mis_conv_k2s2_wgrad against torch for both parameter layouts (Conv3d: coarse = dy; ConvTranspose3d: coarse = x),
+    ragged 16-voxel tiles, channel-slice views, accumulate, run-to-run identical."""
+    from mis_hip import ops
+    Do, Ho, Wo = dims
+    assert ops.conv_k2s2_wgrad_eligible(CF, CC, dims)
+    x = _rand(N, CF, 2 * Do, 2 * Ho, 2 * Wo, seed=31)
+    w = _rand(CC, CF, 2, 2, 2, seed=32, scale=0.2).requires_grad_(True)
+    y = F.conv3d(x, w, None, stride=2)
+    dy = _rand(*y.shape, seed=33)
+    y.backward(dy)
+    wide = torch.zeros(N, CF + 4, 2 * Do, 2 * Ho, 2 * Wo)
+    wide[:, 4:] = x
+    xd = wide.cuda()[:, 4:]
+    dw = torch.full((CC, CF * 8), float("nan"), device="cuda")
+    ops.conv_k2s2_wgrad(dy.cuda(), xd, dw.view(-1))
+    _close(dw.view_as(w), w.grad, rtol=3e-4, atol=1e-4)
+    dw2 = dw.clone()
+    ops.conv_k2s2_wgrad(dy.cuda(), xd, dw2.view(-1), accumulate=True)
+    _close(dw2.view_as(w), 2 * w.grad, rtol=3e-4, atol=1e-4)
+    dw3 = torch.empty_like(dw)
+    ops.conv_k2s2_wgrad(dy.cuda(), xd, dw3.view(-1))
+    assert torch.equal(dw, dw3)
+    # ConvTranspose3d(CC -> CF): coarse = its input, fine = the gradient of its output, dw in its [CC][CF][2][2][2] layout
+    wt = _rand(CC, CF, 2, 2, 2, seed=34, scale=0.2).requires_grad_(True)
+    xc = _rand(N, CC, Do, Ho, Wo, seed=35)
+    yt = F.conv_transpose3d(xc, wt, None, stride=2)
+    g = _rand(*yt.shape, seed=36)
+    yt.backward(g)
+    dwt = torch.full((CC, CF * 8), float("nan"), device="cuda")
+    ops.conv_k2s2_wgrad(xc.cuda(), g.cuda(), dwt.view(-1))
+    _close(dwt.view_as(wt), wt.grad, rtol=3e-4, atol=1e-4)
+
+
 @pytest.mark.parametrize("N,Cin,Cout,d", [(2, 16, 32, 8), (1, 32, 64, 4), (2, 128, 256, 2), (1, 20, 24, 6), (2, 16, 32, 16),
-                                          (1, 32, 64, 18)])
+                                          (1, 32, 64, 18), (1, 32, 64, 24)])
 def test_down_conv_op(N, Cin, Cout, d):
     from mis_hip.plan import DownConvOp
     x = _rand(N, Cin, 2 * d, 2 * d, 2 * d, seed=5).requires_grad_(True)
@@ -122,6 +157,7 @@ def test_down_conv_op(N, Cin, Cout, d):
     wp, bp = _pref(w.detach()), _pref(b)
     op = DownConvOp(xa, ya, wp, bp)
     assert op.direct == op.direct_dx == (d >= 16)          # the in-place kernels serve V-Net's two largest levels
+    assert op.direct_wg == (d >= 16 and d % 8 == 0)
     op.fwd(_ctx())
     _close(ya.t, y_ref)
     ya.g = dy.cuda()
@@ -134,7 +170,7 @@ def test_down_conv_op(N, Cin, Cout, d):
 
 
 @pytest.mark.parametrize("N,Cin,Cout,d", [(2, 32, 16, 8), (1, 64, 32, 4), (2, 256, 128, 2), (1, 24, 20, 6), (2, 32, 16, 16),
-                                          (1, 64, 32, 18)])
+                                          (1, 64, 32, 18), (1, 64, 32, 24)])
 def test_up_conv_op(N, Cin, Cout, d):
     from mis_hip.plan import UpConvOp
     x = _rand(N, Cin, d, d, d, seed=9).requires_grad_(True)
@@ -147,6 +183,7 @@ def test_up_conv_op(N, Cin, Cout, d):
     wp, bp = _pref(w.detach()), _pref(b)
     op = UpConvOp(xa, ya, wp, bp)
     assert op.direct == op.direct_dx == (d >= 16)
+    assert op.direct_wg == (d >= 16 and d % 8 == 0)
     op.fwd(_ctx())
     _close(ya.t, y_ref)
     ya.g = dy.cuda()
