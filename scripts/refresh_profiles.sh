@@ -13,7 +13,7 @@ out=gpurun_out/$tag
 mkdir -p "$out"
 export TMPDIR=/tmp
 python bench.py > "$out/bench_default.json" 2> "$out/bench_default.err"
-for w in unet2d vnet uamt3d swin cross cross224 cnnvit unetr; do
+for w in unet2d vnet uamt3d swin cross cross224 cnnvit unetr swinunetr; do
     python bench.py --workload $w --no-cpu-baseline > "$out/bench_$w.json" 2> "$out/bench_$w.err"
 done
 python bench.py --serial --no-cpu-baseline --no-others > "$out/bench_unet3d_serial.json" 2> "$out/bench_unet3d_serial.err"
