@@ -147,6 +147,40 @@ __device__ __forceinline__ float dot16(const float (&a)[HD], const float* __rest
     }
     return s;
 }
+// packed fp32 (v_pk_fma_f32: two lanes of arithmetic per instruction -- these kernels are vector-ALU bound)
+typedef float f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void load16p(const float* __restrict__ p, f2 (&v)[HD / 2]) {
+#pragma unroll
+    for (int i = 0; i < HD / 4; ++i) {
+        const float4 q = reinterpret_cast<const float4*>(p)[i];
+        v[2 * i] = f2{q.x, q.y}; v[2 * i + 1] = f2{q.z, q.w};
+    }
+}
+__device__ __forceinline__ float dot16p(const f2 (&a)[HD / 2], const float* __restrict__ b) {
+    f2 s = {0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < HD / 4; ++i) {
+        const float4 q = reinterpret_cast<const float4*>(b)[i];
+        s = a[2 * i] * f2{q.x, q.y} + s;
+        s = a[2 * i + 1] * f2{q.z, q.w} + s;
+    }
+    return s.x + s.y;
+}
+// acc += e * b[0..15]
+__device__ __forceinline__ void axpy16p(f2 (&acc)[HD / 2], float e, const float* __restrict__ b) {
+    const f2 e2 = {e, e};
+#pragma unroll
+    for (int i = 0; i < HD / 4; ++i) {
+        const float4 q = reinterpret_cast<const float4*>(b)[i];
+        acc[2 * i] = e2 * f2{q.x, q.y} + acc[2 * i];
+        acc[2 * i + 1] = e2 * f2{q.z, q.w} + acc[2 * i + 1];
+    }
+}
+__device__ __forceinline__ void store16p(float* __restrict__ p, const f2 (&v)[HD / 2], float scale) {
+#pragma unroll
+    for (int i = 0; i < HD / 4; ++i)
+        reinterpret_cast<float4*>(p)[i] = make_float4(v[2 * i].x * scale, v[2 * i].y * scale, v[2 * i + 1].x * scale, v[2 * i + 1].y * scale);
+}
 // relative-position index of (query t, key j): the [:n, :n] block of the full 7^3 window's index matrix
 __device__ __forceinline__ int rel_index(int t, int j) {
     const int tz = t / 49, ty = (t / 7) % 7, tx = t % 7, jz = j / 49, jy = (j / 7) % 7, jx = j % 7;
@@ -178,37 +212,32 @@ __global__ __launch_bounds__(NT) void attn3d_fwd_kernel(const AttnArgs a) {
     __syncthreads();
     const int t = threadIdx.x;
     if (t >= n) return;
-    float q[HD];
-    load16(qb + (long long)t * a.ldq, q);
+    f2 q[HD / 2];
+    load16p(qb + (long long)t * a.ldq, q);
 #pragma unroll
-    for (int i = 0; i < HD; ++i) q[i] *= a.scale;
+    for (int i = 0; i < HD / 2; ++i) q[i] *= a.scale;
     const int rt = a.region ? sr[t] : 0;
-    float m = -INFINITY;
-    for (int j = 0; j < n; ++j) {
-        float s = dot16(q, sk + j * HD) + sb[rel_index(t, j)];
-        if (a.region && sr[j] != rt) s -= 100.f;
-        m = fmaxf(m, s);
-    }
-    float l = 0.f, acc[HD];
+    // one pass, running maximum: a new maximum rescales the sums (rare after the first keys; the branch is wave-divergent
+    // only then) -- the scores are formed once instead of twice
+    float m = -INFINITY, l = 0.f;
+    f2 acc[HD / 2];
 #pragma unroll
-    for (int i = 0; i < HD; ++i) acc[i] = 0.f;
+    for (int i = 0; i < HD / 2; ++i) acc[i] = f2{0.f, 0.f};
     for (int j = 0; j < n; ++j) {
-        float s = dot16(q, sk + j * HD) + sb[rel_index(t, j)];
+        float s = dot16p(q, sk + j * HD) + sb[rel_index(t, j)];
         if (a.region && sr[j] != rt) s -= 100.f;
+        if (s > m) {
+            const float c = __expf(m - s);
+            l *= c;
+#pragma unroll
+            for (int i = 0; i < HD / 2; ++i) acc[i] *= c;
+            m = s;
+        }
         const float e = __expf(s - m);
         l += e;
-#pragma unroll
-        for (int i = 0; i < HD / 4; ++i) {
-            const float4 v = reinterpret_cast<const float4*>(sv + j * HD)[i];
-            acc[4 * i] = fmaf(e, v.x, acc[4 * i]); acc[4 * i + 1] = fmaf(e, v.y, acc[4 * i + 1]);
-            acc[4 * i + 2] = fmaf(e, v.z, acc[4 * i + 2]); acc[4 * i + 3] = fmaf(e, v.w, acc[4 * i + 3]);
-        }
+        axpy16p(acc, e, sv + j * HD);
     }
-    const float inv = 1.f / l;
-    float* __restrict__ ob = a.out + ((long long)bw * n + t) * a.ldo + h * HD;
-#pragma unroll
-    for (int i = 0; i < HD / 4; ++i)
-        reinterpret_cast<float4*>(ob)[i] = make_float4(acc[4 * i] * inv, acc[4 * i + 1] * inv, acc[4 * i + 2] * inv, acc[4 * i + 3] * inv);
+    store16p(a.out + ((long long)bw * n + t) * a.ldo + h * HD, acc, 1.f / l);
     reinterpret_cast<float2*>(a.stats)[((long long)blockIdx.x) * n + t] = make_float2(m, l);
 }
 
@@ -232,39 +261,31 @@ __global__ __launch_bounds__(NT) void attn3d_bwd_q_kernel(const AttnArgs a) {
     __syncthreads();
     const int t = threadIdx.x;
     if (t < n) {
-        float q[HD], dO[HD], o[HD];
-        load16(qb + (long long)t * a.ldq, q);
-        load16(a.dout + ((long long)bw * n + t) * a.ldo + h * HD, dO);
-        load16(a.o + ((long long)bw * n + t) * a.ldo + h * HD, o);
-        float delta = 0.f;
+        f2 q[HD / 2], dO[HD / 2], o[HD / 2];
+        load16p(qb + (long long)t * a.ldq, q);
+        load16p(a.dout + ((long long)bw * n + t) * a.ldo + h * HD, dO);
+        load16p(a.o + ((long long)bw * n + t) * a.ldo + h * HD, o);
+        f2 d2 = {0.f, 0.f};
 #pragma unroll
-        for (int i = 0; i < HD; ++i) { q[i] *= a.scale; delta = fmaf(dO[i], o[i], delta); }
+        for (int i = 0; i < HD / 2; ++i) { q[i] *= a.scale; d2 = dO[i] * o[i] + d2; }
+        const float delta = d2.x + d2.y;
         const float2 st = reinterpret_cast<const float2*>(a.stats)[(long long)blockIdx.x * n + t];
         const float inv = 1.f / st.y;
         const int rt = a.region ? sr[t] : 0;
         float* const mytab = stab + (threadIdx.x >> 6) * TBL;
-        float dq[HD];
+        f2 dq[HD / 2];
 #pragma unroll
-        for (int i = 0; i < HD; ++i) dq[i] = 0.f;
+        for (int i = 0; i < HD / 2; ++i) dq[i] = f2{0.f, 0.f};
         for (int j = 0; j < n; ++j) {
             const int r = rel_index(t, j);
-            float s = dot16(q, sk + j * HD) + sb[r];
+            float s = dot16p(q, sk + j * HD) + sb[r];
             if (a.region && sr[j] != rt) s -= 100.f;
             const float p = __expf(s - st.x) * inv;
-            const float ds = p * (dot16(dO, sv + j * HD) - delta);
+            const float ds = p * (dot16p(dO, sv + j * HD) - delta);
             mytab[r] += ds;
-#pragma unroll
-            for (int i = 0; i < HD / 4; ++i) {
-                const float4 k = reinterpret_cast<const float4*>(sk + j * HD)[i];
-                dq[4 * i] = fmaf(ds, k.x, dq[4 * i]); dq[4 * i + 1] = fmaf(ds, k.y, dq[4 * i + 1]);
-                dq[4 * i + 2] = fmaf(ds, k.z, dq[4 * i + 2]); dq[4 * i + 3] = fmaf(ds, k.w, dq[4 * i + 3]);
-            }
+            axpy16p(dq, ds, sk + j * HD);
         }
-        float* __restrict__ db = a.dqkv + ((long long)bw * n + t) * a.lddq + h * HD;
-#pragma unroll
-        for (int i = 0; i < HD / 4; ++i)
-            reinterpret_cast<float4*>(db)[i] = make_float4(dq[4 * i] * a.scale, dq[4 * i + 1] * a.scale, dq[4 * i + 2] * a.scale,
-                                                           dq[4 * i + 3] * a.scale);
+        store16p(a.dqkv + ((long long)bw * n + t) * a.lddq + h * HD, dq, a.scale);
         a.delta[(long long)blockIdx.x * n + t] = delta;
     }
     __syncthreads();
@@ -301,34 +322,24 @@ __global__ __launch_bounds__(NT) void attn3d_bwd_kv_kernel(const AttnArgs a) {
     __syncthreads();
     const int j = threadIdx.x;
     if (j >= n) return;
-    float k[HD], v[HD], dk[HD], dv[HD];
-    load16(qb + C + (long long)j * a.ldq, k);
-    load16(qb + 2 * C + (long long)j * a.ldq, v);
+    f2 k[HD / 2], v[HD / 2], dk[HD / 2], dv[HD / 2];
+    load16p(qb + C + (long long)j * a.ldq, k);
+    load16p(qb + 2 * C + (long long)j * a.ldq, v);
 #pragma unroll
-    for (int i = 0; i < HD; ++i) { dk[i] = 0.f; dv[i] = 0.f; }
+    for (int i = 0; i < HD / 2; ++i) { dk[i] = f2{0.f, 0.f}; dv[i] = f2{0.f, 0.f}; }
     const int rj = a.region ? sr[j] : 0;
     for (int t = 0; t < n; ++t) {
-        float s = dot16(k, sq + t * HD) + sb[rel_index(t, j)];
+        float s = dot16p(k, sq + t * HD) + sb[rel_index(t, j)];
         if (a.region && sr[t] != rj) s -= 100.f;
         const float p = __expf(s - sm[t]) * sl[t];
-        const float ds = p * (dot16(v, sdo + t * HD) - sdl[t]);
-#pragma unroll
-        for (int i = 0; i < HD / 4; ++i) {
-            const float4 q = reinterpret_cast<const float4*>(sq + t * HD)[i];
-            const float4 g = reinterpret_cast<const float4*>(sdo + t * HD)[i];
-            dk[4 * i] = fmaf(ds, q.x, dk[4 * i]); dk[4 * i + 1] = fmaf(ds, q.y, dk[4 * i + 1]);
-            dk[4 * i + 2] = fmaf(ds, q.z, dk[4 * i + 2]); dk[4 * i + 3] = fmaf(ds, q.w, dk[4 * i + 3]);
-            dv[4 * i] = fmaf(p, g.x, dv[4 * i]); dv[4 * i + 1] = fmaf(p, g.y, dv[4 * i + 1]);
-            dv[4 * i + 2] = fmaf(p, g.z, dv[4 * i + 2]); dv[4 * i + 3] = fmaf(p, g.w, dv[4 * i + 3]);
-        }
+        const float ds = p * (dot16p(v, sdo + t * HD) - sdl[t]);
+        axpy16p(dk, ds, sq + t * HD);
+        axpy16p(dv, p, sdo + t * HD);
     }
     // sq holds q * scale: dK = sum dS * (scale q) already carries the scale
     float* __restrict__ db = a.dqkv + ((long long)bw * n + j) * a.lddq + h * HD;
-#pragma unroll
-    for (int i = 0; i < HD / 4; ++i) {
-        reinterpret_cast<float4*>(db + C)[i] = make_float4(dk[4 * i], dk[4 * i + 1], dk[4 * i + 2], dk[4 * i + 3]);
-        reinterpret_cast<float4*>(db + 2 * C)[i] = make_float4(dv[4 * i], dv[4 * i + 1], dv[4 * i + 2], dv[4 * i + 3]);
-    }
+    store16p(db + C, dk, 1.f);
+    store16p(db + 2 * C, dv, 1.f);
 }
 
 // dtable[r][h] (+)= sum over the windows of tpart[(bw, h)][r], fixed order, in double
