@@ -479,6 +479,7 @@ class Plan:
     def __init__(self, net, in_shape):
         self.net = net
         self.in_shape = tuple(in_shape)      # (N, C, D, H, W)
+        self._tbatch = None
         self.ops = []
         self.acts = []
         self.inp = Act(tensor=torch.empty(0, device="cuda"))
@@ -610,6 +611,22 @@ class Plan:
         if self._packs[mode] is not None:
             self._packs[mode].run()
 
+    def _transpose_linear_weights(self):
+        """Mixed plans (UNETR, SwinUNETR): W^T of every token-major Linear that needs a data gradient in ONE launch (as
+        SwinPlan.transpose_weights; 136 launches of ~5 us per UNETR backward before)."""
+        if self._tbatch is None:
+            from . import tops
+            from .swin_plan import LinearOp
+            jobs = []
+            for op in self.ops:
+                if isinstance(op, LinearOp) and op.need_dx and op.w2.is_contiguous():
+                    op.wT = torch.empty((op.w2.shape[1], op.w2.shape[0]), dtype=torch.float32, device="cuda")
+                    op.wT_batched = True
+                    jobs.append((op.w2, op.wT))
+            self._tbatch = tops.TransposeBatch(jobs) if jobs else False
+        if self._tbatch:
+            self._tbatch.run()
+
     def _fuse_dgrad_norm(self):
         """conv_a -> InstanceNorm -> ReLU -> conv_b (reference UnetConv3, utils.py:99-123): when the activation between
         the two convolutions has no other reader, conv_b's Winograd data gradient also forms the partial sums of the
@@ -687,6 +704,7 @@ class Plan:
         if dlogits5 is not None:
             self.out.g = dlogits5
         self._pack(1)
+        self._transpose_linear_weights()
         main = torch.cuda.current_stream()
         side = None
         if WGRAD_STREAM:
