@@ -108,6 +108,33 @@ def test_k2s2_in_place_kernels(N, Cin, Cout, dims):
     _close(dxc, xc.grad)
 
 
+@pytest.mark.parametrize("N,Cin,Cout,d", [(8, 16, 32, 48), (8, 32, 64, 24)])
+def test_k2s2_full_size_adjoint_identities(N, Cin, Cout, d):
+    """Size-independent properties at the BASELINE geometry (config 3's V-Net: 4+4 volumes of 96^3, the 96^3 <-> 48^3 and
+    48^3 <-> 24^3 levels), where a CPU reference would take minutes: the three in-place kernels are one bilinear form
+    B(w, x, g) = <conv_k2s2(x; w), g>, so  <down(x), g> = <x, up(g)> = <wgrad(g, x), w>  (fp64 dot products of fp32 results)."""
+    from mis_hip import ops
+    gen = torch.Generator(device="cuda").manual_seed(41)
+    x = torch.rand(N, Cin, 2 * d, 2 * d, 2 * d, generator=gen, device="cuda") - 0.5
+    g = torch.rand(N, Cout, d, d, d, generator=gen, device="cuda") - 0.5
+    w = (torch.rand(Cout, Cin * 8, generator=gen, device="cuda") - 0.5) * 0.2
+    y = torch.empty_like(g)
+    ops.conv_k2s2_down(x, w, None, y)
+    dx = torch.empty_like(x)
+    ops.conv_k2s2_up(g, w, None, dx)
+    dw = torch.empty(Cout * Cin * 8, device="cuda")
+    ops.conv_k2s2_wgrad(g, x, dw)
+    a = torch.dot(y.double().view(-1), g.double().view(-1)).item()
+    b = torch.dot(x.double().view(-1), dx.double().view(-1)).item()
+    c = torch.dot(dw.double(), w.double().view(-1)).item()
+    scale = (y.double().norm() * g.double().norm()).item()
+    assert abs(a - b) <= 1e-6 * scale and abs(a - c) <= 1e-6 * scale, (a, b, c, scale)
+    # linearity in x
+    y2 = torch.empty_like(y)
+    ops.conv_k2s2_down(2.5 * x, w, None, y2)
+    assert (y2 - 2.5 * y).abs().max().item() <= 1e-5 * y.abs().max().item()
+
+
 @pytest.mark.parametrize("N,CF,CC,dims", [(2, 16, 32, (4, 16, 16)), (1, 32, 64, (3, 18, 24)), (3, 16, 32, (2, 20, 16))])
 def test_k2s2_weight_gradient_in_place(N, CF, CC, dims):
     """mis_conv_k2s2_wgrad against torch for both parameter layouts (Conv3d: coarse = dy; ConvTranspose3d: coarse = x),
