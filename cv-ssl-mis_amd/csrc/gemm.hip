@@ -511,11 +511,14 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const GemmArgs a) {
     const int bc = tid % BT, bh = tid / BT;
     float bsum = 0.f;
 
-    for (int k0 = kbeg; k0 < kend; k0 += BK) {
-        __syncthreads();
-        // rows = k (contraction), BT floats = Q float4 per row; branch-free, zero fill outside the matrices
+    // rows = k (contraction), BT floats = Q float4 per row; branch-free, zero fill outside the matrices.  The tiles of
+    // k-step s + 1 are loaded into registers before the MFMAs of k-step s and stored to LDS after them: the global-load
+    // latency hides behind the workgroup's own MFMAs (no second LDS buffer: four workgroups stay resident per CU)
+    constexpr int NLD = (BK * Q + 255) / 256;
+    float4 ra[NLD], rb[NLD];
+    auto fetch = [&](int k0) {
 #pragma unroll
-        for (int it = 0; it < (BK * Q + 255) / 256; ++it) {
+        for (int it = 0; it < NLD; ++it) {
             const int e = tid + it * 256;
             const int r = e / Q, q = e - r * Q;
             const int k = k0 + r;
@@ -523,18 +526,30 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const GemmArgs a) {
             {
                 const bool ok = in && k < kend && m0 + q * 4 < a.M;
                 const long long off = ok ? (long long)k * a.lda + m0 + q * 4 : 0;
-                float4 v = *reinterpret_cast<const float4*>(a.A + off);
-                if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (in) *reinterpret_cast<float4*>(sA + r * LD + q * 4) = v;
+                ra[it] = *reinterpret_cast<const float4*>(a.A + off);
+                if (!ok) ra[it] = make_float4(0.f, 0.f, 0.f, 0.f);
             }
             {
                 const bool ok = in && k < kend && n0 + q * 4 < a.N;
                 const long long off = ok ? (long long)k * a.ldb + n0 + q * 4 : 0;
-                float4 v = *reinterpret_cast<const float4*>(a.B + off);
-                if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (in) *reinterpret_cast<float4*>(sB + r * LD + q * 4) = v;
+                rb[it] = *reinterpret_cast<const float4*>(a.B + off);
+                if (!ok) rb[it] = make_float4(0.f, 0.f, 0.f, 0.f);
             }
         }
+    };
+    fetch(kbeg);
+    for (int k0 = kbeg; k0 < kend; k0 += BK) {
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < NLD; ++it) {
+            const int e = tid + it * 256;
+            const int r = e / Q, q = e - r * Q;
+            if (e < BK * Q) {
+                *reinterpret_cast<float4*>(sA + r * LD + q * 4) = ra[it];
+                *reinterpret_cast<float4*>(sB + r * LD + q * 4) = rb[it];
+            }
+        }
+        if (k0 + BK < kend) fetch(k0 + BK);
         __syncthreads();
         if (colsum && bh < 2) {
 #pragma unroll
