@@ -705,7 +705,11 @@ int pick_ks(int M, int N, int K, int trans) {
     const int bt = tn_tile(M, N);
     const long long tiles = mis_cdiv(M, bt) * mis_cdiv(N, bt);
     if (tiles >= 256) return 1;
-    static const int slots = getenv("MIS_GEMM_TN_SLOTS") ? atoi(getenv("MIS_GEMM_TN_SLOTS")) : 768;      // slices x tiles ~ three workgroups per CU (512: 36.6, 768: 35.5, 1024: 35.8 ms per SwinUnet step)
+    // slices x tiles ~ three workgroups per CU for the short contractions (deep Swin stages, UNETR's 1 728 token rows); with
+    // the register prefetch of the k-loop a long contraction (>= 32 768 rows) runs better on half as many, longer slices
+    // (less partial traffic): SwinUnet 28.9 -> 28.5 ms per step, UNETR keeps 43.5 (44.5 with 384 everywhere)
+    static const int forced = getenv("MIS_GEMM_TN_SLOTS") ? atoi(getenv("MIS_GEMM_TN_SLOTS")) : 0;
+    const int slots = forced ? forced : (K >= 32768 ? 384 : 768);
     long long ks = slots / tiles;
     const long long kmax = mis_cdiv(K, 4 * BK);   // at least 4 k-steps per slice
     if (ks > kmax) ks = kmax;
