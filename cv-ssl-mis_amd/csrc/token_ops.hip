@@ -622,6 +622,128 @@ __global__ __launch_bounds__(256) void head_dw_final_kernel(const float* __restr
     dw[i] = accumulate ? dw[i] + (float)s : (float)s;
 }
 
+// ------------------------------------------------------------------ LayerNorm + output head in one pass
+// The last two layers of SwinUnet: FinalPatchExpand_X4.norm = nn.LayerNorm(C = 96) on the 16x expanded token tensor, then
+// self.output = nn.Conv2d(C, NC, 1, bias=False) (reference swin_transformer_unet_skip_expand_decoder_sys.py:390-409, :671,
+// :749-752).  The normalised tensor (925 MB at 24+24 images of 224^2) has one reader; here it never exists:
+//   forward   x -> (mean, rstd) and logits[b][n][pix] = sum_c w[n][c] * (xhat_c gamma_c + beta_c)        one read of x
+//   backward  dlogits, x -> dx (LayerNorm backward of dy_c = sum_n dlogits_n w[n][c]), and the column sums that make
+//             dgamma, dbeta, dw -- one read of x, one write of dx (un-fused: 3 reads + 2 writes of a 925 MB tensor more)
+// 32 lanes per row (C <= 128), a float4 of columns per lane, 8 rows per 256 threads.
+template <int NC>
+__global__ __launch_bounds__(256) void ln_head_fwd_kernel(const float* __restrict__ x, long long ldx,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          const float* __restrict__ w, float* __restrict__ mean,
+                                                          float* __restrict__ rstd, float* __restrict__ y, long long y_bs,
+                                                          long long M, long long S, int C, float eps) {
+    const int lane = threadIdx.x & 31, rg = threadIdx.x >> 5;
+    const int c = lane * 4;
+    const bool act = c < C;
+    float4 g = make_float4(0.f, 0.f, 0.f, 0.f), bt = g, wv[NC];
+    if (act) { g = *reinterpret_cast<const float4*>(gamma + c); bt = *reinterpret_cast<const float4*>(beta + c); }
+#pragma unroll
+    for (int n = 0; n < NC; ++n) wv[n] = act ? *reinterpret_cast<const float4*>(w + (long long)n * C + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (long long row = blockIdx.x * 8LL + rg; row < M; row += (long long)gridDim.x * 8) {
+        const float4 v = act ? *reinterpret_cast<const float4*>(x + row * ldx + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float m = group_sum<32>((v.x + v.y) + (v.z + v.w)) / (float)C;
+        const float a0 = v.x - m, a1 = v.y - m, a2 = v.z - m, a3 = v.w - m;
+        const float ss = act ? (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3) : 0.f;
+        const float rs = 1.f / sqrtf(group_sum<32>(ss) / (float)C + eps);
+        const float y0 = a0 * rs * g.x + bt.x, y1 = a1 * rs * g.y + bt.y, y2 = a2 * rs * g.z + bt.z, y3 = a3 * rs * g.w + bt.w;
+        float p[NC];
+#pragma unroll
+        for (int n = 0; n < NC; ++n) p[n] = group_sum<32>((y0 * wv[n].x + y1 * wv[n].y) + (y2 * wv[n].z + y3 * wv[n].w));
+        if (lane == 0) {
+            mean[row] = m; rstd[row] = rs;
+            const long long b = row / S, pix = row - b * S;
+#pragma unroll
+            for (int n = 0; n < NC; ++n) y[b * y_bs + (long long)n * S + pix] = p[n];
+        }
+    }
+}
+
+// one block per slab of rows; partial column sums per slab: pln[slab][c] = (sum dy xhat, sum dy), pw[slab][n][c] = sum dl_n y_c
+template <int NC>
+__global__ __launch_bounds__(256) void ln_head_bwd_kernel(const float* __restrict__ x, long long ldx,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          const float* __restrict__ w, const float* __restrict__ mean,
+                                                          const float* __restrict__ rstd, const float* __restrict__ dl,
+                                                          long long dl_bs, float* __restrict__ dx, long long lddx,
+                                                          int accumulate, long long M, long long S, int C,
+                                                          long long rows_per_slab, float2* __restrict__ pln,
+                                                          float* __restrict__ pw) {
+    __shared__ float4 red[256];
+    const int lane = threadIdx.x & 31, rg = threadIdx.x >> 5;
+    const int c = lane * 4;
+    const bool act = c < C;
+    float4 g = make_float4(0.f, 0.f, 0.f, 0.f), bt = g, wv[NC], aw[NC];
+    if (act) { g = *reinterpret_cast<const float4*>(gamma + c); bt = *reinterpret_cast<const float4*>(beta + c); }
+#pragma unroll
+    for (int n = 0; n < NC; ++n) {
+        wv[n] = act ? *reinterpret_cast<const float4*>(w + (long long)n * C + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        aw[n] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    float4 dg = make_float4(0.f, 0.f, 0.f, 0.f), db = dg;
+    const long long r0 = blockIdx.x * rows_per_slab;
+    long long r1 = r0 + rows_per_slab;
+    if (r1 > M) r1 = M;
+    for (long long row = r0 + rg; row < r1; row += 8) {
+        const long long b = row / S, pix = row - b * S;
+        float d[NC];
+#pragma unroll
+        for (int n = 0; n < NC; ++n) d[n] = dl[b * dl_bs + (long long)n * S + pix];
+        const float m = mean[row], rs = rstd[row];
+        const float4 v = act ? *reinterpret_cast<const float4*>(x + row * ldx + c) : make_float4(m, m, m, m);
+        const float h0 = (v.x - m) * rs, h1 = (v.y - m) * rs, h2 = (v.z - m) * rs, h3 = (v.w - m) * rs;      // xhat
+        const float y0 = h0 * g.x + bt.x, y1 = h1 * g.y + bt.y, y2 = h2 * g.z + bt.z, y3 = h3 * g.w + bt.w;
+        float e0 = 0.f, e1 = 0.f, e2 = 0.f, e3 = 0.f;                                                     // dy
+#pragma unroll
+        for (int n = 0; n < NC; ++n) {
+            e0 += d[n] * wv[n].x; e1 += d[n] * wv[n].y; e2 += d[n] * wv[n].z; e3 += d[n] * wv[n].w;
+            aw[n].x += d[n] * y0; aw[n].y += d[n] * y1; aw[n].z += d[n] * y2; aw[n].w += d[n] * y3;
+        }
+        dg.x += e0 * h0; dg.y += e1 * h1; dg.z += e2 * h2; dg.w += e3 * h3;
+        db.x += e0; db.y += e1; db.z += e2; db.w += e3;
+        const float q0 = e0 * g.x, q1 = e1 * g.y, q2 = e2 * g.z, q3 = e3 * g.w;
+        const float s1 = group_sum<32>((q0 + q1) + (q2 + q3)) / (float)C;
+        const float s2 = group_sum<32>((q0 * h0 + q1 * h1) + (q2 * h2 + q3 * h3)) / (float)C;
+        if (act) {
+            float4 o = make_float4(rs * (q0 - s1 - h0 * s2), rs * (q1 - s1 - h1 * s2), rs * (q2 - s1 - h2 * s2),
+                                   rs * (q3 - s1 - h3 * s2));
+            float* const op = dx + row * lddx + c;
+            if (accumulate) {
+                const float4 pv = *reinterpret_cast<const float4*>(op);
+                o.x += pv.x; o.y += pv.y; o.z += pv.z; o.w += pv.w;
+            }
+            *reinterpret_cast<float4*>(op) = o;
+        }
+    }
+    // the 8 row groups of the block, fixed order, one quantity at a time through LDS
+    auto combine = [&](float4 val) -> float4 {
+        __syncthreads();
+        red[threadIdx.x] = val;
+        __syncthreads();
+        float4 s = red[lane];
+#pragma unroll
+        for (int k = 1; k < 8; ++k) {
+            const float4 pv = red[k * 32 + lane];
+            s.x += pv.x; s.y += pv.y; s.z += pv.z; s.w += pv.w;
+        }
+        return s;
+    };
+    const float4 sg = combine(dg), sb = combine(db);
+    if (rg == 0 && act) {
+        float2* o = pln + (long long)blockIdx.x * C + c;
+        o[0] = make_float2(sg.x, sb.x); o[1] = make_float2(sg.y, sb.y);
+        o[2] = make_float2(sg.z, sb.z); o[3] = make_float2(sg.w, sb.w);
+    }
+#pragma unroll
+    for (int n = 0; n < NC; ++n) {
+        const float4 sw_ = combine(aw[n]);
+        if (rg == 0 && act) *reinterpret_cast<float4*>(pw + ((long long)blockIdx.x * NC + n) * C + c) = sw_;
+    }
+}
+
 // out[c][r] = in[r][c]   (weight transpose for the Linear input-gradient GEMM; 32x32 LDS tiles)
 __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ in, long long ldi,
                                                         float* __restrict__ out, long long ldo, int rows, int cols) {
@@ -937,5 +1059,67 @@ extern "C" int mis_head_bwd(const float* x, long long ldx, const float* w, const
     }
     hipLaunchKernelGGL(head_dw_final_kernel, dim3((NC * K + 255) / 256), dim3(256), 0, stream, part, HEAD_BLOCKS, NC * K,
                        dw, accumulate_dw);
+    return mis_launch_status();
+}
+
+// LayerNorm(C) + the bias-free 1x1 output convolution in one pass (the tail of SwinUnet: FinalPatchExpand_X4.norm + output,
+// reference swin_transformer_unet_skip_expand_decoder_sys.py:390-409, :671, :749-752).  x [B*S][C] token-major (row stride
+// ldx), w [NC][C], logits [B][NC][S] (batch stride y_bs).  C % 4 == 0, C <= 128, NC in 2..4.  mean / rstd [B*S] are kept
+// for the backward.
+extern "C" int mis_ln_head_fwd(const float* x, long long ldx, const float* gamma, const float* beta, const float* w,
+                               float* mean, float* rstd, float* logits, long long y_bs, int B, long long S, int C, int NC,
+                               float eps, hipStream_t stream) {
+    if (!x || !gamma || !beta || !w || !mean || !rstd || !logits || B <= 0 || S <= 0 || C <= 0) return MIS_ERR_ARG;
+    if (C % 4 || C > 128 || ldx % 4 || !a16(x) || !a16(gamma) || !a16(beta) || !a16(w)) return MIS_ERR_UNSUPPORTED;
+    const long long M = (long long)B * S;
+    long long blocks = mis_cdiv(M, 8);
+    if (blocks > 8192) blocks = 8192;
+#define MIS_LNH_F(N_) hipLaunchKernelGGL(ln_head_fwd_kernel<N_>, dim3((unsigned)blocks), dim3(256), 0, stream, x, ldx, gamma, \
+                                         beta, w, mean, rstd, logits, y_bs, M, S, C, eps)
+    switch (NC) {
+        case 2: MIS_LNH_F(2); break;
+        case 3: MIS_LNH_F(3); break;
+        case 4: MIS_LNH_F(4); break;
+        default: return MIS_ERR_UNSUPPORTED;
+    }
+#undef MIS_LNH_F
+    return mis_launch_status();
+}
+
+extern "C" long long mis_ln_head_workspace_bytes(long long M, int C, int NC) {
+    if (M <= 0 || C <= 0 || NC <= 0) return MIS_ERR_ARG;
+    return mis_cdiv(M, COL_SLAB_ROWS) * C * (long long)(sizeof(float2) + NC * sizeof(float));
+}
+
+// Backward of mis_ln_head_fwd: dx [B*S][C] (+)= LayerNorm backward of dy = dlogits . w;  dgamma, dbeta [C] and dw [NC][C] (+)=
+// their column sums (accumulate_params).  Deterministic (per-slab partials, fixed-order sums).
+extern "C" int mis_ln_head_bwd(const float* x, long long ldx, const float* gamma, const float* beta, const float* w,
+                               const float* mean, const float* rstd, const float* dlogits, long long dl_bs, float* dx,
+                               long long lddx, int accumulate_dx, float* dgamma, float* dbeta, float* dw,
+                               int accumulate_params, int B, long long S, int C, int NC, void* workspace,
+                               long long workspace_bytes, hipStream_t stream) {
+    if (!x || !gamma || !beta || !w || !mean || !rstd || !dlogits || !dx || !dgamma || !dbeta || !dw || !workspace ||
+        B <= 0 || S <= 0 || C <= 0)
+        return MIS_ERR_ARG;
+    if (C % 4 || C > 128 || ldx % 4 || lddx % 4 || !a16(x) || !a16(dx) || !a16(gamma) || !a16(beta) || !a16(w))
+        return MIS_ERR_UNSUPPORTED;
+    const long long M = (long long)B * S;
+    if (workspace_bytes < mis_ln_head_workspace_bytes(M, C, NC)) return MIS_ERR_WORKSPACE;
+    const int slabs = (int)mis_cdiv(M, COL_SLAB_ROWS);
+    float2* pln = reinterpret_cast<float2*>(workspace);
+    float* pw = reinterpret_cast<float*>(pln + (long long)slabs * C);
+#define MIS_LNH_B(N_) hipLaunchKernelGGL(ln_head_bwd_kernel<N_>, dim3(slabs), dim3(256), 0, stream, x, ldx, gamma, beta, w, mean, \
+                                         rstd, dlogits, dl_bs, dx, lddx, accumulate_dx, M, S, C, (long long)COL_SLAB_ROWS, pln, pw)
+    switch (NC) {
+        case 2: MIS_LNH_B(2); break;
+        case 3: MIS_LNH_B(3); break;
+        case 4: MIS_LNH_B(4); break;
+        default: return MIS_ERR_UNSUPPORTED;
+    }
+#undef MIS_LNH_B
+    hipLaunchKernelGGL(col_final_kernel, dim3((C + 31) / 32), dim3(1024), 0, stream, pln, slabs, C, dgamma, dbeta,
+                       accumulate_params);
+    hipLaunchKernelGGL(head_dw_final_kernel, dim3((NC * C + 255) / 256), dim3(256), 0, stream, pw, slabs, NC * C, dw,
+                       accumulate_params);
     return mis_launch_status();
 }

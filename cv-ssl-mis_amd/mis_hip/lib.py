@@ -163,6 +163,10 @@ PROTOTYPES = {
                                     c_i, c_p]),
     "mis_token_rearrange": (c_i, [c_p, c_ll, c_p, c_ll, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
     "mis_patch_im2col": (c_i, [c_p, c_ll, c_p, c_i, c_i, c_i, c_i, c_p]),
+    "mis_ln_head_fwd": (c_i, [c_p, c_ll, c_p, c_p, c_p, c_p, c_p, c_p, c_ll, c_i, c_ll, c_i, c_i, c_f, c_p]),
+    "mis_ln_head_workspace_bytes": (c_ll, [c_ll, c_i, c_i]),
+    "mis_ln_head_bwd": (c_i, [c_p, c_ll, c_p, c_p, c_p, c_p, c_p, c_p, c_ll, c_p, c_ll, c_i, c_p, c_p, c_p, c_i, c_i, c_ll,
+                              c_i, c_i, c_p, c_ll, c_p]),
     "mis_head_fwd": (c_i, [c_p, c_ll, c_p, c_p, c_ll, c_i, c_ll, c_i, c_i, c_p]),
     "mis_head_workspace_bytes": (c_ll, [c_i, c_i]),
     "mis_head_bwd": (c_i, [c_p, c_ll, c_p, c_p, c_ll, c_p, c_ll, c_p, c_i, c_i, c_ll, c_i, c_i, c_p, c_ll, c_p]),

@@ -16,6 +16,7 @@ from .plan import Act
 
 # GEMM epilogue fusions (GELU into fc1 / fc2-dX, DropPath + residual add into proj / fc2); MIS_SWIN_FUSE=0 runs the
 # separate element-wise passes (A/B timing, and the reference point of the fusion tests)
+LN_HEAD = os.environ.get("MIS_LN_HEAD", "1") != "0"        # last LayerNorm + output head in one pass (LnHeadOp)
 FUSE = int(os.environ.get("MIS_SWIN_FUSE", "7"))      # bit 0: GELU forward, bit 1: GELU backward, bit 2: residual
 
 
@@ -282,6 +283,32 @@ class HeadOp:
     def bwd(self, ctx):
         assert not self.x.written
         tops.head_bwd(self.x.t, self.w2, self.logits.grad(), self.x.grad(), self.gw2)
+        self.x.mark_written()
+
+
+class LnHeadOp:
+    """LayerNorm(x) -> bias-free 1x1 output head in one pass (tops.ln_head_fwd): the normalised tensor -- the largest of the
+    network, read by nobody else -- is never written; the backward forms dx and the three parameter gradients from one
+    more read of x."""
+
+    def __init__(self, x, g, b, w, logits):
+        self.x, self.g, self.b, self.w, self.logits = x, g, b, w, logits
+        self.w2 = w.data.view(w.data.shape[0], -1)
+        self.gw2 = w.grad.view(w.grad.shape[0], -1)
+        self.mean = torch.empty(x.rows, dtype=torch.float32, device="cuda")
+        self.rstd = torch.empty(x.rows, dtype=torch.float32, device="cuda")
+
+    @staticmethod
+    def eligible(C, num_classes):
+        return LN_HEAD and C % 4 == 0 and C <= 128 and 2 <= num_classes <= 4
+
+    def fwd(self, ctx):
+        ok = tops.ln_head_fwd(self.x.t, self.g.data, self.b.data, self.w2, self.mean, self.rstd, self.logits.t)
+        assert ok
+
+    def bwd(self, ctx):
+        tops.ln_head_bwd(self.x.t, self.g.data, self.b.data, self.w2, self.mean, self.rstd, self.logits.grad(),
+                         self.x.grad(), self.g.grad, self.b.grad, self.gw2, accumulate_dx=self.x.written)
         self.x.mark_written()
 
 

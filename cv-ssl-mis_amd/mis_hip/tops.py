@@ -295,6 +295,31 @@ def head_fwd(x, w, logits5):
                             _l.stream_ptr()), "mis_head_fwd")
 
 
+def ln_head_fwd(x, gamma, beta, w, mean, rstd, logits5, eps=1e-5):
+    """logits [B, NC, 1, H, W] = head(LayerNorm(x)) in one pass over x [B*S, C] (mis_ln_head_fwd); False when the shape
+    is outside the fused form."""
+    L = _l.load()
+    M, C, ldx = _mat(x)
+    B, NC = logits5.shape[0], logits5.shape[1]
+    if C % 4 or C > 128 or not 2 <= NC <= 4 or M % B:
+        return False
+    _l.check(L.mis_ln_head_fwd(_l.ptr(x), ldx, _l.ptr(gamma), _l.ptr(beta), _l.ptr(w), _l.ptr(mean), _l.ptr(rstd),
+                               _l.ptr(logits5), logits5.stride(0), B, M // B, C, NC, eps, _l.stream_ptr()), "mis_ln_head_fwd")
+    return True
+
+
+def ln_head_bwd(x, gamma, beta, w, mean, rstd, dlogits5, dx, dgamma, dbeta, dw, accumulate_dx=False):
+    L = _l.load()
+    M, C, ldx = _mat(x)
+    _, _, lddx = _mat(dx)
+    B, NC = dlogits5.shape[0], dlogits5.shape[1]
+    ws = scratch(L.mis_ln_head_workspace_bytes(M, C, NC), "head")
+    _l.check(L.mis_ln_head_bwd(_l.ptr(x), ldx, _l.ptr(gamma), _l.ptr(beta), _l.ptr(w), _l.ptr(mean), _l.ptr(rstd),
+                               _l.ptr(dlogits5), dlogits5.stride(0), _l.ptr(dx), lddx, int(accumulate_dx), _l.ptr(dgamma),
+                               _l.ptr(dbeta), _l.ptr(dw), 0, B, M // B, C, NC, _l.ptr(ws), ws.numel(), _l.stream_ptr()),
+             "mis_ln_head_bwd")
+
+
 def head_bwd(x, w, dlogits5, dx, dw, accumulate_dw=False):
     L = _l.load()
     M, K, ldx = _mat(x)

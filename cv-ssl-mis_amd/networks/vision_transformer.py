@@ -216,14 +216,17 @@ class SwinUnet(HipNet):
         fc2.res = plan.add(sp.ResidualOp(x1, m, x2, L, dp, plan.next_site()))      # residual add in fc2's epilogue
         return x2
 
-    def _expand(self, plan, p, x, out, B, res, dim, P_):
-        """PatchExpand (P_=2: dim -> 2dim -> shuffle -> dim/2) / FinalPatchExpand_X4 (P_=4: dim -> 16dim -> dim)."""
+    def _expand(self, plan, p, x, out, B, res, dim, P_, norm=True):
+        """PatchExpand (P_=2: dim -> 2dim -> shuffle -> dim/2) / FinalPatchExpand_X4 (P_=4: dim -> 16dim -> dim);
+        ``norm=False``: the caller applies the LayerNorm (fused with the output head)."""
         rows = B * res * res
         cout = (2 * dim) if P_ == 2 else 16 * dim
         c = cout // (P_ * P_)
         e = plan.new(rows, cout)               # token-major expansion: only its gradient is ever materialised
         sh = plan.new(rows * P_ * P_, c)
         plan.add(sp.ExpandLinearOp(x, e, sh, self.P(p + ".expand.weight"), (B, res, res, c, P_)))
+        if not norm:
+            return sh
         y = out if out is not None else plan.new(rows * P_ * P_, c)
         plan.add(sp.LayerNormOp(sh, y, self.P(p + ".norm.weight"), self.P(p + ".norm.bias")))
         return y
@@ -289,9 +292,14 @@ class SwinUnet(HipNet):
                                  res, dim, 2)
         xu = plan.new(B * pr * pr, E)
         plan.add(sp.LayerNormOp(x, xu, Pn("swin_unet.norm_up.weight"), Pn("swin_unet.norm_up.bias")))
-        xf = self._expand(plan, "swin_unet.up", xu, None, B, pr, E, 4)
         plan.out = sp.new_logits(B, self.num_classes, H, W)
-        plan.add(sp.HeadOp(xf, Pn("swin_unet.output.weight"), plan.out))
+        if sp.LnHeadOp.eligible(E, self.num_classes):      # up.norm + output in one pass over the 16x expanded tokens
+            sh = self._expand(plan, "swin_unet.up", xu, None, B, pr, E, 4, norm=False)
+            plan.add(sp.LnHeadOp(sh, Pn("swin_unet.up.norm.weight"), Pn("swin_unet.up.norm.bias"),
+                                 Pn("swin_unet.output.weight"), plan.out))
+        else:
+            xf = self._expand(plan, "swin_unet.up", xu, None, B, pr, E, 4)
+            plan.add(sp.HeadOp(xf, Pn("swin_unet.output.weight"), plan.out))
 
 
 ViT_seg = SwinUnet

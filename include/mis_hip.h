@@ -492,6 +492,19 @@ long long mis_head_workspace_bytes(int K, int NC);
 int mis_head_bwd(const float* x, long long ldx, const float* w, const float* dlogits, long long dy_bs, float* dx,
                  long long lddx, float* dw, int accumulate_dw, int B, long long S, int K, int NC, void* workspace,
                  long long workspace_bytes, mis_stream_t stream);
+/* LayerNorm(C) + the bias-free 1x1 output convolution of SwinUnet's tail in one pass (FinalPatchExpand_X4.norm + output:
+ * swin_transformer_unet_skip_expand_decoder_sys.py:390-409, :671, :749-752): the normalised 16x expanded token tensor is
+ * never written.  x [B*S][C] token-major, w [NC][C], logits [B][NC][S]; C % 4 == 0, C <= 128, NC in 2..4; mean / rstd
+ * [B*S] are kept for the backward, which writes dx (+)= and dgamma / dbeta / dw (+)= from one more read of x.
+ * Deterministic.  workspace >= mis_ln_head_workspace_bytes(B*S, C, NC). */
+int mis_ln_head_fwd(const float* x, long long ldx, const float* gamma, const float* beta, const float* w, float* mean,
+                    float* rstd, float* logits, long long y_bs, int B, long long S, int C, int NC, float eps,
+                    mis_stream_t stream);
+long long mis_ln_head_workspace_bytes(long long M, int C, int NC);
+int mis_ln_head_bwd(const float* x, long long ldx, const float* gamma, const float* beta, const float* w, const float* mean,
+                    const float* rstd, const float* dlogits, long long dl_bs, float* dx, long long lddx, int accumulate_dx,
+                    float* dgamma, float* dbeta, float* dw, int accumulate_params, int B, long long S, int C, int NC,
+                    void* workspace, long long workspace_bytes, mis_stream_t stream);
 /* (shifted-)window attention core (:115-150 with the roll/partition/reverse of :244-288 folded into the
  * token addressing): qkv [B*H*W][3*nH*32] in natural token order -> out [B*H*W][nH*32]; window 7x7,
  * head_dim 32; bias_table = relative_position_bias_table [169][nH]; shift in {0,3}. */

@@ -95,6 +95,40 @@ def test_gemm_dw_weight_and_bias_gradient_in_one_pass(T, Cout, Cin):
     assert torch.equal(dW, dW3) and torch.equal(db, db3)
 
 
+@pytest.mark.parametrize("B,S,C,NC", [(2, 3136, 96, 4), (3, 1000, 96, 2), (1, 50, 128, 3), (2, 77, 36, 4)])
+def test_layernorm_and_output_head_in_one_pass(B, S, C, NC):
+    """mis_ln_head_{fwd,bwd}: nn.LayerNorm(C) + the bias-free 1x1 output convolution of SwinUnet's tail (reference
+    swin_transformer_unet_skip_expand_decoder_sys.py:390-409, :671) against torch autograd in double; ragged slabs, C < 128
+    (idle lanes), accumulate into dx, deterministic."""
+    tops = _t()
+    x = (_rand(B * S, C, seed=21, scale=2.0) + 0.3).double().requires_grad_(True)
+    g = (1 + 0.2 * _rand(C, seed=22)).double().requires_grad_(True)
+    b = (0.1 * _rand(C, seed=23)).double().requires_grad_(True)
+    w = (_rand(NC, C, seed=24, scale=0.3)).double().requires_grad_(True)
+    y = torch.nn.functional.layer_norm(x, (C,), g, b, 1e-5)
+    logits = (y @ w.t()).view(B, S, NC).permute(0, 2, 1)                 # [B, NC, S]
+    dl = _rand(B, NC, S, seed=25).double()
+    logits.backward(dl)
+    xd, gd, bd, wd = x.detach().float().cuda(), g.detach().float().cuda(), b.detach().float().cuda(), w.detach().float().cuda()
+    mean, rstd = torch.empty(B * S, device="cuda"), torch.empty(B * S, device="cuda")
+    out = torch.full((B, NC, 1, 1, S), float("nan"), device="cuda")
+    assert tops.ln_head_fwd(xd, gd, bd, wd, mean, rstd, out)
+    _close(out.view(B, NC, S), logits.detach())
+    dx = torch.full((B * S, C), float("nan"), device="cuda")
+    dg, db, dw = (torch.full((C,), float("nan"), device="cuda"), torch.full((C,), float("nan"), device="cuda"),
+                  torch.full((NC, C), float("nan"), device="cuda"))
+    dld = dl.float().cuda().view(B, NC, 1, 1, S)
+    tops.ln_head_bwd(xd, gd, bd, wd, mean, rstd, dld, dx, dg, db, dw)
+    _close(dx, x.grad, rtol=3e-4)
+    _close(dg, g.grad, rtol=3e-4)
+    _close(db, b.grad, rtol=3e-4)
+    _close(dw, w.grad, rtol=3e-4)
+    dx2, dg2, db2, dw2 = dx.clone(), torch.empty_like(dg), torch.empty_like(db), torch.empty_like(dw)
+    tops.ln_head_bwd(xd, gd, bd, wd, mean, rstd, dld, dx2, dg2, db2, dw2, accumulate_dx=True)
+    assert torch.allclose(dx2, 2 * dx, rtol=1e-6, atol=1e-7)
+    assert torch.equal(dg, dg2) and torch.equal(db, db2) and torch.equal(dw, dw2)
+
+
 @pytest.mark.parametrize("M,C", [(784, 96), (50, 1536), (3137, 384)])
 def test_layernorm(M, C):
     tops = _t()
