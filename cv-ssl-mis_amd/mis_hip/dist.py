@@ -10,6 +10,8 @@ of per-rank sums), per-rank BatchNorm statistics (the reference has no SyncBN).
 
 ``backend``: "nccl" is RCCL on ROCm; the CPU tests drive the same functions over "gloo".
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -41,10 +43,15 @@ class GradBucketer:
     of the whole buffer; every rank cuts the same buckets (a pure function of the buffer size).
 
     Bucket size: xGMI is point-to-point (7 links x ~153 GB/s per GPU), a ring all-reduce is per-link bound and needs
-    messages of several MB to reach its bandwidth; 8 MiB buckets give 3 (unet_3D, 23.5 MB) to 13 (SwinUnet, 108.7 MB)
-    collectives per step instead of ~240 per-tensor ones."""
+    messages of several MB to reach its bandwidth, and every collective costs the LAUNCHING thread ~0.1 ms of host time
+    (c10d work object + events) during which no kernel is enqueued: SwinUnet's 700 launches per 28 ms step leave no
+    slack for 13 of them (8 MiB buckets: +0.6 ms per step, scripts/ddp_overhead.py; 32 MiB: +0.0).  16 MiB buckets give
+    2 (unet_3D, 23.5 MB) to 7 (SwinUnet, 108.7 MB) collectives per step; the last one to finish -- the remainder bucket at
+    offset 0 -- stays small (<= 16 MiB exposed after the backward).  MIS_BUCKET_MB overrides."""
 
-    def __init__(self, flat_grad, group=None, bucket_bytes=8 << 20):
+    def __init__(self, flat_grad, group=None, bucket_bytes=None):
+        if bucket_bytes is None:
+            bucket_bytes = int(float(os.environ.get("MIS_BUCKET_MB", "16")) * (1 << 20))
         self.flat, self.group = flat_grad, group
         n, per = flat_grad.numel(), max(1, bucket_bytes // flat_grad.element_size())
         # cut from the end (the part that finishes first); the first bucket takes the remainder
@@ -55,8 +62,13 @@ class GradBucketer:
     def begin(self):
         self._next, self._works = 0, []
 
+    def would_issue(self, lo):
+        """True when ``advance(lo)`` would start an all-reduce (Plan.backward skips the stream hand-off otherwise)."""
+        return self._next < len(self.buckets) and self.buckets[self._next][0] >= lo
+
     def advance(self, lo):
-        """All gradient elements at offsets >= ``lo`` are final."""
+        """All gradient elements at offsets >= ``lo`` are final (on the CURRENT stream: the all-reduce orders itself
+        behind it)."""
         while self._next < len(self.buckets) and self.buckets[self._next][0] >= lo:
             b_lo, b_hi = self.buckets[self._next]
             self._works.append(dist.all_reduce(self.flat[b_lo:b_hi], op=dist.ReduceOp.SUM, group=self.group,

@@ -41,6 +41,7 @@ WGRAD_STREAM = os.environ.get("MIS_WGRAD_STREAM", "1") != "0"
 # first stage of the InstanceNorm + ReLU backward (sum dz, sum dz * x) in the epilogue of the Winograd data-gradient launch
 # that produces the gradient at the activation (mis_conv3d_wino_dgrad_norm): the partial-sum pass over da and x is not run
 FUSE_DGRAD_NORM = os.environ.get("MIS_FUSE_DGRAD_NORM", "1") != "0"
+PROGRESS_SYNC_MAIN = os.environ.get("MIS_PROGRESS_SYNC_MAIN", "0") == "1"
 # residual blocks (UNETR / SwinUNETR): normalise + add the shortcut + activate in one pass, forward and backward
 NORM_RES = os.environ.get("MIS_NORM_RES", "1") != "0"
 
@@ -721,12 +722,13 @@ class Plan:
         if self._progress is None:
             from .dist import param_progress
             self._progress = param_progress(self.ops, self.net.flat_grad)
+        report = progress_reporter(on_progress, main, side)
         for i in range(len(self.ops) - 1, -1, -1):
             self.ops[i].bwd(ctx)
             if i == 0 or self._progress[i] != self._progress[i - 1] or i == len(self.ops) - 1:
-                if side is not None:
-                    main.wait_stream(side)  # the reported suffix includes weight gradients issued on the side stream
-                on_progress(self._progress[i])
+                report(self._progress[i])
+        if side is not None:
+            main.wait_stream(side)          # every weight gradient is in the flat buffer before the optimizer reads it
 
     def drop_sites(self):
         """Site ids (keys of ``net.drop_masks``) of the active dropout layers, in forward order."""
@@ -735,6 +737,35 @@ class Plan:
     def drop_site_shape(self, site):
         """Activation shape an explicit ``net.drop_masks[site]`` tensor must have."""
         return next(op.y.shape for op in self.ops if isinstance(op, NormActOp) and op.site == site)
+
+
+def progress_reporter(on_progress, main, side):
+    """How a backward pass reports ``on_progress(lo)`` when weight gradients run on a side stream.
+
+    The finished suffix includes gradients still in flight on ``side``.  The compute stream must NOT wait for them (that
+    would serialise every weight gradient behind the data-gradient chain again, on multi-GPU runs only): instead ``side``
+    waits for ``main`` (free: its later work is issued behind main's anyway) and the callback runs with ``side`` as the
+    current stream, so whatever it enqueues -- the bucket all-reduce of mis_hip.dist.GradBucketer, which orders itself
+    behind the current stream -- sees both streams' work.  A callback that is a bound method of an object with
+    ``would_issue(lo)`` (the bucketer) is only called when it would do something: no stream dependency otherwise."""
+    probe = getattr(getattr(on_progress, "__self__", None), "would_issue", None)
+    if PROGRESS_SYNC_MAIN:          # A/B switch (scripts/ddp_overhead.py): the compute stream waits at every report
+        probe = None
+
+    def report(lo):
+        if PROGRESS_SYNC_MAIN and side is not None:
+            main.wait_stream(side)
+            on_progress(lo)
+            return
+        if probe is not None and not probe(lo):
+            return
+        if side is None:
+            on_progress(lo)
+            return
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            on_progress(lo)
+    return report
 
 
 class _PRef:

@@ -278,13 +278,22 @@ class CrossTeachingTrainer:
             main.wait_stream(self._side)
             scales = [dist.sync_gradients(m.flat_grad, self.pg) for m in (self.model1, self.model2)]
         elif self._bucketers[0] is not None:
-            # both students' buckets are in flight while the other student's backward runs; one wait at the end
+            # both students' buckets are in flight while the other student's backward runs; one wait at the end.  With
+            # TWO_STREAM the second student's backward runs on the side stream as on one GPU: its collectives are still
+            # ENQUEUED by this thread in program order (model2's buckets, then model1's), the same on every rank.
             b1, b2 = self._bucketers
             b1.begin()
-            self.model1.backward_raw(on_progress=b1.advance)
-            b1.advance(0)
             b2.begin()
-            self.model2.backward_raw(on_progress=b2.advance)
+            if TWO_STREAM:
+                self._side.wait_stream(main)
+                with torch.cuda.stream(self._side):
+                    self.model2.backward_raw(on_progress=b2.advance)
+                self.model1.backward_raw(on_progress=b1.advance)
+                main.wait_stream(self._side)
+            else:
+                self.model1.backward_raw(on_progress=b1.advance)
+                b1.advance(0)
+                self.model2.backward_raw(on_progress=b2.advance)
             scales = [b1.finish(), b2.finish()]
         else:
             self.model1.backward_raw()

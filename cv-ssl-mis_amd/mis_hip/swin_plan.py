@@ -561,12 +561,13 @@ class SwinPlan:
         if self._progress is None:
             from .dist import param_progress
             self._progress = param_progress(self.ops, self.net.flat_grad)
+        report = _plan.progress_reporter(on_progress, main, side)
         for i in range(len(self.ops) - 1, -1, -1):      # see mis_hip.plan.Plan.backward
             self.ops[i].bwd(ctx)
             if i == 0 or self._progress[i] != self._progress[i - 1] or i == len(self.ops) - 1:
-                if side is not None:
-                    main.wait_stream(side)
-                on_progress(self._progress[i])
+                report(self._progress[i])
+        if side is not None:
+            main.wait_stream(side)
 
     def drop_sites(self):
         return [op.site for op in self.ops if isinstance(op, ResidualOp) and op.drop_p > 0]

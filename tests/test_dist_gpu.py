@@ -31,38 +31,51 @@ def _worker(rank, world, port, out_dir, overlap, kind):
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
     from mis_hip import step as mstep
-    from mis_hip.step import MeanTeacherTrainer
+    from mis_hip.step import CrossTeachingTrainer, MeanTeacherTrainer
+    from mis_hip.dist import GradBucketer
     from test_grad_progress_gpu import _make
     assert mstep.GRAD_OVERLAP == bool(overlap)
     torch.manual_seed(5)                                   # identical initial weights on both ranks
-    C = 4 if kind == "unet2d" else 2
-    model, ema = _make(kind, C), _make(kind, C)
-    ema.load_state_dict(model.state_dict())
-    model.train(); ema.train()
-    tr = MeanTeacherTrainer(model, ema, labeled_bs=1, num_classes=C, cons_start_iter=0, iter_num=1000, seed=7)
-    assert (tr._bucketer is not None) == bool(overlap)
-    if tr._bucketer is not None:
-        # small buckets: several collectives per backward even for the small test networks
-        from mis_hip.dist import GradBucketer
-        tr._bucketer = GradBucketer(model.flat_grad, None, bucket_bytes=1 << 20)
-        assert len(tr._bucketer.buckets) >= 3
+    C = 2 if kind == "unet3d" else 4
+    if kind == "cross":      # two students (UNet + SwinUnet), the second one's backward on the side stream (TWO_STREAM)
+        model, ema = _make("unet2d", C), _make("swin", C)
+        model.train(); ema.train()
+        tr = CrossTeachingTrainer(model, ema, labeled_bs=1, num_classes=C, iter_num=1000, seed=7)
+        assert mstep.TWO_STREAM and (tr._bucketers[0] is not None) == bool(overlap)
+        if overlap:
+            tr._bucketers = (GradBucketer(model.flat_grad, None, bucket_bytes=1 << 20),
+                             GradBucketer(ema.flat_grad, None, bucket_bytes=8 << 20))
+    else:
+        model, ema = _make(kind, C), _make(kind, C)
+        ema.load_state_dict(model.state_dict())
+        model.train(); ema.train()
+        tr = MeanTeacherTrainer(model, ema, labeled_bs=1, num_classes=C, cons_start_iter=0, iter_num=1000, seed=7)
+        assert (tr._bucketer is not None) == bool(overlap)
+        if tr._bucketer is not None:
+            # small buckets: several collectives per backward even for the small test networks
+            tr._bucketer = GradBucketer(model.flat_grad, None, bucket_bytes=1 << 20)
+            assert len(tr._bucketer.buckets) >= 3
     g = torch.Generator(device="cuda").manual_seed(100 + rank)          # a different shard per rank
-    shape = (2, 1, 64, 64) if kind == "unet2d" else (2, 1, 32, 32, 32)
+    shape = {"unet2d": (2, 1, 64, 64), "cross": (2, 1, 224, 224)}.get(kind, (2, 1, 32, 32, 32))
     vol = torch.rand(shape, generator=g, device="cuda")
-    lab = torch.randint(0, C, (shape[0],) + shape[2:], generator=g, device="cuda").to(torch.uint8 if kind == "unet2d" else torch.int64)
+    lab = torch.randint(0, C, (shape[0],) + shape[2:], generator=g, device="cuda").to(torch.int64 if kind == "unet3d" else torch.uint8)
     noise = torch.zeros((1,) + shape[1:], device="cuda")                 # injected: no device RNG in the comparison
     model.dropout_enabled = ema.dropout_enabled = False
     for _ in range(3):
-        tr.step(vol, lab, noise=noise)
+        if kind == "cross":
+            out1, _ = tr.step(vol, lab)
+        else:
+            tr.step(vol, lab, noise=noise)
     torch.cuda.synchronize()
-    torch.save(dict(student=model.flat_param.cpu(), teacher=ema.flat_param.cpu(), loss=tr.losses()["loss"]),
+    loss = float(out1[0]) if kind == "cross" else tr.losses()["loss"]
+    torch.save(dict(student=model.flat_param.cpu(), teacher=ema.flat_param.cpu(), loss=loss),
                os.path.join(out_dir, f"{kind}_{int(overlap)}_{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
 
 
 @pytest.mark.timeout(900)
-@pytest.mark.parametrize("kind", ["unet3d", "unet2d"])
+@pytest.mark.parametrize("kind", ["unet3d", "unet2d", "cross"])
 def test_two_ranks_on_one_gpu_exchange_gradients(tmp_path, kind):
     world = 2
     for overlap in (0, 1):
