@@ -57,6 +57,12 @@ class GradBucketer:
         # cut from the end (the part that finishes first); the first bucket takes the remainder
         cuts = list(range(n, 0, -per)) + [0]
         self.buckets = [(cuts[i + 1], cuts[i]) for i in range(len(cuts) - 1)]     # (lo, hi), descending
+        # the bucket at offset 0 is complete only when the backward is: its all-reduce is the exposed one.  Keep it small
+        # (2 MiB: a latency-bound ring step) by splitting the remainder
+        tail = max(1, (2 << 20) // flat_grad.element_size())
+        lo, hi = self.buckets[-1]
+        if hi - lo > 2 * tail:
+            self.buckets[-1:] = [(lo + tail, hi), (lo, lo + tail)]
         self._next, self._works = 0, []
 
     def begin(self):
