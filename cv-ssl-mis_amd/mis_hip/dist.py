@@ -45,13 +45,16 @@ class GradBucketer:
     Bucket size: xGMI is point-to-point (7 links x ~153 GB/s per GPU), a ring all-reduce is per-link bound and needs
     messages of several MB to reach its bandwidth, and every collective costs the LAUNCHING thread ~0.1 ms of host time
     (c10d work object + events) during which no kernel is enqueued: SwinUnet's 700 launches per 28 ms step leave no
-    slack for 13 of them (8 MiB buckets: +0.6 ms per step, scripts/ddp_overhead.py; 32 MiB: +0.0).  16 MiB buckets give
-    2 (unet_3D, 23.5 MB) to 7 (SwinUnet, 108.7 MB) collectives per step; the last one to finish -- the remainder bucket at
-    offset 0 -- stays small (<= 16 MiB exposed after the backward).  MIS_BUCKET_MB overrides."""
+    slack for 13 of them (8 MiB buckets: +0.6 ms per step, scripts/ddp_overhead.py; 32 MiB: +0.0).  Buckets are
+    max(16 MiB, a quarter of the buffer): 2 (unet_3D, 23.5 MB) to 4 (SwinUnet, 108.7 MB; UNETR, 371 MB) collectives per
+    step plus the small tail bucket below.  MIS_BUCKET_MB overrides."""
 
     def __init__(self, flat_grad, group=None, bucket_bytes=None):
         if bucket_bytes is None:
-            bucket_bytes = int(float(os.environ.get("MIS_BUCKET_MB", "16")) * (1 << 20))
+            if "MIS_BUCKET_MB" in os.environ:
+                bucket_bytes = int(float(os.environ["MIS_BUCKET_MB"]) * (1 << 20))
+            else:       # at most ~4 collectives (+ the small tail) per model and step
+                bucket_bytes = max(16 << 20, -(-flat_grad.numel() * flat_grad.element_size() // 4))
         self.flat, self.group = flat_grad, group
         n, per = flat_grad.numel(), max(1, bucket_bytes // flat_grad.element_size())
         # cut from the end (the part that finishes first); the first bucket takes the remainder
