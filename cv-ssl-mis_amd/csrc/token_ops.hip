@@ -54,53 +54,84 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
     }
 }
 
+// Sum over the LPR (32 or 64) lanes of a row group, result in every lane.  The first four steps are DPP modifiers of the
+// add (quad_perm 1032 / 2301, row_half_mirror, row_mirror: vector-ALU rate), the step across the two 16-lane rows is one
+// ds_swizzle (xor 16), the one across the wave's halves one ds_bpermute -- __shfl_xor is a ds_bpermute per step on gfx9
+// (5 per sum: the fused LayerNorm + head forward issues 6 sums per row and ran at 2.1 TB/s on them).
+__device__ __forceinline__ float dpp_f(float v, int ctrl) {
+    switch (ctrl) {      // the control word is an immediate
+        case 0: return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, false));
+        case 1: return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, false));
+        case 2: return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, false));
+        default: return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, false));
+    }
+}
 template <int LPR>
 __device__ __forceinline__ float group_sum(float v) {
-#pragma unroll
-    for (int o = LPR / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    static_assert(LPR == 32 || LPR == 64, "row groups of 32 or 64 lanes");
+    v += dpp_f(v, 0);
+    v += dpp_f(v, 1);
+    v += dpp_f(v, 2);
+    v += dpp_f(v, 3);
+    v += __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), (0x10 << 10) | 0x1F));
+    if (LPR == 64) v += __shfl_xor(v, 32, 64);
     return v;
 }
 
 // Register-resident rows: LPR lanes per row (32 -> two rows per wave for C <= 128), NV float4 per lane,
 // so x is read from HBM/L2 once and the three passes run on registers.  C <= LPR*4*NV.
-template <int LPR, int NV>
+// RU rows of a row group are loaded before any of them is reduced (a thread otherwise has one 16-byte load in flight and
+// the kernel runs at 45 % of the HBM rate on the 96-channel stages).
+template <int LPR, int NV, int RU>
 __global__ __launch_bounds__(256) void ln_fwd_reg_kernel(const float* __restrict__ x, long long ldx,
                                                          float* __restrict__ y, long long ldy,
                                                          const float* __restrict__ gamma,
                                                          const float* __restrict__ beta, float* __restrict__ mean,
                                                          float* __restrict__ rstd, long long M, int C, float eps) {
-    const long long row = blockIdx.x * (long long)(256 / LPR) + (threadIdx.x / LPR);
-    if (row >= M) return;
-    const int lane = threadIdx.x % LPR;
-    const float* __restrict__ xr = x + row * ldx;
-    float4 v[NV];
-    float s = 0.f;
+    constexpr int RPI = 256 / LPR;
+    const int lane = threadIdx.x % LPR, rg = threadIdx.x / LPR;
+    const long long base = (long long)blockIdx.x * (RPI * RU) + rg;
+    float4 v[RU][NV], g[NV], b[NV];
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        const int c = (lane + i * LPR) * 4;
-        v[i] = c < C ? *reinterpret_cast<const float4*>(xr + c) : make_float4(0.f, 0.f, 0.f, 0.f);
-        s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    for (int u = 0; u < RU; ++u) {
+        const long long row = base + (long long)u * RPI;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = (lane + i * LPR) * 4;
+            v[u][i] = (row < M && c < C) ? *reinterpret_cast<const float4*>(x + row * ldx + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
     }
-    const float m = group_sum<LPR>(s) / (float)C;
-    float ss = 0.f;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         const int c = (lane + i * LPR) * 4;
-        const float a = v[i].x - m, b = v[i].y - m, cc = v[i].z - m, d = v[i].w - m;
-        ss += c < C ? (a * a + b * b) + (cc * cc + d * d) : 0.f;
+        g[i] = c < C ? *reinterpret_cast<const float4*>(gamma + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        b[i] = c < C ? *reinterpret_cast<const float4*>(beta + c) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    const float rs = 1.f / sqrtf(group_sum<LPR>(ss) / (float)C + eps);
-    if (lane == 0) { mean[row] = m; rstd[row] = rs; }
-    float* __restrict__ yr = y + row * ldy;
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        const int c = (lane + i * LPR) * 4;
-        if (c < C) {
-            const float4 g = *reinterpret_cast<const float4*>(gamma + c);
-            const float4 b = *reinterpret_cast<const float4*>(beta + c);
-            *reinterpret_cast<float4*>(yr + c) =
-                make_float4((v[i].x - m) * rs * g.x + b.x, (v[i].y - m) * rs * g.y + b.y,
-                            (v[i].z - m) * rs * g.z + b.z, (v[i].w - m) * rs * g.w + b.w);
+    for (int u = 0; u < RU; ++u) {
+        const long long row = base + (long long)u * RPI;
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) s += (v[u][i].x + v[u][i].y) + (v[u][i].z + v[u][i].w);
+        const float m = group_sum<LPR>(s) / (float)C;
+        float ss = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = (lane + i * LPR) * 4;
+            const float a = v[u][i].x - m, bb = v[u][i].y - m, cc = v[u][i].z - m, d = v[u][i].w - m;
+            ss += c < C ? (a * a + bb * bb) + (cc * cc + d * d) : 0.f;
+        }
+        const float rs = 1.f / sqrtf(group_sum<LPR>(ss) / (float)C + eps);
+        if (row >= M) continue;          // after the lane reductions: every lane of the group takes part in them
+        if (lane == 0) { mean[row] = m; rstd[row] = rs; }
+        float* __restrict__ yr = y + row * ldy;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = (lane + i * LPR) * 4;
+            if (c < C)
+                *reinterpret_cast<float4*>(yr + c) =
+                    make_float4((v[u][i].x - m) * rs * g[i].x + b[i].x, (v[u][i].y - m) * rs * g[i].y + b[i].y,
+                                (v[u][i].z - m) * rs * g[i].z + b[i].z, (v[u][i].w - m) * rs * g[i].w + b[i].w);
         }
     }
 }
@@ -131,42 +162,58 @@ __global__ __launch_bounds__(256) void ln_bwd_dx_reg_kernel(const float* __restr
         dg[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         db[i] = dg[i];
     }
-    for (long long row = r0 + rg; row < r1; row += RPI) {
-        const float* __restrict__ xr = x + row * ldx;
-        const float* __restrict__ gr = dy + row * lddy;
-        const float m = mean[row], rs = rstd[row];
-        float4 xc[NV], a[NV];   // centred x, dy*gamma
-        float s1 = 0.f, s2 = 0.f;
+    constexpr int RU = 1;      // (two rows in flight measured slower here: 4.3 against 4.5 TB/s at 150 528 x 96)
+    for (long long row0 = r0 + rg; row0 < r1; row0 += RPI * RU) {
+        float4 vv[RU][NV], dd[RU][NV];
+        float mm[RU], rr[RU];
 #pragma unroll
-        for (int i = 0; i < NV; ++i) {
-            const int c = (lane + i * LPR) * 4;
-            float4 v = make_float4(m, m, m, m), d = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (c < C) {
-                v = *reinterpret_cast<const float4*>(xr + c);
-                d = *reinterpret_cast<const float4*>(gr + c);
-            }
-            xc[i] = make_float4(v.x - m, v.y - m, v.z - m, v.w - m);
-            a[i] = make_float4(d.x * g[i].x, d.y * g[i].y, d.z * g[i].z, d.w * g[i].w);
-            dg[i].x += d.x * xc[i].x * rs; dg[i].y += d.y * xc[i].y * rs;
-            dg[i].z += d.z * xc[i].z * rs; dg[i].w += d.w * xc[i].w * rs;
-            db[i].x += d.x; db[i].y += d.y; db[i].z += d.z; db[i].w += d.w;
-            s1 += (a[i].x + a[i].y) + (a[i].z + a[i].w);
-            s2 += (a[i].x * xc[i].x + a[i].y * xc[i].y) + (a[i].z * xc[i].z + a[i].w * xc[i].w);
-        }
-        s1 = group_sum<LPR>(s1) / (float)C;
-        s2 = group_sum<LPR>(s2) * rs / (float)C;
-        float* __restrict__ or_ = dx + row * lddx;
+        for (int u = 0; u < RU; ++u) {
+            const long long row = row0 + (long long)u * RPI < r1 ? row0 + (long long)u * RPI : row0;   // dead slot: the live row again
+            mm[u] = mean[row]; rr[u] = rstd[row];
 #pragma unroll
-        for (int i = 0; i < NV; ++i) {
-            const int c = (lane + i * LPR) * 4;
-            if (c < C) {
-                float4 o = make_float4(rs * (a[i].x - s1 - xc[i].x * rs * s2), rs * (a[i].y - s1 - xc[i].y * rs * s2),
-                                       rs * (a[i].z - s1 - xc[i].z * rs * s2), rs * (a[i].w - s1 - xc[i].w * rs * s2));
-                if (accumulate) {
-                    const float4 p = *reinterpret_cast<const float4*>(or_ + c);
-                    o.x += p.x; o.y += p.y; o.z += p.z; o.w += p.w;
+            for (int i = 0; i < NV; ++i) {
+                const int c = (lane + i * LPR) * 4;
+                vv[u][i] = make_float4(mm[u], mm[u], mm[u], mm[u]);
+                dd[u][i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (c < C) {
+                    vv[u][i] = *reinterpret_cast<const float4*>(x + row * ldx + c);
+                    dd[u][i] = *reinterpret_cast<const float4*>(dy + row * lddy + c);
                 }
-                *reinterpret_cast<float4*>(or_ + c) = o;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < RU; ++u) {
+            const long long row = row0 + (long long)u * RPI;
+            if (row >= r1) break;                  // uniform within the row group
+            const float m = mm[u], rs = rr[u];
+            float4 xc[NV], a[NV];   // centred x, dy*gamma
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const float4 v = vv[u][i], d = dd[u][i];
+                xc[i] = make_float4(v.x - m, v.y - m, v.z - m, v.w - m);
+                a[i] = make_float4(d.x * g[i].x, d.y * g[i].y, d.z * g[i].z, d.w * g[i].w);
+                dg[i].x += d.x * xc[i].x * rs; dg[i].y += d.y * xc[i].y * rs;
+                dg[i].z += d.z * xc[i].z * rs; dg[i].w += d.w * xc[i].w * rs;
+                db[i].x += d.x; db[i].y += d.y; db[i].z += d.z; db[i].w += d.w;
+                s1 += (a[i].x + a[i].y) + (a[i].z + a[i].w);
+                s2 += (a[i].x * xc[i].x + a[i].y * xc[i].y) + (a[i].z * xc[i].z + a[i].w * xc[i].w);
+            }
+            s1 = group_sum<LPR>(s1) / (float)C;
+            s2 = group_sum<LPR>(s2) * rs / (float)C;
+            float* __restrict__ or_ = dx + row * lddx;
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const int c = (lane + i * LPR) * 4;
+                if (c < C) {
+                    float4 o = make_float4(rs * (a[i].x - s1 - xc[i].x * rs * s2), rs * (a[i].y - s1 - xc[i].y * rs * s2),
+                                           rs * (a[i].z - s1 - xc[i].z * rs * s2), rs * (a[i].w - s1 - xc[i].w * rs * s2));
+                    if (accumulate) {
+                        const float4 p = *reinterpret_cast<const float4*>(or_ + c);
+                        o.x += p.x; o.y += p.y; o.z += p.z; o.w += p.w;
+                    }
+                    *reinterpret_cast<float4*>(or_ + c) = o;
+                }
             }
         }
     }
@@ -643,22 +690,44 @@ __global__ __launch_bounds__(256) void ln_head_fwd_kernel(const float* __restric
     if (act) { g = *reinterpret_cast<const float4*>(gamma + c); bt = *reinterpret_cast<const float4*>(beta + c); }
 #pragma unroll
     for (int n = 0; n < NC; ++n) wv[n] = act ? *reinterpret_cast<const float4*>(w + (long long)n * C + c) : make_float4(0.f, 0.f, 0.f, 0.f);
-    for (long long row = blockIdx.x * 8LL + rg; row < M; row += (long long)gridDim.x * 8) {
-        const float4 v = act ? *reinterpret_cast<const float4*>(x + row * ldx + c) : make_float4(0.f, 0.f, 0.f, 0.f);
-        const float m = group_sum<32>((v.x + v.y) + (v.z + v.w)) / (float)C;
-        const float a0 = v.x - m, a1 = v.y - m, a2 = v.z - m, a3 = v.w - m;
-        const float ss = act ? (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3) : 0.f;
-        const float rs = 1.f / sqrtf(group_sum<32>(ss) / (float)C + eps);
-        const float y0 = a0 * rs * g.x + bt.x, y1 = a1 * rs * g.y + bt.y, y2 = a2 * rs * g.z + bt.z, y3 = a3 * rs * g.w + bt.w;
-        float p[NC];
+    constexpr int RU = 4;      // rows of a row group in flight
+    __shared__ float sl[NC][8 * RU];
+    for (long long row0 = blockIdx.x * (8LL * RU) + rg; row0 - rg < M; row0 += (long long)gridDim.x * 8 * RU) {
+        float4 vv[RU];
 #pragma unroll
-        for (int n = 0; n < NC; ++n) p[n] = group_sum<32>((y0 * wv[n].x + y1 * wv[n].y) + (y2 * wv[n].z + y3 * wv[n].w));
-        if (lane == 0) {
-            mean[row] = m; rstd[row] = rs;
-            const long long b = row / S, pix = row - b * S;
-#pragma unroll
-            for (int n = 0; n < NC; ++n) y[b * y_bs + (long long)n * S + pix] = p[n];
+        for (int u = 0; u < RU; ++u) {
+            const long long row = row0 + 8LL * u;
+            vv[u] = (act && row < M) ? *reinterpret_cast<const float4*>(x + row * ldx + c) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
+#pragma unroll
+        for (int u = 0; u < RU; ++u) {
+            const long long row = row0 + 8LL * u;
+            const float4 v = vv[u];
+            const float m = group_sum<32>((v.x + v.y) + (v.z + v.w)) / (float)C;
+            const float a0 = v.x - m, a1 = v.y - m, a2 = v.z - m, a3 = v.w - m;
+            const float ss = act ? (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3) : 0.f;
+            const float rs = 1.f / sqrtf(group_sum<32>(ss) / (float)C + eps);
+            const float y0 = a0 * rs * g.x + bt.x, y1 = a1 * rs * g.y + bt.y, y2 = a2 * rs * g.z + bt.z, y3 = a3 * rs * g.w + bt.w;
+            float p[NC];
+#pragma unroll
+            for (int n = 0; n < NC; ++n) p[n] = group_sum<32>((y0 * wv[n].x + y1 * wv[n].y) + (y2 * wv[n].z + y3 * wv[n].w));
+            if (lane == 0) {
+                if (row < M) { mean[row] = m; rstd[row] = rs; }
+#pragma unroll
+                for (int n = 0; n < NC; ++n) sl[n][u * 8 + rg] = p[n];
+            }
+        }
+        // the block's 32 rows are consecutive pixels: one 128-byte piece per class instead of 4-byte stores from lane 0
+        __syncthreads();
+        if (threadIdx.x < NC * 32) {
+            const int n = threadIdx.x >> 5, j = threadIdx.x & 31;
+            const long long row = row0 - rg + (j >> 3) * 8LL + (j & 7);      // slot u*8 + rg  <->  row row0' + 8u + rg
+            if (row < M) {
+                const long long b = row / S, pix = row - b * S;
+                y[b * y_bs + (long long)n * S + pix] = sl[n][j];
+            }
+        }
+        __syncthreads();
     }
 }
 
@@ -687,35 +756,49 @@ __global__ __launch_bounds__(256) void ln_head_bwd_kernel(const float* __restric
     const long long r0 = blockIdx.x * rows_per_slab;
     long long r1 = r0 + rows_per_slab;
     if (r1 > M) r1 = M;
-    for (long long row = r0 + rg; row < r1; row += 8) {
-        const long long b = row / S, pix = row - b * S;
-        float d[NC];
+    constexpr int RU = 2;      // rows of a row group in flight (loads first, then the reductions)
+    for (long long row0 = r0 + rg; row0 < r1; row0 += 8 * RU) {
+        float d[RU][NC], mm[RU], rr[RU];
+        float4 vv[RU];
 #pragma unroll
-        for (int n = 0; n < NC; ++n) d[n] = dl[b * dl_bs + (long long)n * S + pix];
-        const float m = mean[row], rs = rstd[row];
-        const float4 v = act ? *reinterpret_cast<const float4*>(x + row * ldx + c) : make_float4(m, m, m, m);
-        const float h0 = (v.x - m) * rs, h1 = (v.y - m) * rs, h2 = (v.z - m) * rs, h3 = (v.w - m) * rs;      // xhat
-        const float y0 = h0 * g.x + bt.x, y1 = h1 * g.y + bt.y, y2 = h2 * g.z + bt.z, y3 = h3 * g.w + bt.w;
-        float e0 = 0.f, e1 = 0.f, e2 = 0.f, e3 = 0.f;                                                     // dy
+        for (int u = 0; u < RU; ++u) {
+            const long long row = row0 + 8 * u < r1 ? row0 + 8 * u : row0;      // a dead slot re-reads the live row
+            const long long b = row / S, pix = row - b * S;
 #pragma unroll
-        for (int n = 0; n < NC; ++n) {
-            e0 += d[n] * wv[n].x; e1 += d[n] * wv[n].y; e2 += d[n] * wv[n].z; e3 += d[n] * wv[n].w;
-            aw[n].x += d[n] * y0; aw[n].y += d[n] * y1; aw[n].z += d[n] * y2; aw[n].w += d[n] * y3;
+            for (int n = 0; n < NC; ++n) d[u][n] = dl[b * dl_bs + (long long)n * S + pix];
+            mm[u] = mean[row]; rr[u] = rstd[row];
+            vv[u] = act ? *reinterpret_cast<const float4*>(x + row * ldx + c) : make_float4(mm[u], mm[u], mm[u], mm[u]);
         }
-        dg.x += e0 * h0; dg.y += e1 * h1; dg.z += e2 * h2; dg.w += e3 * h3;
-        db.x += e0; db.y += e1; db.z += e2; db.w += e3;
-        const float q0 = e0 * g.x, q1 = e1 * g.y, q2 = e2 * g.z, q3 = e3 * g.w;
-        const float s1 = group_sum<32>((q0 + q1) + (q2 + q3)) / (float)C;
-        const float s2 = group_sum<32>((q0 * h0 + q1 * h1) + (q2 * h2 + q3 * h3)) / (float)C;
-        if (act) {
-            float4 o = make_float4(rs * (q0 - s1 - h0 * s2), rs * (q1 - s1 - h1 * s2), rs * (q2 - s1 - h2 * s2),
-                                   rs * (q3 - s1 - h3 * s2));
-            float* const op = dx + row * lddx + c;
-            if (accumulate) {
-                const float4 pv = *reinterpret_cast<const float4*>(op);
-                o.x += pv.x; o.y += pv.y; o.z += pv.z; o.w += pv.w;
+#pragma unroll
+        for (int u = 0; u < RU; ++u) {
+            const long long row = row0 + 8 * u;
+            if (row >= r1) break;          // uniform within the row group (all 32 lanes share the row)
+            const float m = mm[u], rs = rr[u];
+            const float4 v = vv[u];
+            const float h0 = (v.x - m) * rs, h1 = (v.y - m) * rs, h2 = (v.z - m) * rs, h3 = (v.w - m) * rs;      // xhat
+            const float y0 = h0 * g.x + bt.x, y1 = h1 * g.y + bt.y, y2 = h2 * g.z + bt.z, y3 = h3 * g.w + bt.w;
+            float e0 = 0.f, e1 = 0.f, e2 = 0.f, e3 = 0.f;                                                     // dy
+#pragma unroll
+            for (int n = 0; n < NC; ++n) {
+                const float dn = d[u][n];
+                e0 += dn * wv[n].x; e1 += dn * wv[n].y; e2 += dn * wv[n].z; e3 += dn * wv[n].w;
+                aw[n].x += dn * y0; aw[n].y += dn * y1; aw[n].z += dn * y2; aw[n].w += dn * y3;
             }
-            *reinterpret_cast<float4*>(op) = o;
+            dg.x += e0 * h0; dg.y += e1 * h1; dg.z += e2 * h2; dg.w += e3 * h3;
+            db.x += e0; db.y += e1; db.z += e2; db.w += e3;
+            const float q0 = e0 * g.x, q1 = e1 * g.y, q2 = e2 * g.z, q3 = e3 * g.w;
+            const float s1 = group_sum<32>((q0 + q1) + (q2 + q3)) / (float)C;
+            const float s2 = group_sum<32>((q0 * h0 + q1 * h1) + (q2 * h2 + q3 * h3)) / (float)C;
+            if (act) {
+                float4 o = make_float4(rs * (q0 - s1 - h0 * s2), rs * (q1 - s1 - h1 * s2), rs * (q2 - s1 - h2 * s2),
+                                       rs * (q3 - s1 - h3 * s2));
+                float* const op = dx + row * lddx + c;
+                if (accumulate) {
+                    const float4 pv = *reinterpret_cast<const float4*>(op);
+                    o.x += pv.x; o.y += pv.y; o.z += pv.z; o.w += pv.w;
+                }
+                *reinterpret_cast<float4*>(op) = o;
+            }
         }
     }
     // the 8 row groups of the block, fixed order, one quantity at a time through LDS
@@ -857,15 +940,15 @@ extern "C" int mis_layernorm_fwd(const float* x, long long ldx, float* y, long l
                                  hipStream_t stream) {
     if (!x || !y || !gamma || !beta || !mean || !rstd || M <= 0 || C <= 0) return MIS_ERR_ARG;
     if (C % 4 || ldx % 4 || ldy % 4 || !a16(x) || !a16(y) || !a16(gamma) || !a16(beta)) return MIS_ERR_UNSUPPORTED;
-#define MIS_LN_FWD(LPR, NV)                                                                                        \
-    hipLaunchKernelGGL((ln_fwd_reg_kernel<LPR, NV>), dim3((unsigned)mis_cdiv(M, 256 / LPR)), dim3(256), 0, stream, \
+#define MIS_LN_FWD(LPR, NV, RU)                                                                                             \
+    hipLaunchKernelGGL((ln_fwd_reg_kernel<LPR, NV, RU>), dim3((unsigned)mis_cdiv(M, (256 / LPR) * RU)), dim3(256), 0, stream, \
                        x, ldx, y, ldy, gamma, beta, mean, rstd, M, C, eps)
-    if (C <= 128) MIS_LN_FWD(32, 1);
-    else if (C <= 256) MIS_LN_FWD(64, 1);
-    else if (C <= 512) MIS_LN_FWD(64, 2);
-    else if (C <= 768) MIS_LN_FWD(64, 3);
-    else if (C <= 1024) MIS_LN_FWD(64, 4);
-    else if (C <= 1536) MIS_LN_FWD(64, 6);
+    if (C <= 128) MIS_LN_FWD(32, 1, 4);
+    else if (C <= 256) MIS_LN_FWD(64, 1, 4);
+    else if (C <= 512) MIS_LN_FWD(64, 2, 2);
+    else if (C <= 768) MIS_LN_FWD(64, 3, 2);
+    else if (C <= 1024) MIS_LN_FWD(64, 4, 1);
+    else if (C <= 1536) MIS_LN_FWD(64, 6, 1);
     else
         hipLaunchKernelGGL(ln_fwd_kernel, dim3((unsigned)mis_cdiv(M, 4)), dim3(256), 0, stream, x, ldx, y, ldy,
                            gamma, beta, mean, rstd, M, C, eps);
@@ -1072,7 +1155,7 @@ extern "C" int mis_ln_head_fwd(const float* x, long long ldx, const float* gamma
     if (!x || !gamma || !beta || !w || !mean || !rstd || !logits || B <= 0 || S <= 0 || C <= 0) return MIS_ERR_ARG;
     if (C % 4 || C > 128 || ldx % 4 || !a16(x) || !a16(gamma) || !a16(beta) || !a16(w)) return MIS_ERR_UNSUPPORTED;
     const long long M = (long long)B * S;
-    long long blocks = mis_cdiv(M, 8);
+    long long blocks = mis_cdiv(M, 32);
     if (blocks > 8192) blocks = 8192;
 #define MIS_LNH_F(N_) hipLaunchKernelGGL(ln_head_fwd_kernel<N_>, dim3((unsigned)blocks), dim3(256), 0, stream, x, ldx, gamma, \
                                          beta, w, mean, rstd, logits, y_bs, M, S, C, eps)
