@@ -29,6 +29,14 @@ def wrapped(A, B, C, bias=None, trans=False, accumulate=False):
     return orig(A, B, C, bias=bias, trans=trans, accumulate=accumulate)
 
 
+orig_dw = tops.gemm_dw
+
+
+def wrapped_dw(dy, x, dW, db, accumulate=False):
+    geo.append((tuple(dW.shape), dy.shape[0], True))
+    return orig_dw(dy, x, dW, db, accumulate=accumulate)
+
+
 orig_ex, orig_expand = tops.gemm_ex, tops.gemm_expand
 
 
@@ -47,6 +55,7 @@ def wrapped_expand(x, w, out, B, H, W, P, c):
 
 
 tops.gemm = wrapped
+tops.gemm_dw = wrapped_dw
 tops.gemm_ex = wrapped_ex
 tops.gemm_expand = wrapped_expand
 prof = []
