@@ -660,13 +660,31 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
     }
 }
 
-__global__ __launch_bounds__(256) void head_dw_final_kernel(const float* __restrict__ part, int blocks, int n,
-                                                            float* __restrict__ dw, int accumulate) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
+__global__ __launch_bounds__(1024) void head_dw_final_kernel(const float* __restrict__ part, int blocks, int n,
+                                                             float* __restrict__ dw, int accumulate) {
+    // block = 32 outputs x 32 partial lanes (coalesced 128-byte reads of the partial rows), double accumulators, fixed-order
+    // LDS tree: the fused LayerNorm + head backward leaves ~2 000 partial rows -- one thread per output summed them serially
+    // in 0.67 ms
+    __shared__ double red[1024];
+    const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
+    const int i = blockIdx.x * 32 + cl;
     double s = 0.0;
-    for (int b = 0; b < blocks; ++b) s += part[(long long)b * n + i];
-    dw[i] = accumulate ? dw[i] + (float)s : (float)s;
+    if (i < n) {
+        int b = sl;
+        for (; b + 96 < blocks; b += 128) {
+            const float p0 = part[(long long)b * n + i], p1 = part[(long long)(b + 32) * n + i];
+            const float p2 = part[(long long)(b + 64) * n + i], p3 = part[(long long)(b + 96) * n + i];
+            s += p0; s += p1; s += p2; s += p3;
+        }
+        for (; b < blocks; b += 32) s += part[(long long)b * n + i];
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (sl == 0 && i < n) {
+#pragma unroll
+        for (int k = 1; k < 32; ++k) s += red[k * 32 + cl];
+        dw[i] = accumulate ? dw[i] + (float)s : (float)s;
+    }
 }
 
 // ------------------------------------------------------------------ LayerNorm + output head in one pass
@@ -1140,7 +1158,7 @@ extern "C" int mis_head_bwd(const float* x, long long ldx, const float* w, const
         case 4: hipLaunchKernelGGL(head_bwd_kernel<4>, dim3(HEAD_BLOCKS), dim3(256), sh, stream, x, ldx, w, dlogits, dy_bs, dx, lddx, part, B, S, K); break;
         default: return MIS_ERR_UNSUPPORTED;
     }
-    hipLaunchKernelGGL(head_dw_final_kernel, dim3((NC * K + 255) / 256), dim3(256), 0, stream, part, HEAD_BLOCKS, NC * K,
+    hipLaunchKernelGGL(head_dw_final_kernel, dim3((NC * K + 31) / 32), dim3(1024), 0, stream, part, HEAD_BLOCKS, NC * K,
                        dw, accumulate_dw);
     return mis_launch_status();
 }
@@ -1202,7 +1220,7 @@ extern "C" int mis_ln_head_bwd(const float* x, long long ldx, const float* gamma
 #undef MIS_LNH_B
     hipLaunchKernelGGL(col_final_kernel, dim3((C + 31) / 32), dim3(1024), 0, stream, pln, slabs, C, dgamma, dbeta,
                        accumulate_params);
-    hipLaunchKernelGGL(head_dw_final_kernel, dim3((NC * C + 255) / 256), dim3(256), 0, stream, pw, slabs, NC * C, dw,
+    hipLaunchKernelGGL(head_dw_final_kernel, dim3((NC * C + 31) / 32), dim3(1024), 0, stream, pw, slabs, NC * C, dw,
                        accumulate_params);
     return mis_launch_status();
 }
