@@ -226,7 +226,7 @@ def test_step_matches_reference_golden_and_oracle(name):
         assert st["iter_num"] == it + 1
 
 
-@pytest.mark.parametrize("name", ["unet2d_64_dropoff", "unet3d_64_dropoff", "vnet_64_dropoff"])
+@pytest.mark.parametrize("name", ["unet2d_64_dropoff", "unet3d_64_dropoff", "vnet_64_dropoff", "swin_224_dropoff"])
 def test_three_consecutive_steps_track_the_oracle(name):
     """SURVEY s.8c: a short TRAJECTORY (three consecutive Mean-Teacher steps from the fixture state: SGD momentum, EMA
     teacher, BatchNorm running statistics and the poly learning rate all carried over) against the CPU oracle run here --
