@@ -271,6 +271,62 @@ __global__ __launch_bounds__(256) void upsample_bi2_fwd_kernel(const UpArgs a) {
     }
 }
 
+// The same up-sampling through LDS: a workgroup owns a 32 x 64 tile of the output; the 18 x 34 input cells it reads are
+// staged once, and the source index / weight of each of its 64 output columns and 32 output rows is computed once (the
+// register form above evaluates them per thread and picks neighbours with select chains: ~300 vector instructions per
+// 8 outputs, 2.6 TB/s at 24+24 images of 128^2 -> 256^2 x 16 channels).  A thread writes 8 consecutive outputs of one row
+// (two float4).  Same per-output arithmetic and association.  Wo % 4 == 0.
+constexpr int BF_TY = 32, BF_TX = 64, BF_RY = BF_TY / 2 + 2, BF_RX = BF_TX / 2 + 2, BF_LD = BF_RX + 1;
+
+__global__ __launch_bounds__(256) void upsample_bi2_fwd_lds_kernel(const UpArgs a) {
+    __shared__ float tile[BF_RY * BF_LD];
+    __shared__ int tx0[BF_TX], ty0[BF_TY];
+    __shared__ float tlx[BF_TX], tly[BF_TY];
+    const int oy0 = blockIdx.y * BF_TY, ox0 = blockIdx.x * BF_TX, nc = blockIdx.z;
+    const int n = nc / a.C, c = nc - n * a.C;
+    const int tid = threadIdx.x;
+    if (tid < BF_TX) {
+        const int ox = ox0 + tid < a.Wo ? ox0 + tid : a.Wo - 1;
+        int i0, i1;
+        float l;
+        src_index(ox, a.W, a.Wo, 1, i0, i1, l);
+        tx0[tid] = i0; tlx[tid] = l;
+    } else if (tid < BF_TX + BF_TY) {
+        const int k = tid - BF_TX;
+        const int oy = oy0 + k < a.Ho ? oy0 + k : a.Ho - 1;
+        int i0, i1;
+        float l;
+        src_index(oy, a.H, a.Ho, 1, i0, i1, l);
+        ty0[k] = i0; tly[k] = l;
+    }
+    __syncthreads();
+    const int ry0 = ty0[0], rx0 = tx0[0];
+    const float* __restrict__ xb = a.x + (long long)n * a.x_bs + (long long)c * a.H * a.W;
+    for (int i = tid; i < BF_RY * BF_RX; i += 256) {
+        const int r = i / BF_RX, q = i - r * BF_RX;
+        const int rr = ry0 + r < a.H ? ry0 + r : a.H - 1, cc = rx0 + q < a.W ? rx0 + q : a.W - 1;     // clamped: finite values
+        tile[r * BF_LD + q] = xb[(long long)rr * a.W + cc];                                         // under zero weights
+    }
+    __syncthreads();
+    const int oyl = tid >> 3, oxl = (tid & 7) * 8;
+    const int oy = oy0 + oyl;
+    if (oy >= a.Ho || ox0 + oxl >= a.Wo) return;
+    const int r0 = ty0[oyl] - ry0;
+    const float ly = tly[oyl], hy = 1.f - ly;
+    const float* __restrict__ t0 = tile + r0 * BF_LD;
+    const float* __restrict__ t1 = t0 + BF_LD;
+    float o[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int c0 = tx0[oxl + j] - rx0;
+        const float lx = tlx[oxl + j], hx = 1.f - lx;
+        o[j] = 1.f * (hy * (hx * t0[c0] + lx * t0[c0 + 1]) + ly * (hx * t1[c0] + lx * t1[c0 + 1]));
+    }
+    float* dst = a.y + (long long)n * a.y_bs + (long long)c * a.Ho * a.Wo + (long long)oy * a.Wo + ox0 + oxl;
+    *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
+    if (ox0 + oxl + 4 < a.Wo) *reinterpret_cast<float4*>(dst + 4) = make_float4(o[4], o[5], o[6], o[7]);
+}
+
 struct UpBwdArgs {
     const float* dy; long long dy_bs;
     float* dx; long long dx_bs;
@@ -638,58 +694,86 @@ __global__ __launch_bounds__(256) void upsample_tri2_bwd_lds_kernel(const UpBwdA
 // (6 shared candidate rows x 8 candidate columns).  Gather form: deterministic.
 constexpr int BI_TY = 16, BI_TX = 32, BI_RY = 2 * BI_TY + 4, BI_RX = 2 * BI_TX + 4, BI_LD = BI_RX + 1;
 
+// Separable form: the weights with which the candidate outputs 2x-2 .. 2x+5 reach input column x (and 2y-2 .. 2y+3 input row
+// y) are computed ONCE per column / row of the tile (one source-index evaluation per thread, tables in LDS), the staged
+// dy region is first reduced along x (36 rows x 32 columns, 8 multiply-adds each), then along y (6 each).  The first
+// version evaluated 14 source indices per thread and 108 multiply-adds per output pair: ~350 vector instructions per
+// pair, 1.7 TB/s at 24+24 images of 256^2 -> 128^2 x 16 channels.  Gather form, fixed order: deterministic.
 __global__ __launch_bounds__(256) void upsample_bi2_bwd_kernel(const UpBwdArgs a) {
     __shared__ float s[BI_RY * BI_LD];
+    __shared__ float hb[BI_RY * (BI_TX + 1)];
+    __shared__ float cw[BI_TX * 8], rw[BI_TY * 6];
     const int nc = blockIdx.z;
     const int n = nc / a.C, c = nc - n * a.C;
     const int y0 = blockIdx.y * BI_TY, x0 = blockIdx.x * BI_TX;
     const int S = a.H * a.W, So = a.Ho * a.Wo;
     const float* __restrict__ db = a.dy + (long long)n * a.dy_bs + (long long)c * So;
-    for (int e = threadIdx.x; e < BI_RY * BI_RX; e += 256) {
-        const int r = e / BI_RX, q = e - r * BI_RX;
-        const int oy = 2 * y0 - 2 + r, ox = 2 * x0 - 2 + q;
-        const bool in = oy >= 0 && oy < a.Ho && ox >= 0 && ox < a.Wo;
-        s[r * BI_LD + q] = in ? db[oy * a.Wo + ox] : 0.f;
+    {   // weight of output column 2x - 2 + k for input column x = x0 + (tid >> 3), k = tid & 7 (0 outside the image)
+        const int xl = threadIdx.x >> 3, k = threadIdx.x & 7;
+        const int x = x0 + xl, o = 2 * x - 2 + k;
+        float w = 0.f;
+        if (x < a.W && o >= 0 && o < a.Wo) {
+            int i0, i1;
+            float l1;
+            src_index(o, a.W, a.Wo, 1, i0, i1, l1);
+            w = (i0 == x ? 1.f - l1 : 0.f) + (i1 == x ? l1 : 0.f);
+        }
+        cw[threadIdx.x] = w;
+        if (threadIdx.x < BI_TY * 6) {
+            const int yl = threadIdx.x / 6, ky = threadIdx.x - yl * 6;
+            const int y = y0 + yl, oy = 2 * y - 2 + ky;
+            float wyv = 0.f;
+            if (y < a.H && oy >= 0 && oy < a.Ho) {
+                int i0, i1;
+                float l1;
+                src_index(oy, a.H, a.Ho, 1, i0, i1, l1);
+                wyv = (i0 == y ? 1.f - l1 : 0.f) + (i1 == y ? l1 : 0.f);
+            }
+            rw[threadIdx.x] = wyv;
+        }
+    }
+    if (!(a.dy_bs & 1) && !((uintptr_t)a.dy & 7)) {      // pairs of outputs: 2 x0 - 2 + 2 q is even, Wo is even (8-byte loads)
+        for (int e = threadIdx.x; e < BI_RY * (BI_RX / 2); e += 256) {
+            const int r = e / (BI_RX / 2), q = e - r * (BI_RX / 2);
+            const int oy = 2 * y0 - 2 + r, ox = 2 * x0 - 2 + 2 * q;
+            const bool in = oy >= 0 && oy < a.Ho && ox >= 0 && ox < a.Wo;
+            const float2 v = in ? *reinterpret_cast<const float2*>(db + oy * a.Wo + ox) : make_float2(0.f, 0.f);
+            s[r * BI_LD + 2 * q] = v.x;
+            s[r * BI_LD + 2 * q + 1] = v.y;
+        }
+    } else {
+        for (int e = threadIdx.x; e < BI_RY * BI_RX; e += 256) {
+            const int r = e / BI_RX, q = e - r * BI_RX;
+            const int oy = 2 * y0 - 2 + r, ox = 2 * x0 - 2 + q;
+            const bool in = oy >= 0 && oy < a.Ho && ox >= 0 && ox < a.Wo;
+            s[r * BI_LD + q] = in ? db[oy * a.Wo + ox] : 0.f;
+        }
+    }
+    __syncthreads();
+    {   // along x: hb[r][x] = sum_k cw[x][k] * s[r][2x + k]; thread = column x (its 8 weights in registers), rows r = tid >> 5 + 8 j
+        const int xl = threadIdx.x & 31;
+        float w[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) w[k] = cw[xl * 8 + k];
+        for (int r = threadIdx.x >> 5; r < BI_RY; r += 8) {
+            const float* __restrict__ row = s + r * BI_LD + 2 * xl;
+            float acc = 0.f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) acc += w[k] * row[k];
+            hb[r * (BI_TX + 1) + xl] = acc;
+        }
     }
     __syncthreads();
     const int ly = threadIdx.x >> 4, lx = (threadIdx.x & 15) * 2;
     const int y = y0 + ly, x = x0 + lx;
     if (y >= a.H || x >= a.W) return;
-    float wx0[8], wx1[8], wy[6];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        // one source-index evaluation per candidate column serves both cells of the pair
-        const int o = 2 * x - 2 + k;
-        const bool in = o >= 0 && o < a.Wo;
-        int i0, i1;
-        float l1;
-        src_index(in ? o : 0, a.W, a.Wo, 1, i0, i1, l1);
-        const float h1 = 1.f - l1;
-        wx0[k] = in ? (i0 == x ? h1 : 0.f) + (i1 == x ? l1 : 0.f) : 0.f;
-        wx1[k] = (in && x + 1 < a.W) ? (i0 == x + 1 ? h1 : 0.f) + (i1 == x + 1 ? l1 : 0.f) : 0.f;
-    }
-#pragma unroll
-    for (int k = 0; k < 6; ++k) {
-        const int o = 2 * y - 2 + k;
-        const bool in = o >= 0 && o < a.Ho;
-        int i0, i1;
-        float l1;
-        src_index(in ? o : 0, a.H, a.Ho, 1, i0, i1, l1);
-        wy[k] = in ? (i0 == y ? 1.f - l1 : 0.f) + (i1 == y ? l1 : 0.f) : 0.f;
-    }
     float g0 = 0.f, g1 = 0.f;
 #pragma unroll
     for (int ky = 0; ky < 6; ++ky) {
-        const float* __restrict__ row = s + (2 * ly + ky) * BI_LD + 2 * lx;
-        float r0 = 0.f, r1 = 0.f;
-#pragma unroll
-        for (int kx = 0; kx < 8; ++kx) {
-            const float v = row[kx];
-            r0 += wx0[kx] * v;
-            r1 += wx1[kx] * v;
-        }
-        g0 += wy[ky] * r0;
-        g1 += wy[ky] * r1;
+        const float wv = rw[ly * 6 + ky];
+        const float* __restrict__ hr = hb + (2 * ly + ky) * (BI_TX + 1) + lx;
+        g0 += wv * hr[0];
+        g1 += wv * hr[1];
     }
     float* p = a.dx + (long long)n * a.dx_bs + (long long)c * S + y * a.W + x;
     p[0] = a.accumulate ? p[0] + g0 : g0;
@@ -744,12 +828,17 @@ extern "C" int mis_upsample2_fwd(const float* x, long long x_bs, float* y, long 
     // z-marching form, 4 input planes per thread (measured 300 -> 237 us at 48^3 -> 96^3 x 32 channels x 8; 8 planes per
     // thread and an x-pair per thread with float4 stores are slower: 242 / 276 us); MIS_TRI2_FWD_Z=0: the one-cell kernel
     static const int zmarch = getenv("MIS_TRI2_FWD_Z") ? atoi(getenv("MIS_TRI2_FWD_Z")) : 4;
+    static const int bi2_lds = getenv("MIS_BI2_FWD_LDS") ? atoi(getenv("MIS_BI2_FWD_LDS")) : 1;
     if (!a.align && D > 1 && So < (1LL << 31) && zmarch >= 8 && D >= 8 && (long long)H * W * N * C >= 256 * 512)
         hipLaunchKernelGGL(upsample_tri2_fwd_z_kernel<8>, dim3((H * W + 255) / 256, (D + 7) / 8, N * C), dim3(256), 0, stream, a);
     else if (!a.align && D > 1 && So < (1LL << 31) && zmarch >= 4 && D >= 4 && (long long)H * W * N * C >= 256 * 256)
         hipLaunchKernelGGL(upsample_tri2_fwd_z_kernel<4>, dim3((H * W + 255) / 256, (D + 3) / 4, N * C), dim3(256), 0, stream, a);
     else if (!a.align && D > 1 && So < (1LL << 31))
         hipLaunchKernelGGL(upsample_tri2_fwd_kernel, dim3((H * W + 255) / 256, D, N * C), dim3(256), 0, stream, a);
+    else if (a.align && D == 1 && a.Wo % 4 == 0 && H > 1 && W > 1 && !(y_bs & 3) && !((uintptr_t)y & 15) && bi2_lds &&
+             (long long)N * C <= 65535)
+        hipLaunchKernelGGL(upsample_bi2_fwd_lds_kernel, dim3((a.Wo + BF_TX - 1) / BF_TX, (a.Ho + BF_TY - 1) / BF_TY, N * C),
+                           dim3(256), 0, stream, a);
     else if (a.align && D == 1 && a.Wo % 4 == 0 && H > 1 && W > 1 && !(y_bs & 3) && !((uintptr_t)y & 15))
         hipLaunchKernelGGL(upsample_bi2_fwd_kernel, dim3(((a.Ho / 2) * (a.Wo / 4) + 255) / 256, 1, N * C), dim3(256), 0,
                            stream, a);
