@@ -752,14 +752,16 @@ __global__ __launch_bounds__(256) void upsample_bi2_bwd_kernel(const UpBwdArgs a
     __syncthreads();
     {   // along x: hb[r][x] = sum_k cw[x][k] * s[r][2x + k]; thread = column x (its 8 weights in registers), rows r = tid >> 5 + 8 j
         const int xl = threadIdx.x & 31;
-        float w[8];
+        // candidates 2x-2 .. 2x+3 only: 2x+4 and 2x+5 never reach column x (their table entries are 0) and lie outside
+        // the staged region for the tile's last column -- 0 * (uninitialised LDS) is a NaN
+        float w[6];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) w[k] = cw[xl * 8 + k];
+        for (int k = 0; k < 6; ++k) w[k] = cw[xl * 8 + k];
         for (int r = threadIdx.x >> 5; r < BI_RY; r += 8) {
             const float* __restrict__ row = s + r * BI_LD + 2 * xl;
             float acc = 0.f;
 #pragma unroll
-            for (int k = 0; k < 8; ++k) acc += w[k] * row[k];
+            for (int k = 0; k < 6; ++k) acc += w[k] * row[k];
             hb[r * (BI_TX + 1) + xl] = acc;
         }
     }
