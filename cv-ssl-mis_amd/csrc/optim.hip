@@ -215,3 +215,24 @@ extern "C" int mis_argmax_channels(const float* x, long long x_bs, unsigned char
 }
 
 extern "C" int mis_abi_version(void) { return 1; }
+
+// Test support: fill the LDS of every CU with NaNs.  LDS keeps what the previous kernel left there, so a kernel that reads a
+// cell it never wrote (typically under a zero weight: 0 * NaN) is correct or not depending on what ran before it; the GPU
+// tests call this in front of every test to make such reads fail deterministically.  Not used by the product path.
+namespace {
+extern __shared__ __attribute__((aligned(16))) float mis_poison_lds[];
+__global__ __launch_bounds__(1024) void poison_lds_kernel(int floats, float* sink) {
+    for (int i = threadIdx.x; i < floats; i += 1024) mis_poison_lds[i] = __builtin_nanf("");
+    __syncthreads();
+    if (sink && mis_poison_lds[threadIdx.x % floats] == 1.f) sink[0] = 1.f;      // keeps the stores
+}
+}  // namespace
+
+extern "C" int mis_debug_poison_lds(float* sink, hipStream_t stream) {
+    constexpr int BYTES = 160 * 1024;
+    static std::atomic<unsigned long long> done{0};
+    if (mis_set_lds_attr(reinterpret_cast<const void*>(&poison_lds_kernel), BYTES, done) != MIS_OK) return MIS_ERR_LAUNCH;
+    // one workgroup holds a CU's whole LDS: 2048 of them pass over all 256 CUs several times
+    hipLaunchKernelGGL(poison_lds_kernel, dim3(2048), dim3(1024), BYTES, stream, BYTES / 4, sink);
+    return mis_launch_status();
+}

@@ -594,6 +594,10 @@ int mis_win3d_attn_bwd(const float* qkv, long long ldq, const float* out, const 
                        int accumulate_table, int BW, int nW, int n, int nH, void* workspace, long long workspace_bytes,
                        mis_stream_t stream);
 
+/* Test support (never on the product path): fills the LDS of every CU with NaNs so that a kernel reading LDS it did not write
+ * fails deterministically instead of depending on the previous launch.  sink: any device float (or NULL). */
+int mis_debug_poison_lds(float* sink, mis_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -378,7 +378,8 @@ def test_maxpool3d_ties_and_strided_views():
 @pytest.mark.parametrize("shape,align", [((2, 8, 1, 16, 16), True), ((1, 4, 1, 8, 24), True),
                                          ((2, 4, 6, 6, 6), False), ((1, 3, 8, 4, 12), False),
                                          ((1, 2, 5, 3, 7), False), ((2, 1, 1, 5, 4), False), ((1, 2, 2, 1, 1), False),
-                                         ((1, 2, 12, 12, 12), False), ((1, 2, 1, 5, 7), True), ((2, 3, 1, 1, 2), True)])
+                                         ((1, 2, 12, 12, 12), False), ((1, 2, 1, 5, 7), True), ((2, 3, 1, 1, 2), True),
+                                         ((2, 3, 1, 32, 64), True), ((1, 2, 1, 48, 40), True)])     # full / ragged LDS tiles
 def test_upsample(shape, align):
     ops = _ops()
     x = _rand(*shape, seed=14)
