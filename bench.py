@@ -107,14 +107,55 @@ def _free_port():
         return s.getsockname()[1]
 
 
+def _pg_timeout():
+    """Explicit process-group timeout (default 600 s; MIS_PG_TIMEOUT_S): a rank that never reaches a collective aborts
+    the run with RCCL's watchdog message instead of hanging the node until the driver's limit."""
+    import datetime
+    return datetime.timedelta(seconds=int(os.environ.get("MIS_PG_TIMEOUT_S", "600")))
+
+
+def nccl_debug_env(env):
+    """NCCL_DEBUG=WARN into per-process files (unless the caller configured RCCL's logging): a failed multi-GPU run
+    reports RCCL's own warnings in its JSON line."""
+    if "NCCL_DEBUG" in env or "NCCL_DEBUG_FILE" in env:
+        return None
+    import tempfile
+    d = tempfile.mkdtemp(prefix="mis_bench_nccl_")
+    env["NCCL_DEBUG"] = "WARN"
+    env["NCCL_DEBUG_FILE"] = os.path.join(d, "nccl.%h.%p.log")
+    return d
+
+
+def collect_nccl_warnings(log_dir, limit=40):
+    lines = []
+    if log_dir and os.path.isdir(log_dir):
+        for fn in sorted(os.listdir(log_dir)):
+            try:
+                with open(os.path.join(log_dir, fn), errors="replace") as f:
+                    lines += [f"{fn}: {ln.rstrip()}" for ln in f if ln.strip()]
+            except OSError:
+                pass
+    return lines[-limit:]
+
+
 def self_launch(argv, gpus):
-    """Re-execute this script under torch.distributed.run with one rank per GPU; forward rank 0's output."""
+    """Re-execute this script under torch.distributed.run with one rank per GPU; forward rank 0's output.  A failed run
+    still prints ONE JSON line: the exit status, the tail of the ranks' stderr and RCCL's warnings."""
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")    # dmabuf IPC: RCCL across processes needs it on this host
     env.setdefault("OMP_NUM_THREADS", "8")
+    env["MIS_BENCH_LAUNCHED"] = "1"          # the ranks leave the failure report to this process
+    log_dir = nccl_debug_env(env)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}",
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + argv
-    return subprocess.call(cmd, env=env)
+    p = subprocess.run(cmd, env=env, stderr=subprocess.PIPE, text=True, errors="replace")
+    sys.stderr.write(p.stderr)
+    if p.returncode != 0:
+        print(json.dumps({"metric": "training images-or-volumes/sec/node (Mean-Teacher step)", "value": None,
+                          "n_gpus": gpus, "error": f"multi-GPU run failed with exit status {p.returncode}",
+                          "stderr_tail": p.stderr.strip().splitlines()[-25:],
+                          "nccl_warnings": collect_nccl_warnings(log_dir)}), flush=True)
+    return p.returncode
 
 
 # ------------------------------------------------------------------------------------------------ workloads
@@ -265,7 +306,8 @@ def run_workload(name, args, rank, world, kernel_events=True):
             d[2] += 1
         def reduction(k):
             """Winograd F(2x2x2, 3x3x3) / F(2x2, 3x3): 64 (16) multiplies per 2x2x2 (2x2) outputs instead of 216 (36)."""
-            return 3.375 if k.startswith("wino_fwd_kernel") else 2.25 if k.startswith("wino2d_fwd_kernel") else 1.0
+            return (3.375 if k.startswith(("wino_fwd_kernel", "wino_wgrad_kernel")) else
+                    2.25 if k.startswith(("wino2d_fwd_kernel", "wino2d_wgrad_kernel")) else 1.0)
 
         fam_alg = sum(d[0] for d in per.values())
         fam_exec = sum(d[0] / reduction(k) for k, d in per.items())
@@ -274,16 +316,20 @@ def run_workload(name, args, rank, world, kernel_events=True):
         red = reduction(dom)
         alg_tf = per[dom][0] / per[dom][1] / 1e12           # direct-convolution (algorithmic) flops over time
         achieved = alg_tf / red                             # flops the matrix pipe executes over time: <= peak
-        # HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this same
-        # command (FETCH_SIZE / WRITE_SIZE in separate runs, scripts/pmc_traffic.py); null if not collected
-        traffic, traffic_src = None, None
-        for rnd in ("r03", "r02", "r01"):
+        # HBM bytes per launch need the PMC counters (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes,
+        # scripts/pmc_traffic.py): they cannot be read from inside this process, so `traffic` of THIS run is null; the
+        # figure of the last committed PMC pass of this same command is quoted beside it, labelled as such
+        traffic_prof = None
+        for rnd in ("r04", "r03", "r02", "r01"):
             tfile = os.path.join(ROOT, "profiles", f"{rnd}_{name}_pmc_traffic.json")
             if os.path.exists(tfile):
                 with open(tfile) as f:
                     ent = json.load(f)["kernels"].get(dom)
                 if ent:
-                    traffic, traffic_src = ent["hbm_bytes_per_launch"], os.path.relpath(tfile, ROOT)
+                    traffic_prof = dict(hbm_bytes_per_launch=ent["hbm_bytes_per_launch"],
+                                        source=os.path.relpath(tfile, ROOT),
+                                        note="a separate rocprofv3 PMC pass of this command, committed under profiles/; "
+                                             "NOT a measurement of this run")
                     break
         # `achieved` / `frac` = EXECUTED matrix-pipe flops (algorithmic flops / winograd_reduction) over the kernel's
         # summed launch durations, against the fp32 MFMA peak: a fraction of the pipe, <= 1 by construction and the
@@ -292,12 +338,13 @@ def run_workload(name, args, rank, world, kernel_events=True):
         roofline = dict(bound="mfma", kernel=dom, achieved=round(achieved, 3), peak=PEAK_FP32_MFMA_TFLOPS,
                         unit="TFLOP/s", frac=round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
                         algorithmic_tflops=round(alg_tf, 3), winograd_reduction=red,
-                        traffic=traffic, traffic_unit="HBM bytes per launch (PMC)", traffic_source=traffic_src,
+                        traffic=None, traffic_from_profiles=traffic_prof,
                         launches=per[dom][2], avg_launch_ms=round(per[dom][1] / per[dom][2] * 1e3, 4),
                         algorithmic_flops_per_launch_avg=per[dom][0] / per[dom][2],
                         executed_flops_per_launch_avg=per[dom][0] / per[dom][2] / red,
                         family=dict(kernel="all event-timed MFMA launches (wino*_fwd_kernel<*> / conv_fwd_kernel<*> forward + "
-                                           "data gradient; gemm_nt_kernel<*> / gemm_tn_kernel<*> for SwinUnet)",
+                                           "data gradient, wino*_wgrad_kernel<*> / conv_wgrad_kernel<*> weight gradient; "
+                                           "gemm_nt_kernel<*> / gemm_tn_kernel<*> for SwinUnet)",
                                     achieved=round(fam_exec / fam_time / 1e12, 3),
                                     frac=round(fam_exec / fam_time / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
                                     algorithmic_tflops=round(fam_alg / fam_time / 1e12, 3),
@@ -308,11 +355,18 @@ def run_workload(name, args, rank, world, kernel_events=True):
         roofline["serial_ms_per_step"] = round(serial_dt / serial_steps * 1e3, 3)
     step_s = dt / args.steps
     step_frac = wl["step_gflop"] * 1e9 / step_s / (PEAK_FP32_MFMA_TFLOPS * 1e12)
+    exec_frac = None
     if roofline is not None:
         roofline["step_algorithmic_flops"] = wl["step_gflop"] * 1e9
         roofline["step_algorithmic_flop_frac"] = round(step_frac, 4)      # direct-convolution flops: may exceed 1
+        # the flops the matrix pipe EXECUTES per step (every event-timed launch of the serial region, Winograd launches
+        # at 1/3.375 resp. 1/2.25 of their direct-convolution count) over the TIMED region's step time: <= 1
+        exec_frac = fam_exec / serial_steps / step_s / (PEAK_FP32_MFMA_TFLOPS * 1e12)
+        roofline["executed_step_flops"] = fam_exec / serial_steps
+        roofline["executed_step_frac"] = round(exec_frac, 4)
     res = dict(value=round(shape[0] * world * args.steps / dt, 3), unit=UNIT.get(name, "images/s"),
-               ms_per_step=round(step_s * 1e3, 3), step_flop_frac=round(step_frac, 4), roofline=roofline,
+               ms_per_step=round(step_s * 1e3, 3), step_flop_frac=round(step_frac, 4),
+               executed_step_frac=None if exec_frac is None else round(exec_frac, 4), roofline=roofline,
                losses={k: round(v, 6) for k, v in losses.items()},
                per_rank_ms_per_step=[round(t / args.steps * 1e3, 3) for t in per_rank], distributed=dist_info)
     del tr
@@ -500,14 +554,18 @@ def main():
     backend = None
     if not args.stub:
         torch.cuda.set_device(local_rank)
+    nccl_logs = None
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if not args.stub and "MIS_BENCH_LAUNCHED" not in os.environ:
+            nccl_logs = nccl_debug_env(os.environ)       # launched by torchrun directly: RCCL's warnings on failure
         if args.stub:
             backend = "gloo"
-            torch.distributed.init_process_group("gloo")
+            torch.distributed.init_process_group("gloo", timeout=_pg_timeout())
         else:
             backend = "nccl (RCCL)"
-            torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", local_rank),
+                                                 timeout=_pg_timeout())
 
     two_stream = wgrad_stream = False
     if not args.stub:
@@ -517,7 +575,14 @@ def main():
         two_stream, wgrad_stream = _step.TWO_STREAM, _plan.WGRAD_STREAM
 
     wl = WORKLOADS[args.workload]
-    res = run_workload(args.workload, args, rank, world, kernel_events=not args.no_kernel_events)
+    try:
+        res = run_workload(args.workload, args, rank, world, kernel_events=not args.no_kernel_events)
+    except BaseException as e:
+        if world > 1 and rank == 0 and "MIS_BENCH_LAUNCHED" not in os.environ:
+            print(json.dumps({"metric": "training images-or-volumes/sec/node (Mean-Teacher step)", "value": None,
+                              "n_gpus": world, "error": f"{type(e).__name__}: {e}"[:2000],
+                              "nccl_warnings": collect_nccl_warnings(nccl_logs)}), flush=True)
+        raise
 
     if rank == 0:
         out = {
@@ -549,10 +614,24 @@ def main():
             r = run_workload(name, oargs, rank, world, kernel_events=not args.no_kernel_events)
             rf = r["roofline"] or {}
             others[name] = dict(workload=WORKLOADS[name]["config"], value=r["value"], unit=r["unit"],
-                                ms_per_step=r["ms_per_step"], steps=oargs.steps, flop_frac=r["step_flop_frac"],
+                                ms_per_step=r["ms_per_step"], steps=oargs.steps,
+                                executed_step_frac=r["executed_step_frac"],          # matrix-pipe flops executed: <= 1
+                                algorithmic_step_flop_frac=r["step_flop_frac"],      # direct-convolution flops: may exceed 1
                                 dominant_kernel=rf.get("kernel"), dominant_kernel_frac=rf.get("frac"),
                                 dominant_kernel_algorithmic_tflops=rf.get("algorithmic_tflops"))
         out["others"] = others
+    if world > 1 and not args.no_others and args.workload == "unet3d":
+        # config 5 (cross teaching, the BASELINE configuration that is DEFINED on 8 GPUs: 16+16 images per GPU) behind the
+        # default workload: two students, two gradient bucketers, the second student's backward on a side stream
+        import copy
+        oargs = copy.copy(args)
+        oargs.steps, oargs.warmup = max(5, args.steps // 2), min(args.warmup, 2)
+        r = run_workload("cross", oargs, rank, world, kernel_events=False)
+        if rank == 0:
+            out["others"] = {"cross": dict(workload=WORKLOADS["cross"]["config"], value=r["value"], unit=r["unit"],
+                                           ms_per_step=r["ms_per_step"], steps=oargs.steps, n_gpus=world,
+                                           per_rank_ms_per_step=r["per_rank_ms_per_step"],
+                                           distributed=r["distributed"])}
     if rank == 0:
         if world == 1 and not args.stub and not args.no_cpu_baseline and wl["cpu_sample"] is not None:
             out["cpu_baseline"] = cpu_baseline(args.workload, wl)

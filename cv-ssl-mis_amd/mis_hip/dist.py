@@ -16,6 +16,10 @@ import torch
 import torch.distributed as dist
 
 
+def initialized():
+    return dist.is_available() and dist.is_initialized()
+
+
 def world_size(group=None):
     if dist.is_available() and dist.is_initialized():
         return dist.get_world_size(group)
@@ -49,13 +53,28 @@ class GradBucketer:
     max(16 MiB, a quarter of the buffer): 2 (unet_3D, 23.5 MB) to 4 (SwinUnet, 108.7 MB; UNETR, 371 MB) collectives per
     step plus the small tail bucket below.  MIS_BUCKET_MB overrides."""
 
-    def __init__(self, flat_grad, group=None, bucket_bytes=None):
+    def __init__(self, flat_grad, group=None, bucket_bytes=None, defer_tail=False):
         if bucket_bytes is None:
             if "MIS_BUCKET_MB" in os.environ:
                 bucket_bytes = int(float(os.environ["MIS_BUCKET_MB"]) * (1 << 20))
             else:       # at most ~4 collectives (+ the small tail) per model and step
                 bucket_bytes = max(16 << 20, -(-flat_grad.numel() * flat_grad.element_size() // 4))
+        bucket_bytes = int(bucket_bytes)
+        if world_size(group) > 1:
+            # the cut points must be the same on every rank (MIS_BUCKET_MB is a per-process environment variable): ranks
+            # that disagree would issue collectives of different sizes and counts -- a hang or silently wrong sums
+            probe = torch.tensor([bucket_bytes, -bucket_bytes, flat_grad.numel(), -flat_grad.numel()],
+                                 dtype=torch.int64, device=flat_grad.device)
+            dist.all_reduce(probe, op=dist.ReduceOp.MAX, group=group)
+            hi_b, lo_b, hi_n, lo_n = (int(v) for v in probe.cpu())
+            if hi_b != -lo_b or hi_n != -lo_n:
+                raise RuntimeError(f"GradBucketer: ranks disagree on the bucket layout (bucket bytes {-lo_b}..{hi_b}, "
+                                   f"gradient elements {-lo_n}..{hi_n}); set MIS_BUCKET_MB identically on every rank")
         self.flat, self.group = flat_grad, group
+        # defer_tail: ``advance`` never issues the bucket at offset 0 (complete only when the backward is); ``finish``
+        # does.  For a backward whose collectives are ENQUEUED before another network's (cross teaching: the side-stream
+        # student): the in-order RCCL stream would otherwise hold the other network's early buckets behind this tail
+        self.defer_tail = bool(defer_tail)
         n, per = flat_grad.numel(), max(1, bucket_bytes // flat_grad.element_size())
         # cut from the end (the part that finishes first); the first bucket takes the remainder
         cuts = list(range(n, 0, -per)) + [0]
@@ -71,21 +90,27 @@ class GradBucketer:
     def begin(self):
         self._next, self._works = 0, []
 
+    def _ready(self, lo, final=False):
+        if self._next >= len(self.buckets):
+            return False
+        b_lo = self.buckets[self._next][0]
+        return b_lo >= lo and (final or not (self.defer_tail and b_lo == 0))
+
     def would_issue(self, lo):
         """True when ``advance(lo)`` would start an all-reduce (Plan.backward skips the stream hand-off otherwise)."""
-        return self._next < len(self.buckets) and self.buckets[self._next][0] >= lo
+        return self._ready(lo)
 
-    def advance(self, lo):
+    def advance(self, lo, final=False):
         """All gradient elements at offsets >= ``lo`` are final (on the CURRENT stream: the all-reduce orders itself
         behind it)."""
-        while self._next < len(self.buckets) and self.buckets[self._next][0] >= lo:
+        while self._ready(lo, final):
             b_lo, b_hi = self.buckets[self._next]
             self._works.append(dist.all_reduce(self.flat[b_lo:b_hi], op=dist.ReduceOp.SUM, group=self.group,
                                                async_op=True))
             self._next += 1
 
     def finish(self):
-        self.advance(0)
+        self.advance(0, final=True)
         for w in self._works:
             w.wait()
         self._works = []

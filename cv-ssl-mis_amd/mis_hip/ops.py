@@ -124,6 +124,28 @@ def conv_k2s2_wgrad_eligible(cf, cc, coarse):
     return K2S2 and bool(_l.load().mis_conv_k2s2_wgrad_eligible(int(cf), int(cc), *[int(v) for v in coarse]))
 
 
+# When set to a set(), the ops below add a short tag of the path they dispatched (tests assert that the full-batch
+# instantiations -- in-place kernel-2 / stride-2 kernels, Winograd weight-gradient variants -- are the ones that ran).
+DISPATCH = None
+
+
+def _tag(name):
+    if DISPATCH is not None:
+        DISPATCH.add(name)
+
+
+def conv_k2s2_up_output_ok(y):
+    """mis_conv_k2s2_up stores float2 pairs: the fine output (possibly a channel-slice view) must start on 8 bytes with an
+    even batch stride (the kernel returns MIS_ERR_UNSUPPORTED otherwise)."""
+    return y.data_ptr() % 8 == 0 and _geom(y)[6] % 2 == 0
+
+
+def conv_k2s2_wgrad_operands_ok(coarse, fine):
+    """mis_conv_k2s2_wgrad reads float4 rows: both operands on 16 bytes, batch strides multiples of 4 floats."""
+    return (coarse.data_ptr() % 16 == 0 and fine.data_ptr() % 16 == 0 and _geom(coarse)[6] % 4 == 0
+            and _geom(fine)[6] % 4 == 0)
+
+
 def conv_k2s2_wgrad(coarse, fine, dw, accumulate=False):
     """dw[cc][cf*8 + tap] (+)= sum coarse[n][cc][v] * fine[n][cf][2v + tap] (mis_conv_k2s2_wgrad): the parameter gradient of
     Conv3d(k2s2) (coarse = dy, fine = x) and of ConvTranspose3d(k2s2) (coarse = x, fine = dy), in the parameter's layout."""
@@ -132,6 +154,7 @@ def conv_k2s2_wgrad(coarse, fine, dw, accumulate=False):
     _, CF, _, _, _, _, fbs = _geom(fine)
     assert dw.is_contiguous() and dw.numel() == CC * CF * 8
     ws = scratch(L.mis_conv_k2s2_wgrad_workspace_bytes(CF, CC), "wgrad")
+    _tag(f"k2s2_wgrad:{CF}x{CC}@{Do}")
     _l.check(L.mis_conv_k2s2_wgrad(_l.ptr(coarse), cbs, _l.ptr(fine), fbs, _l.ptr(dw), N, CF, CC, Do, Ho, Wo,
                                    int(accumulate), _l.ptr(ws), ws.numel(), _l.stream_ptr()), "mis_conv_k2s2_wgrad")
 
@@ -142,6 +165,7 @@ def conv_k2s2_down(x, w, bias, y, accumulate=False):
     N, Cin, _, _, _, _, xbs = _geom(x)
     _, Cout, Do, Ho, Wo, _, ybs = _geom(y)
     assert w.is_contiguous() and w.numel() == Cin * Cout * 8
+    _tag(f"k2s2_down:{Cin}x{Cout}@{Do}")
     _l.check(L.mis_conv_k2s2_down(_l.ptr(x), xbs, _l.ptr(w), _l.ptr(bias), _l.ptr(y), ybs, N, Cin, Cout, Do, Ho, Wo,
                                   int(accumulate), _l.stream_ptr()), "mis_conv_k2s2_down")
 
@@ -152,6 +176,7 @@ def conv_k2s2_up(x, w, bias, y, accumulate=False):
     N, Cin, Do, Ho, Wo, _, xbs = _geom(x)
     _, Cout, _, _, _, _, ybs = _geom(y)
     assert w.is_contiguous() and w.numel() == Cin * Cout * 8
+    _tag(f"k2s2_up:{Cin}x{Cout}@{Do}")
     _l.check(L.mis_conv_k2s2_up(_l.ptr(x), xbs, _l.ptr(w), _l.ptr(bias), _l.ptr(y), ybs, N, Cin, Cout, Do, Ho, Wo,
                                 int(accumulate), _l.stream_ptr()), "mis_conv_k2s2_up")
 
@@ -311,6 +336,17 @@ def conv_wgrad(x, dy, dw, ksize, accumulate=False):
     _, Cout, _, _, _, _, dbs = _geom(dy)
     kd, kh, kw = _ksize(ksize)
     assert dw.is_contiguous() and dw.numel() == Cout * Cin * kd * kh * kw
+    prof = PROFILE
+    if prof is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    name = _conv_wgrad_launch(L, x, dy, dw, N, Cin, Cout, D, H, W, xbs, dbs, kd, kh, kw, accumulate)
+    if prof is not None:       # bench.py's live roofline: the weight gradients count towards the executed step flops
+        e1.record()
+        prof.append((name, 2.0 * N * Cout * Cin * kd * kh * kw * S, e0, e1))
+
+
+def _conv_wgrad_launch(L, x, dy, dw, N, Cin, Cout, D, H, W, xbs, dbs, kd, kh, kw, accumulate):
     # 3x3x3 on large volumes: the Winograd F(2^3, 3^3) form (conv_wino_wgrad.hip), 3.375x fewer matrix-pipe flops
     wino = int(L.mis_conv3d_wino_wgrad_select(N, Cin, Cout, D, H, W)) if ((WINO & 1) and (kd, kh, kw) == (3, 3, 3)) else -1
     if wino >= 0 and xbs % 4 == 0 and dbs % 4 == 0 and x.data_ptr() % 16 == 0 and dy.data_ptr() % 16 == 0:
@@ -318,9 +354,10 @@ def conv_wgrad(x, dy, dw, ksize, accumulate=False):
         if nb < 0:
             _l.check(nb, "mis_conv3d_wino_wgrad_workspace_bytes")
         ws = scratch(nb, "wgrad")
+        _tag(f"wino_wgrad:v{wino}@{W}")
         _l.check(L.mis_conv3d_wino_wgrad(_l.ptr(x), xbs, _l.ptr(dy), dbs, _l.ptr(dw), _l.ptr(ws), ws.numel(), N, Cin,
                                          Cout, D, H, W, int(accumulate), wino, _l.stream_ptr()), "mis_conv3d_wino_wgrad")
-        return
+        return f"wino_wgrad_kernel<variant {wino}>"
     wino2 = int(L.mis_conv2d_wino_wgrad_select(N, Cin, Cout, H, W)) if ((WINO & 2) and (kd, kh, kw) == (1, 3, 3) and D == 1) else -1
     if wino2 >= 0 and xbs % 4 == 0 and dbs % 4 == 0 and x.data_ptr() % 16 == 0 and dy.data_ptr() % 16 == 0:
         nb = L.mis_conv2d_wino_wgrad_workspace_bytes(N, Cin, Cout, H, W, wino2)
@@ -329,13 +366,15 @@ def conv_wgrad(x, dy, dw, ksize, accumulate=False):
         ws = scratch(nb, "wgrad")
         _l.check(L.mis_conv2d_wino_wgrad(_l.ptr(x), xbs, _l.ptr(dy), dbs, _l.ptr(dw), _l.ptr(ws), ws.numel(), N, Cin, Cout,
                                          H, W, int(accumulate), wino2, _l.stream_ptr()), "mis_conv2d_wino_wgrad")
-        return
+        return f"wino2d_wgrad_kernel<variant {wino2}>"
     nb = L.mis_conv_wgrad_workspace_bytes(N, Cin, Cout, D, H, W, kd, kh, kw)
     if nb < 0:
         _l.check(nb, "mis_conv_wgrad_workspace_bytes")
     ws = scratch(nb, "wgrad")
+    _tag(f"direct_wgrad:k{kd}{kh}{kw}@{W}")
     _l.check(L.mis_conv_wgrad(_l.ptr(x), xbs, _l.ptr(dy), dbs, _l.ptr(dw), _l.ptr(ws), ws.numel(), N, Cin, Cout,
                               D, H, W, kd, kh, kw, int(accumulate), _l.stream_ptr()), "mis_conv_wgrad")
+    return f"conv_wgrad_kernel<k{kd}{kh}{kw}>"
 
 
 # ------------------------------------------------------- norm + act + dropout

@@ -368,16 +368,16 @@ class DownConvOp:
     def fwd(self, ctx):
         if self.direct:
             self._xs_valid = False
-            ops.conv_k2s2_down(self.x.t, self.w.data, self.b.data, self.y.t)
+            ops.conv_k2s2_down(self.x.t, self.w.data, None if self.b is None else self.b.data, self.y.t)
             return
         ops.space_to_depth2(self.x.t, self._xs, self.in_shape, True)
         self._xs_valid = True
         self.wp = ops.conv_pack_raw(self.w.data, self.cout, self.cin8, 1, 0, out=self.wp)
-        ops.conv_fwd(self._xs, self.wp, self.b.data, self.y.t, self.cin8, self.cout, (1, 1, 1))
+        ops.conv_fwd(self._xs, self.wp, None if self.b is None else self.b.data, self.y.t, self.cin8, self.cout, (1, 1, 1))
 
     def bwd(self, ctx):
         dy = self.y.grad()
-        if self.direct_wg and self.x.t.data_ptr() % 16 == 0 and dy.data_ptr() % 16 == 0:
+        if self.direct_wg and ops.conv_k2s2_wgrad_operands_ok(dy, self.x.t):
             ops.conv_k2s2_wgrad(dy, self.x.t, self.w.grad.view(-1))
         else:
             if not self._xs_valid:
@@ -386,11 +386,13 @@ class DownConvOp:
                 ops.space_to_depth2(self.x.t, self._xs, self.in_shape, True)
             ops.conv_wgrad(self._xs, dy, self.w.grad, (1, 1, 1))      # [Cout][8Cin] == [Cout][Cin][2][2][2] in memory
         # bias gradient exactly 0 when the conv feeds a normalisation (see ConvOp)
-        if self.bias_grad:
+        if self.bias_grad and self.b is not None:
             ops.channel_sum(dy, self.b.grad)
         if not self.need_dx:
             return
-        if self.direct_dx:       # dX = ConvTranspose3d(dy) with the parameter read as [K = Cout][M = 8 Cin]
+        # the in-place kernels' operand requirements (pointer / batch-stride alignment of a channel-slice view) are checked
+        # per call; a view that misses them takes the space-to-depth path instead of failing mid-step
+        if self.direct_dx and ops.conv_k2s2_up_output_ok(self.x.grad()):       # dX = ConvTranspose3d(dy), parameter read as [K = Cout][M = 8 Cin]
             ops.conv_k2s2_up(dy, self.w.data, None, self.x.grad(), accumulate=self.x.written)
             self.x.mark_written()
             return
@@ -424,9 +426,11 @@ class UpConvOp:
         return torch.empty((N, self.cout8, d, h, wd), dtype=torch.float32, device="cuda")
 
     def fwd(self, ctx):
-        if self.direct:
+        if self.direct and ops.conv_k2s2_up_output_ok(self.y.t):
             ops.conv_k2s2_up(self.x.t, self.w.data, None if self.b is None else self.b.data, self.y.t)
             return
+        if self.y8 is None:
+            self.y8 = self._new_y8()
         self.wp = ops.conv_pack_raw(self.w.data, self.cout8, self.cin, 1, 2, out=self.wp)
         ops.conv_fwd(self.x.t, self.wp, None, self.y8, self.cin, self.cout8, (1, 1, 1))
         ops.space_to_depth2(self.y8, self.y.t, self.y.shape, False, bias=None if self.b is None else self.b.data)
@@ -436,7 +440,7 @@ class UpConvOp:
         if self.bias_grad and self.b is not None:
             ops.channel_sum(self.y.grad(), self.b.grad)
         dyf = self.y.grad()
-        if self.direct_wg and self.direct_dx and self.x.t.data_ptr() % 16 == 0 and dyf.data_ptr() % 16 == 0:
+        if self.direct_wg and self.direct_dx and ops.conv_k2s2_wgrad_operands_ok(self.x.t, dyf):
             ops.conv_k2s2_wgrad(self.x.t, dyf, self.w.grad.view(-1))             # the parameter's own [Cin][8Cout] layout
         else:
             if self.dy8 is None:
@@ -553,8 +557,9 @@ class Plan:
         self.ops.append(UpConvOp(x, y, w, b, bias_grad))
         return y
 
-    def add(self, a, b, out, fuse=False):
-        """out = a + b.  ``fuse``: the caller guarantees that ``a`` -- the output of the norm/activation op just appended --
+    def add(self, a, b, out=None, fuse=False):
+        """out = a + b (``out`` None: a new buffer of ``a``'s shape, allocated only when an AddOp is really needed).
+        ``fuse``: the caller guarantees that ``a`` -- the output of the norm/activation op just appended --
         has no other reader; that op then writes act(norm(x)) + b itself (one pass, forward and backward) and ``a`` is returned."""
         prev = self.ops[-1] if self.ops else None
         if (fuse and NORM_RES and type(prev) is NormActOp and prev.y is a and a.parent is None and prev.res is None
@@ -562,9 +567,11 @@ class Plan:
                 and not (prev.per_sample and (prev.gamma is not None or prev.beta is not None))
                 and self.can_norm_res_act(a)):
             prev.res, prev.res_post = b, True        # the sum lands in ``a``; ``out`` is not needed
-            if out in self.acts:
+            if out is not None and out in self.acts:
                 self.acts.remove(out)
             return a
+        if out is None:
+            out = self.new(a.shape[1], a.shape[2:], N=a.shape[0])
         self.ops.append(AddOp(a, b, out))
         return out
 

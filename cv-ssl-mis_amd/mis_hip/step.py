@@ -39,8 +39,11 @@ def backward_and_sync(model, pg, bucketer=None):
     return bucketer.finish()
 
 
-def make_bucketer(model, pg):
-    return dist.GradBucketer(model.flat_grad, pg) if (GRAD_OVERLAP and dist.world_size(pg) > 1) else None
+def make_bucketer(model, pg, defer_tail=False):
+    """MIS_FORCE_BUCKETER=1: the bucketer also for a single-rank group (tests / scripts/ddp_overhead.py run the RCCL
+    stream machinery on one GPU)."""
+    on = dist.world_size(pg) > 1 or (os.environ.get("MIS_FORCE_BUCKETER", "0") == "1" and dist.initialized())
+    return dist.GradBucketer(model.flat_grad, pg, defer_tail=defer_tail) if (GRAD_OVERLAP and on) else None
 
 
 class MeanTeacherTrainer:
@@ -172,22 +175,41 @@ class UAMTTrainer(MeanTeacherTrainer):
             ops.teacher_noise(unl, self._ema_in, self.state)
         else:
             torch.add(unl, noise, out=self._ema_in)
-        s_logits = self.model.forward_raw(volume)
-        self.ema_model.rng_stream = 2
-        t_logits = self.ema_model.forward_raw(self._ema_in)
-        if self._mean_probs is None or self._mean_probs.shape != t_logits.shape:
-            self._mean_probs = torch.empty_like(t_logits)
-        for i in range(self.T // 2):
-            for r in range(2):
-                half = self._rep_in[r * U:(r + 1) * U]
-                if mc_noise is None:
-                    ops.teacher_noise(unl, half, self.state, salt=0x7EAC4E5 + 1 + 2 * i + r)
-                else:
-                    torch.add(unl, mc_noise[i][r * U:(r + 1) * U], out=half)
-            self.ema_model.rng_stream = 3 + i          # a fresh dropout stream per MC pass
-            mc_logits = self.ema_model.forward_raw(self._rep_in)
-            ops.softmax_mean_accumulate(mc_logits, self._mean_probs, 2, 1.0 / self.T, first=(i == 0))
-        self.ema_model.rng_stream = 2
+        if self._mean_probs is None or self._mean_probs.shape[0] != U:
+            self._mean_probs = None
+
+        def teacher_passes():
+            self.ema_model.rng_stream = 2
+            t_logits = self.ema_model.forward_raw(self._ema_in)
+            if self._mean_probs is None or self._mean_probs.shape != t_logits.shape:
+                self._mean_probs = torch.empty_like(t_logits)
+            for i in range(self.T // 2):
+                for r in range(2):
+                    half = self._rep_in[r * U:(r + 1) * U]
+                    if mc_noise is None:
+                        ops.teacher_noise(unl, half, self.state, salt=0x7EAC4E5 + 1 + 2 * i + r)
+                    else:
+                        torch.add(unl, mc_noise[i][r * U:(r + 1) * U], out=half)
+                self.ema_model.rng_stream = 3 + i          # a fresh dropout stream per MC pass
+                mc_logits = self.ema_model.forward_raw(self._rep_in)
+                ops.softmax_mean_accumulate(mc_logits, self._mean_probs, 2, 1.0 / self.T, first=(i == 0))
+            self.ema_model.rng_stream = 2
+            return t_logits
+
+        if TWO_STREAM:
+            # the five teacher forwards (one plain, four MC passes: sequential, they share the teacher's buffers) only meet
+            # the student in the loss tail: they run on a side stream beside the student's forward (bit-identical)
+            main = torch.cuda.current_stream()
+            if self._side is None:
+                self._side = torch.cuda.Stream()
+            self._side.wait_stream(main)
+            with torch.cuda.stream(self._side):
+                t_logits = teacher_passes()
+            s_logits = self.model.forward_raw(volume)
+            main.wait_stream(self._side)
+        else:
+            s_logits = self.model.forward_raw(volume)
+            t_logits = teacher_passes()
         ops.uamt_tail(s_logits, t_logits, self._mean_probs, label[:L].contiguous(), L, self.out,
                       self.hyper["max_iterations"], dlogits=self.model.logits_grad_buffer(), state=self.state)
         grad_scale = backward_and_sync(self.model, self.pg, self._bucketer)
@@ -246,7 +268,10 @@ class CrossTeachingTrainer:
         self.out2 = torch.zeros(16, dtype=torch.float32, device="cuda")
         self.iter_num = iter_num
         self._side = None
-        self._bucketers = (make_bucketer(model1, process_group), make_bucketer(model2, process_group))
+        # model2's backward is enqueued first (side stream): its exposed tail bucket is issued by finish(), after model1's
+        # buckets, so that the in-order RCCL stream does not hold model1's early buckets behind the end of model2's backward
+        self._bucketers = (make_bucketer(model1, process_group),
+                           make_bucketer(model2, process_group, defer_tail=TWO_STREAM))
 
     def step(self, volume_batch, label_batch):
         if not (self.model1.training and self.model2.training):
@@ -290,11 +315,12 @@ class CrossTeachingTrainer:
                     self.model2.backward_raw(on_progress=b2.advance)
                 self.model1.backward_raw(on_progress=b1.advance)
                 main.wait_stream(self._side)
+                scales = [b1.finish(), b2.finish()]           # b1's tail went out with its backward; b2's goes now
             else:
                 self.model1.backward_raw(on_progress=b1.advance)
-                b1.advance(0)
+                b1.advance(0, final=True)
                 self.model2.backward_raw(on_progress=b2.advance)
-            scales = [b1.finish(), b2.finish()]
+                scales = [b1.finish(), b2.finish()]
         else:
             self.model1.backward_raw()
             self.model2.backward_raw()
@@ -358,7 +384,9 @@ class CnnMeetVitTrainer:
         self.out2 = torch.zeros(16, dtype=torch.float32, device="cuda")
         self.iter_num = iter_num
         self._ema_in = None
-        self._bucketers = (make_bucketer(model1, process_group), make_bucketer(model2, process_group))
+        self._side = None
+        self._bucketers = (make_bucketer(model1, process_group, defer_tail=TWO_STREAM),
+                           make_bucketer(model2, process_group))
 
     def weights(self):
         """(pseudo-supervision weight, mean-teacher weight) of the current iteration"""
@@ -377,17 +405,47 @@ class CnnMeetVitTrainer:
             ops.teacher_noise(unl, self._ema_in, self.state)
         else:
             torch.add(unl, noise, out=self._ema_in)     # injected noise: parity tests only
-        o1 = self.model1.forward_raw(volume_batch)
-        o2 = self.model2.forward_raw(volume_batch)
-        t = self.ema_model.forward_raw(self._ema_in)
+        two = TWO_STREAM
+        if two:
+            # three independent forwards: the CNN student and the (half-batch) teacher on a side stream beside the
+            # Transformer student -- roughly equal work; later the CNN's backward beside the Transformer's.  Bit-identical
+            main = torch.cuda.current_stream()
+            if self._side is None:
+                self._side = torch.cuda.Stream()
+            self._side.wait_stream(main)
+            with torch.cuda.stream(self._side):
+                o1 = self.model1.forward_raw(volume_batch)
+                t = self.ema_model.forward_raw(self._ema_in)
+            o2 = self.model2.forward_raw(volume_batch)
+            main.wait_stream(self._side)
+        else:
+            o1 = self.model1.forward_raw(volume_batch)
+            o2 = self.model2.forward_raw(volume_batch)
+            t = self.ema_model.forward_raw(self._ema_in)
         lab = label_batch[:L].contiguous()
         w_cps, w_mt = self.weights()
         ops.cross_teaching_tail(o1, o2, lab, L, self.out1, dlogits=self.model1.logits_grad_buffer(),
                                 cons_weight=w_cps, teacher=t, mt_weight=w_mt)
         ops.cross_teaching_tail(o2, o1, lab, L, self.out2, dlogits=self.model2.logits_grad_buffer(),
                                 cons_weight=w_cps, teacher=t, mt_weight=w_mt)
-        scales = [backward_and_sync(self.model1, self.pg, self._bucketers[0]),
-                  backward_and_sync(self.model2, self.pg, self._bucketers[1])]
+        b1, b2 = self._bucketers
+        if two:
+            # model1's backward is enqueued first, on the side stream: with bucketers its tail bucket is deferred to
+            # finish() (defer_tail), as for the side-stream student of cross teaching
+            self._side.wait_stream(main)
+            if b1 is not None:
+                b1.begin()
+                b2.begin()
+            with torch.cuda.stream(self._side):
+                self.model1.backward_raw(on_progress=None if b1 is None else b1.advance)
+            self.model2.backward_raw(on_progress=None if b2 is None else b2.advance)
+            main.wait_stream(self._side)
+            if b1 is not None:
+                scales = [b1.finish(), b2.finish()]
+            else:
+                scales = [dist.sync_gradients(m.flat_grad, self.pg) for m in (self.model1, self.model2)]
+        else:
+            scales = [backward_and_sync(self.model1, self.pg, b1), backward_and_sync(self.model2, self.pg, b2)]
         for m, mom, ema, scale in ((self.model1, self.mom1, None, scales[0]),
                                    (self.model2, self.mom2, self.ema_model.flat_param, scales[1])):
             ops.sgd_ema_step(m.flat_param, m.flat_grad, mom, ema, momentum=self.momentum,

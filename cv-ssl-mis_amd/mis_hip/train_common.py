@@ -181,9 +181,10 @@ class Validator:
     rank 0's.  When the validation list file is missing (the synthetic runs) nothing is scored and ``finish`` writes
     the final weights under the best-model name, so that the inference CLIs always find their checkpoint."""
 
-    def __init__(self, args, snapshot_path, scalars=None, rank=0, world=1):
+    def __init__(self, args, snapshot_path, scalars=None, rank=0, world=1, process_group=None):
         self.args, self.snapshot_path, self.scalars = args, snapshot_path, scalars
         self.rank, self.world = rank, world
+        self.pg = process_group          # the trainer's group: validation collectives must run where the gradients do
         self.three_d = len(args.patch_size) == 3
         self.best = {}
         self.db_val = None
@@ -196,9 +197,35 @@ class Validator:
     def score(self, model):
         """(mean Dice, mean HD95, per-class [[dice, hd95], ...]) of ``model`` on the validation split."""
         args = self.args
-        if self.world > 1:      # score with rank 0's BatchNorm running statistics on every rank
-            for b in model.buffers():
-                torch.distributed.broadcast(b, 0)
+        saved = None
+        if self.world > 1:
+            # score with rank 0's BatchNorm running statistics on every rank: ONE broadcast of the floating-point buffers
+            # packed into a flat tensor (dozens of tiny collectives per model before).  The rank's own statistics are put
+            # back after the scoring -- validation must not change the training state (per-rank running statistics, no
+            # SyncBN, are what the reference's single-GPU semantics give every rank).
+            bufs = [b for b in model.buffers() if b.is_floating_point() and b.numel()]
+            if bufs:
+                saved = [b.detach().clone() for b in bufs]
+                flat = torch.cat([b.detach().reshape(-1).float() for b in bufs])
+                src = torch.distributed.get_global_rank(self.pg, 0) if self.pg is not None else 0
+                torch.distributed.broadcast(flat, src, group=self.pg)
+                off = 0
+                with torch.no_grad():
+                    for b in bufs:
+                        b.copy_(flat[off:off + b.numel()].view_as(b))
+                        off += b.numel()
+        try:
+            total, count = self._score_shard(model)
+        finally:
+            if saved is not None:
+                with torch.no_grad():
+                    for b, v in zip(bufs, saved):
+                        b.copy_(v)
+        m = self._reduce(total, count)
+        return float(np.mean(m, axis=0)[0]), float(np.mean(m, axis=0)[1]), m
+
+    def _score_shard(self, model):
+        args = self.args
         if self.three_d:
             from val_3D import test_all_case
             total, count = test_all_case(model, args.root_path, test_list="val.txt", num_classes=args.num_classes,
@@ -214,15 +241,14 @@ class Validator:
                 total = total + np.array(test_single_volume(image, label, model, classes=args.num_classes,
                                                             patch_size=args.patch_size), dtype=np.float64)
                 count += 1
-        m = self._reduce(total, count)
-        return float(np.mean(m, axis=0)[0]), float(np.mean(m, axis=0)[1]), m
+        return total, count
 
     def _reduce(self, total, count):
         """Mean over all ranks' cases: all-reduce (sum) of the metric sums and the case count."""
         if self.world > 1:
             t = torch.tensor(np.append(np.asarray(total, dtype=np.float64).ravel(), float(count)), dtype=torch.float64,
-                             device="cuda" if torch.distributed.get_backend() == "nccl" else "cpu")
-            torch.distributed.all_reduce(t)
+                             device="cuda" if torch.distributed.get_backend(self.pg) == "nccl" else "cpu")
+            torch.distributed.all_reduce(t, group=self.pg)
             t = t.cpu().numpy()
             total, count = t[:-1].reshape(np.shape(total)), t[-1]
         return np.asarray(total, dtype=np.float64) / max(count, 1)
@@ -321,7 +347,7 @@ def run_cross_teaching(args, make_model1, make_model2, log_every=1, label_dtype=
     if rank == 0:
         logging.info("{} iterations per epoch ({})".format(len(loader), source))
     scalars = ScalarLog(snapshot_path, enabled=(rank == 0))
-    validator = Validator(args, snapshot_path, scalars, rank, world)
+    validator = Validator(args, snapshot_path, scalars, rank, world, process_group=trainer.pg)
     val_models = [('model1_', 'model1_', 'best_model1', model1), ('model2_', 'model2_', 'best_model2', model2)]
     if ema_model is not None:     # train_cnn_meet_vit_2D.py:441-468
         val_models.append(('ema_model_', 'ema_model_', 'best_ema_model', ema_model))
@@ -394,7 +420,7 @@ def run_training(args, make_model, *, label_dtype, cons_start_iter, save_ema, lo
     if rank == 0:
         logging.info("{} iterations per epoch ({})".format(len(loader), source))
     scalars = ScalarLog(snapshot_path, enabled=(rank == 0))
-    validator = Validator(args, snapshot_path, scalars, rank, world)
+    validator = Validator(args, snapshot_path, scalars, rank, world, process_group=trainer.pg)
     val_models = [('', '', 'best_model', model)]
     iter_num = 0
     max_epoch = args.max_iterations // len(loader) + 1

@@ -122,7 +122,7 @@ class VNet(HipNet):
                 if name in ("block_six", "block_seven", "block_eight", "block_nine"):
                     skip = {"block_six": "block_four", "block_seven": "block_three", "block_eight": "block_two",
                             "block_nine": "block_one"}[name]
-                    x = plan.add(x, feats[skip], plan.new(cout, sp), fuse=True)       # x_up + skip (vnet.py:210-222)
+                    x = plan.add(x, feats[skip], fuse=True)       # x_up + skip (vnet.py:210-222)
                 for s in range(stages):
                     t = plan.new(cout, sp)
                     ck, nk = self._keys(name, s)

@@ -13,6 +13,7 @@ Fixtures are data only: scalars, checksums and sampled values -- no reference so
 """
 import json
 import os
+import re
 import sys
 
 import numpy as np
@@ -824,6 +825,69 @@ CFG3D = dict(num_classes=2, base_lr=0.01, max_iterations=30000, ema_decay=0.99, 
              cons_start_iter=0)
 
 
+def load_from_checkpoints(key_shapes, which):
+    """The two checkpoint formats SwinUnet.load_from reads (vision_transformer.py:54-89), filled in closed form so that
+    the GPU test can rebuild them from the key / shape lists stored in the golden (no reference needed there).
+    key_shapes: [(name, shape, dtype str)] of SwinTransformerSys.state_dict()."""
+    def val(tag, k, shape, dt):
+        if "int" in dt:
+            return torch.full(shape, 7, dtype=getattr(torch, dt))
+        return filler.uniform(shape, tag + ":" + k, -0.5, 0.5)
+    if which == "split":
+        # a checkpoint of a whole (DataParallel-wrapped) SwinUnet: "module.swin_unet." + key, head included
+        return {"module.swin_unet." + k: val("split", k, sh, dt) for k, sh, dt in key_shapes}
+    # an ImageNet Swin-T encoder checkpoint {"model": ...}: encoder keys only (depths [2, 2, 6, 2]: stage 2 carries four
+    # blocks the network does not have), a 1000-class head, and one relative-position table of a window-12 model
+    # (shape mismatch: dropped)
+    enc = {}
+    for k, sh, dt in key_shapes:
+        if k.startswith(("patch_embed.", "layers.")) or k in ("norm.weight", "norm.bias"):
+            enc[k] = val("enc", k, sh, dt)
+    for k, sh, dt in key_shapes:
+        m = re.match(r"layers\.2\.blocks\.([01])\.(.*)", k)
+        if m:
+            for extra in (2, 4):
+                k2 = f"layers.2.blocks.{int(m.group(1)) + extra}.{m.group(2)}"
+                enc[k2] = val("enc", k2, sh, dt)
+    enc["head.weight"] = val("enc", "head.weight", (1000, 768), "float32")
+    enc["head.bias"] = val("enc", "head.bias", (1000,), "float32")
+    enc["layers.1.blocks.0.attn.relative_position_bias_table"] = val("enc", "rpb12", (23 * 23, 6), "float32")
+    return {"model": enc}
+
+
+def run_load_from_case(name):
+    """SwinUnet.load_from on both checkpoint formats, by the REAL class: which entries of the network end up with
+    which checkpoint tensor (prefix stripping, encoder -> decoder mirroring, head / shape-mismatch drops)."""
+    import tempfile
+    from types import SimpleNamespace as NS
+    _install_timm_shim()
+    out = {}
+    model = build_reference("swin", 1, 4)
+    ks = [(k, tuple(v.shape), str(v.dtype).replace("torch.", "")) for k, v in model.swin_unet.state_dict().items()]
+    out["meta"] = json.dumps(dict(name=name, kind="load_from", key_shapes=ks))
+    for which in ("split", "encoder"):
+        model = build_reference("swin", 1, 4)
+        model.load_state_dict(filler.fill_state_dict(model.state_dict()))
+        before = {k: v.clone() for k, v in model.state_dict().items()}
+        ck = load_from_checkpoints(ks, which)
+        with tempfile.TemporaryDirectory() as d:
+            path = os.path.join(d, "ck.pth")
+            torch.save(ck, path)
+            model.load_from(NS(MODEL=NS(PRETRAIN_CKPT=path)))
+        after = model.state_dict()
+        names = list(after.keys())
+        changed = [bool((after[k] != before[k]).any()) for k in names]
+        out[which + "_names"] = np.array(names)
+        out[which + "_changed"] = np.array(changed)
+        out[which + "_sum"] = np.array([float(after[k].double().sum()) for k in names])
+        out[which + "_abssum"] = np.array([float(after[k].double().abs().sum()) for k in names])
+        out[which + "_first"] = np.array([float(after[k].double().flatten()[0]) for k in names])
+        out[which + "_last"] = np.array([float(after[k].double().flatten()[-1]) for k in names])
+        print(f"{name}/{which}: {sum(changed)} of {len(names)} entries replaced by the checkpoint")
+    np.savez_compressed(os.path.join(GOLD, name + ".npz"), **out)
+    print(f"wrote {name}.npz")
+
+
 def main():
     torch.set_num_threads(8)
     only = set(sys.argv[1:])
@@ -906,6 +970,10 @@ def main():
         _install_timm_shim()
         sys.path.insert(0, REF)
         run_cnnvit_case("cnnvit_224", dict(CFG2D, batch_size=2, labeled_bs=1, spatial=[224, 224]), 3100)
+    # SwinUnet.load_from (vision_transformer.py:54-89): both checkpoint formats through the real class
+    if not only or "swin_load_from" in only:
+        sys.path.insert(0, REF)
+        run_load_from_case("swin_load_from")
 
 
 if __name__ == "__main__":

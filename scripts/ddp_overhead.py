@@ -46,7 +46,7 @@ def main():
         for _ in range(2):       # alternate: the chip's clocks drift over a run
             mstep.make_bucketer = keep
             plain.append(run(name, None))
-            mstep.make_bucketer = lambda model, group: mdist.GradBucketer(model.flat_grad, group)      # also with one rank
+            mstep.make_bucketer = lambda model, group, defer_tail=False: mdist.GradBucketer(model.flat_grad, group, defer_tail=defer_tail)      # also with one rank
             ddp.append(run(name, pg))
         plain, ddp = min(plain), min(ddp)
         print(f"{name}: single-GPU step {plain:.3f} ms, data-parallel code path (world 1) {ddp:.3f} ms  (+{ddp - plain:.3f})",

@@ -262,3 +262,52 @@ def test_recorded_plan_backward_order_through_bucketer(tmp_path):
     world = 2
     mp.spawn(_recorded_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
     assert sorted(os.listdir(tmp_path)) == ["swin.ok", "unet2d.ok", "unet3d.ok", "vnet_groupnorm.ok"]
+
+
+def _bucket_layout_worker(rank, world, port, out_dir):
+    for p in (os.path.join(ROOT, "cv-ssl-mis_amd"), ROOT):
+        sys.path.insert(0, p)
+    import torch.distributed as dist
+    from mis_hip.dist import GradBucketer
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    res = {}
+    # (1) two models whose collectives interleave: A's backward is enqueued first with its tail deferred (the side-stream
+    # student of cross teaching / CNN-meets-ViT), B's second; sums must equal one all-reduce of each buffer
+    g = torch.Generator().manual_seed(10 + rank)
+    a, b = torch.randn(700_000, generator=g), torch.randn(300_000, generator=g)
+    ref_a, ref_b = a.clone(), b.clone()
+    dist.all_reduce(ref_a)
+    dist.all_reduce(ref_b)
+    ba = GradBucketer(a, None, bucket_bytes=1 << 20, defer_tail=True)
+    bb = GradBucketer(b, None, bucket_bytes=1 << 19)
+    ba.begin(); bb.begin()
+    for lo in (600_000, 300_000, 5, 0):
+        ba.advance(lo)
+    issued_before_finish = ba._next
+    assert ba.buckets[-1][0] == 0 and issued_before_finish == len(ba.buckets) - 1      # the offset-0 bucket is held back
+    assert not ba.would_issue(0)
+    for lo in (200_000, 0):
+        bb.advance(lo)
+    assert bb._next == len(bb.buckets)                                                   # B's tail went with its backward
+    ba.finish(); bb.finish()
+    res["sum_ok"] = bool(torch.equal(a, ref_a) and torch.equal(b, ref_b))
+    # (2) ranks that disagree on MIS_BUCKET_MB must fail loudly at construction, not hang in mismatched collectives
+    os.environ["MIS_BUCKET_MB"] = "1" if rank == 0 else "2"
+    try:
+        GradBucketer(torch.zeros(1 << 20), None)
+        res["mismatch_raised"] = False
+    except RuntimeError as e:
+        res["mismatch_raised"] = "disagree" in str(e)
+    del os.environ["MIS_BUCKET_MB"]
+    torch.save(res, os.path.join(out_dir, f"layout{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_deferred_tail_bucket_and_rank_agreement_on_the_layout(tmp_path):
+    world = 2
+    mp.spawn(_bucket_layout_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
+        res = torch.load(os.path.join(tmp_path, f"layout{r}.pt"))
+        assert res["sum_ok"] and res["mismatch_raised"], res

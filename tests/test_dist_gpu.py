@@ -43,8 +43,9 @@ def _worker(rank, world, port, out_dir, overlap, kind):
         tr = CrossTeachingTrainer(model, ema, labeled_bs=1, num_classes=C, iter_num=1000, seed=7)
         assert mstep.TWO_STREAM and (tr._bucketers[0] is not None) == bool(overlap)
         if overlap:
+            assert tr._bucketers[1].defer_tail and not tr._bucketers[0].defer_tail
             tr._bucketers = (GradBucketer(model.flat_grad, None, bucket_bytes=1 << 20),
-                             GradBucketer(ema.flat_grad, None, bucket_bytes=8 << 20))
+                             GradBucketer(ema.flat_grad, None, bucket_bytes=8 << 20, defer_tail=True))
     else:
         model, ema = _make(kind, C), _make(kind, C)
         ema.load_state_dict(model.state_dict())
@@ -88,3 +89,88 @@ def test_two_ranks_on_one_gpu_exchange_gradients(tmp_path, kind):
     # overlapped, bucketed exchange == one blocking all-reduce
     assert torch.equal(r[(0, 0)]["student"], r[(1, 0)]["student"])
     assert torch.equal(r[(0, 0)]["teacher"], r[(1, 0)]["teacher"])
+
+
+def _rccl_worker(rank, port, out_dir, bucketed, kind):
+    """ONE rank, backend nccl (= RCCL) on the one GPU: ProcessGroupNCCL's own stream, the event hand-over of
+    ``async_op=True`` work objects, ``work.wait()`` on the compute stream and collectives enqueued from a callback that
+    runs behind a SIDE stream -- none of which gloo exercises (it stages through the host after a stream sync)."""
+    import datetime
+    os.environ["MIS_GRAD_OVERLAP"] = "1"
+    os.environ["MIS_FORCE_BUCKETER"] = "1" if bucketed else "0"
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    for p in (os.path.join(ROOT, "cv-ssl-mis_amd"), ROOT, os.path.join(ROOT, "tests")):
+        sys.path.insert(0, p)
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
+                            device_id=torch.device("cuda", 0), timeout=datetime.timedelta(seconds=120))
+    from mis_hip import plan as mplan, step as mstep
+    from mis_hip.dist import GradBucketer
+    from mis_hip.step import CnnMeetVitTrainer, CrossTeachingTrainer, MeanTeacherTrainer, UAMTTrainer
+    from test_grad_progress_gpu import _make
+    assert mstep.TWO_STREAM and mplan.WGRAD_STREAM          # both side streams on (the product configuration)
+    torch.manual_seed(5)
+    C = 2 if kind in ("unet3d", "uamt3d") else 4
+    pg = dist.group.WORLD
+    nets = []
+    if kind in ("cross", "cnnvit"):
+        m1, m2 = _make("unet2d", C), _make("swin", C)
+        nets = [m1, m2]
+        if kind == "cnnvit":
+            t = _make("swin", C)
+            t.load_state_dict(m2.state_dict())
+            nets.append(t)
+            tr = CnnMeetVitTrainer(m1, m2, t, labeled_bs=1, num_classes=C, iter_num=1200, seed=7, process_group=pg)
+        else:
+            tr = CrossTeachingTrainer(m1, m2, labeled_bs=1, num_classes=C, iter_num=1000, seed=7, process_group=pg)
+        assert (tr._bucketers[0] is not None) == bool(bucketed)
+        if bucketed:
+            tr._bucketers = (GradBucketer(m1.flat_grad, pg, bucket_bytes=1 << 20, defer_tail=tr._bucketers[0].defer_tail),
+                             GradBucketer(m2.flat_grad, pg, bucket_bytes=8 << 20, defer_tail=tr._bucketers[1].defer_tail))
+    else:
+        base = "unet3d" if kind == "uamt3d" else kind
+        m, e = _make(base, C), _make(base, C)
+        e.load_state_dict(m.state_dict())
+        nets = [m, e]
+        cls = UAMTTrainer if kind == "uamt3d" else MeanTeacherTrainer
+        tr = cls(m, e, labeled_bs=1, num_classes=C, iter_num=1000, seed=7, process_group=pg)
+        assert (tr._bucketer is not None) == bool(bucketed)
+        if bucketed:
+            tr._bucketer = GradBucketer(m.flat_grad, pg, bucket_bytes=1 << 20)
+            assert len(tr._bucketer.buckets) >= 3
+    for n in nets:
+        n.train()
+        n.dropout_enabled = False
+    g = torch.Generator(device="cuda").manual_seed(100)
+    shape = {"unet2d": (2, 1, 64, 64), "cross": (2, 1, 224, 224), "cnnvit": (2, 1, 224, 224)}.get(kind, (2, 1, 32, 32, 32))
+    vol = torch.rand(shape, generator=g, device="cuda")
+    lab = torch.randint(0, C, (shape[0],) + shape[2:], generator=g, device="cuda").to(
+        torch.int64 if C == 2 else torch.uint8)
+    noise = torch.zeros((1,) + shape[1:], device="cuda")
+    for _ in range(3):
+        if kind == "cross":
+            tr.step(vol, lab)
+        elif kind == "uamt3d":
+            tr.step(vol, lab, noise=noise, mc_noise=[torch.zeros((2,) + shape[1:], device="cuda")] * 4)
+        else:
+            tr.step(vol, lab, noise=noise)
+    torch.cuda.synchronize()
+    torch.save([n.flat_param.cpu() for n in nets], os.path.join(out_dir, f"rccl_{kind}_{int(bucketed)}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("kind", ["unet3d", "unet2d", "cross", "cnnvit", "uamt3d"])
+def test_single_rank_rccl_group_bucketed_step_is_bit_identical(tmp_path, kind):
+    """The step with a real RCCL process group (one rank) and the gradient bucketer forced on -- small buckets, teacher /
+    second student and weight gradients on their side streams -- leaves bit for bit the weights of the plain
+    single-GPU step after three iterations."""
+    for bucketed in (0, 1):
+        mp.spawn(_rccl_worker, args=(_free_port(), str(tmp_path), bucketed, kind), nprocs=1, join=True)
+    a = torch.load(os.path.join(tmp_path, f"rccl_{kind}_0.pt"))
+    b = torch.load(os.path.join(tmp_path, f"rccl_{kind}_1.pt"))
+    assert len(a) == len(b) >= 2
+    for x, y in zip(a, b):
+        assert torch.isfinite(x).all() and torch.equal(x, y)

@@ -24,7 +24,8 @@ TOL_LOGIT, TOL_LOSS = 1e-3, 2e-4          # the north-star bar on logits; scalar
 # cross teaching 2.0e-2 on the CNN / inside the absolute term on the Transformer) -- the fixture-size envelope of
 # test_parity_gpu.py (6 x the reference's own fp32 noise + 2e-3), not a dispatch-only bound
 GRAD_REL, GRAD_ABS = 0.1, 2e-3
-GRAD_REL_CASE = {"config2_unet2d_24+24_256": 0.03, "config3_unet3d_4+4_96": 0.015, "config4_swin_24+24_224": 0.01}
+GRAD_REL_CASE = {"config2_unet2d_24+24_256": 0.03, "config3_unet3d_4+4_96": 0.015, "config4_swin_24+24_224": 0.01,
+                 "config3_vnet_4+4_96": 0.1}
 
 
 def _states(onet, tag=""):
@@ -37,12 +38,14 @@ def _record_kernels(fn):
     """Run ``fn`` with the conv-launch hook armed; returns the set of conv_fwd instantiation names it dispatched."""
     from mis_hip import ops
     ops.PROFILE = []
+    ops.DISPATCH = set()
     try:
         fn()
         torch.cuda.synchronize()
-        return {name for name, *_ in ops.PROFILE}
+        return {name for name, *_ in ops.PROFILE} | ops.DISPATCH
     finally:
         ops.PROFILE = None
+        ops.DISPATCH = None
 
 
 def _check_grads_and_params(model, grads, student_after, lr, what, grad_rel=GRAD_REL):
@@ -76,6 +79,17 @@ MT_CASES = {
                                "wino:WinoCfg<1, 4, 4, 4, 1, 1, 1, 4, 1, 0>",       # 24^3, 6^3: 8 x 8 x 8 boxes
                                "wino:WinoCfg<3, 3, 6, 1, 1, 1, 1, 4, 1, 1>"]),     # 12^3: 6 x 6 x 12 boxes, 54 tiles
     "config4_swin_24+24_224": ("swin", (48, 1, 224, 224), 24, 4, torch.uint8, 1200, 1000, []),
+    # BASELINE configs[2] says "3D UNet (vnet-style)": the reference's other 3-D backbone on the same 4+4 @ 96^3 batch.
+    # Only this size reaches the in-place kernel-2 / stride-2 kernels (conv_k2s2.hip: 16<->32 channels at 96^3<->48^3,
+    # 32<->64 at 48^3<->24^3; forward, data gradient, weight gradient) and V-Net's 96^3 / 48^3 Winograd instantiations
+    "config3_vnet_4+4_96": ("vnet", (8, 1, 96, 96, 96), 4, 2, torch.int64, 1200, 0,
+                            ["name:conv_fwd_cin1_kernel<3>",
+                             "wino:WinoCfg<1, 1, 16, 2, 2, 1, 1, 4, 0, 0>",
+                             "wino:WinoCfg<1, 2, 8, 2, 2, 1, 1, 4, 0, 0>",
+                             "tag:k2s2_down:16x32@48", "tag:k2s2_down:32x64@24",        # Conv3d(k2s2) forward
+                             "tag:k2s2_up:32x16@48", "tag:k2s2_up:64x32@24",            # ConvTranspose3d(k2s2) forward
+                             "tag:k2s2_wgrad:16x32@48", "tag:k2s2_wgrad:32x64@24",
+                             "tag:wino_wgrad:v0@96", "tag:wino_wgrad:v1@48"]),
 }
 
 
@@ -106,7 +120,7 @@ def test_mean_teacher_step_at_full_batch(name):
     vol_d, lab_d, noise_d = volume.cuda(), label.cuda(), noise.cuda()
     names = _record_kernels(lambda: tr.step(vol_d, lab_d, noise=noise_d))
     for e in expect:
-        kname = (e[5:] if e.startswith("name:") else f"wino_fwd_kernel<{e[5:]}, false>" if e.startswith("wino:") else
+        kname = (e[5:] if e.startswith("name:") else e[4:] if e.startswith("tag:") else f"wino_fwd_kernel<{e[5:]}, false>" if e.startswith("wino:") else
                  f"wino2d_fwd_kernel<{e[7:]}>" if e.startswith("wino2d:") else f"conv_fwd_kernel<{e}>")
         assert kname in names, (e, sorted(names))
     got = tr.losses()
@@ -183,3 +197,91 @@ def test_cross_teaching_step_at_full_batch(size, window):
         lg = models[m]._last[0].out.t.cpu().reshape(r[f"logits{m + 1}"].shape)
         assert (lg - r[f"logits{m + 1}"]).abs().max().item() <= TOL_LOGIT
         _check_grads_and_params(models[m], r["grads"][m], osd[m], r["lr"], f"model{m + 1}", 0.08 if m == 0 else 0.01)
+
+
+@pytest.mark.timeout(2400)
+def test_uamt_3d_step_at_full_batch():
+    """UA-MT on unet_3D at the batch bench.py's `uamt3d` workload times (4 + 4 volumes of 96^3, T = 8 MC passes of the
+    doubled unlabeled half): five teacher forwards of 4 / 8 volumes pick other Winograd box counts and the MC mean /
+    entropy-masked tail runs over 4 x 96^3 voxels.  Against oracle.step.uamt_step on the host CPU, same inputs."""
+    from mis_hip.step import UAMTTrainer
+    from networks.net_factory_3d import net_factory_3d
+    from oracle import filler
+    from oracle.nets import OracleUNet3D
+    from oracle.step import uamt_step
+    C, L, B, sp, it, max_it = 2, 4, 8, (96, 96, 96), 2500, 3000
+    onet = OracleUNet3D(C, 1)
+    sd0, tsd0 = _states(onet), _states(onet, "t.")
+    tsd0["final.weight"] = tsd0["final.weight"] * 40.0       # confident teacher: the entropy threshold splits the voxels
+    volume = filler.image((B, 1) + sp, "volume")
+    label = filler.labels((B,) + sp, C, torch.int64)
+    noise = filler.noise((B - L, 1) + sp, "noise")
+    mc_noise = [filler.noise((2 * (B - L), 1) + sp, f"mc_noise{i}") for i in range(4)]
+    model, ema = net_factory_3d("unet_3D", 1, C), net_factory_3d("unet_3D", 1, C)
+    model.train(); ema.train()
+    model.dropout_enabled = ema.dropout_enabled = False
+    model.load_state_dict(sd0)
+    ema.load_state_dict(tsd0)
+    tr = UAMTTrainer(model, ema, labeled_bs=L, num_classes=C, max_iterations=max_it, iter_num=it)
+    mom = {}
+    for n, v in model.named_flat(tr.momentum_buf):
+        m = filler.uniform(v.shape, "mom." + n, -0.01, 0.01)
+        v.copy_(m)
+        mom[n] = m.clone()
+    names = _record_kernels(lambda: tr.step(volume.cuda(), label.cuda(), noise=noise.cuda(),
+                                            mc_noise=[m.cuda() for m in mc_noise]))
+    assert "wino_fwd_kernel<WinoCfg<1, 1, 16, 2, 2, 1, 1, 4, 0, 0>, false>" in names, sorted(names)
+    got = tr.losses()
+    s_logits = model._last[0].out.t.cpu()
+    student = {k: v.clone() for k, v in sd0.items()}
+    teacher = {k: v.clone() for k, v in tsd0.items()}
+    orc = uamt_step(onet, student, teacher, mom, volume, label, noise, mc_noise, it, labeled_bs=L, num_classes=C,
+                    max_iterations=max_it, drop_student="off", drop_teacher="off")
+    assert (s_logits.reshape(orc["logits"].shape) - orc["logits"]).abs().max().item() <= TOL_LOGIT
+    for k in ("loss", "loss_ce", "loss_dice", "consistency_loss"):
+        assert abs(got[k] - orc[k]) <= TOL_LOSS, (k, got[k], orc[k])
+    assert abs(got["threshold"] - orc["threshold"]) <= 1e-6
+    nvox = (B - L) * 96 ** 3
+    assert 0.02 * nvox < orc["unmasked"] < 0.98 * nvox          # the mask is neither empty nor full
+    assert abs(got["unmasked_voxels"] - orc["unmasked"]) <= max(4.0, 2e-4 * nvox)
+    mp = tr._mean_probs.cpu().reshape((B - L, C) + sp)
+    unc = -1.0 * torch.sum(mp * torch.log(mp + 1e-6), dim=1, keepdim=True)
+    assert (unc - orc["uncertainty"]).abs().max().item() <= 1e-3
+    _check_grads_and_params(model, orc["grads"], student, orc["lr"], "uamt3d", 0.03)
+
+
+@pytest.mark.timeout(1500)
+def test_cnn_meet_vit_step_at_full_batch():
+    """train_cnn_meet_vit_2D at the script's default batch (8 + 8 images of 224^2: bench.py's `cnnvit` workload): UNet
+    student, SwinUnet student, EMA SwinUnet teacher -- against oracle.step.cnn_meet_vit_step on the host CPU."""
+    from config import lite_config
+    from mis_hip.step import CnnMeetVitTrainer
+    from networks.net_factory import net_factory
+    from networks.vision_transformer import SwinUnet
+    from oracle.step import cnn_meet_vit_step
+    from test_oracle_cpu import _cnnvit_inputs
+    C, L, B, it = 4, 8, 16, 3100
+    nets, sds, moms, volume, label, noise = _cnnvit_inputs(dict(num_classes=C, labeled_bs=L, batch_size=B,
+                                                                spatial=[224, 224]))
+    models = [net_factory("unet", 1, C), SwinUnet(lite_config(), img_size=224, num_classes=C),
+              SwinUnet(lite_config(), img_size=224, num_classes=C)]
+    for m in range(3):
+        models[m].load_state_dict(sds[m])
+        models[m].train()
+        models[m].dropout_enabled = False
+    tr = CnnMeetVitTrainer(models[0], models[1], models[2], labeled_bs=L, num_classes=C, iter_num=it)
+    for m, buf in enumerate((tr.mom1, tr.mom2)):
+        for n, v in models[m].named_flat(buf):
+            v.copy_(moms[m][n])
+    tr.step(volume.cuda(), label.cuda(), noise=noise.cuda())
+    got = tr.losses()
+    lgs = [models[m]._last[0].out.t.detach().cpu() for m in range(3)]
+    r = cnn_meet_vit_step(nets[0], nets[1], sds[0], sds[1], sds[2], moms[0], moms[1], volume, label, noise, it,
+                          labeled_bs=L, num_classes=C, drop1="off", drop2="off", drop_t="off")
+    for m, key in ((0, "logits1"), (1, "logits2"), (2, "teacher_logits")):
+        assert (lgs[m].reshape(r[key].shape) - r[key]).abs().max().item() <= TOL_LOGIT, key
+    assert abs(got["model1_loss"] - r["model1_loss"]) <= TOL_LOSS and abs(got["model2_loss"] - r["model2_loss"]) <= TOL_LOSS
+    for m in range(2):
+        assert abs(got[f"pseudo_supervision{m + 1}"] - r["parts"][m][2]) <= TOL_LOSS
+        assert abs(got[f"consistency_loss{m + 1}"] - r["parts"][m][3]) <= TOL_LOSS
+        _check_grads_and_params(models[m], r["grads"][m], sds[m], r["lr"], f"cnnvit model{m + 1}", 0.08 if m == 0 else 0.01)

@@ -216,3 +216,85 @@ def test_backward_after_same_shape_forward_fails_loudly():
     y = model(x)
     y.mean().backward()
     assert torch.equal(model.flat_grad, g0)
+
+
+@pytest.mark.parametrize("kind", ["uamt2d", "uamt3d", "cnnvit"])
+def test_side_stream_trainers_are_bit_identical(kind, monkeypatch):
+    """UA-MT (five teacher forwards beside the student's) and CNN-meets-ViT (CNN student + teacher beside the Transformer
+    student, the CNN's backward beside the Transformer's) with MIS_TWO_STREAM on and off: same kernels, same order per
+    stream, same reduction trees -- bit-identical weights, BatchNorm statistics and losses after two steps (device-side
+    Philox dropout and noise included)."""
+    from mis_hip import step
+    from mis_hip.step import CnnMeetVitTrainer, UAMTTrainer
+    from test_grad_progress_gpu import _make
+    C = 2 if kind == "uamt3d" else 4
+    shape = {"uamt2d": (4, 1, 64, 64), "uamt3d": (2, 1, 32, 32, 32), "cnnvit": (2, 1, 224, 224)}[kind]
+    g = torch.Generator().manual_seed(3)
+    vol = torch.rand(shape, generator=g).cuda()
+    lab = torch.randint(0, C, (shape[0],) + shape[2:], generator=g).to(torch.int64 if C == 2 else torch.uint8).cuda()
+    res = []
+    for two in (False, True):
+        monkeypatch.setattr(step, "TWO_STREAM", two)
+        torch.manual_seed(11)
+        if kind == "cnnvit":
+            nets = [_make("unet2d", C), _make("swin", C), _make("swin", C)]
+            nets[2].load_state_dict(nets[1].state_dict())
+            tr = CnnMeetVitTrainer(nets[0], nets[1], nets[2], labeled_bs=1, num_classes=C, seed=5, iter_num=1500)
+        else:
+            base = "unet2d" if kind == "uamt2d" else "unet3d"
+            nets = [_make(base, C), _make(base, C)]
+            nets[1].load_state_dict(nets[0].state_dict())
+            tr = UAMTTrainer(nets[0], nets[1], labeled_bs=shape[0] // 2, num_classes=C, seed=5, max_iterations=2000,
+                             iter_num=1500)
+        for n in nets:
+            n.train()
+        for _ in range(2):
+            tr.step(vol, lab)
+        torch.cuda.synchronize()
+        res.append(([n.flat_param.clone() for n in nets],
+                    [b.clone() for n in nets for b in n.buffers() if b.is_floating_point()], tr.losses()))
+    (p0, b0, l0), (p1, b1, l1) = res
+    assert all(torch.equal(x, y) for x, y in zip(p0, p1))
+    assert all(torch.equal(x, y) for x, y in zip(b0, b1))
+    assert l0 == l1 and all(np.isfinite(v) for v in l0.values())
+
+
+@pytest.mark.parametrize("which", ["split", "encoder"])
+def test_swinunet_load_from_matches_the_reference_class(which, tmp_path):
+    """SwinUnet.load_from (reference vision_transformer.py:54-89; called unconditionally by train_mean_teacher_ViT.py:
+    147-156) on both checkpoint formats: a wrapped whole-network checkpoint (17-character prefix stripped, head dropped)
+    and an ImageNet encoder checkpoint {"model": ...} (encoder stages mirrored into the decoder, shape mismatches and
+    foreign keys dropped).  Golden: which entry ends with which tensor, from the REAL class (oracle/gen_golden.py)."""
+    import json
+    from types import SimpleNamespace as NS
+    from config import lite_config
+    from networks.vision_transformer import SwinUnet
+    from oracle import filler
+    from oracle.gen_golden import load_from_checkpoints
+    z = np.load(os.path.join(ROOT, "tests", "golden", "swin_load_from.npz"), allow_pickle=False)
+    ks = [(k, tuple(sh), dt) for k, sh, dt in json.loads(str(z["meta"]))["key_shapes"]]
+    model = SwinUnet(lite_config(), img_size=224, num_classes=4)
+    names = [str(n) for n in z[which + "_names"]]
+    assert list(model.state_dict().keys()) == names
+    model.load_state_dict(filler.fill_state_dict({k: v.cpu() for k, v in model.state_dict().items()}))
+    before = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    path = str(tmp_path / "ck.pth")
+    torch.save(load_from_checkpoints(ks, which), path)
+    model.load_from(NS(MODEL=NS(PRETRAIN_CKPT=path)))
+    after = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    n_changed = 0
+    for i, k in enumerate(names):
+        changed = bool((after[k] != before[k]).any())
+        assert changed == bool(z[which + "_changed"][i]), (k, changed)
+        n_changed += changed
+        t = after[k].double()
+        assert abs(float(t.sum()) - float(z[which + "_sum"][i])) <= 1e-9 * max(1.0, float(z[which + "_abssum"][i])), k
+        assert abs(float(t.abs().sum()) - float(z[which + "_abssum"][i])) <= 1e-9 * max(1.0, float(z[which + "_abssum"][i])), k
+        assert float(t.flatten()[0]) == float(z[which + "_first"][i]) and float(t.flatten()[-1]) == float(z[which + "_last"][i]), k
+    assert n_changed == (237 if which == "split" else 215)
+    # the flat parameter buffer (what the kernels read) saw the load: the views still alias it
+    p = dict(model.named_parameters())["swin_unet.layers_up.1.blocks.0.attn.qkv.weight"]
+    assert p.data_ptr() >= model.flat_param.data_ptr() and \
+        p.data_ptr() < model.flat_param.data_ptr() + model.flat_param.numel() * 4
+    # no checkpoint: the reference prints "none pretrain" and leaves the weights alone
+    model.load_from(NS(MODEL=NS(PRETRAIN_CKPT=None)))
