@@ -25,7 +25,7 @@ TOL_LOGIT, TOL_LOSS = 1e-3, 2e-4          # the north-star bar on logits; scalar
 # test_parity_gpu.py (6 x the reference's own fp32 noise + 2e-3), not a dispatch-only bound
 GRAD_REL, GRAD_ABS = 0.1, 2e-3
 GRAD_REL_CASE = {"config2_unet2d_24+24_256": 0.03, "config3_unet3d_4+4_96": 0.015, "config4_swin_24+24_224": 0.01,
-                 "config3_vnet_4+4_96": 0.1}
+                 "config3_vnet_4+4_96": 0.08}       # V-Net: 1.5e-2 measured (round 4), x5
 
 
 def _states(onet, tag=""):
@@ -247,7 +247,7 @@ def test_uamt_3d_step_at_full_batch():
     mp = tr._mean_probs.cpu().reshape((B - L, C) + sp)
     unc = -1.0 * torch.sum(mp * torch.log(mp + 1e-6), dim=1, keepdim=True)
     assert (unc - orc["uncertainty"]).abs().max().item() <= 1e-3
-    _check_grads_and_params(model, orc["grads"], student, orc["lr"], "uamt3d", 0.03)
+    _check_grads_and_params(model, orc["grads"], student, orc["lr"], "uamt3d", 0.005)       # 9.3e-4 measured, x5
 
 
 @pytest.mark.timeout(1500)
