@@ -25,6 +25,7 @@
 // partials in a fixed order (deterministic) into dw[Cout][Cin][27].
 #include "common.h"
 #include "wino.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -38,6 +39,8 @@ struct WgArgs {
     int N, Cin, Cout, D, H, W;
     int sz, sy, sx, n_stage;            // stages per image along z, y, x; N * sz * sy * sx
     int ci_blocks, co_blocks, splits;   // tasks = co_blocks * ci_blocks * splits, splits = 8 * nt (nt per XCD)
+    int seg, nseg;                      // z-ring kernel: a unit = `seg` consecutive stages along z, nseg units per column
+    unsigned long long* prof;           // MIS_WR_PROF builds only: per (workgroup, wave) cycle sums of the loop's phases
 };
 
 // stage = TZ x TY x TX tiles (32), TX a multiple of 4: 8 chunks of 4 x-adjacent tiles
@@ -63,6 +66,12 @@ struct WgCfg {
 
 #ifndef MIS_WGW_DBG_CT
 #define MIS_WGW_DBG_CT 0
+#endif
+#ifndef MIS_WR_ABL
+#define MIS_WR_ABL 0           // ablation builds of the ring kernel (timing only, results wrong): 1 no DMA in the loop, 2 no
+#endif                         // transforms, 4 no patch loads, 8 no barrier, 16 no MFMAs
+#ifndef MIS_WR_PROF
+#define MIS_WR_PROF 0          // 1: the ring kernel times its loop phases with s_memtime (development builds, scripts/wgrad_prof.sh)
 #endif
 // ablation builds (timing only, results wrong): 1 no DMA issue in the loop, 2 no transforms, 4 no patch loads, 8 no barrier
 constexpr int WDBG = MIS_WGW_DBG_CT;
@@ -151,6 +160,49 @@ __device__ __forceinline__ void wg_slots(f32x2 (&u)[32], const f32x2 (&v)[16], f
         __builtin_amdgcn_sched_barrier(0);
         wg_slots<C, ISSUE, K + 1>(u, v, acc, rn, xsrc, dsrc, is, wave, av);
     }
+}
+
+// ---- G^T . G: 64 points -> 27 taps for the lane's 4 (co, ci) pairs, two accumulator rows at a time; the 4 waves are
+// summed through LDS (the stage buffers are free by now) and the workgroup's partial goes to out[27][16 co][16 ci] ----
+__device__ __forceinline__ void wg_finish(f32x4 (&acc)[64], float* lds, float* __restrict__ out, int tid, int wave, int lt, int lc) {
+    float* const red = lds + wave * (27 * 256);
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");          // the last MFMAs have left the pipe
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        f32x2 gz[3][16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const f32x2 m0 = acc_pair(acc[i], h), m1 = acc_pair(acc[16 + i], h), m2 = acc_pair(acc[32 + i], h),
+                        m3 = acc_pair(acc[48 + i], h);
+            const f32x2 t = (m1 + m2) * 0.5f;
+            gz[0][i] = m0 + t; gz[1][i] = (m1 - m2) * 0.5f; gz[2][i] = t + m3;
+        }
+#pragma unroll
+        for (int z = 0; z < 3; ++z) {
+            f32x2 gy[3][4];
+#pragma unroll
+            for (int x = 0; x < 4; ++x) {
+                const f32x2 t = (gz[z][4 + x] + gz[z][8 + x]) * 0.5f;
+                gy[0][x] = gz[z][x] + t; gy[1][x] = (gz[z][4 + x] - gz[z][8 + x]) * 0.5f; gy[2][x] = t + gz[z][12 + x];
+            }
+#pragma unroll
+            for (int y = 0; y < 3; ++y) {
+                const f32x2 t = (gy[y][1] + gy[y][2]) * 0.5f;
+                const f32x2 w0 = gy[y][0] + t, w1 = (gy[y][1] - gy[y][2]) * 0.5f, w2 = t + gy[y][3];
+                const int tap = (z * 3 + y) * 3;
+#pragma unroll
+                for (int rr = 0; rr < 2; ++rr) {
+                    const int e = (lt * 4 + 2 * h + rr) * 16 + lc;          // co * 16 + ci
+                    red[(tap + 0) * 256 + e] = w0[rr];
+                    red[(tap + 1) * 256 + e] = w1[rr];
+                    red[(tap + 2) * 256 + e] = w2[rr];
+                }
+            }
+        }
+    }
+    __syncthreads();
+    for (int e = tid; e < 27 * 256; e += 256)
+        out[e] = (lds[e] + lds[27 * 256 + e]) + (lds[2 * 27 * 256 + e] + lds[3 * 27 * 256 + e]);
 }
 
 template <class C>
@@ -302,46 +354,326 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     vmwait<0>::go();
     __syncthreads();
 
-    // ---- G^T . G: 64 points -> 27 taps for the lane's 4 (co, ci) pairs, two accumulator rows at a time ----
-    float* const red = lds + wave * (27 * 256);
-    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");          // the last MFMAs have left the pipe
+    wg_finish(acc, lds, a.ws + (long long)task * (27 * 256), tid, wave, lt, lc);
+}
+
+
+// =====================================================================================================================
+// z-ring form (round 4).  A stage is ONE pair of output planes (2 x OY x OX voxels, 32 tiles).  A workgroup owns a
+// CONTIGUOUS range of the launch's stage sequence (image, y, x column, then z fastest) and walks it down z: consecutive
+// stages share two of their four input planes, so the haloed x planes live in a RING of 8 plane slots in LDS and a stage
+// fetches only its two NEW planes (1.9x the useful input instead of 3.75x / 3.4x for the boxes of the kernel above).  The
+// new planes of stage s + 2 go to ring slots nobody reads during stage s, so they are issued in the FIRST chunk's MFMA
+// run; only dy (double buffered) has to wait for the mid-stage barrier and goes out in the second run.
+//
+// What this kernel is really built around (measured this round): with one wave per SIMD the wave issues at
+// most one instruction every ~4 cycles, of ANY kind.  A 32-cycle MFMA hides ~6 other instructions; the box kernel's DMA
+// slots carried ~16 (M0 save / restore, s_nop, per-piece selects and class tests) and its per-stage cursor ~110 scalar
+// instructions in one block -- that, not the bytes, was its "DMA issue cost" (halving the bytes alone gained 4 %).  Here
+//   * a DMA slot is ds_read + buffer_load ... lds; M0 is set one slot earlier by a single s_add (nothing else in the
+//     kernel uses M0; no save / restore, no s_nop: the MFMA in between provides the wait state);
+//   * the lane's DMA offset already contains the y / x face test (recomputed once per column, not per piece), the z faces
+//     are whole planes and handled by the descriptor's range (one scalar select per plane and stage);
+//   * the per-stage scalar bookkeeping (~15 instructions) sits inside the MFMA runs, the part used by one run is computed
+//     during the other;
+//   * no stage kinds: inside a column every stage issues one plane pair + dy.  A change of column drains the pipeline and
+//     re-runs the prologue (~1 stage of 48 or 24; workgroups cross 1-3 columns per launch).
+template <int TY_, int TX_, int DPAD_ = 1>
+struct WrCfg {
+    static constexpr int TY = TY_, TX = TX_;
+    static constexpr int OY = 2 * TY, OX = 2 * TX, HY = OY + 2;
+    static constexpr int NQ = (OX + 8) / 4, RX = NQ * 4;                  // x rows hold [x0 - 4, x0 + OX + 4)
+    static constexpr int PLG = HY * 16 * NQ, PLF = PLG * 4, PLB = PLF * 4;  // one z plane of 16 channels: groups / floats / bytes
+    static constexpr int PP = PLG / 64;                                   // DMA pieces per plane
+    static constexpr int PW = (PP + 3) / 4;                               // ... per wave (pieces w, w + 4, ...; surplus: the last)
+    static constexpr int R = 8;                                           // ring slots
+    static constexpr int DQ = OX / 4 + DPAD_, DRX = DQ * 4;
+    static constexpr int DROWS = 2 * OY, DG = DROWS * 16 * DQ, DF = DG * 4, DP = DG / 64;
+    static constexpr int DW = (DP + 3) / 4;                               // dy pieces per wave
+    static constexpr int LDS_BYTES = R * PLB + 2 * DF * 4;
+    static constexpr int CX = TX / 4;
+    static_assert(TY * TX == 32 && TX % 4 == 0, "32 tiles, chunks of 4 along x");
+    static_assert(PLG % 64 == 0 && DG % 64 == 0, "whole DMA pieces");
+    static_assert(LDS_BYTES <= 160 * 1024, "LDS");
+    static_assert(4 * 27 * 256 * 4 <= LDS_BYTES, "the final cross-wave sum reuses the ring");
+    static_assert(PW == 4 && DW <= 5, "slot maps of the two runs: 2 x 4 plane pieces, 5 dy pieces");
+};
+
+// M0 := a + b (LDS byte address of the next DMA piece).  M0 is reserved for hipcc but unused by anything it generates here
+// (gfx9 LDS instructions do not need it); checked in the ISA: the only writers are these statements.
+// (s_add writes SCC: declared, or hipcc keeps a compare result alive across the statement)
+__device__ __forceinline__ void set_m0(unsigned a, unsigned b) { asm volatile("s_add_i32 m0, %0, %1" ::"s"(a), "s"(b) : "scc"); }
+__device__ __forceinline__ void dma_x4_m0(unsigned voff, unsigned soff, i32x4 rsrc) {
+    asm volatile("buffer_load_dwordx4 %0, %1, %2 offen lds" ::"v"(voff), "s"(rsrc), "s"(soff) : "memory");
+}
+
+template <class C>
+struct WrState {
+    // per lane
+    unsigned e_vo[C::PW];       // DMA byte offset of this lane's 16-byte group inside a plane (piece slot e), y / x faces applied
+    unsigned d_rel[C::DW];
+    // per wave
+    unsigned e_off[C::PW], d_off[C::DW];            // LDS byte offset of the slot's piece inside its plane / the dy buffer
+    // per column
+    i32x4 rxa, rxb, rd;         // x descriptor for the first / second new plane (word 2 = range, 0: plane beyond the volume), dy
+    unsigned full;              // range of a live x descriptor
+    // the fill cursor (stage f + 2 while stage f computes)
+    unsigned dst_a;             // LDS address of the first new plane's ring slot; the second follows it
+    unsigned qa;                // its slot index (even)
+    unsigned soff_a;            // byte offset of the first new plane (plane 2 of the stage being filled)
+    unsigned dsoff, ddst;       // dy of the stage being filled: byte offset, LDS address
+    int f_left;                 // stages of this column segment still to be filled (<= 0: dead fills)
+    int f_bz;                   // z index of the stage being filled
+    unsigned hw_bytes, lds0, dbase;
+    int sz;
+
+    // early plane pair of the NEXT fill: run in the second chunk (its DMAs use only dy state)
+    __device__ __forceinline__ void prep_planes() {
+        ++f_bz; --f_left;
+        soff_a += 2u * hw_bytes;
+        qa = (qa + 2u) & 7u;
+        dst_a = lds0 + qa * (unsigned)C::PLB;
+        rxa[2] = (int)(f_left > 0 ? full : 0u);
+        rxb[2] = (int)((f_left > 0 && f_bz < sz - 1) ? full : 0u);       // plane 3 of the column's last stage: below the volume
+    }
+    // dy of the CURRENT fill: run in the first chunk (its DMAs use only the plane state)
+    __device__ __forceinline__ void prep_dy(unsigned parity) {
+        dsoff = soff_a - 2u * hw_bytes;                                  // plane 2 of a stage is its first output plane + 1 ... see soff_a
+        ddst = dbase + parity * (unsigned)(C::DF * 4);
+        rd[2] = (int)(f_left > 0 ? full : 0u);
+    }
+};
+
+// One chunk of the ring kernel: 64 MFMAs; the next chunk's patch comes from four plane pointers (ring slots).
+// SECOND = false: the stage's first chunk -- 8 plane pieces (M0 at K = 8 e + 3, DMA at 8 e + 4), dy bookkeeping at K = 62;
+// SECOND = true: 5 dy pieces (M0 at K = 12 l + 5, DMA at 12 l + 6), plane bookkeeping of the next fill at K = 62.
+template <class C, bool SECOND, int K>
+__device__ __forceinline__ void wr_slots(f32x2 (&u)[32], const f32x2 (&v)[16], f32x4 (&acc)[64], f32x2 (&rn)[4],
+                                         const float* __restrict__ x0, const float* __restrict__ x1,
+                                         const float* __restrict__ x2, const float* __restrict__ x3,
+                                         const float* __restrict__ dsrc, WrState<C>& st, unsigned parity, float (&av)[4]) {
+    if constexpr (K < 64) {
+        if constexpr (K % 4 == 0) {
+            const f32x2 p = v[K / 4];
+            f32x2 pm;
+            asm volatile("v_pk_add_f32 %0, %1, %1 op_sel:[0,1] op_sel_hi:[0,1] neg_hi:[0,1]" : "=v"(pm) : "v"(p));
+            av[0] = p[0]; av[1] = pm[0]; av[2] = pm[1]; av[3] = f_sub(0.f, p[1]);
+        }
+        if constexpr (!(MIS_WR_ABL & 16))
+            acc[K] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[K % 4], u[K / 2][K % 2], acc[K], 0, 0, 0);
+        else asm volatile("" :: "v"(av[K % 4]), "v"(u[K / 2][K % 2]));
+        if constexpr (!(MIS_WR_ABL & 4)) {
+            constexpr int z = K / 16, y = (K / 4) % 4, xx = K % 4;
+            const float* __restrict__ xs = z == 0 ? x0 : z == 1 ? x1 : z == 2 ? x2 : x3;
+            u[K / 2][K % 2] = ((const volatile __attribute__((address_space(3))) float*)xs)[y * 16 * C::RX + xx];
+        }
+        if constexpr (K < 4 && !(MIS_WR_ABL & 4)) rn[K] = *reinterpret_cast<const f32x2*>(dsrc + ((K / 2) * C::OY + (K % 2)) * 16 * C::DRX);
+        if constexpr (MIS_WR_ABL & 1) {
+            if constexpr (K == 62) { if constexpr (SECOND) st.prep_planes(); else st.prep_dy(parity); }
+        } else if constexpr (!SECOND) {
+            if constexpr (K % 8 == 3) {
+                constexpr int E = K / 8;                                   // slots 0..3: first new plane, 4..7: second
+                set_m0(E < 4 ? st.dst_a : st.dst_a + (unsigned)C::PLB, st.e_off[E % 4]);
+            }
+            if constexpr (K % 8 == 4) {
+                constexpr int E = K / 8;
+                dma_x4_m0(st.e_vo[E % 4], E < 4 ? st.soff_a : st.soff_a + st.hw_bytes, E < 4 ? st.rxa : st.rxb);
+            }
+            if constexpr (K == 62) st.prep_dy(parity);
+        } else {
+            if constexpr (K % 12 == 5 && K / 12 < C::DW) set_m0(st.ddst, st.d_off[K / 12]);
+            if constexpr (K % 12 == 6 && K / 12 < C::DW) dma_x4_m0(st.d_rel[K / 12], st.dsoff, st.rd);
+            if constexpr (K == 62) st.prep_planes();
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        wr_slots<C, SECOND, K + 1>(u, v, acc, rn, x0, x1, x2, x3, dsrc, st, parity, av);
+    }
+}
+
+template <class C>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void wino_wgrad_ring_kernel(const WgArgs a) {
+    float* const lds = mis_wgw_lds;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lt = lane >> 4, lc = lane & 15;
+    const long long S = (long long)a.D * a.H * a.W;
+    const unsigned s_bytes = (unsigned)S * 4u;
+    const int HW = a.H * a.W;
+
+    // workgroup -> (channel-block pair, chunk of the stage sequence).  Workgroup b runs on XCD b % 8: XCD x owns the chunks
+    // [x * nt, (x + 1) * nt) -- neighbouring columns -- and all channel-block pairs of a chunk sit on the same XCD (they
+    // share x or dy in its L2)
+    const int pairs = a.ci_blocks * a.co_blocks, nt = a.splits / MIS_NUM_XCD;
+    const int xcd = blockIdx.x % MIS_NUM_XCD, local = blockIdx.x / MIS_NUM_XCD;
+    const int pair = local % pairs, j = local / pairs;
+    const int cib = pair % a.ci_blocks, cob = pair / a.ci_blocks;
+    const int chunk = xcd * nt + j;
+    const int task = pair * a.splits + chunk;
+    const long long g_begin = (long long)a.n_stage * chunk / a.splits, g_end = (long long)a.n_stage * (chunk + 1) / a.splits;
+
+    WrState<C> st;
+    st.hw_bytes = (unsigned)HW * 4u;
+    st.sz = a.sz;
+    st.lds0 = lds_addr(lds);
+    st.dbase = st.lds0 + (unsigned)(C::R * C::PLB);
+    const unsigned x_bias = (unsigned)(HW + a.W + 4) * 4u;
+    st.full = 17u * s_bytes + x_bias;
+
+    // ---- per-lane DMA geometry ----
+    // x: the descriptor starts (HW + W + 4) floats before the channel block; a lane's offset inside a plane is
+    // (hy W + 4 q) floats (>= 0), the plane index adds t HW through the scalar offset
+    unsigned e_rel[C::PW], e_cls = 0;
+#pragma unroll
+    for (int e = 0; e < C::PW; ++e) {
+        const int pin = wave + 4 * e < C::PP ? wave + 4 * e : C::PP - 1;       // surplus slot: the plane's last piece again
+        const int g = pin * 64 + lane;
+        const int hy = g / (16 * C::NQ), rem = g - hy * (16 * C::NQ), ci = rem / C::NQ, q = rem - ci * C::NQ;
+        unsigned rel = (unsigned)((hy * a.W + 4 * q) * 4) + (unsigned)ci * s_bytes;
+        if (cib * 16 + ci >= a.Cin) rel = OOB;
+        e_rel[e] = rel;
+        e_cls |= ((hy == 0 ? 1u : 0u) | (hy == C::HY - 1 ? 2u : 0u) | (q == 0 ? 4u : 0u) | (q == C::NQ - 1 ? 8u : 0u)) << (4 * e);
+        st.e_off[e] = (unsigned)pin * 1024u;
+    }
+#pragma unroll
+    for (int l = 0; l < C::DW; ++l) {
+        const int p = wave + 4 * l < C::DP ? wave + 4 * l : C::DP - 1;
+        const int g = p * 64 + lane;
+        const int row = g / (16 * C::DQ), rem = g - row * (16 * C::DQ), co = rem / C::DQ, q = rem - co * C::DQ;
+        const int oz = row / C::OY, oy = row - oz * C::OY;
+        unsigned rel = OOB;
+        if (q < C::OX / 4 && cob * 16 + co < a.Cout) rel = (unsigned)(((oz * a.H + oy) * a.W + 4 * q) * 4) + (unsigned)co * s_bytes;
+        st.d_rel[l] = rel;
+        st.d_off[l] = (unsigned)p * 1024u;
+    }
+
+    // ---- this wave's two chunks (c = wave, wave + 4) and this lane's patch inside them ----
+    int xoff[2], doff[2];
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-        f32x2 gz[3][16];
+        const int c = wave + 4 * h;
+        const int cx = c % C::CX, cy = c / C::CX;
+        const int tx = 4 * cx + lt;
+        xoff[h] = (2 * cy) * 16 * C::RX + lc * C::RX + 3 + 2 * tx;
+        doff[h] = (2 * cy) * 16 * C::DRX + lc * C::DRX + 2 * tx;
+    }
+
+    f32x4 acc[64];
+    const f32x2 zero = {0.f, 0.f};
+    {
+        float z0 = 0.f;
+        asm volatile("" : "+v"(z0));
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const f32x2 m0 = acc_pair(acc[i], h), m1 = acc_pair(acc[16 + i], h), m2 = acc_pair(acc[32 + i], h),
-                        m3 = acc_pair(acc[48 + i], h);
-            const f32x2 t = (m1 + m2) * 0.5f;
-            gz[0][i] = m0 + t; gz[1][i] = (m1 - m2) * 0.5f; gz[2][i] = t + m3;
-        }
+        for (int i = 0; i < 64; ++i)
+            acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(z0, z0, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+    }
+    f32x2 u[32], v[16], rn[4];
+    float av[4];
+    float* const dbuf = lds + C::R * C::PLF;
+#if MIS_WR_PROF
+    const unsigned long long prof_c0 = __builtin_amdgcn_s_memtime(), prof_w0 = __builtin_amdgcn_s_memrealtime();
+#endif
+
+    for (long long g = g_begin; g < g_end;) {
+        // ---- a column segment: stages bz0 .. bz0 + cnt - 1 of column `col` ----
+        const int col = (int)(g / a.sz), bz0 = (int)(g - (long long)col * a.sz);
+        const int cnt = (int)((long long)(a.sz - bz0) < g_end - g ? (long long)(a.sz - bz0) : g_end - g);
+        g += cnt;
+        int t = col;
+        const int bx = t % a.sx; t /= a.sx;
+        const int by = t % a.sy; const int n = t / a.sy;
+        const unsigned flags = (by == 0 ? 1u : 0u) | (by == a.sy - 1 ? 2u : 0u) | (bx == 0 ? 4u : 0u) | (bx == a.sx - 1 ? 8u : 0u);
 #pragma unroll
-        for (int z = 0; z < 3; ++z) {
-            f32x2 gy[3][4];
+        for (int e = 0; e < C::PW; ++e) st.e_vo[e] = (((e_cls >> (4 * e)) & 15u) & flags) ? OOB : e_rel[e];
+        st.rxa = make_rsrc(reinterpret_cast<const char*>(a.x + (long long)n * a.x_bs + (long long)cib * 16 * S) - x_bias, st.full);
+        st.rxb = st.rxa;
+        st.rd = make_rsrc(a.dy + (long long)n * a.dy_bs + (long long)cob * 16 * S, st.full);
+        // byte offset of plane 0 (input plane 2 bz0 - 1, biased by the descriptor base) of the segment's first stage
+        const unsigned soff0 = (unsigned)(((2 * bz0) * a.H + by * C::OY) * a.W + bx * C::OX) * 4u;
+
+        // ---- prologue (not overlapped): stage bz0 = four planes + dy, stage bz0 + 1 = its two new planes + dy ----
+        // (second and later segments) the previous segment's last -- dead -- DMAs of every wave have landed and its last
+        // LDS reads are done before anything is written to the ring again
+        vmwait<0>::go();
+        __syncthreads();
+        {
+            i32x4 r = st.rxa;
 #pragma unroll
-            for (int x = 0; x < 4; ++x) {
-                const f32x2 t = (gz[z][4 + x] + gz[z][8 + x]) * 0.5f;
-                gy[0][x] = gz[z][x] + t; gy[1][x] = (gz[z][4 + x] - gz[z][8 + x]) * 0.5f; gy[2][x] = t + gz[z][12 + x];
+            for (int tt = 0; tt < 6; ++tt) {               // ring slots 0..5: planes 0..3 of the first stage, 2..3 of the second
+                const int zp = 2 * bz0 - 1 + tt;
+                r[2] = (int)((zp >= 0 && zp < a.D && (tt < 4 || cnt > 1)) ? st.full : 0u);
+#pragma unroll
+                for (int e = 0; e < C::PW; ++e) {
+                    set_m0(st.lds0 + (unsigned)(tt * C::PLB), st.e_off[e]);
+                    asm volatile("s_nop 0");
+                    dma_x4_m0(st.e_vo[e], soff0 + (unsigned)tt * st.hw_bytes, r);
+                }
             }
+            i32x4 rdd = st.rd;
 #pragma unroll
-            for (int y = 0; y < 3; ++y) {
-                const f32x2 t = (gy[y][1] + gy[y][2]) * 0.5f;
-                const f32x2 w0 = gy[y][0] + t, w1 = (gy[y][1] - gy[y][2]) * 0.5f, w2 = t + gy[y][3];
-                const int tap = (z * 3 + y) * 3;
+            for (int k = 0; k < 2; ++k) {
+                rdd[2] = (int)((k == 0 || cnt > 1) ? st.full : 0u);
 #pragma unroll
-                for (int rr = 0; rr < 2; ++rr) {
-                    const int e = (lt * 4 + 2 * h + rr) * 16 + lc;          // co * 16 + ci
-                    red[(tap + 0) * 256 + e] = w0[rr];
-                    red[(tap + 1) * 256 + e] = w1[rr];
-                    red[(tap + 2) * 256 + e] = w2[rr];
+                for (int l = 0; l < C::DW; ++l) {
+                    set_m0(st.dbase + (unsigned)(k * C::DF * 4), st.d_off[l]);
+                    asm volatile("s_nop 0");
+                    dma_x4_m0(st.d_rel[l], soff0 + (unsigned)k * 2u * st.hw_bytes, rdd);
                 }
             }
         }
+        // fill cursor: the next fill is stage bz0 + 2 (its planes 2, 3 -> ring slots 6, 7)
+        st.f_bz = bz0 + 2; st.f_left = cnt - 2;
+        st.qa = 6u; st.dst_a = st.lds0 + 6u * (unsigned)C::PLB;
+        st.soff_a = soff0 + (2u * 2u + 2u) * st.hw_bytes;                 // stage bz0 + 2, plane 2
+        st.rxa[2] = (int)(st.f_left > 0 ? st.full : 0u);
+        st.rxb[2] = (int)((st.f_left > 0 && st.f_bz < a.sz - 1) ? st.full : 0u);
+        st.prep_dy(0u);
+        vmwait<0>::go();
+        __syncthreads();
+
+        unsigned r_jb = 0;               // ring slot of plane 0 of the stage being computed
+        auto plane_ptr = [&](unsigned jb, int z, int h) -> const float* {
+            return lds + (((jb + (unsigned)z) & 7u) * (unsigned)C::PLF) + xoff[h];
+        };
+        {
+#pragma unroll
+            for (int k = 0; k < 64; ++k) {
+                const int z = k / 16, y = (k / 4) % 4, xx = k % 4;
+                u[k / 2][k % 2] = plane_ptr(0, z, 0)[y * 16 * C::RX + xx];
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                rn[k] = *reinterpret_cast<const f32x2*>(dbuf + doff[0] + ((k / 2) * C::OY + (k % 2)) * 16 * C::DRX);
+            in_units<0, 24>(u);
+            vzy_transform(rn, v, zero);
+        }
+        for (int s = 0; s < cnt; ++s) {
+            const unsigned par = (unsigned)(s & 1);
+            // first chunk; LDS reads of the second chunk of the same stage; the new plane pair of stage s + 2
+            wr_slots<C, false, 0>(u, v, acc, rn, plane_ptr(r_jb, 0, 1), plane_ptr(r_jb, 1, 1), plane_ptr(r_jb, 2, 1),
+                                  plane_ptr(r_jb, 3, 1), dbuf + par * C::DF + doff[1], st, par, av);
+            if (!(MIS_WR_ABL & 2)) { in_units<0, 24>(u); vzy_transform(rn, v, zero); }
+            if (!(MIS_WR_ABL & 1)) vmwait<2 * C::PW>::go();   // everything but the 8 pieces just issued: stage s + 1 has landed
+            if (!(MIS_WR_ABL & 8)) __syncthreads();   // every wave has read stage s completely
+            // second chunk; LDS reads of the first chunk of stage s + 1 (stale data after the last stage: unused); dy of s + 2
+            r_jb = (r_jb + 2u) & 7u;
+            wr_slots<C, true, 0>(u, v, acc, rn, plane_ptr(r_jb, 0, 0), plane_ptr(r_jb, 1, 0), plane_ptr(r_jb, 2, 0),
+                                 plane_ptr(r_jb, 3, 0), dbuf + (par ^ 1u) * C::DF + doff[0], st, par, av);
+            if (!(MIS_WR_ABL & 2)) { in_units<0, 24>(u); vzy_transform(rn, v, zero); }
+        }
     }
+#if MIS_WR_PROF
+    if (a.prof && lane == 0) {
+        unsigned long long* o = a.prof + ((long long)blockIdx.x * 4 + wave) * 8;
+        o[4] = __builtin_amdgcn_s_memtime() - prof_c0;
+        o[0] = __builtin_amdgcn_s_memrealtime() - prof_w0;
+        o[5] = (unsigned long long)(g_end - g_begin);
+    }
+#endif
+    vmwait<0>::go();
     __syncthreads();
-    float* __restrict__ out = a.ws + (long long)task * (27 * 256);
-    for (int e = tid; e < 27 * 256; e += 256)
-        out[e] = (lds[e] + lds[27 * 256 + e]) + (lds[2 * 27 * 256 + e] + lds[3 * 27 * 256 + e]);
+
+    // ---- G^T . G: 64 points -> 27 taps for the lane's 4 (co, ci) pairs, two accumulator rows at a time ----
+    wg_finish(acc, lds, a.ws + (long long)task * (27 * 256), tid, wave, lt, lc);
 }
 
 // dw[co][ci][tap] (+)= sum over the splits of the task partials: 16 lanes per output, each a strided share, combined
@@ -392,25 +724,82 @@ int launch_wg(WgArgs a, float* dw, int accumulate, hipStream_t stream) {
 using WgV0 = WgCfg<1, 2, 16>;     // stages of 2 x 4 x 32 voxels (W a multiple of 32)
 using WgV1 = WgCfg<2, 2, 8>;      // stages of 4 x 4 x 16 voxels (W a multiple of 16)
 using WgV2 = WgCfg<4, 2, 4, 0>;   // stages of 8 x 4 x 8 voxels (W a multiple of 8: the 24^3 level); no dy pad group: LDS
+using WrV3 = WrCfg<2, 16>;        // z-ring, stages of 2 x 4 x 32 voxels (W a multiple of 32, H of 4): the 96^3 level
+using WrV4 = WrCfg<4, 8>;         // z-ring, stages of 2 x 8 x 16 voxels (W a multiple of 16, H of 8): the 48^3 level
+
+// z-ring geometry: the stage sequence (image, y, x column, z fastest) is cut into splits = 8 * nt equal contiguous chunks,
+// one workgroup per (channel-block pair, chunk); one resident workgroup per CU (160 KB of LDS), so one round of the 256
+// CUs, or two when one round would leave more than a tenth of them idle.
+template <class C>
+void ring_geometry(WgArgs& a) {
+    a.sz = a.D / 2; a.sy = a.H / C::OY; a.sx = a.W / C::OX;
+    a.ci_blocks = (a.Cin + 15) / 16; a.co_blocks = (a.Cout + 15) / 16;
+    a.n_stage = a.N * a.sy * a.sx * a.sz;
+    const int pairs = a.ci_blocks * a.co_blocks;
+    const int nt1 = 256 / (MIS_NUM_XCD * pairs), nt2 = 512 / (MIS_NUM_XCD * pairs);
+    int nt = (nt1 >= 1 && MIS_NUM_XCD * pairs * nt1 * 10 >= 256 * 9) ? nt1 : (nt2 >= 1 ? nt2 : 1);
+    const int cap = a.n_stage / (MIS_NUM_XCD * 4);                      // at least ~4 stages per workgroup
+    if (nt > cap) nt = cap < 1 ? 1 : cap;
+    a.splits = MIS_NUM_XCD * nt;
+    a.seg = a.nseg = 0;
+}
+
+template <class C>
+int launch_ring(WgArgs a, float* dw, int accumulate, hipStream_t stream) {
+    ring_geometry<C>(a);
+    static std::atomic<unsigned long long> attr_done{0};
+    if (mis_set_lds_attr(reinterpret_cast<const void*>(&wino_wgrad_ring_kernel<C>), C::LDS_BYTES, attr_done) != MIS_OK)
+        return MIS_ERR_LAUNCH;
+    const int tasks = a.ci_blocks * a.co_blocks * a.splits;
+    hipLaunchKernelGGL(wino_wgrad_ring_kernel<C>, dim3(tasks), dim3(256), C::LDS_BYTES, stream, a);
+    const int total = a.Cout * a.Cin * 27;
+    hipLaunchKernelGGL(wino_wgrad_reduce_kernel, dim3((total + 15) / 16), dim3(256), 0, stream, a.ws, dw, a.Cout, a.Cin,
+                       a.ci_blocks, a.splits, accumulate);
+    return mis_launch_status();
+}
+
+unsigned long long* g_wr_prof = nullptr;
+
+// MIS_WGRAD_RING=0: the box kernels of round 2 for every level (A/B switch)
+bool ring_enabled() {
+    static const bool on = [] { const char* e = getenv("MIS_WGRAD_RING"); return !(e && e[0] == '0'); }();
+    return on;
+}
+
+bool variant_fits(int variant, int D, int H, int W) {
+    switch (variant) {
+        case 0: return W % 32 == 0 && H % 4 == 0 && D % 2 == 0;
+        case 1: return W % 16 == 0 && H % 4 == 0 && D % 4 == 0;
+        case 2: return W % 8 == 0 && H % 4 == 0 && D % 8 == 0;
+        case 3: return W % 32 == 0 && H % 4 == 0 && D % 2 == 0;
+        case 4: return W % 16 == 0 && H % 8 == 0 && D % 2 == 0;
+    }
+    return false;
+}
 
 }  // namespace
 
-// Which variant serves the weight gradient of this 3x3x3 'same' convolution, or -1 (use mis_conv_wgrad)
+// Which variant serves the weight gradient of this 3x3x3 'same' convolution, or -1 (use mis_conv_wgrad).
+// 3 / 4: the z-ring kernels (96^3 / 48^3 levels), 0 / 1 / 2: the box kernels
 extern "C" int mis_conv3d_wino_wgrad_select(int N, int Cin, int Cout, int D, int H, int W) {
     if (N <= 0 || Cin < 8 || Cout < 8 || D <= 0 || H <= 0 || W <= 0) return -1;
     if (((long long)17 * D * H * W + (long long)H * W + W + 64) * 4 >= (1LL << 31)) return -1;
-    if (W % 32 == 0 && H % 4 == 0 && D % 2 == 0) return 0;
-    if (W % 16 == 0 && H % 4 == 0 && D % 4 == 0) return 1;
-    if (W % 8 == 0 && H % 4 == 0 && D % 8 == 0) return 2;
+    if (ring_enabled()) {
+        if (variant_fits(3, D, H, W)) return 3;
+        if (variant_fits(4, D, H, W)) return 4;
+    }
+    for (int v = 0; v < 3; ++v)
+        if (variant_fits(v, D, H, W)) return v;
     return -1;
 }
 
 extern "C" long long mis_conv3d_wino_wgrad_workspace_bytes(int N, int Cin, int Cout, int D, int H, int W, int variant) {
     if (N <= 0 || Cin <= 0 || Cout <= 0 || D <= 0 || H <= 0 || W <= 0) return MIS_ERR_ARG;
+    if (variant < 0 || variant > 4 || !variant_fits(variant, D, H, W)) return MIS_ERR_UNSUPPORTED;
     WgArgs a{};
     a.N = N; a.Cin = Cin; a.Cout = Cout; a.D = D; a.H = H; a.W = W;
     if (variant == 0) geometry<WgV0>(a); else if (variant == 1) geometry<WgV1>(a); else if (variant == 2) geometry<WgV2>(a);
-    else return MIS_ERR_UNSUPPORTED;
+    else if (variant == 3) ring_geometry<WrV3>(a); else ring_geometry<WrV4>(a);
     return (long long)a.ci_blocks * a.co_blocks * a.splits * 27 * 256 * 4;
 }
 
@@ -421,10 +810,8 @@ extern "C" int mis_conv3d_wino_wgrad(const float* x, long long x_bs, const float
     if (!x || !dy || !dw || !workspace || N <= 0 || Cin <= 0 || Cout <= 0 || D <= 0 || H <= 0 || W <= 0) return MIS_ERR_ARG;
     const long long S = (long long)D * H * W;
     if (x_bs < (long long)Cin * S || dy_bs < (long long)Cout * S) return MIS_ERR_ARG;
-    if (mis_conv3d_wino_wgrad_select(N, Cin, Cout, D, H, W) < 0 || variant < 0 || variant > 2) return MIS_ERR_UNSUPPORTED;
-    if ((variant == 0 && (W % 32 || H % 4 || D % 2)) || (variant == 1 && (W % 16 || H % 4 || D % 4)) ||
-        (variant == 2 && (W % 8 || H % 4 || D % 8)))
-        return MIS_ERR_UNSUPPORTED;
+    if (Cin < 8 || Cout < 8 || ((long long)17 * S + (long long)H * W + W + 64) * 4 >= (1LL << 31)) return MIS_ERR_UNSUPPORTED;
+    if (variant < 0 || variant > 4 || !variant_fits(variant, D, H, W)) return MIS_ERR_UNSUPPORTED;
     if (((uintptr_t)x & 15) || ((uintptr_t)dy & 15) || x_bs % 4 || dy_bs % 4 || W % 4) return MIS_ERR_UNSUPPORTED;
     if (workspace_bytes < mis_conv3d_wino_wgrad_workspace_bytes(N, Cin, Cout, D, H, W, variant)) return MIS_ERR_WORKSPACE;
     WgArgs a{};
@@ -432,5 +819,16 @@ extern "C" int mis_conv3d_wino_wgrad(const float* x, long long x_bs, const float
     a.N = N; a.Cin = Cin; a.Cout = Cout; a.D = D; a.H = H; a.W = W;
     if (variant == 0) return launch_wg<WgV0>(a, dw, accumulate, stream);
     if (variant == 1) return launch_wg<WgV1>(a, dw, accumulate, stream);
-    return launch_wg<WgV2>(a, dw, accumulate, stream);
+    if (variant == 2) return launch_wg<WgV2>(a, dw, accumulate, stream);
+    a.prof = g_wr_prof;
+    if (variant == 3) return launch_ring<WrV3>(a, dw, accumulate, stream);
+    return launch_ring<WrV4>(a, dw, accumulate, stream);
+}
+
+// Development hook (MIS_WR_PROF builds): device buffer of 8 x uint64 per (workgroup, wave) that the z-ring kernel fills
+// with the cycles it spent in [set-up, first chunk + transforms, DMA wait, barrier, second chunk + transforms] and its
+// stage count.  NULL (the default) switches it off; the product build ignores it.
+extern "C" int mis_debug_wgrad_prof(unsigned long long* buf) {
+    g_wr_prof = buf;
+    return MIS_WR_PROF ? MIS_OK : MIS_ERR_UNSUPPORTED;
 }

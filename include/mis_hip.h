@@ -597,6 +597,10 @@ int mis_win3d_attn_bwd(const float* qkv, long long ldq, const float* out, const 
 /* Test support (never on the product path): fills the LDS of every CU with NaNs so that a kernel reading LDS it did not write
  * fails deterministically instead of depending on the previous launch.  sink: any device float (or NULL). */
 int mis_debug_poison_lds(float* sink, mis_stream_t stream);
+/* Development support (never on the product path): a device buffer of 8 x uint64 per (workgroup, wave) that a -DMIS_WR_PROF=1
+ * build of the z-ring Winograd weight-gradient kernel fills with the cycles of its loop phases (scripts/wgrad_prof.py); NULL
+ * switches it off.  Returns MIS_ERR_UNSUPPORTED in the product build, which never writes the buffer. */
+int mis_debug_wgrad_prof(unsigned long long* buf);
 
 #ifdef __cplusplus
 }

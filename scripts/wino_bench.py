@@ -96,6 +96,24 @@ def wgrad_main():
         sc = ref.abs().max().item()
         print(f"wgrad N{N} {Cin}->{Cout} {D}x{H}x{W} v{var}: wino err {(dww.double() - ref).abs().max().item() / sc:.3e}  "
               f"direct err {(dwd.double() - ref).abs().max().item() / sc:.3e} (rel. to max {sc:.1f})", flush=True)
+    if "ab" in sys.argv[1:]:        # box kernels (0 / 1) against the z-ring kernels (3 / 4) on the config-3 / V-Net layers
+        for (N, Cin, Cout, S, va, vb) in [(8, 16, 16, 96, 0, 3), (8, 48, 16, 96, 0, 3), (8, 32, 32, 48, 1, 4),
+                                          (8, 96, 32, 48, 1, 4), (8, 16, 32, 48, 1, 4), (8, 32, 32, 48, 0, 4)]:
+            x = torch.randn(N, Cin, S, S, S, device="cuda")
+            dy = torch.randn(N, Cout, S, S, S, device="cuda")
+            fl = 2.0 * N * Cout * Cin * 27 * S ** 3
+            try:
+                da, ra = wino_wg(x, dy, va)
+            except RuntimeError as e:
+                print("skip", N, Cin, Cout, S, va, e)
+                continue
+            db, rb = wino_wg(x, dy, vb)
+            err = (da - db).abs().max().item() / da.abs().max().item()
+            ta, tb = timeit(ra), timeit(rb)
+            print(f"wgrad N{N} {Cin}->{Cout} {S}^3: v{va} {ta:8.1f} us ({fl / ta / 1e6:6.1f} TF eq, {fl / 3.375 / ta / 157.3e6:.3f} of the pipe)"
+                  f"   v{vb} {tb:8.1f} us ({fl / tb / 1e6:6.1f} TF eq, {fl / 3.375 / tb / 157.3e6:.3f})  x{ta / tb:.3f}  rel diff {err:.2e}",
+                  flush=True)
+        return
     for (N, Cin, Cout, S, var) in [(8, 16, 16, 96, 0), (8, 48, 16, 96, 0), (8, 32, 32, 48, 1), (8, 96, 32, 48, 1),
                                    (8, 16, 32, 48, 1), (8, 64, 64, 24, 2), (8, 192, 64, 24, 2), (8, 32, 64, 24, 2)]:
         x = torch.randn(N, Cin, S, S, S, device="cuda")

@@ -147,6 +147,17 @@ WGRAD_CASES = [
     (3, 8, 8, 4, 4, 16),
     (2, 32, 16, 8, 4, 8),         # stages of 8 x 4 x 8 voxels (24^3 level)
     (1, 64, 64, 8, 12, 24),
+    # z-ring kernels (round 4: W % 32 / H % 4 -> 2 x 4 x 32-voxel stages, W % 16 / H % 8 -> 2 x 8 x 16); a workgroup owns a
+    # contiguous range of the (image, y, x, z) stage sequence
+    (1, 16, 16, 4, 4, 32),        # two stages, eight workgroups: single-stage and empty ranges
+    (8, 16, 16, 4, 4, 32),        # one whole two-stage column per workgroup: the prologue alone feeds it
+    (1, 16, 16, 64, 4, 32),       # ranges of four stages inside one column: segments that start mid-column (real z halo)
+    (2, 16, 16, 12, 8, 32),       # ranges that cross column ends (drain + prologue inside the kernel)
+    (3, 16, 16, 16, 16, 64),      # many columns, > 256 stages: every y / x face class
+    (1, 24, 40, 8, 8, 32),        # ragged channel blocks, 6 pairs
+    (2, 32, 32, 8, 16, 48),       # 2 x 8 x 16-voxel stages (48^3 level geometry), 3 columns along x
+    (1, 16, 48, 20, 8, 16),       # 10 stages per column, 2 x 8 x 16
+    (2, 16, 16, 24, 24, 96),      # a 96^3-level slab: long ranges, the steady-state loop
 ]
 
 
@@ -201,6 +212,11 @@ def test_wino_select_and_refusal():
     with pytest.raises(RuntimeError, match="UNSUPPORTED"):
         ops.conv_fwd(x, wt, None, y, 16, 16, (3, 3, 3), wino=0)
     assert L.mis_conv3d_wino_wgrad_select(1, 16, 16, 6, 6, 30) == -1
+    wsel = L.mis_conv3d_wino_wgrad_select
+    assert wsel(8, 16, 16, 96, 96, 96) == 3 and wsel(8, 32, 32, 48, 48, 48) == 4      # z-ring kernels
+    assert wsel(8, 64, 64, 24, 24, 24) == 2 and wsel(1, 16, 16, 2, 4, 32) == 3          # box kernel at 24^3
+    assert wsel(1, 16, 16, 6, 4, 16) == -1 and wsel(1, 16, 16, 4, 4, 16) == 1           # 2 x 8 x 16 stages need H % 8
+    assert wsel(1, 16, 16, 3, 4, 32) == -1                                              # odd depth: no stage of two planes
     with pytest.raises(RuntimeError):
         ops.conv_pack(torch.zeros(16, 16, 3, 3, device="cuda"), 4)      # the transform is defined for 3x3x3 only
 
