@@ -692,6 +692,217 @@ __global__ __launch_bounds__(256) void wino_wgrad_reduce_kernel(const float* __r
     if (sub == 0) dw[idx] = accumulate ? dw[idx] + s : s;
 }
 
+// =====================================================================================================================
+// Flat form for the 12^3 level (round 4).  Their tensors live in L2 (128 channels x 12^3 x 8 volumes =
+// 7 MB), their 6 / 3 tiles per row do not split into the 4-tile chunks of the staged kernels above, and the channel-block
+// pairs (32 ... 256 of them) already fill the chip -- so there is no LDS stage, no DMA and no barrier: a WAVE walks its own
+// run of chunks, a chunk is ANY 4 tiles of the flattened (image, z, y, x) tile list (a table in LDS gives each tile's byte
+// offsets) and a lane fetches its own 4 x 4 x 4 patch of x and 2 x 2 x 2 patch of dy straight into registers, one chunk
+// ahead of the MFMAs that consume them (two patch buffers, ping-pong).  x comes from a re-laid, zero-padded copy
+//     xp[n][ci block][z + 1][y + 1][(x + 1) / 2][ci % 16][(x + 1) % 2]
+// made by one small launch: no face tests, and the 16 channel lanes of a load read 128 contiguous bytes (an x pair per
+// channel) -- with the plain NCDHW layout every load instruction touched 16 channel planes, and the texture-address unit, not
+// the MFMAs, set the pace (3.3 us per chunk; first version of this kernel).  64 MFMAs + ~165 vector instructions per chunk as
+// in the staged kernels; all 36 loads of the next chunk are issued in the first 20 slots of the run.
+struct FlatArgs {
+    const float* xp;                    // packed padded x (see above); image stride = ci_blocks * PB floats
+    const float* dy; long long dy_bs;
+    float* ws;                          // [task][27][16 co][16 ci]
+    int N, Cin, Cout, D, H, W;
+    int nchunks, ci_blocks, co_blocks, splits;
+};
+
+template <int HD, int WD>
+struct FlatGeoC {
+    static constexpr int HP = HD + 2, WPH = (WD + 2) / 2;               // padded rows, x pairs per row
+    static constexpr int ROW = WPH * 32;                                // floats per padded row of a 16-channel block
+    static constexpr int row_bytes(int z, int y) { return ((z * HP + y) * ROW) * 4; }
+};
+
+template <int HD, int WD, int K>
+__device__ __forceinline__ void fl_slots(const f32x2 (&u)[32], f32x2 (&un)[32], const f32x2 (&v)[16], f32x4 (&acc)[64],
+                                         f32x2 (&rnn)[4], __amdgpu_buffer_rsrc_t rx, __amdgpu_buffer_rsrc_t rd, int vx, int vd,
+                                         float (&av)[4]) {
+    if constexpr (K < 64) {
+        using G = FlatGeoC<HD, WD>;
+        if constexpr (K % 4 == 0) {
+            const f32x2 p = v[K / 4];
+            f32x2 pm;
+            asm volatile("v_pk_add_f32 %0, %1, %1 op_sel:[0,1] op_sel_hi:[0,1] neg_hi:[0,1]" : "=v"(pm) : "v"(p));
+            av[0] = p[0]; av[1] = pm[0]; av[2] = pm[1]; av[3] = f_sub(0.f, p[1]);
+        }
+        acc[K] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[K % 4], u[K / 2][K % 2], acc[K], 0, 0, 0);
+        if constexpr (K < 16) {           // rows (z, y) = (K / 4, K % 4) of the next chunk's x patch: both x pairs
+            constexpr int z = K / 4, y = K % 4;
+            un[2 * K] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rx, vx, G::row_bytes(z, y), 0));
+            un[2 * K + 1] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rx, vx + 128, G::row_bytes(z, y), 0));
+        }
+        if constexpr (K >= 16 && K < 20) {           // ... and its dy patch: (z, y) = (j / 2, j % 2)
+            constexpr int j = K - 16;
+            rnn[j] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rd, vd, (((j / 2) * HD + (j % 2)) * WD) * 4, 0));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        fl_slots<HD, WD, K + 1>(u, un, v, acc, rnn, rx, rd, vx, vd, av);
+    }
+}
+
+template <int HD, int WD>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void wino_wgrad_flat_kernel(const FlatArgs a) {
+    using G = FlatGeoC<HD, WD>;
+    float* const lds = mis_wgw_lds;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lt = lane >> 4, lc = lane & 15;
+    const int pairs = a.ci_blocks * a.co_blocks;
+    const int pair = blockIdx.x % pairs, split = blockIdx.x / pairs;
+    const int cib = pair % a.ci_blocks, cob = pair / a.ci_blocks;
+    const int task = pair * a.splits + split;
+    const long long S = (long long)a.D * HD * WD;
+    const long long PB = (long long)(a.D + 2) * G::HP * G::ROW;          // floats of one (image, channel block) of xp
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(a.xp) + (long long)cib * PB, 0, (int)((((long long)(a.N - 1) * a.ci_blocks + 1) * PB) * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(a.dy) + (long long)cob * 16 * S, 0, (int)(((long long)(a.N - 1) * a.dy_bs + ((long long)a.Cout - cob * 16) * S) * 4), 0x00020000);
+    const bool d_live = cob * 16 + lc < a.Cout;
+    const unsigned xc = (unsigned)lc * 8u, dc = (unsigned)(lc * S) * 4u;
+
+    // tile table in LDS (behind the reduction area): byte offsets of tile t = (n, tz, ty, tx) in xp and in dy
+    int2* const tab = reinterpret_cast<int2*>(lds + 4 * 27 * 256);
+    {
+        const int TX = WD / 2, TY = HD / 2, T = TX * TY * (a.D / 2), total = a.N * T;
+        for (int t = tid; t < 4 * a.nchunks; t += 256) {
+            int2 e = make_int2((int)OOB, (int)OOB);
+            if (t < total) {
+                const int n = t / T, r = t - n * T, tx = r % TX, ty = (r / TX) % TY, tz = r / (TX * TY);
+                e.x = (int)(((long long)n * a.ci_blocks * PB + ((long long)(2 * tz) * G::HP + 2 * ty) * G::ROW + tx * 32) * 4);
+                e.y = (int)(((long long)n * a.dy_bs + ((long long)(2 * tz) * HD + 2 * ty) * WD + 2 * tx) * 4);
+            }
+            tab[t] = e;
+        }
+    }
+    __syncthreads();
+
+    // this wave's run of chunks
+    const int nw = a.splits * 4, gw = split * 4 + wave;
+    const int c_begin = (int)((long long)a.nchunks * gw / nw), c_end = (int)((long long)a.nchunks * (gw + 1) / nw);
+
+    f32x4 acc[64];
+    const f32x2 zero = {0.f, 0.f};
+    {
+        float z0 = 0.f;
+        asm volatile("" : "+v"(z0));
+#pragma unroll
+        for (int i = 0; i < 64; ++i)
+            acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(z0, z0, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+    }
+    f32x2 ua[32], ub[32], v[16], rn[4];
+    float av[4];
+    auto offsets = [&](int c, int& vx, int& vd) {         // a chunk past the run: everything out of range (zeros)
+        int2 t = make_int2((int)OOB, (int)OOB);
+        if (c < c_end) t = tab[4 * c + lt];
+        vx = (unsigned)t.x != OOB ? (int)((unsigned)t.x + xc) : (int)OOB;
+        vd = (d_live && (unsigned)t.y != OOB) ? (int)((unsigned)t.y + dc) : (int)OOB;
+    };
+    if (c_begin < c_end) {
+        int vx, vd, vxn, vdn;
+        offsets(c_begin, vx, vd);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            ua[2 * k] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rx, vx, G::row_bytes(k / 4, k % 4), 0));
+            ua[2 * k + 1] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rx, vx + 128, G::row_bytes(k / 4, k % 4), 0));
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            rn[j] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rd, vd, (((j / 2) * HD + (j % 2)) * WD) * 4, 0));
+        offsets(c_begin + 1, vxn, vdn);
+        in_units<0, 24>(ua);
+        vzy_transform(rn, v, zero);
+        for (int c = c_begin; c < c_end; c += 2) {
+            // chunk c from ua while chunk c + 1 arrives in ub; then the roles swap (c + 1 past the run: zeros, no effect)
+            fl_slots<HD, WD, 0>(ua, ub, v, acc, rn, rx, rd, vxn, vdn, av);
+            offsets(c + 2, vx, vd);
+            in_units<0, 24>(ub); vzy_transform(rn, v, zero);
+            fl_slots<HD, WD, 0>(ub, ua, v, acc, rn, rx, rd, vx, vd, av);
+            offsets(c + 3, vxn, vdn);
+            in_units<0, 24>(ua); vzy_transform(rn, v, zero);
+        }
+    }
+    __syncthreads();
+    wg_finish(acc, lds, a.ws + (long long)task * (27 * 256), tid, wave, lt, lc);
+}
+
+// xp[n][cb][pz][py][pp][c][e] = x[n][cb * 16 + c][pz - 1][py - 1][2 pp + e - 1], zero outside the volume and for channels
+// >= C (one thread per element of xp: the 32 lanes of an (x pair, channel block) write 128 contiguous bytes)
+template <int HD, int WD>
+__global__ __launch_bounds__(256) void wino_flat_pack_kernel(const float* __restrict__ x, long long x_bs, float* __restrict__ xp,
+                                                             int N, int C, int CB, int D) {
+    using G = FlatGeoC<HD, WD>;
+    const long long total = (long long)N * CB * (D + 2) * G::HP * G::ROW;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    long long t = i;
+    const int e = (int)(t & 1), c = (int)((t >> 1) & 15); t >>= 5;
+    const int pp = (int)(t % G::WPH); t /= G::WPH;
+    const int py = (int)(t % G::HP); t /= G::HP;
+    const int pz = (int)(t % (D + 2)); t /= (D + 2);
+    const int cb = (int)(t % CB), n = (int)(t / CB);
+    const int ch = cb * 16 + c, xx = 2 * pp + e - 1, yy = py - 1, zz = pz - 1;
+    float v = 0.f;
+    if (ch < C && (unsigned)xx < (unsigned)WD && (unsigned)yy < (unsigned)HD && (unsigned)zz < (unsigned)D)
+        v = x[(long long)n * x_bs + ((long long)ch * D + zz) * HD * WD + (long long)yy * WD + xx];
+    xp[i] = v;
+}
+
+struct FlatGeo { int nchunks, ci_blocks, co_blocks, splits; long long part_bytes, pad_bytes; };
+
+FlatGeo flat_geometry(int N, int Cin, int Cout, int D, int H, int W) {
+    FlatGeo g;
+    const int T = (D / 2) * (H / 2) * (W / 2);
+    g.nchunks = (N * T + 3) / 4;
+    g.ci_blocks = (Cin + 15) / 16; g.co_blocks = (Cout + 15) / 16;
+    const int pairs = g.ci_blocks * g.co_blocks;
+    // one resident workgroup per CU (512 registers per wave); a wave wants >= ~8 chunks to pay for the 27-tap reduction
+    int splits = 256 / pairs;
+    const int cap = g.nchunks / (4 * 8);
+    if (splits > cap) splits = cap;
+    if (splits < 1) splits = 1;
+    g.splits = splits;
+    g.part_bytes = ((long long)pairs * splits * 27 * 256 * 4 + 255) / 256 * 256;
+    g.pad_bytes = (long long)N * g.ci_blocks * (D + 2) * (H + 2) * ((W + 2) / 2) * 32 * 4;
+    return g;
+}
+
+bool flat_fits(int N, int Cin, int Cout, int D, int H, int W) {
+    // 12 x 12 planes only: at 6^3 (54 chunks per pair for 8 volumes) the pack / reduce launches and the 27-tap epilogue cost
+    // what the Winograd form saves (measured 71 / 108 us against the direct kernel's 62 / 104 us)
+    if (!(H == 12 && W == 12) || D % 2 || D < 2 || D > 16) return false;
+    const FlatGeo g = flat_geometry(N, Cin, Cout, D, H, W);
+    return g.pad_bytes < (1LL << 30) && (long long)N * Cout * D * H * W * 4 < (1LL << 30) &&
+           4 * 27 * 256 * 4 + (long long)g.nchunks * 4 * 8 <= 160 * 1024;
+}
+
+template <int HD, int WD>
+int launch_flat(const float* x, long long x_bs, const float* dy, long long dy_bs, float* dw, float* workspace, int N, int Cin,
+                int Cout, int D, int accumulate, hipStream_t stream) {
+    const FlatGeo g = flat_geometry(N, Cin, Cout, D, HD, WD);
+    float* xp = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + g.part_bytes);
+    const long long padded = g.pad_bytes / 4;
+    hipLaunchKernelGGL((wino_flat_pack_kernel<HD, WD>), dim3((unsigned)((padded + 255) / 256)), dim3(256), 0, stream, x, x_bs, xp, N,
+                       Cin, g.ci_blocks, D);
+    FlatArgs a{};
+    a.xp = xp; a.dy = dy; a.dy_bs = dy_bs; a.ws = workspace;
+    a.N = N; a.Cin = Cin; a.Cout = Cout; a.D = D; a.H = HD; a.W = WD;
+    a.nchunks = g.nchunks; a.ci_blocks = g.ci_blocks; a.co_blocks = g.co_blocks; a.splits = g.splits;
+    const int ldsb = 4 * 27 * 256 * 4 + g.nchunks * 4 * 8;
+    static std::atomic<unsigned long long> attr_done{0};
+    if (mis_set_lds_attr(reinterpret_cast<const void*>(&wino_wgrad_flat_kernel<HD, WD>), 160 * 1024, attr_done) != MIS_OK) return MIS_ERR_LAUNCH;
+    hipLaunchKernelGGL((wino_wgrad_flat_kernel<HD, WD>), dim3(g.ci_blocks * g.co_blocks * g.splits), dim3(256), ldsb, stream, a);
+    const int total = Cout * Cin * 27;
+    hipLaunchKernelGGL(wino_wgrad_reduce_kernel, dim3((total + 15) / 16), dim3(256), 0, stream, workspace, dw, Cout, Cin,
+                       g.ci_blocks, g.splits, accumulate);
+    return mis_launch_status();
+}
+
 template <class C>
 void geometry(WgArgs& a) {
     a.sz = a.D / C::OZ; a.sy = a.H / C::OY; a.sx = a.W / C::OX;
@@ -777,6 +988,11 @@ bool variant_fits(int variant, int D, int H, int W) {
     return false;
 }
 
+bool flat_enabled() {
+    static const bool on = [] { const char* e = getenv("MIS_WGRAD_FLAT"); return !(e && e[0] == '0'); }();
+    return on;
+}
+
 }  // namespace
 
 // Which variant serves the weight gradient of this 3x3x3 'same' convolution, or -1 (use mis_conv_wgrad).
@@ -790,11 +1006,17 @@ extern "C" int mis_conv3d_wino_wgrad_select(int N, int Cin, int Cout, int D, int
     }
     for (int v = 0; v < 3; ++v)
         if (variant_fits(v, D, H, W)) return v;
+    if (flat_enabled() && flat_fits(N, Cin, Cout, D, H, W)) return 5;       // 12^3: the flat form
     return -1;
 }
 
 extern "C" long long mis_conv3d_wino_wgrad_workspace_bytes(int N, int Cin, int Cout, int D, int H, int W, int variant) {
     if (N <= 0 || Cin <= 0 || Cout <= 0 || D <= 0 || H <= 0 || W <= 0) return MIS_ERR_ARG;
+    if (variant == 5) {
+        if (!flat_fits(N, Cin, Cout, D, H, W)) return MIS_ERR_UNSUPPORTED;
+        const FlatGeo g = flat_geometry(N, Cin, Cout, D, H, W);
+        return g.part_bytes + g.pad_bytes;
+    }
     if (variant < 0 || variant > 4 || !variant_fits(variant, D, H, W)) return MIS_ERR_UNSUPPORTED;
     WgArgs a{};
     a.N = N; a.Cin = Cin; a.Cout = Cout; a.D = D; a.H = H; a.W = W;
@@ -811,6 +1033,12 @@ extern "C" int mis_conv3d_wino_wgrad(const float* x, long long x_bs, const float
     const long long S = (long long)D * H * W;
     if (x_bs < (long long)Cin * S || dy_bs < (long long)Cout * S) return MIS_ERR_ARG;
     if (Cin < 8 || Cout < 8 || ((long long)17 * S + (long long)H * W + W + 64) * 4 >= (1LL << 31)) return MIS_ERR_UNSUPPORTED;
+    if (variant == 5) {
+        if (!flat_fits(N, Cin, Cout, D, H, W)) return MIS_ERR_UNSUPPORTED;
+        if (((uintptr_t)dy & 7) || dy_bs % 2 || ((uintptr_t)workspace & 255)) return MIS_ERR_UNSUPPORTED;
+        if (workspace_bytes < mis_conv3d_wino_wgrad_workspace_bytes(N, Cin, Cout, D, H, W, 5)) return MIS_ERR_WORKSPACE;
+        return launch_flat<12, 12>(x, x_bs, dy, dy_bs, dw, workspace, N, Cin, Cout, D, accumulate, stream);
+    }
     if (variant < 0 || variant > 4 || !variant_fits(variant, D, H, W)) return MIS_ERR_UNSUPPORTED;
     if (((uintptr_t)x & 15) || ((uintptr_t)dy & 15) || x_bs % 4 || dy_bs % 4 || W % 4) return MIS_ERR_UNSUPPORTED;
     if (workspace_bytes < mis_conv3d_wino_wgrad_workspace_bytes(N, Cin, Cout, D, H, W, variant)) return MIS_ERR_WORKSPACE;

@@ -96,6 +96,19 @@ def wgrad_main():
         sc = ref.abs().max().item()
         print(f"wgrad N{N} {Cin}->{Cout} {D}x{H}x{W} v{var}: wino err {(dww.double() - ref).abs().max().item() / sc:.3e}  "
               f"direct err {(dwd.double() - ref).abs().max().item() / sc:.3e} (rel. to max {sc:.1f})", flush=True)
+    if "flat" in sys.argv[1:]:      # the flat form (variant 5) against the direct kernel on the deep levels of unet_3D / V-Net
+        for (N, Cin, Cout, S) in [(8, 64, 128, 12), (8, 128, 128, 12), (8, 384, 128, 12), (8, 128, 256, 6), (8, 256, 256, 6),
+                                  (4, 128, 256, 6), (8, 256, 128, 12)]:
+            x = torch.randn(N, Cin, S, S, S, device="cuda")
+            dy = torch.randn(N, Cout, S, S, S, device="cuda")
+            fl = 2.0 * N * Cout * Cin * 27 * S ** 3
+            da, ra = wino_wg(x, dy, 5)
+            db, rb = direct_wg(x, dy)
+            err = (da - db).abs().max().item() / db.abs().max().item()
+            ta, tb = timeit(ra), timeit(rb)
+            print(f"wgrad N{N} {Cin}->{Cout} {S}^3: flat {ta:8.1f} us ({fl / ta / 1e6:6.1f} TF eq)   direct {tb:8.1f} us ({fl / tb / 1e6:6.1f} TF)"
+                  f"  x{tb / ta:.2f}  rel diff {err:.2e}", flush=True)
+        return
     if "ab" in sys.argv[1:]:        # box kernels (0 / 1) against the z-ring kernels (3 / 4) on the config-3 / V-Net layers
         for (N, Cin, Cout, S, va, vb) in [(8, 16, 16, 96, 0, 3), (8, 48, 16, 96, 0, 3), (8, 32, 32, 48, 1, 4),
                                           (8, 96, 32, 48, 1, 4), (8, 16, 32, 48, 1, 4), (8, 32, 32, 48, 0, 4)]:

@@ -136,6 +136,19 @@ def test_wino_channel_slices_of_concat_buffers():
     _close(dw, wr.grad, rtol=3e-4, atol=1e-4)
 
 
+def test_flat_weight_gradient_from_channel_slices():
+    """12^3 level: x = the skip half of a decoder's concat buffer, dy = a slice too (batch strides != C * S)."""
+    ops = _ops()
+    N, C0, Cin, Cout, S = 2, 32, 32, 16, 12
+    cat = _rand(N, C0 + Cin, S, S, S, seed=15).float().cuda()
+    dy = _rand(N, 16 + Cout, S, S, S, seed=17).float().cuda()
+    dw = torch.full((Cout, Cin, 3, 3, 3), float("nan"), device="cuda")
+    ops.conv_wgrad(cat[:, C0:], dy[:, 16:], dw, (3, 3, 3))
+    wr = torch.zeros(Cout, Cin, 3, 3, 3, dtype=torch.float64, requires_grad=True)
+    F.conv3d(cat[:, C0:].cpu().double(), wr, padding=1).backward(dy[:, 16:].cpu().double())
+    _close(dw, wr.grad, rtol=1e-5, atol=1e-6)
+
+
 # N, Cin, Cout, D, H, W
 WGRAD_CASES = [
     (1, 16, 16, 2, 4, 32),
@@ -158,6 +171,13 @@ WGRAD_CASES = [
     (2, 32, 32, 8, 16, 48),       # 2 x 8 x 16-voxel stages (48^3 level geometry), 3 columns along x
     (1, 16, 48, 20, 8, 16),       # 10 stages per column, 2 x 8 x 16
     (2, 16, 16, 24, 24, 96),      # a 96^3-level slab: long ranges, the steady-state loop
+    # flat form (round 4): 12 x 12 planes, lanes fetch their own patches from a packed zero-padded copy, no LDS stage
+    (1, 16, 16, 12, 12, 12),      # 216 tiles, 54 chunks
+    (3, 24, 40, 2, 12, 12),       # 108 tiles, ragged channel blocks on both sides
+    (1, 16, 16, 6, 12, 12),       # 108 tiles over 8 workgroup waves: a ragged last chunk is impossible (36 | tiles), odd runs are
+    (2, 64, 128, 12, 12, 12),     # 32 pairs, several waves per pair
+    (8, 128, 128, 12, 12, 12),    # unet_3D conv4 at the full batch
+    (2, 16, 32, 4, 12, 12),       # a slab of 12 x 12 planes
 ]
 
 
@@ -217,6 +237,8 @@ def test_wino_select_and_refusal():
     assert wsel(8, 64, 64, 24, 24, 24) == 2 and wsel(1, 16, 16, 2, 4, 32) == 3          # box kernel at 24^3
     assert wsel(1, 16, 16, 6, 4, 16) == -1 and wsel(1, 16, 16, 4, 4, 16) == 1           # 2 x 8 x 16 stages need H % 8
     assert wsel(1, 16, 16, 3, 4, 32) == -1                                              # odd depth: no stage of two planes
+    assert wsel(8, 128, 128, 12, 12, 12) == 5 and wsel(2, 16, 32, 4, 12, 12) == 5       # flat form: 12 x 12 planes
+    assert wsel(8, 128, 256, 6, 6, 6) == -1 and wsel(8, 128, 128, 10, 10, 10) == -1     # 6^3 stays on the direct kernel
     with pytest.raises(RuntimeError):
         ops.conv_pack(torch.zeros(16, 16, 3, 3, device="cuda"), 4)      # the transform is defined for 3x3x3 only
 
