@@ -676,20 +676,36 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     wg_finish(acc, lds, a.ws + (long long)task * (27 * 256), tid, wave, lt, lc);
 }
 
-// dw[co][ci][tap] (+)= sum over the splits of the task partials: 16 lanes per output, each a strided share, combined
-// in a fixed order (a single thread per output walking 256 partials 27 KB apart took 31 us per layer)
+// dw[co][ci][tap] (+)= sum over the splits of the task partials [pair][split][27][16 co][16 ci].  A workgroup owns 64
+// consecutive elements of a pair's 27 x 256 partial; thread (e = tid & 63, g = tid >> 6) sums the splits k = g, g + 4, ... in
+// ascending order -- every load of a wave is 256 contiguous bytes -- and the four groups are combined in a fixed order through
+// LDS (deterministic).  (Round 3's version gave 16 lanes to one output, each lane walking partials 27 KB apart: 64 cache lines
+// per load instruction, 0.7 GB of HBM / L2 reads per config-3 step for 30 MB of partials.)
 __global__ __launch_bounds__(256) void wino_wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw,
                                                                 int Cout, int Cin, int ci_blocks, int splits,
                                                                 int accumulate) {
-    const int idx = blockIdx.x * 16 + (threadIdx.x >> 4), sub = threadIdx.x & 15;
-    if (idx >= Cout * Cin * 27) return;                    // whole 16-lane groups leave together
-    const int tap = idx % 27, ci = (idx / 27) % Cin, co = idx / (27 * Cin);
-    const float* p = ws + ((long long)((co / 16) * ci_blocks + ci / 16) * splits) * (27 * 256) + tap * 256 + (co % 16) * 16 + ci % 16;
-    float s = 0.f;
-    for (int k = sub; k < splits; k += 16) s += p[(long long)k * (27 * 256)];
-#pragma unroll
-    for (int d = 8; d > 0; d >>= 1) s += __shfl_xor(s, d, 16);
-    if (sub == 0) dw[idx] = accumulate ? dw[idx] + s : s;
+    __shared__ float red[4][64];
+    const int per_pair = 27 * 256 / 64;                       // 108 workgroups per channel-block pair
+    const int pair = blockIdx.x / per_pair, e = (blockIdx.x - pair * per_pair) * 64 + (threadIdx.x & 63), g = threadIdx.x >> 6;
+    const float* p = ws + (long long)pair * splits * (27 * 256) + e;
+    float s0 = 0.f, s1 = 0.f;
+    int k = g;
+    for (; k + 4 < splits; k += 8) {                          // two independent chains per thread: loads in flight together
+        s0 += p[(long long)k * (27 * 256)];
+        s1 += p[(long long)(k + 4) * (27 * 256)];
+    }
+    if (k < splits) s0 += p[(long long)k * (27 * 256)];
+    red[g][threadIdx.x & 63] = s0 + s1;
+    __syncthreads();
+    if (g == 0) {
+        const int l = threadIdx.x;
+        const float s = (red[0][l] + red[1][l]) + (red[2][l] + red[3][l]);
+        const int tap = e / 256, co = (pair / ci_blocks) * 16 + (e % 256) / 16, ci = (pair % ci_blocks) * 16 + e % 16;
+        if (co < Cout && ci < Cin) {
+            const long long o = ((long long)co * Cin + ci) * 27 + tap;
+            dw[o] = accumulate ? dw[o] + s : s;
+        }
+    }
 }
 
 // =====================================================================================================================
@@ -897,8 +913,8 @@ int launch_flat(const float* x, long long x_bs, const float* dy, long long dy_bs
     static std::atomic<unsigned long long> attr_done{0};
     if (mis_set_lds_attr(reinterpret_cast<const void*>(&wino_wgrad_flat_kernel<HD, WD>), 160 * 1024, attr_done) != MIS_OK) return MIS_ERR_LAUNCH;
     hipLaunchKernelGGL((wino_wgrad_flat_kernel<HD, WD>), dim3(g.ci_blocks * g.co_blocks * g.splits), dim3(256), ldsb, stream, a);
-    const int total = Cout * Cin * 27;
-    hipLaunchKernelGGL(wino_wgrad_reduce_kernel, dim3((total + 15) / 16), dim3(256), 0, stream, workspace, dw, Cout, Cin,
+
+    hipLaunchKernelGGL(wino_wgrad_reduce_kernel, dim3(g.ci_blocks * g.co_blocks * 108), dim3(256), 0, stream, workspace, dw, Cout, Cin,
                        g.ci_blocks, g.splits, accumulate);
     return mis_launch_status();
 }
@@ -926,8 +942,8 @@ int launch_wg(WgArgs a, float* dw, int accumulate, hipStream_t stream) {
         return MIS_ERR_LAUNCH;
     const int tasks = a.ci_blocks * a.co_blocks * a.splits;
     hipLaunchKernelGGL(wino_wgrad_kernel<C>, dim3(tasks), dim3(256), C::LDS_BYTES, stream, a);
-    const int total = a.Cout * a.Cin * 27;
-    hipLaunchKernelGGL(wino_wgrad_reduce_kernel, dim3((total + 15) / 16), dim3(256), 0, stream, a.ws, dw, a.Cout, a.Cin,
+
+    hipLaunchKernelGGL(wino_wgrad_reduce_kernel, dim3(a.ci_blocks * a.co_blocks * 108), dim3(256), 0, stream, a.ws, dw, a.Cout, a.Cin,
                        a.ci_blocks, a.splits, accumulate);
     return mis_launch_status();
 }
@@ -963,8 +979,8 @@ int launch_ring(WgArgs a, float* dw, int accumulate, hipStream_t stream) {
         return MIS_ERR_LAUNCH;
     const int tasks = a.ci_blocks * a.co_blocks * a.splits;
     hipLaunchKernelGGL(wino_wgrad_ring_kernel<C>, dim3(tasks), dim3(256), C::LDS_BYTES, stream, a);
-    const int total = a.Cout * a.Cin * 27;
-    hipLaunchKernelGGL(wino_wgrad_reduce_kernel, dim3((total + 15) / 16), dim3(256), 0, stream, a.ws, dw, a.Cout, a.Cin,
+
+    hipLaunchKernelGGL(wino_wgrad_reduce_kernel, dim3(a.ci_blocks * a.co_blocks * 108), dim3(256), 0, stream, a.ws, dw, a.Cout, a.Cin,
                        a.ci_blocks, a.splits, accumulate);
     return mis_launch_status();
 }

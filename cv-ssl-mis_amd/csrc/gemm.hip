@@ -604,6 +604,216 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const GemmArgs a) {
         }
 }
 
+// ------------------------------------------------------------------------------------------------ TN, register-only
+// dW = dY^T . X for the Linear layers whose widths are multiples of 96 (every Linear of SwinUnet and of UNETR's ViT): round 4.
+// The contraction runs over ~10^5 token rows and both operands are contraction-major (a row of A / B = one token, contiguous
+// along m / n): exactly the v_mfma_f32_16x16x4_f32 operand layout if lane (i = lane & 15, kk = lane >> 4) loads the float2
+// A[k + kk][m0 + 32 t + 2 i .. + 1] -- component c is the A operand of the 16 x 16 tile whose row i stands for m = m0 + 32 t +
+// 2 i + c.  So there is NO LDS stage, no barrier and no vector ALU work in the k-loop at all: a wave owns a 96 x 96 output tile
+// (36 accumulator tiles, 144 registers) over its own range of token rows and per group of 4 rows issues 6 buffer_load_dwordx2
+// (3 for A, 3 for B: 4 rows x 128 contiguous bytes each) and 36 MFMAs; loads run 4 groups ahead in a register ring.  Rows past
+// the wave's range are the descriptor's range check (zeros).  The staged kernel above spends 268 vector instructions per 72
+// MFMAs on the same job (operand staging through registers into LDS, scalar LDS reads) and runs the matrix pipe at 0.46.
+// The 4 waves of a workgroup take 4 consecutive row ranges of the same tile and sum their tiles through LDS (fixed tree:
+// deterministic), so a launch writes tiles x workgroup-slices partials, summed by gemm_reduce_kernel as before.
+// The bias gradient (column sums of A) rides on the waves of the first tile column: 3 packed adds per group.
+constexpr int RT = 96;                 // wave tile edge
+constexpr int RD = 4;                  // groups (of 4 rows) in flight
+
+template <bool COLSUM>
+__device__ __forceinline__ void tn_reg_loop(f32x4 (&acc)[6][6], float2 (&bs)[3], __amdgpu_buffer_rsrc_t rA, __amdgpu_buffer_rsrc_t rB,
+                                            int va, int vb, unsigned sa, unsigned sb, unsigned step_a, unsigned step_b, int ngroups) {
+    float2 ra[RD][3], rb[RD][3];
+    auto issue = [&](int d) {
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            ra[d][t] = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(rA, va + t * 128, (int)sa, 0));
+            rb[d][t] = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(rB, vb + t * 128, (int)sb, 0));
+        }
+        sa += step_a; sb += step_b;
+    };
+#pragma unroll
+    for (int d = 0; d < RD; ++d) issue(d);
+    for (int g = 0; g < ngroups; g += RD) {
+#pragma unroll
+        for (int d = 0; d < RD; ++d) {
+            float af[6], bf[6];
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                af[2 * t] = ra[d][t].x; af[2 * t + 1] = ra[d][t].y;
+                bf[2 * t] = rb[d][t].x; bf[2 * t + 1] = rb[d][t].y;
+                if constexpr (COLSUM) { bs[t].x += ra[d][t].x; bs[t].y += ra[d][t].y; }
+            }
+#pragma unroll
+            for (int i = 0; i < 6; ++i)
+#pragma unroll
+                for (int j = 0; j < 6; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+            issue(d);           // the group RD ahead, into the registers just consumed (past the range: zeros)
+        }
+    }
+}
+
+#ifndef MIS_TN_REG_WAVES
+#define MIS_TN_REG_WAVES 1
+#endif
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MIS_TN_REG_WAVES, MIS_TN_REG_WAVES))) void gemm_tn_reg_kernel(const GemmArgs a) {
+    float* const lds = mis_gemm_lds;                   // 2 x 36 KiB: the in-workgroup sum of the 4 waves' tiles
+    const unsigned L = mis_xcd_remap(blockIdx.x, a.n_blocks_padded);
+    if (L >= a.n_blocks) return;
+    const unsigned tiles = (unsigned)(a.tiles_n * a.tiles_m);
+    const int kz = L / tiles;                          // workgroup slice
+    const unsigned tl = L - kz * tiles;
+    const int tn = tl % a.tiles_n, tm = tl / a.tiles_n;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, kk = lane >> 4;
+    const int m0 = tm * RT, n0 = tn * RT;
+    // rows of this wave: a quarter (multiple of 4 rows) of the workgroup's slice
+    const int kq = a.kchunk / 4;
+    const int kbeg = kz * a.kchunk + wave * kq;
+    int kend = kbeg + kq < a.K ? kbeg + kq : a.K;
+    if (kend < kbeg) kend = kbeg;
+    const int ngroups = (kend - kbeg + 3) / 4;
+    // descriptors end at the wave's last row: the ring's loads past it (and the K tail inside a group) read zeros
+    const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.A), 0, (int)((long long)kend * a.lda * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.B), 0, (int)((long long)kend * a.ldb * 4), 0x00020000);
+    const int va = (int)(((long long)kk * a.lda + m0 + 2 * li) * 4), vb = (int)(((long long)kk * a.ldb + n0 + 2 * li) * 4);
+    const unsigned sa = (unsigned)((long long)kbeg * a.lda * 4), sb = (unsigned)((long long)kbeg * a.ldb * 4);
+
+    f32x4 acc[6][6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = 0; j < 6; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float2 bs[3] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
+    const bool colsum = a.dbias != nullptr && tn == 0;          // workgroup-uniform
+    if (colsum) tn_reg_loop<true>(acc, bs, rA, rB, va, vb, sa, sb, (unsigned)(a.lda * 16), (unsigned)(a.ldb * 16), ngroups);
+    else tn_reg_loop<false>(acc, bs, rA, rB, va, vb, sa, sb, (unsigned)(a.lda * 16), (unsigned)(a.ldb * 16), ngroups);
+
+    // ---- sum of the 4 waves: (w2 -> w0, w3 -> w1), then w1 -> w0; fixed order ----
+    f32x4* const l4 = reinterpret_cast<f32x4*>(lds);
+    float* const lb = lds + 2 * 36 * 64 * 4;                    // bias sums: [2][64 lanes][6]
+    if (wave >= 2) {
+        f32x4* dst = l4 + (wave - 2) * (36 * 64) + lane;
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+#pragma unroll
+            for (int j = 0; j < 6; ++j) dst[(i * 6 + j) * 64] = acc[i][j];
+        if (colsum) {
+#pragma unroll
+            for (int t = 0; t < 3; ++t) { lb[((wave - 2) * 64 + lane) * 6 + 2 * t] = bs[t].x; lb[((wave - 2) * 64 + lane) * 6 + 2 * t + 1] = bs[t].y; }
+        }
+    }
+    __syncthreads();
+    if (wave < 2) {
+        const f32x4* src = l4 + wave * (36 * 64) + lane;
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+#pragma unroll
+            for (int j = 0; j < 6; ++j) acc[i][j] += src[(i * 6 + j) * 64];
+        if (colsum) {
+#pragma unroll
+            for (int t = 0; t < 3; ++t) { bs[t].x += lb[(wave * 64 + lane) * 6 + 2 * t]; bs[t].y += lb[(wave * 64 + lane) * 6 + 2 * t + 1]; }
+        }
+    }
+    __syncthreads();
+    if (wave == 1) {
+        f32x4* dst = l4 + lane;
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+#pragma unroll
+            for (int j = 0; j < 6; ++j) dst[(i * 6 + j) * 64] = acc[i][j];
+        if (colsum) {
+#pragma unroll
+            for (int t = 0; t < 3; ++t) { lb[lane * 6 + 2 * t] = bs[t].x; lb[lane * 6 + 2 * t + 1] = bs[t].y; }
+        }
+    }
+    __syncthreads();
+    if (wave != 0) return;
+    {
+        const f32x4* src = l4 + lane;
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+#pragma unroll
+            for (int j = 0; j < 6; ++j) acc[i][j] += src[(i * 6 + j) * 64];
+    }
+    const bool direct = a.KS == 1;
+    if (colsum) {
+        // lanes (i, kk = 0..3) hold the sums of their own rows of every group: add the 4 row lanes (fixed order)
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            float x = bs[t].x + lb[lane * 6 + 2 * t], y = bs[t].y + lb[lane * 6 + 2 * t + 1];
+            x = (x + __shfl_xor(x, 16, 64)) + (__shfl_xor(x, 32, 64) + __shfl_xor(x, 48, 64));
+            y = (y + __shfl_xor(y, 16, 64)) + (__shfl_xor(y, 32, 64) + __shfl_xor(y, 48, 64));
+            if (kk == 0) {
+                const int m = m0 + 32 * t + 2 * li;
+                if (direct) {
+                    a.dbias[m] = a.dbias_acc ? a.dbias[m] + x : x;
+                    a.dbias[m + 1] = a.dbias_acc ? a.dbias[m + 1] + y : y;
+                } else {
+                    a.wsb[(long long)kz * a.M + m] = x;
+                    a.wsb[(long long)kz * a.M + m + 1] = y;
+                }
+            }
+        }
+    }
+    // accumulator tile (i, j), register r, lane (kk, li): row 4 kk + r of the tile = m0 + 32 (i / 2) + 2 (4 kk + r) + i % 2,
+    // column li = n0 + 32 (j / 2) + 2 li + j % 2: tiles (i, 2 q) and (i, 2 q + 1) make a float2 per lane, 128 bytes per 16 lanes
+    float* __restrict__ out = direct ? a.C : a.ws + (long long)kz * a.M * a.N;
+    const long long ldo = direct ? a.ldc : a.N;
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int m = m0 + 32 * (i / 2) + 2 * (4 * kk + r) + (i % 2);
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const int n = n0 + 32 * q + 2 * li;
+                float2 v = make_float2(acc[i][2 * q][r], acc[i][2 * q + 1][r]);
+                float2* p = reinterpret_cast<float2*>(out + (long long)m * ldo + n);
+                if (direct) {
+                    if (a.bias) { v.x += a.bias[n]; v.y += a.bias[n + 1]; }
+                    if (a.accumulate) { const float2 o = *p; v.x += o.x; v.y += o.y; }
+                }
+                *p = v;
+            }
+        }
+}
+
+// the register-only TN form serves this shape (widths multiples of 96, 8-byte aligned float2 rows)
+bool tn_reg_ok(const float* A, long long lda, const float* B, long long ldb, const float* C, long long ldc, int M, int N, int K) {
+    static const bool on = [] { const char* e = getenv("MIS_GEMM_TN_REG"); return !(e && e[0] == '0'); }();
+    return on && M % RT == 0 && N % RT == 0 && lda % 2 == 0 && ldb % 2 == 0 && ldc % 2 == 0 &&
+           !((uintptr_t)A & 7) && !((uintptr_t)B & 7) && !((uintptr_t)C & 7) && K >= 64;
+}
+// workgroup slices: one resident workgroup per CU (a wave = 144 accumulator + 48 ring registers); a wave wants >= 16 groups
+int tn_reg_slices(int M, int N, int K) {
+    const long long tiles = (long long)(M / RT) * (N / RT);
+    long long ks = (256 * MIS_TN_REG_WAVES) / tiles;
+    const long long kmax = K / (4 * 64);
+    if (ks > kmax) ks = kmax;
+    if (ks < 1) ks = 1;
+    return (int)ks;
+}
+// rows per workgroup slice: a multiple of 16 (4 waves x groups of 4 rows)
+void tn_reg_plan(GemmArgs& a) {
+    a.KS = tn_reg_slices(a.M, a.N, a.K);
+    a.kchunk = (int)(mis_cdiv(mis_cdiv(a.K, a.KS), 16) * 16);
+    a.KS = (int)mis_cdiv(a.K, a.kchunk);
+    a.tiles_n = a.N / RT; a.tiles_m = a.M / RT;
+    const long long nb = (long long)a.tiles_n * a.tiles_m * a.KS;
+    a.n_blocks = (unsigned)nb;
+    a.n_blocks_padded = (unsigned)(mis_cdiv(nb, MIS_NUM_XCD) * MIS_NUM_XCD);
+}
+int launch_tn_reg(GemmArgs& a, hipStream_t stream) {
+    constexpr int LDSB = 2 * 36 * 64 * 16 + 2 * 64 * 6 * 4;
+    static std::atomic<unsigned long long> attr_done{0};
+    if (mis_set_lds_attr(reinterpret_cast<const void*>(&gemm_tn_reg_kernel), LDSB, attr_done) != MIS_OK) return MIS_ERR_LAUNCH;
+    hipLaunchKernelGGL(gemm_tn_reg_kernel, dim3(a.n_blocks_padded), dim3(256), LDSB, stream, a);
+    return mis_launch_status();
+}
+
 // C[m][n] (+)= bias[n] + sum_k ws[k][m][n]   (fixed order)
 // block = 32 consecutive elements x 8 slice lanes: lane kl sums slices kl, kl+8, ... (four loads in flight), then a
 // fixed-order LDS tree over the 8 lanes -- the reduction is latency-bound (dW of a 96 x 288 Linear: 64+ slices of
@@ -810,7 +1020,8 @@ extern "C" int mis_gemm_nt_kernel_name(int M, int N, int K, int epilogue, char* 
 
 extern "C" long long mis_gemm_workspace_bytes(int M, int N, int K, int trans) {
     if (M <= 0 || N <= 0 || K <= 0) return MIS_ERR_ARG;
-    const int ks = pick_ks(M, N, K, trans);
+    int ks = pick_ks(M, N, K, trans);
+    if (trans && M % RT == 0 && N % RT == 0) { const int kr = tn_reg_slices(M, N, K); if (kr > ks) ks = kr; }   // either TN form
     return ks > 1 ? (long long)ks * M * N * 4 : 0;
 }
 
@@ -872,6 +1083,16 @@ extern "C" int mis_gemm(const float* A, long long lda, const float* B, long long
     a.ex_P = 0;
     a.ep = EP_NONE;
     a.vec4 = (!trans && N % 4 == 0 && ldc % 4 == 0 && a16(C) && (!bias || a16(bias))) ? 1 : 0;
+    if (trans && tn_reg_ok(A, lda, B, ldb, C, ldc, M, N, K)) {
+        a.dbias = nullptr;
+        tn_reg_plan(a);
+        if (a.KS > 1 && (!workspace || workspace_bytes < (long long)a.KS * M * N * 4)) return MIS_ERR_WORKSPACE;
+        const int st = launch_tn_reg(a, stream);
+        if (st) return st;
+        if (a.KS > 1)
+            hipLaunchKernelGGL(gemm_reduce_kernel, dim3((unsigned)mis_cdiv((long long)M * N, 32)), dim3(256), 0, stream, a);
+        return mis_launch_status();
+    }
     a.KS = pick_ks(M, N, K, trans);
     if (a.KS > 1) {
         if (!workspace || workspace_bytes < (long long)a.KS * M * N * 4) return MIS_ERR_WORKSPACE;
@@ -911,7 +1132,8 @@ extern "C" int mis_gemm(const float* A, long long lda, const float* B, long long
 // Deterministic: fixed slices, fixed-order sums.  workspace >= mis_gemm_dw_workspace_bytes(M, N, K).
 extern "C" long long mis_gemm_dw_workspace_bytes(int M, int N, int K) {
     if (M <= 0 || N <= 0 || K <= 0) return MIS_ERR_ARG;
-    const int ks = pick_ks(M, N, K, 1);
+    int ks = pick_ks(M, N, K, 1);
+    if (M % RT == 0 && N % RT == 0) { const int kr = tn_reg_slices(M, N, K); if (kr > ks) ks = kr; }             // either TN form
     return ks > 1 ? (long long)ks * M * (N + 1) * 4 : 0;
 }
 
@@ -926,6 +1148,19 @@ extern "C" int mis_gemm_dw(const float* dy, long long lddy, const float* x, long
     a.vec4 = 0;
     a.dbias = db;
     a.dbias_acc = accumulate;
+    if (tn_reg_ok(dy, lddy, x, ldx, dW, lddw, M, N, K) && (long long)K * lddy * 4 < (1LL << 31) && (long long)K * ldx * 4 < (1LL << 31)) {
+        tn_reg_plan(a);
+        if (a.KS > 1) {
+            if (!workspace || workspace_bytes < (long long)a.KS * M * (N + 1) * 4) return MIS_ERR_WORKSPACE;
+            a.wsb = workspace + (long long)a.KS * M * N;
+        }
+        const int st = launch_tn_reg(a, stream);
+        if (st) return st;
+        if (a.KS > 1)
+            hipLaunchKernelGGL(gemm_reduce_kernel, dim3((unsigned)(mis_cdiv((long long)M * N, 32) + mis_cdiv(M, 32))), dim3(256),
+                               0, stream, a);
+        return mis_launch_status();
+    }
     a.KS = pick_ks(M, N, K, 1);
     if (a.KS > 1) {
         if (!workspace || workspace_bytes < (long long)a.KS * M * (N + 1) * 4) return MIS_ERR_WORKSPACE;
