@@ -930,6 +930,14 @@ int pick_ks(int M, int N, int K, int trans) {
 
 bool a16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
+// (Round 4 also tried the register-only form for the NT GEMMs -- forward and dX: lanes load float4 A[m0 + 16 t + i][k0 + 4 kk ..]
+// straight into the MFMA layout, 64 x 96 wave tiles, two waves per SIMD, epilogues on registers.  Correct, and SLOWER than the
+// staged kernels on every SwinUnet shape: 2277 us against 1750 us for the 20 Linear shapes of a step, 0.26-0.47 of the pipe on the
+// K = 96 / 192 layers.  Row-major operands put the 16 lanes of a load group on 16 different rows -- 64 separate 16-byte accesses
+// per instruction for the texture-address unit, ~5000 of its cycles per 6144-cycle k-step of a CU's 8 waves; the TN form above
+// works because ITS operands are contraction-major and a lane group reads 128 contiguous bytes.  The NT GEMMs need the transpose
+// that the LDS stage provides.  Removed; scripts/gemm_nt_bench.py is the measurement.)
+
 template <int BMT, int BN, int EP>
 int launch_nt_ep(const GemmArgs& a, hipStream_t stream) {
     static std::atomic<unsigned long long> attr_done{0};   // per instantiation, one bit per device

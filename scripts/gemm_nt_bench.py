@@ -1,0 +1,44 @@
+"""Forward and dX GEMMs of SwinUnet (24 + 24 images of 224 x 224) through mis_gemm: time per shape (the staged NT kernels;
+round 4 measured a register-only NT form against them with this script -- 2277 us against 1750 us -- and dropped it, gemm.hip)."""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "cv-ssl-mis_amd"))
+from mis_hip import tops  # noqa: E402
+
+
+def timeit(fn, n=20):
+    for _ in range(10):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n * 1e3
+
+
+B = 48
+shapes = []
+for stage, C in enumerate((96, 192, 384, 768)):
+    T = B * (56 >> stage) ** 2
+    for cout, cin in ((3 * C, C), (C, C), (4 * C, C), (C, 4 * C)):
+        shapes += [(T, cout, cin), (T, cin, cout)]          # forward, dX
+tot = 0.0
+seen = set()
+for M, N, K in shapes:
+    if (M, N, K) in seen:
+        continue
+    seen.add((M, N, K))
+    a, w, bias = torch.randn(M, K, device="cuda"), torch.randn(N, K, device="cuda") * K ** -0.5, torch.randn(N, device="cuda")
+    c = torch.empty(M, N, device="cuda")
+    t = timeit(lambda: tops.gemm(a, w, c, bias=bias))
+    ref = a[:512].double() @ w.double().t() + bias.double()
+    err = (c[:512].double() - ref).abs().max().item() / ref.abs().max().item()
+    fl = 2.0 * M * N * K
+    tot += t
+    print(f"M={M:7d} N={N:5d} K={K:5d}: {t:8.1f} us  {fl / t / 1e6:6.1f} TF ({fl / t / 1e6 / 157.3:.3f})  rel err {err:.1e}", flush=True)
+print(f"sum {tot:.1f} us")

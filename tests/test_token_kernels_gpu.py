@@ -29,7 +29,8 @@ def _close(a, b, rtol=2e-4, atol=1e-5):
                                    # few tiles, long K: the NT form splits K too (ragged last slice for K = 1000)
                                    (1176, 768, 3072), (300, 200, 1000),
                                    # short contraction over many rows: gemm_nt_short_kernel (64-row tiles, ragged last)
-                                   (50000, 288, 96), (33000, 384, 192)])
+                                   (50000, 288, 96), (33000, 384, 192),
+                                   (16401, 576, 1536)])          # long K over many ragged row tiles
 def test_gemm_nt_and_tn(M, N, K):
     tops = _t()
     A, B, bias = _rand(M, K, seed=1), _rand(N, K, seed=2), _rand(N, seed=3)
@@ -333,7 +334,8 @@ def test_gemm_expand_equals_gemm_plus_pixel_shuffle(B, H, K, P, c):
 
 
 @pytest.mark.parametrize("M,N,K", [(6272, 384, 96), (6272, 96, 384), (200, 96, 48), (98, 3072, 768), (98, 768, 3072),
-                                   (33000, 384, 96), (65570, 96, 96)])       # the short-contraction kernel's epilogues
+                                   (33000, 384, 96), (65570, 96, 96),       # the short-contraction kernel's epilogues
+                                   (20000, 768, 192), (16400, 192, 768)])   # many row tiles, ragged last one, K = 192 / 768
 def test_gemm_fused_epilogues(M, N, K):
     """mis_gemm_ex: GELU forward / backward and DropPath + residual add in the NT GEMM's epilogue (also through the
     split-K reduction for the deep-stage shapes) against torch in float64."""
