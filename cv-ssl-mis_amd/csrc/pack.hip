@@ -17,9 +17,15 @@
 
 namespace {
 
+// The filter transform G g G^T (G^T) runs in DOUBLE and is rounded to fp32 once per point (round 4): three nested fp32 passes
+// put three roundings on every transformed value, and a filter error is a systematic error of the whole layer -- it was the
+// largest term of the Winograd forward's excess over the direct kernel in the float64 gradient gate (tests/test_parity_gpu.py).
+// The pass is HBM-bound (27 -> 64 floats per (m, k) pair), the fp64 adds are free.
+typedef double wt_t;
+
 // G g of one dimension: point xi of (g0, g1, g2)
-__device__ __forceinline__ float wino_g(int xi, float g0, float g1, float g2) {
-    return xi == 0 ? g0 : (xi == 3 ? g2 : 0.5f * (xi == 1 ? (g0 + g1 + g2) : (g0 - g1 + g2)));
+__device__ __forceinline__ wt_t wino_g(int xi, wt_t g0, wt_t g1, wt_t g2) {
+    return xi == 0 ? g0 : (xi == 3 ? g2 : 0.5 * (xi == 1 ? (g0 + g1 + g2) : (g0 - g1 + g2)));
 }
 
 // element i of the transformed filter of one layer (mode 4: forward, mode 5: data gradient)
@@ -32,10 +38,10 @@ __device__ __forceinline__ float wino_element(const float* __restrict__ w, int C
     if (m >= M || k >= K) return 0.f;
     const float* g = mode == 4 ? w + ((long long)m * Cin + k) * 27 : w + ((long long)k * Cin + m) * 27;
     const int xz = xi >> 4, xy = (xi >> 2) & 3, xx = xi & 3;
-    float pz[3];
+    wt_t pz[3];
 #pragma unroll
     for (int z = 0; z < 3; ++z) {
-        float py[3];
+        wt_t py[3];
 #pragma unroll
         for (int y = 0; y < 3; ++y) {
             const int t = (z * 3 + y) * 3;
@@ -44,7 +50,7 @@ __device__ __forceinline__ float wino_element(const float* __restrict__ w, int C
         }
         pz[z] = wino_g(xy, py[0], py[1], py[2]);
     }
-    return wino_g(xz, pz[0], pz[1], pz[2]);
+    return (float)wino_g(xz, pz[0], pz[1], pz[2]);
 }
 
 // ... and of the 2-D transform F(2x2, 3x3) (mode 6: forward, mode 7: data gradient): wt[M/16][K/4][4][64 lanes][4]
@@ -57,13 +63,13 @@ __device__ __forceinline__ float wino2_element(const float* __restrict__ w, int 
     if (m >= M || k >= K) return 0.f;
     const float* g = mode == 6 ? w + ((long long)m * Cin + k) * 9 : w + ((long long)k * Cin + m) * 9;
     const int xy = xi >> 2, xx = xi & 3;
-    float py[3];
+    wt_t py[3];
 #pragma unroll
     for (int y = 0; y < 3; ++y) {
         const int t = y * 3;
         py[y] = mode == 6 ? wino_g(xx, g[t], g[t + 1], g[t + 2]) : wino_g(xx, g[8 - t], g[7 - t], g[6 - t]);
     }
-    return wino_g(xy, py[0], py[1], py[2]);
+    return (float)wino_g(xy, py[0], py[1], py[2]);
 }
 
 __global__ __launch_bounds__(256) void pack_kernel(const float* __restrict__ w, float* __restrict__ wp,
@@ -103,8 +109,8 @@ struct PackJob {
 constexpr int MAX_JOBS = 256;
 
 // G g of one dimension, all 4 points (the expressions of wino_g: the batched and the single-layer pack agree bit for bit)
-__device__ __forceinline__ void wino_g4(float g0, float g1, float g2, float (&o)[4]) {
-    o[0] = g0; o[1] = 0.5f * (g0 + g1 + g2); o[2] = 0.5f * (g0 - g1 + g2); o[3] = g2;
+__device__ __forceinline__ void wino_g4(wt_t g0, wt_t g1, wt_t g2, wt_t (&o)[4]) {
+    o[0] = g0; o[1] = 0.5 * (g0 + g1 + g2); o[2] = 0.5 * (g0 - g1 + g2); o[3] = g2;
 }
 
 // One thread = one (m, k) pair of a Winograd job: reads its 27 (9) taps once, applies G along x, y, z and writes the 64
@@ -125,29 +131,30 @@ __device__ __forceinline__ void wino_pair3(const PackJob& j, unsigned item) {
         return;
     }
     const float* __restrict__ src = fwd ? j.w + ((long long)m * j.Cin + k) * 27 : j.w + ((long long)k * j.Cin + m) * 27;
-    float g[27];
+    wt_t g[27];
 #pragma unroll
     for (int t = 0; t < 27; ++t) g[t] = fwd ? src[t] : src[26 - t];       // data gradient: the spatially flipped filter
-    float a[9][4];                      // x pass: rows (z, y)
+    wt_t a[9][4];                       // x pass: rows (z, y)
 #pragma unroll
     for (int r = 0; r < 9; ++r) wino_g4(g[3 * r], g[3 * r + 1], g[3 * r + 2], a[r]);
-    float b[3][4][4];                   // y pass: [z][xy][xx]
+    wt_t b[3][4][4];                    // y pass: [z][xy][xx]
 #pragma unroll
     for (int z = 0; z < 3; ++z)
 #pragma unroll
         for (int xx = 0; xx < 4; ++xx) {
-            float o[4];
+            wt_t o[4];
             wino_g4(a[z * 3][xx], a[z * 3 + 1][xx], a[z * 3 + 2][xx], o);
 #pragma unroll
             for (int xy = 0; xy < 4; ++xy) b[z][xy][xx] = o[xy];
         }
 #pragma unroll
     for (int xy = 0; xy < 4; ++xy) {    // z pass, point xi = xz * 16 + xy * 4 + xx: float4 number xz * 4 + xy
-        float c[4][4];                  // [xx][xz]
+        wt_t c[4][4];                   // [xx][xz]
 #pragma unroll
         for (int xx = 0; xx < 4; ++xx) wino_g4(b[0][xy][xx], b[1][xy][xx], b[2][xy][xx], c[xx]);
 #pragma unroll
-        for (int xz = 0; xz < 4; ++xz) out[(xz * 4 + xy) * 64] = make_float4(c[0][xz], c[1][xz], c[2][xz], c[3][xz]);
+        for (int xz = 0; xz < 4; ++xz)
+            out[(xz * 4 + xy) * 64] = make_float4((float)c[0][xz], (float)c[1][xz], (float)c[2][xz], (float)c[3][xz]);
     }
 }
 
@@ -165,17 +172,17 @@ __device__ __forceinline__ void wino_pair2(const PackJob& j, unsigned item) {
         return;
     }
     const float* __restrict__ src = fwd ? j.w + ((long long)m * j.Cin + k) * 9 : j.w + ((long long)k * j.Cin + m) * 9;
-    float g[9];
+    wt_t g[9];
 #pragma unroll
     for (int t = 0; t < 9; ++t) g[t] = fwd ? src[t] : src[8 - t];
-    float a[3][4];
+    wt_t a[3][4];
 #pragma unroll
     for (int r = 0; r < 3; ++r) wino_g4(g[3 * r], g[3 * r + 1], g[3 * r + 2], a[r]);
-    float c[4][4];                      // [xx][xy]
+    wt_t c[4][4];                       // [xx][xy]
 #pragma unroll
     for (int xx = 0; xx < 4; ++xx) wino_g4(a[0][xx], a[1][xx], a[2][xx], c[xx]);
 #pragma unroll
-    for (int xy = 0; xy < 4; ++xy) out[xy * 64] = make_float4(c[0][xy], c[1][xy], c[2][xy], c[3][xy]);
+    for (int xy = 0; xy < 4; ++xy) out[xy * 64] = make_float4((float)c[0][xy], (float)c[1][xy], (float)c[2][xy], (float)c[3][xy]);
 }
 
 // work items of a job: (m, k) pairs for the Winograd transforms (64 / 16 outputs each), single floats otherwise

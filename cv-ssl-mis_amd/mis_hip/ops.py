@@ -198,6 +198,11 @@ def _ksize(k):
 
 K2S2 = _os.environ.get("MIS_K2S2", "1") != "0"      # kernel-2 / stride-2 (de)convolutions in place (conv_k2s2.hip)
 WINO = int(_os.environ.get("MIS_WINO", "3"))      # bit 0: Winograd form of the 3x3x3 convolutions, bit 1: of the 3x3 ones
+# diagnostics (numerics studies, tests/test_parity_gpu.py): the 3-D forward / data gradient resp. weight gradient alone on the
+# direct kernels, and the smallest volume edge W the 3-D Winograd kernels are used for
+WINO_FWD = _os.environ.get("MIS_WINO_FWD", "1") != "0"
+WINO_WGRAD = _os.environ.get("MIS_WINO_WGRAD", "1") != "0"
+WINO_MIN_W = int(_os.environ.get("MIS_WINO_MIN_W", "0"))
 
 
 WINO2D = 10       # ids >= WINO2D: variant id - WINO2D of the 2-D kernels (conv_wino2d.hip); below: 3-D (conv_wino.hip)
@@ -210,6 +215,8 @@ def conv_wino_select(N, Cin, Cout, D, H, W, ksize):
         return -1
     k = _ksize(ksize)
     if k == (3, 3, 3) and (WINO & 1):
+        if not WINO_FWD or W < WINO_MIN_W:
+            return -1
         return int(_l.load().mis_conv3d_wino_select(N, Cin, Cout, D, H, W))
     if k == (1, 3, 3) and D == 1 and (WINO & 2):
         v = int(_l.load().mis_conv2d_wino_select(N, Cin, Cout, H, W))
@@ -348,7 +355,8 @@ def conv_wgrad(x, dy, dw, ksize, accumulate=False):
 
 def _conv_wgrad_launch(L, x, dy, dw, N, Cin, Cout, D, H, W, xbs, dbs, kd, kh, kw, accumulate):
     # 3x3x3 on large volumes: the Winograd F(2^3, 3^3) form (conv_wino_wgrad.hip), 3.375x fewer matrix-pipe flops
-    wino = int(L.mis_conv3d_wino_wgrad_select(N, Cin, Cout, D, H, W)) if ((WINO & 1) and (kd, kh, kw) == (3, 3, 3)) else -1
+    wino = int(L.mis_conv3d_wino_wgrad_select(N, Cin, Cout, D, H, W)) if ((WINO & 1) and WINO_WGRAD and W >= WINO_MIN_W and
+                                                                          (kd, kh, kw) == (3, 3, 3)) else -1
     if wino >= 0 and xbs % 4 == 0 and dbs % 4 == 0 and x.data_ptr() % 16 == 0 and dy.data_ptr() % 16 == 0:
         nb = L.mis_conv3d_wino_wgrad_workspace_bytes(N, Cin, Cout, D, H, W, wino)
         if nb < 0:

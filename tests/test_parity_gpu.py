@@ -342,11 +342,14 @@ F64_MEDIAN_RATIO = 2.0
 # GroupNorm nets: torch's CPU GroupNorm kernels accumulate their sums in double (at::acc_type<float> on the CPU), so the
 # reference's own fp32 noise e32 is ~3x lower there (1.8e-2 at the worst tensors) than for its BatchNorm / InstanceNorm
 # nets (5e-2).  Round 3: the HIP GroupNorm path accumulates in double too (statistics pass and backward partial sums,
-# norm_act.hip) -- medians of HIP / e32 went from 2.1-2.7 to 1.2-1.9 (BatchNorm / InstanceNorm nets: 0.1-0.8).  What is
-# left is the fp32 rounding of everything else on an ill-conditioned fixture: single tensors land anywhere between 0.1x
-# and 22x the reference's own error (block_five.conv.3.weight, the 4^3 level, with the Winograd kernels; with MIS_WINO=0
-# the same tensor is at 2.7x and another case's median moves from 1.2 to 2.1), so the per-tensor factor stays wide.
-F64_GN = dict(K=30.0, median=2.5)
+# norm_act.hip).  Round 4 found where the rest came from: with the Winograd kernels single tensors landed at up to 22x the
+# reference's own error (block_five.conv.3.weight, 32 % relative) and the gate was K = 30 -- MIS_WINO_FWD=0 / MIS_WINO_WGRAD=0 /
+# MIS_WINO_MIN_W pinned it on the FORWARD / data-gradient kernels of the two LARGEST levels, and there on the filter
+# transform G g G^T done in three nested fp32 passes (pack.hip): a rounding error of the transformed filter is a systematic
+# error of the whole layer, amplified by every normalisation below it.  The transform now runs in double and is rounded
+# once: worst tensor 3.1x the reference's error (was 21x), better than the direct kernels (4.3x), medians 1.3.
+# -> GroupNorm nets are held to the SAME gate as every other net (measured: worst tensor 3.3x, medians 1.3 / 1.6)
+F64_GN = dict(K=F64_K, median=F64_MEDIAN_RATIO)
 
 
 @pytest.mark.parametrize("name,it", F64_CASES)
