@@ -259,20 +259,37 @@ __global__ __launch_bounds__(256, 2) void wino2d_wgrad_kernel(const Wg2Args a) {
         out[e] = (lds[e] + lds[C::RED + e]) + (lds[2 * C::RED + e] + lds[3 * C::RED + e]);
 }
 
-// dw[co][ci][tap] (+)= sum over the splits of the task partials: 16 lanes per output, fixed order
+// dw[co][ci][tap] (+)= sum over the splits of the task partials [pair][split][9][dc co][16 ci].  As in conv_wino_wgrad.hip
+// (round 4): a workgroup owns 64 consecutive elements of a pair's partial, thread (e = tid & 63, g = tid >> 6) sums the splits
+// k = g, g + 4, ... in ascending order -- 256 contiguous bytes per load of a wave -- and the four groups are combined in a fixed
+// order through LDS.  (Before: 16 lanes per output walking partials one whole partial apart, 64 cache lines per load.)
 __global__ __launch_bounds__(256) void wino2d_wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw,
                                                                   int Cout, int Cin, int ci_blocks, int splits, int dc,
                                                                   int accumulate) {
-    const int idx = blockIdx.x * 16 + (threadIdx.x >> 4), sub = threadIdx.x & 15;
-    if (idx >= Cout * Cin * 9) return;
-    const int tap = idx % 9, ci = (idx / 9) % Cin, co = idx / (9 * Cin);
-    const long long red = 9LL * dc * 16;
-    const float* p = ws + ((long long)((co / dc) * ci_blocks + ci / 16) * splits) * red + tap * (dc * 16) + (co % dc) * 16 + ci % 16;
-    float s = 0.f;
-    for (int k = sub; k < splits; k += 16) s += p[(long long)k * red];
-#pragma unroll
-    for (int d = 8; d > 0; d >>= 1) s += __shfl_xor(s, d, 16);
-    if (sub == 0) dw[idx] = accumulate ? dw[idx] + s : s;
+    __shared__ float red_s[4][64];
+    const int red = 9 * dc * 16;                              // elements of one partial (a multiple of 64: dc = 16 / 32)
+    const int per_pair = red / 64;
+    const int pair = blockIdx.x / per_pair, e = (blockIdx.x - pair * per_pair) * 64 + (threadIdx.x & 63), g = threadIdx.x >> 6;
+    const float* p = ws + (long long)pair * splits * red + e;
+    float s0 = 0.f, s1 = 0.f;
+    int k = g;
+    for (; k + 4 < splits; k += 8) {
+        s0 += p[(long long)k * red];
+        s1 += p[(long long)(k + 4) * red];
+    }
+    if (k < splits) s0 += p[(long long)k * red];
+    red_s[g][threadIdx.x & 63] = s0 + s1;
+    __syncthreads();
+    if (g == 0) {
+        const int l = threadIdx.x;
+        const float s = (red_s[0][l] + red_s[1][l]) + (red_s[2][l] + red_s[3][l]);
+        const int tap = e / (dc * 16), r = e - tap * (dc * 16);
+        const int co = (pair / ci_blocks) * dc + r / 16, ci = (pair % ci_blocks) * 16 + r % 16;
+        if (co < Cout && ci < Cin) {
+            const long long o = ((long long)co * Cin + ci) * 9 + tap;
+            dw[o] = accumulate ? dw[o] + s : s;
+        }
+    }
 }
 
 template <class C>
@@ -297,9 +314,9 @@ int launch_wg2(Wg2Args a, float* dw, int accumulate, hipStream_t stream) {
         return MIS_ERR_LAUNCH;
     const int tasks = a.ci_blocks * a.co_groups * a.splits;
     hipLaunchKernelGGL(wino2d_wgrad_kernel<C>, dim3(tasks), dim3(256), C::LDS_BYTES, stream, a);
-    const int total = a.Cout * a.Cin * 9;
-    hipLaunchKernelGGL(wino2d_wgrad_reduce_kernel, dim3((total + 15) / 16), dim3(256), 0, stream, a.ws, dw, a.Cout, a.Cin,
-                       a.ci_blocks, a.splits, C::DC, accumulate);
+    static_assert((9 * C::DC * 16) % 64 == 0, "whole 64-element pieces of a partial");
+    hipLaunchKernelGGL(wino2d_wgrad_reduce_kernel, dim3(a.ci_blocks * a.co_groups * (9 * C::DC * 16 / 64)), dim3(256), 0, stream, a.ws,
+                       dw, a.Cout, a.Cin, a.ci_blocks, a.splits, C::DC, accumulate);
     return mis_launch_status();
 }
 
