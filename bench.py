@@ -138,6 +138,17 @@ def collect_nccl_warnings(log_dir, limit=40):
     return lines[-limit:]
 
 
+def _stderr_digest(text, keep=25):
+    """The ranks' own failure lines (torch.distributed.run appends a long summary behind them) + the last lines."""
+    lines = text.strip().splitlines()
+    hits = [l for l in lines if any(w in l for w in ("FAILED", "Error", "error:", "Exception", "NCCL WARN", "Traceback"))]
+    out = hits[:15]
+    for l in lines[-keep:]:
+        if l not in out:
+            out.append(l)
+    return [l[:400] for l in out]
+
+
 def self_launch(argv, gpus):
     """Re-execute this script under torch.distributed.run with one rank per GPU; forward rank 0's output.  A failed run
     still prints ONE JSON line: the exit status, the tail of the ranks' stderr and RCCL's warnings."""
@@ -153,7 +164,7 @@ def self_launch(argv, gpus):
     if p.returncode != 0:
         print(json.dumps({"metric": "training images-or-volumes/sec/node (Mean-Teacher step)", "value": None,
                           "n_gpus": gpus, "error": f"multi-GPU run failed with exit status {p.returncode}",
-                          "stderr_tail": p.stderr.strip().splitlines()[-25:],
+                          "stderr_tail": _stderr_digest(p.stderr),
                           "nccl_warnings": collect_nccl_warnings(log_dir)}), flush=True)
     return p.returncode
 

@@ -35,6 +35,10 @@ def test_self_launch_world2_gloo():
     d = out["distributed"]
     assert d["params_identical"] is True and len(d["weights_fingerprint"]) == 2
     assert d["no_exchange_ms_per_step"] > 0 and "exposed_allreduce_ms_per_step" in d
+    # N > 1: cross teaching (BASELINE config 5, the configuration defined on 8 GPUs) is timed after the default workload,
+    # with its own proof of the exchange
+    c = out["others"]["cross"]
+    assert c["n_gpus"] == 2 and c["distributed"]["params_identical"] is True and len(c["per_rank_ms_per_step"]) == 2
 
 
 @pytest.mark.timeout(900)
@@ -44,6 +48,12 @@ def test_missing_gradient_exchange_fails_the_run():
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--stub", "--steps", "3", "--warmup", "1",
                         "--gpus", "2"], capture_output=True, text=True, timeout=600, env=env)
     assert p.returncode != 0 and "data-parallel check FAILED" in (p.stderr + p.stdout)
+    # a failed multi-process run still prints ONE JSON line: the status, the ranks' stderr tail, RCCL's warnings (none over gloo)
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    out = json.loads(lines[0])
+    assert out["value"] is None and out["n_gpus"] == 2 and "exit status" in out["error"]
+    assert any("data-parallel check FAILED" in l for l in out["stderr_tail"]) and out["nccl_warnings"] == []
 
 
 @pytest.mark.timeout(600)
