@@ -272,6 +272,11 @@ def run_workload(name, args, rank, world, kernel_events=True):
         sync()
         return time.perf_counter() - t0
 
+    if not stub:
+        # once per run, in front of the warm-up: NaNs into every CU's LDS (the test suite's fixture, tests/conftest.py) -- a kernel
+        # that reads an LDS cell it never wrote shows up as non-finite losses here instead of depending on the previous process
+        from mis_hip import lib as _lib
+        _lib.check(_lib.load().mis_debug_poison_lds(None, _lib.stream_ptr()), "mis_debug_poison_lds")
     for _ in range(args.warmup):
         tr.step(vol, lab)
     dt_local = timed(args.steps)
