@@ -500,16 +500,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const unsigned s_bytes = (unsigned)S * 4u;
     const int HW = a.H * a.W;
 
-    // workgroup -> (channel-block pair, chunk of the stage sequence).  Workgroup b runs on XCD b % 8: XCD x owns the chunks
-    // [x * nt, (x + 1) * nt) -- neighbouring columns -- and all channel-block pairs of a chunk sit on the same XCD (they
-    // share x or dy in its L2)
+    // workgroup -> (channel-block pair, XCD, j).  A UNIT is a segment of `seg` stages of one (image, y, x) column; units are
+    // numbered (image, z segment, y, x) with x fastest.  Workgroup b runs on XCD b % 8: XCD x owns the units [x per8, (x + 1)
+    // per8) and its nt workgroups per pair walk them interleaved (j, j + nt, ...), so at any time they sit on NEIGHBOURING columns
+    // at the same depth, going down z in lock-step: the y / x halo rows a workgroup fetches are in the XCD's L2 for its
+    // neighbours (PMC: with one contiguous stage range per workgroup -- no bubbles, perfect balance -- the 96^3 launches read
+    // 3.07 GB from HBM instead of 1.7: every halo came from HBM again), and all channel-block pairs of a unit share x or dy there
     const int pairs = a.ci_blocks * a.co_blocks, nt = a.splits / MIS_NUM_XCD;
     const int xcd = blockIdx.x % MIS_NUM_XCD, local = blockIdx.x / MIS_NUM_XCD;
     const int pair = local % pairs, j = local / pairs;
     const int cib = pair % a.ci_blocks, cob = pair / a.ci_blocks;
+    const int task = pair * a.splits + xcd * nt + j;
+    // a.seg == 0 (the smaller levels: tensors that the 256 MB infinity cache holds, short columns): one CONTIGUOUS range of the
+    // (image, y, x, z) stage sequence per workgroup instead -- perfect balance, a prologue only where the range crosses a
+    // column end (48^3 level: 178 us against 188 us with units; at 96^3 the other way round, 367 against 386 us)
+    const bool by_units = a.seg > 0;
+    const int per8 = (a.n_stage + MIS_NUM_XCD - 1) / MIS_NUM_XCD;      // a.n_stage: UNITS (by_units) or stages of the launch
+    const int u_begin = xcd * per8 + j, u_lim = (xcd + 1) * per8 < a.n_stage ? (xcd + 1) * per8 : a.n_stage;
     const int chunk = xcd * nt + j;
-    const int task = pair * a.splits + chunk;
-    const long long g_begin = (long long)a.n_stage * chunk / a.splits, g_end = (long long)a.n_stage * (chunk + 1) / a.splits;
+    long long g = (long long)a.n_stage * chunk / a.splits;
+    const long long g_end = (long long)a.n_stage * (chunk + 1) / a.splits;
+    int unit = u_begin;
 
     WrState<C> st;
     st.hw_bytes = (unsigned)HW * 4u;
@@ -573,14 +584,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const unsigned long long prof_c0 = __builtin_amdgcn_s_memtime(), prof_w0 = __builtin_amdgcn_s_memrealtime();
 #endif
 
-    for (long long g = g_begin; g < g_end;) {
-        // ---- a column segment: stages bz0 .. bz0 + cnt - 1 of column `col` ----
-        const int col = (int)(g / a.sz), bz0 = (int)(g - (long long)col * a.sz);
-        const int cnt = (int)((long long)(a.sz - bz0) < g_end - g ? (long long)(a.sz - bz0) : g_end - g);
-        g += cnt;
-        int t = col;
-        const int bx = t % a.sx; t /= a.sx;
-        const int by = t % a.sy; const int n = t / a.sy;
+    while (by_units ? unit < u_lim : g < g_end) {
+        // ---- a column segment: stages bz0 .. bz0 + cnt - 1 of column (n, by, bx) ----
+        int bx, by, n, bz0, cnt;
+        if (by_units) {
+            int t = unit;
+            bx = t % a.sx; t /= a.sx;
+            by = t % a.sy; t /= a.sy;
+            const int zs = t % a.nseg;
+            n = t / a.nseg; bz0 = zs * a.seg; cnt = a.seg;
+            unit += nt;
+        } else {
+            const int col = (int)(g / a.sz);
+            bz0 = (int)(g - (long long)col * a.sz);
+            cnt = (int)((long long)(a.sz - bz0) < g_end - g ? (long long)(a.sz - bz0) : g_end - g);
+            g += cnt;
+            int t = col;
+            bx = t % a.sx; t /= a.sx;
+            by = t % a.sy; n = t / a.sy;
+        }
         const unsigned flags = (by == 0 ? 1u : 0u) | (by == a.sy - 1 ? 2u : 0u) | (bx == 0 ? 4u : 0u) | (bx == a.sx - 1 ? 8u : 0u);
 #pragma unroll
         for (int e = 0; e < C::PW; ++e) st.e_vo[e] = (((e_cls >> (4 * e)) & 15u) & flags) ? OOB : e_rel[e];
@@ -666,7 +688,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         unsigned long long* o = a.prof + ((long long)blockIdx.x * 4 + wave) * 8;
         o[4] = __builtin_amdgcn_s_memtime() - prof_c0;
         o[0] = __builtin_amdgcn_s_memrealtime() - prof_w0;
-        o[5] = (unsigned long long)(g_end - g_begin);
+        o[5] = by_units ? (unsigned long long)(u_begin < u_lim ? (u_lim - u_begin + nt - 1) / nt : 0) * a.seg
+                        : (unsigned long long)((long long)a.n_stage * (chunk + 1) / a.splits - (long long)a.n_stage * chunk / a.splits);
     }
 #endif
     vmwait<0>::go();
@@ -954,21 +977,44 @@ using WgV2 = WgCfg<4, 2, 4, 0>;   // stages of 8 x 4 x 8 voxels (W a multiple of
 using WrV3 = WrCfg<2, 16>;        // z-ring, stages of 2 x 4 x 32 voxels (W a multiple of 32, H of 4): the 96^3 level
 using WrV4 = WrCfg<4, 8>;         // z-ring, stages of 2 x 8 x 16 voxels (W a multiple of 16, H of 8): the 48^3 level
 
-// z-ring geometry: the stage sequence (image, y, x column, z fastest) is cut into splits = 8 * nt equal contiguous chunks,
-// one workgroup per (channel-block pair, chunk); one resident workgroup per CU (160 KB of LDS), so one round of the 256
-// CUs, or two when one round would leave more than a tenth of them idle.
+// z-ring geometry: units = (image, z segment, y, x) with x fastest, `seg` stages each.  The segment count and the workgroups
+// per (pair, XCD) come from a small model of the busiest workgroup: units per workgroup x (seg + the cost of a unit start --
+// drain, prologue of six planes, first patch load: ~1 stage), times the residency rounds (one workgroup per CU).
 template <class C>
 void ring_geometry(WgArgs& a) {
     a.sz = a.D / 2; a.sy = a.H / C::OY; a.sx = a.W / C::OX;
     a.ci_blocks = (a.Cin + 15) / 16; a.co_blocks = (a.Cout + 15) / 16;
-    a.n_stage = a.N * a.sy * a.sx * a.sz;
     const int pairs = a.ci_blocks * a.co_blocks;
-    const int nt1 = 256 / (MIS_NUM_XCD * pairs), nt2 = 512 / (MIS_NUM_XCD * pairs);
-    int nt = (nt1 >= 1 && MIS_NUM_XCD * pairs * nt1 * 10 >= 256 * 9) ? nt1 : (nt2 >= 1 ? nt2 : 1);
-    const int cap = a.n_stage / (MIS_NUM_XCD * 4);                      // at least ~4 stages per workgroup
-    if (nt > cap) nt = cap < 1 ? 1 : cap;
-    a.splits = MIS_NUM_XCD * nt;
-    a.seg = a.nseg = 0;
+    const int cols = a.N * a.sy * a.sx;
+    // long columns over tensors the infinity cache cannot hold (the 96^3 level): units.  Otherwise contiguous stage ranges
+    const long long bytes = ((long long)a.Cin + a.Cout) * a.N * a.D * a.H * a.W * 4;
+    if (a.sz < 32 || bytes <= (256LL << 20)) {
+        a.n_stage = cols * a.sz;
+        const int nt1 = 256 / (MIS_NUM_XCD * pairs), nt2 = 512 / (MIS_NUM_XCD * pairs);
+        int nt = (nt1 >= 1 && MIS_NUM_XCD * pairs * nt1 * 10 >= 256 * 9) ? nt1 : (nt2 >= 1 ? nt2 : 1);
+        const int cap = a.n_stage / (MIS_NUM_XCD * 4);                  // at least ~4 stages per workgroup
+        if (nt > cap) nt = cap < 1 ? 1 : cap;
+        a.splits = MIS_NUM_XCD * nt;
+        a.seg = a.nseg = 0;
+        return;
+    }
+    double best = 1e300;
+    int best_nseg = 1, best_nt = 1;
+    for (int nseg = 1; nseg <= a.sz; ++nseg) {
+        if (a.sz % nseg) continue;
+        const int seg = a.sz / nseg, U = cols * nseg, per8 = (U + MIS_NUM_XCD - 1) / MIS_NUM_XCD;
+        for (int nt = 1; nt <= 64 && nt <= per8; ++nt) {
+            const int wgs = MIS_NUM_XCD * pairs * nt;
+            if (wgs > 512 && nt > 1) break;
+            const int rounds = (wgs + 255) / 256;
+            const int upw = (per8 + nt - 1) / nt;                       // units of the busiest workgroup
+            const double t = (double)rounds * (upw * (seg + 1.0) + 0.5);
+            if (t < best - 1e-9) { best = t; best_nseg = nseg; best_nt = nt; }
+        }
+    }
+    a.nseg = best_nseg; a.seg = a.sz / best_nseg;
+    a.n_stage = cols * a.nseg;                                         // UNITS (the ring kernel's a.n_stage)
+    a.splits = MIS_NUM_XCD * best_nt;
 }
 
 template <class C>
