@@ -988,7 +988,9 @@ void ring_geometry(WgArgs& a) {
     const int cols = a.N * a.sy * a.sx;
     // long columns over tensors the infinity cache cannot hold (the 96^3 level): units.  Otherwise contiguous stage ranges
     const long long bytes = ((long long)a.Cin + a.Cout) * a.N * a.D * a.H * a.W * 4;
-    if (a.sz < 32 || bytes <= (256LL << 20)) {
+    // MIS_WGRAD_RING_UNITS = 1 / 2 forces units / contiguous ranges (tests run the small shapes through both)
+    static const int forced = getenv("MIS_WGRAD_RING_UNITS") ? atoi(getenv("MIS_WGRAD_RING_UNITS")) : 0;
+    if (forced == 2 || (forced != 1 && (a.sz < 32 || bytes <= (256LL << 20)))) {
         a.n_stage = cols * a.sz;
         const int nt1 = 256 / (MIS_NUM_XCD * pairs), nt2 = 512 / (MIS_NUM_XCD * pairs);
         int nt = (nt1 >= 1 && MIS_NUM_XCD * pairs * nt1 * 10 >= 256 * 9) ? nt1 : (nt2 >= 1 ? nt2 : 1);

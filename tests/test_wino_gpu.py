@@ -5,11 +5,14 @@ What they replace: nn.Conv3d(k=3, pad=1) forward, its autograd data gradient and
 UnetUp3_CT / ConvBlock (reference code/networks/utils.py:99-123, unet_3D.py:28-57, vnet.py:15-22).  The arithmetic is
 fp32 end to end; the tolerance is the one the direct kernels are held to in test_kernels_gpu.py (2e-4 relative to the
 largest reference value, fp32 with another summation order)."""
+import os
+
 import pytest
 import torch
 import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _ops():
@@ -209,6 +212,36 @@ def test_wino_weight_gradient(case):
     finally:
         ops.WINO = keep
     _close(dw, dwd, rtol=1e-5, atol=1e-6)
+
+
+def test_ring_weight_gradient_in_units_mode():
+    """The z-ring kernel deals column SEGMENTS to the workgroups of an XCD interleaved at the 96^3 level and contiguous stage
+    ranges elsewhere (by tensor size): MIS_WGRAD_RING_UNITS=1 forces the units mode on the small ring shapes of WGRAD_CASES
+    (segment starts inside a column, single-stage segments, every face class) in a fresh process."""
+    import subprocess
+    import sys
+    code = """
+import sys, torch, torch.nn.functional as F
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+from mis_hip import ops, lib
+cases = [(1, 16, 16, 4, 4, 32), (8, 16, 16, 4, 4, 32), (1, 16, 16, 64, 4, 32), (2, 16, 16, 12, 8, 32), (3, 16, 16, 16, 16, 64),
+         (1, 24, 40, 8, 8, 32), (2, 32, 32, 8, 16, 48), (1, 16, 48, 20, 8, 16), (1, 16, 16, 2, 4, 32)]
+for N, Cin, Cout, D, H, W in cases:
+    assert lib.load().mis_conv3d_wino_wgrad_select(N, Cin, Cout, D, H, W) in (3, 4)
+    g = torch.Generator().manual_seed(N * 1000 + D)
+    x = torch.randn(N, Cin, D, H, W, generator=g, dtype=torch.float64)
+    dy = torch.randn(N, Cout, D, H, W, generator=g, dtype=torch.float64)
+    w = torch.zeros(Cout, Cin, 3, 3, 3, dtype=torch.float64, requires_grad=True)
+    F.conv3d(x, w, padding=1).backward(dy)
+    dw = torch.full((Cout, Cin, 3, 3, 3), float('nan'), device='cuda')
+    ops.conv_wgrad(x.float().cuda(), dy.float().cuda(), dw, (3, 3, 3))
+    err = (dw.cpu().double() - w.grad).abs().max().item()
+    assert err <= 1e-6 + 1e-5 * w.grad.abs().max().item(), (N, Cin, Cout, D, H, W, err)
+print('units mode ok')
+""" % (os.path.join(ROOT, "cv-ssl-mis_amd"), ROOT)
+    env = dict(os.environ, MIS_WGRAD_RING_UNITS="1")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and "units mode ok" in r.stdout, r.stderr[-2000:] + r.stdout[-500:]
 
 
 def test_wino_select_and_refusal():
