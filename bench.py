@@ -370,7 +370,7 @@ def run_workload(name, args, rank, world, kernel_events=True):
                                    "around every MFMA launch")
         roofline["serial_ms_per_step"] = round(serial_dt / serial_steps * 1e3, 3)
         roofline["peak_note"] = ("157.3 TFLOP/s = the fp32 MFMA pipe at 2.4 GHz (MI355X_MICROARCH.md); in-kernel counters show the chip "
-                                 "running the HBM-streaming Winograd kernels at 1.6-2.2 GHz (power budget: DESIGN.md s.3 'Power'), "
+                                 "running the HBM-streaming Winograd kernels at 1.7-2.2 GHz (power budget: DESIGN.md s.3 'Power'), "
                                  "so a fraction of this peak understates the pipe's occupancy in cycles by 10-35 %")
     step_s = dt / args.steps
     step_frac = wl["step_gflop"] * 1e9 / step_s / (PEAK_FP32_MFMA_TFLOPS * 1e12)
