@@ -322,7 +322,7 @@ def run_workload(name, args, rank, world, kernel_events=True):
             d[2] += 1
         def reduction(k):
             """Winograd F(2x2x2, 3x3x3) / F(2x2, 3x3): 64 (16) multiplies per 2x2x2 (2x2) outputs instead of 216 (36)."""
-            return (3.375 if k.startswith(("wino_fwd_kernel", "wino_wgrad_kernel")) else
+            return (3.375 if k.startswith(("wino_fwd_kernel", "wino_wgrad_")) else
                     2.25 if k.startswith(("wino2d_fwd_kernel", "wino2d_wgrad_kernel")) else 1.0)
 
         fam_alg = sum(d[0] for d in per.values())
@@ -360,7 +360,7 @@ def run_workload(name, args, rank, world, kernel_events=True):
                         executed_flops_per_launch_avg=per[dom][0] / per[dom][2] / red,
                         family=dict(kernel="all event-timed MFMA launches (wino*_fwd_kernel<*> / conv_fwd_kernel<*> forward + "
                                            "data gradient, wino*_wgrad_kernel<*> / conv_wgrad_kernel<*> weight gradient; "
-                                           "gemm_nt_kernel<*> / gemm_tn_kernel<*> for SwinUnet)",
+                                           "gemm_nt_kernel<*> / gemm_tn_reg_kernel / gemm_tn_kernel<*> for SwinUnet)",
                                     achieved=round(fam_exec / fam_time / 1e12, 3),
                                     frac=round(fam_exec / fam_time / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
                                     algorithmic_tflops=round(fam_alg / fam_time / 1e12, 3),

@@ -25,6 +25,7 @@
 // partials in a fixed order (deterministic) into dw[Cout][Cin][27].
 #include "common.h"
 #include "wino.h"
+#include <stdio.h>
 #include <stdlib.h>
 
 namespace {
@@ -1058,6 +1059,17 @@ bool flat_enabled() {
 }
 
 }  // namespace
+
+// kernel name of a weight-gradient variant as rocprofv3 prints it (minus the anonymous-namespace prefix), for bench.py
+extern "C" int mis_conv3d_wino_wgrad_kernel_name(int variant, char* name, int name_len) {
+    if (!name || name_len <= 0) return MIS_ERR_ARG;
+    static const char* const names[6] = {"wino_wgrad_kernel<WgCfg<1, 2, 16, 1> >", "wino_wgrad_kernel<WgCfg<2, 2, 8, 1> >",
+                                         "wino_wgrad_kernel<WgCfg<4, 2, 4, 0> >", "wino_wgrad_ring_kernel<WrCfg<2, 16, 1> >",
+                                         "wino_wgrad_ring_kernel<WrCfg<4, 8, 1> >", "wino_wgrad_flat_kernel<12, 12>"};
+    if (variant < 0 || variant > 5) return MIS_ERR_UNSUPPORTED;
+    snprintf(name, name_len, "%s", names[variant]);
+    return MIS_OK;
+}
 
 // Which variant serves the weight gradient of this 3x3x3 'same' convolution, or -1 (use mis_conv_wgrad).
 // 3 / 4: the z-ring kernels (96^3 / 48^3 levels), 0 / 1 / 2: the box kernels

@@ -1026,6 +1026,17 @@ extern "C" int mis_gemm_nt_kernel_name(int M, int N, int K, int epilogue, char* 
     return MIS_OK;
 }
 
+// TN kernel mis_gemm(trans = 1) / mis_gemm_dw run this shape with (operands as the callers pass them: row strides in
+// floats, base pointers), as rocprofv3 prints it minus the anonymous-namespace prefix: for bench.py's attribution
+extern "C" int mis_gemm_tn_kernel_name(const float* A, long long lda, const float* B, long long ldb, const float* C,
+                                       long long ldc, int M, int N, int K, char* name, int name_len) {
+    if (M <= 0 || N <= 0 || K <= 0 || !name || name_len <= 0) return MIS_ERR_ARG;
+    if (tn_reg_ok(A, lda, B, ldb, C, ldc, M, N, K) && (long long)K * lda * 4 < (1LL << 31) && (long long)K * ldb * 4 < (1LL << 31))
+        snprintf(name, name_len, "gemm_tn_reg_kernel");
+    else snprintf(name, name_len, "gemm_tn_kernel<%d>", tn_tile(M, N));
+    return MIS_OK;
+}
+
 extern "C" long long mis_gemm_workspace_bytes(int M, int N, int K, int trans) {
     if (M <= 0 || N <= 0 || K <= 0) return MIS_ERR_ARG;
     int ks = pick_ks(M, N, K, trans);

@@ -64,6 +64,7 @@ PROTOTYPES = {
     "mis_conv2d_wino_wgrad_workspace_bytes": (c_ll, [c_i, c_i, c_i, c_i, c_i, c_i]),
     "mis_conv2d_wino_wgrad": (c_i, [c_p, c_ll, c_p, c_ll, c_p, c_p, c_ll, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
     "mis_conv3d_wino_wgrad_select": (c_i, [c_i, c_i, c_i, c_i, c_i, c_i]),
+    "mis_conv3d_wino_wgrad_kernel_name": (c_i, [c_i, ctypes.c_char_p, c_i]),
     "mis_conv3d_wino_wgrad_workspace_bytes": (c_ll, [c_i, c_i, c_i, c_i, c_i, c_i, c_i]),
     "mis_conv3d_wino_wgrad": (c_i, [c_p, c_ll, c_p, c_ll, c_p, c_p, c_ll, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
     "mis_conv_wgrad_workspace_bytes": (c_ll, [c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i]),
@@ -139,6 +140,7 @@ PROTOTYPES = {
     "mis_gemm_dw_workspace_bytes": (c_ll, [c_i, c_i, c_i]),
     "mis_gemm_dw": (c_i, [c_p, c_ll, c_p, c_ll, c_p, c_ll, c_p, c_i, c_i, c_i, c_i, c_p, c_ll, c_p]),
     "mis_gemm_nt_kernel_name": (c_i, [c_i, c_i, c_i, c_i, ctypes.c_char_p, c_i]),
+    "mis_gemm_tn_kernel_name": (c_i, [c_p, c_ll, c_p, c_ll, c_p, c_ll, c_i, c_i, c_i, ctypes.c_char_p, c_i]),
     "mis_gemm_expand": (c_i, [c_p, c_ll, c_p, c_ll, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
     "mis_gemm": (c_i, [c_p, c_ll, c_p, c_ll, c_p, c_ll, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_ll, c_p]),
     "mis_gemm_ex": (c_i, [c_p, c_ll, c_p, c_ll, c_p, c_ll, c_p, c_i, c_i, c_i, c_i, c_p, c_ll, c_p, c_ll, c_p, c_ll, c_p,

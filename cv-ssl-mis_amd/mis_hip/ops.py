@@ -365,7 +365,9 @@ def _conv_wgrad_launch(L, x, dy, dw, N, Cin, Cout, D, H, W, xbs, dbs, kd, kh, kw
         _tag(f"wino_wgrad:v{wino}@{W}")
         _l.check(L.mis_conv3d_wino_wgrad(_l.ptr(x), xbs, _l.ptr(dy), dbs, _l.ptr(dw), _l.ptr(ws), ws.numel(), N, Cin,
                                          Cout, D, H, W, int(accumulate), wino, _l.stream_ptr()), "mis_conv3d_wino_wgrad")
-        return f"wino_wgrad_kernel<variant {wino}>"
+        buf = _ctypes.create_string_buffer(96)
+        _l.check(L.mis_conv3d_wino_wgrad_kernel_name(wino, buf, 96), "mis_conv3d_wino_wgrad_kernel_name")
+        return buf.value.decode()
     wino2 = int(L.mis_conv2d_wino_wgrad_select(N, Cin, Cout, H, W)) if ((WINO & 2) and (kd, kh, kw) == (1, 3, 3) and D == 1) else -1
     if wino2 >= 0 and xbs % 4 == 0 and dbs % 4 == 0 and x.data_ptr() % 16 == 0 and dy.data_ptr() % 16 == 0:
         nb = L.mis_conv2d_wino_wgrad_workspace_bytes(N, Cin, Cout, H, W, wino2)
@@ -374,7 +376,7 @@ def _conv_wgrad_launch(L, x, dy, dw, N, Cin, Cout, D, H, W, xbs, dbs, kd, kh, kw
         ws = scratch(nb, "wgrad")
         _l.check(L.mis_conv2d_wino_wgrad(_l.ptr(x), xbs, _l.ptr(dy), dbs, _l.ptr(dw), _l.ptr(ws), ws.numel(), N, Cin, Cout,
                                          H, W, int(accumulate), wino2, _l.stream_ptr()), "mis_conv2d_wino_wgrad")
-        return f"wino2d_wgrad_kernel<variant {wino2}>"
+        return f"wino2d_wgrad_kernel<Wg2Cfg<{wino2 + 1}> >"
     nb = L.mis_conv_wgrad_workspace_bytes(N, Cin, Cout, D, H, W, kd, kh, kw)
     if nb < 0:
         _l.check(nb, "mis_conv_wgrad_workspace_bytes")

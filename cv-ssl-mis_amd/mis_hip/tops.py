@@ -28,6 +28,14 @@ def _nt_name(L, M, N, K, epilogue):
     return buf.value.decode()
 
 
+def _tn_name(L, A, lda, B, ldb, C, ldc, M, N, K):
+    """TN kernel mis_gemm(trans) / mis_gemm_dw pick for these operands, as rocprofv3 names it."""
+    buf = ctypes.create_string_buffer(96)
+    _l.check(L.mis_gemm_tn_kernel_name(_l.ptr(A), lda, _l.ptr(B), ldb, _l.ptr(C), ldc, M, N, K, buf, 96),
+             "mis_gemm_tn_kernel_name")
+    return buf.value.decode()
+
+
 def gemm(A, B, C, bias=None, trans=False, accumulate=False):
     """trans=False: C[M,N] (+)= A[M,K] @ B[N,K]^T (+ bias);  trans=True: C[M,N] (+)= A[K,M]^T @ B[K,N]."""
     L = _l.load()
@@ -52,7 +60,7 @@ def gemm(A, B, C, bias=None, trans=False, accumulate=False):
         e1.record()
         # kernel instantiation mis_gemm picks (gemm.hip: tn_tile / nt_tile_n), as rocprofv3 names it
         if trans:
-            name = "gemm_tn_kernel<96>" if (M % 96 == 0 and N % 96 == 0 and (M % 128 or N % 128)) else "gemm_tn_kernel<128>"
+            name = _tn_name(L, A, lda, B, ldb, C, ldc, M, N, K)
         else:
             name = _nt_name(L, M, N, K, 0)
         prof.append((name, 2.0 * M * N * K, e0, e1))
@@ -75,8 +83,7 @@ def gemm_dw(dy, x, dW, db, accumulate=False):
                            _l.ptr(ws), ws.numel() if ws is not None else 0, _l.stream_ptr()), "mis_gemm_dw")
     if prof is not None:
         e1.record()
-        name = "gemm_tn_kernel<96>" if (M % 96 == 0 and N % 96 == 0 and (M % 128 or N % 128)) else "gemm_tn_kernel<128>"
-        prof.append((name, 2.0 * M * N * K, e0, e1))
+        prof.append((_tn_name(L, dy, lddy, x, ldx, dW, ldw, M, N, K), 2.0 * M * N * K, e0, e1))
 
 
 EP_GELU_FWD, EP_GELU_BWD, EP_RESIDUAL = 1, 2, 3

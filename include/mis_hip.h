@@ -131,6 +131,8 @@ int mis_conv2d_wino_wgrad(const float* x, long long x_bs, const float* dy, long 
  * 'same' convolution up to fp32 rounding, deterministic (fixed summation order).  _select: variant or -1 (use
  * mis_conv_wgrad); needs 16-byte aligned x / dy, batch strides and W multiples of 4 floats. */
 int mis_conv3d_wino_wgrad_select(int N, int Cin, int Cout, int D, int H, int W);
+/* the kernel a variant launches, as a profiler names it */
+int mis_conv3d_wino_wgrad_kernel_name(int variant, char* name, int name_len);
 long long mis_conv3d_wino_wgrad_workspace_bytes(int N, int Cin, int Cout, int D, int H, int W, int variant);
 int mis_conv3d_wino_wgrad(const float* x, long long x_bs, const float* dy, long long dy_bs, float* dw, float* workspace,
                           long long workspace_bytes, int N, int Cin, int Cout, int D, int H, int W, int accumulate,
@@ -422,6 +424,9 @@ int mis_gemm_dw(const float* dy, long long lddy, const float* x, long long ldx, 
                 int N, int K, int accumulate, float* workspace, long long workspace_bytes, hipStream_t stream);
 /* the NT kernel instantiation mis_gemm / mis_gemm_ex run this shape with (aligned operands), as a profiler names it */
 int mis_gemm_nt_kernel_name(int M, int N, int K, int epilogue, char* name, int name_len);
+/* the TN kernel mis_gemm(trans = 1) / mis_gemm_dw run this shape and these operands with, as a profiler names it */
+int mis_gemm_tn_kernel_name(const float* A, long long lda, const float* B, long long ldb, const float* C, long long ldc,
+                            int M, int N, int K, char* name, int name_len);
 /* nn.Linear of PatchExpand / FinalPatchExpand_X4 fused with their pixel shuffle
  * 'b h w (p1 p2 c) -> b (h p1) (w p2) c' (swin_transformer_unet_skip_expand_decoder_sys.py:373-380, :401-408):
  * x [B*H*W][K] (row stride lda), W [P*P*c][K] (row stride ldb), out [B*H*P*W*P][c] dense.  No bias.
