@@ -19,6 +19,13 @@
 #include "wino.h"
 #include <stdio.h>
 
+// Prototype of review item 5 (round 4), off in the product build: -DMIS_W2_NORM=1 applies BatchNorm scale / shift +
+// LeakyReLU on the LDS -> register read of the patch (the raw convolution output of the previous layer would then be the only
+// activation kept).  scripts/w2_norm_proto.sh builds a side library with it and measures the cost; DESIGN.md s.7 has the result.
+#ifndef MIS_W2_NORM
+#define MIS_W2_NORM 0
+#endif
+
 namespace {
 
 using namespace mis_dma;
@@ -34,7 +41,13 @@ struct W2Args {
     int boxes_y, boxes_x, co_groups;
     unsigned n_blocks, n_blocks_padded;
     float2* stat; long long stat_sc, stat_sn;
+    const float2* nrm; float slope;      // MIS_W2_NORM: (scale, shift) per input channel, or null
 };
+
+#if MIS_W2_NORM
+const float2* g_w2_nrm = nullptr;
+float g_w2_slope = 0.f;
+#endif
 
 template <int BY_, int BX_, int COB_, int NBUF_>
 struct W2Cfg {
@@ -48,7 +61,7 @@ struct W2Cfg {
     static constexpr int STAGE = IN_FLOATS + W_FLOATS;
     static constexpr int PT = NCH + COB * 4;                                // pieces per stage
     static constexpr int PW = (PT + 3) / 4;                                 // ... per wave (surplus slots repeat the last one)
-    static constexpr int LDS_BYTES = NBUF * STAGE * 4 + 512;                // + statistics scratch
+    static constexpr int LDS_BYTES = NBUF * STAGE * 4 + 512 + (MIS_W2_NORM ? 4096 : 0);   // + statistics scratch (+ norm table)
     static_assert(BY * BX == 64, "4 waves x 16 tiles");
     static_assert(NBUF >= 3 && (NBUF - 1) * PW <= 63, "ring depth / vmcnt range");
     static_assert(LDS_BYTES <= 80 * 1024, "two workgroups per CU");
@@ -114,6 +127,19 @@ __global__ __launch_bounds__(256, 2) void wino2d_fwd_kernel(const W2Args a) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[b][i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+#if MIS_W2_NORM
+    float2* const s_nrm = reinterpret_cast<float2*>(lds + C::NBUF * C::STAGE + 128);
+    const bool norm = a.nrm != nullptr;                      // uniform
+    if (norm) for (int i = tid; i < 4 * nst; i += 256) s_nrm[i] = i < a.Cin ? a.nrm[i] : make_float2(0.f, 0.f);
+    // a box on the image border has patch elements in the zero padding: they must stay zero after the activation
+    const bool border = y0 == 0 || x0 == 0 || y0 + C::OY >= a.H || x0 + C::OX >= a.W;
+    bool rok[4], cok[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        rok[r] = (unsigned)(y0 + 2 * ty - 1 + r) < (unsigned)a.H;
+        cok[r] = (unsigned)(x0 + 2 * tx - 1 + r) < (unsigned)a.W;
+    }
+#endif
     constexpr int A = C::NBUF - 1;
 #pragma unroll
     for (int s = 0; s < A; ++s) issue(s);                    // stages past the last chunk deliver zeros (never read)
@@ -128,6 +154,24 @@ __global__ __launch_bounds__(256, 2) void wino2d_fwd_kernel(const W2Args a) {
             u[r * 2] = f32x2{sb[poff + r * C::RX], sb[poff + r * C::RX + 1]};
             u[r * 2 + 1] = f32x2{sb[poff + r * C::RX + 2], sb[poff + r * C::RX + 3]};
         }
+#if MIS_W2_NORM
+        if (norm) {
+            const float2 st = s_nrm[4 * s + lk];
+            const f32x2 sc = {st.x, st.x}, sh = {st.y, st.y}, sl = {a.slope, a.slope};
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const f32x2 v = u[i] * sc + sh, w = v * sl;
+                u[i] = f32x2{fmaxf(v[0], w[0]), fmaxf(v[1], w[1])};
+            }
+            if (border) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int r = i / 2, c = (i % 2) * 2;
+                    u[i] = f32x2{rok[r] && cok[c] ? u[i][0] : 0.f, rok[r] && cok[c + 1] ? u[i][1] : 0.f};
+                }
+            }
+        }
+#endif
 #pragma unroll
         for (int r = 0; r < 4; ++r) bt4_inner(u[r * 2], u[r * 2 + 1]);
         bt4(u[0], u[2], u[4], u[6]);
@@ -276,5 +320,18 @@ extern "C" int mis_conv2d_wino_fwd(const float* x, long long x_bs, const float* 
     a.N = N; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W;
     a.nci4 = (Cin + 3) / 4;
     a.stat = reinterpret_cast<float2*>(stat); a.stat_sc = stat_sc; a.stat_sn = stat_sn;
+#if MIS_W2_NORM
+    a.nrm = g_w2_nrm; a.slope = g_w2_slope;
+    if (a.nrm && Cin > 512) return MIS_ERR_UNSUPPORTED;
+#endif
     return variant == 0 ? launch_w2<W2V0>(a, stream) : launch_w2<W2V1>(a, stream);
 }
+
+#if MIS_W2_NORM
+// prototype hook: the next mis_conv2d_wino_fwd launches read their input through LeakyReLU(scale * x + shift)
+extern "C" int mis_debug_w2_norm(const float* scale_shift, float slope) {
+    g_w2_nrm = reinterpret_cast<const float2*>(scale_shift);
+    g_w2_slope = slope;
+    return MIS_OK;
+}
+#endif
