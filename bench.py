@@ -201,7 +201,7 @@ def build_trainer(name, wl, world, stub=False):
         key = {"vnet": "vnet", "unetr": "unetr", "swinunetr": "swinunetr"}.get(name, "unet_3D")
         model, ema = net_factory_3d(key, 1, C), net_factory_3d(key, 1, C)
         ema.load_state_dict(model.state_dict())
-    if world > 1:   # identical initial weights on every rank
+    if _dist_on(world):   # identical initial weights on every rank
         for m in (model, ema, vit_teacher):
             if m is not None:
                 torch.distributed.broadcast(m.flat_param, 0)
@@ -214,6 +214,13 @@ def build_trainer(name, wl, world, stub=False):
         return UAMTTrainer(model, ema, labeled_bs=L, num_classes=C, seed=1337, iter_num=1000)
     return MeanTeacherTrainer(model, ema, labeled_bs=L, num_classes=C, cons_start_iter=wl["cons_start"], seed=1337,
                               iter_num=1000, use_graph=os.environ.get("MIS_BENCH_GRAPH", "0") == "1")
+
+
+def _dist_on(world):
+    """The N > 1 code path.  MIS_BENCH_DIST_AT_WORLD1=1 (tests only) runs it in a process group of ONE rank: on the test box's
+    single GPU that is a real RCCL group -- initialisation, broadcast, all-gather, barrier, the bucketed all-reduce -- under the
+    very code an 8-GPU launch executes (tests/test_dist_gpu.py)."""
+    return world > 1 or os.environ.get("MIS_BENCH_DIST_AT_WORLD1") == "1"
 
 
 class _StubTrainer:
@@ -260,14 +267,14 @@ def run_workload(name, args, rank, world, kernel_events=True):
     def timed(steps):
         """`steps` steps between barrier + device sync on both sides; this rank's seconds."""
         sync()
-        if world > 1:
+        if _dist_on(world):
             tdist.barrier()
         sync()
         t0 = time.perf_counter()
         for _ in range(steps):
             tr.step(vol, lab)
         sync()
-        if world > 1:
+        if _dist_on(world):
             tdist.barrier()
         sync()
         return time.perf_counter() - t0
@@ -281,7 +288,7 @@ def run_workload(name, args, rank, world, kernel_events=True):
         tr.step(vol, lab)
     dt_local = timed(args.steps)
     dt, per_rank = dt_local, [dt_local]
-    if world > 1:
+    if _dist_on(world):
         t = torch.tensor([dt_local], device=dev, dtype=torch.float64)
         allt = [torch.zeros_like(t) for _ in range(world)]
         tdist.all_gather(allt, t)
@@ -290,7 +297,7 @@ def run_workload(name, args, rank, world, kernel_events=True):
 
     # ---- data parallel: prove the exchange happened and price it (before any diagnostic region changes the weights)
     dist_info = None
-    if world > 1:
+    if _dist_on(world):
         dist_info = _distributed_checks(tr, timed, args, rank, world, dev, stub, dt_local)
 
     # ---- roofline region: the same step with the side streams off, every MFMA launch bracketed by HIP events on its
@@ -574,7 +581,7 @@ def main():
     if not args.stub:
         torch.cuda.set_device(local_rank)
     nccl_logs = None
-    if world > 1:
+    if _dist_on(world):
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if not args.stub and "MIS_BENCH_LAUNCHED" not in os.environ:
             nccl_logs = nccl_debug_env(os.environ)       # launched by torchrun directly: RCCL's warnings on failure
@@ -597,7 +604,7 @@ def main():
     try:
         res = run_workload(args.workload, args, rank, world, kernel_events=not args.no_kernel_events)
     except BaseException as e:
-        if world > 1 and rank == 0 and "MIS_BENCH_LAUNCHED" not in os.environ:
+        if _dist_on(world) and rank == 0 and "MIS_BENCH_LAUNCHED" not in os.environ:
             print(json.dumps({"metric": "training images-or-volumes/sec/node (Mean-Teacher step)", "value": None,
                               "n_gpus": world, "error": f"{type(e).__name__}: {e}"[:2000],
                               "nccl_warnings": collect_nccl_warnings(nccl_logs)}), flush=True)
@@ -623,7 +630,7 @@ def main():
         }
         if args.stub:
             out["data"] = "stub (CPU/gloo launcher test, not a measurement)"
-    if world == 1 and not args.stub and not args.no_others and args.workload == "unet3d":
+    if not _dist_on(world) and not args.stub and not args.no_others and args.workload == "unet3d":
         # the other single-GPU configurations of BASELINE.json, shorter runs of the same protocol
         import copy
         oargs = copy.copy(args)
@@ -639,7 +646,7 @@ def main():
                                 dominant_kernel=rf.get("kernel"), dominant_kernel_frac=rf.get("frac"),
                                 dominant_kernel_algorithmic_tflops=rf.get("algorithmic_tflops"))
         out["others"] = others
-    if world > 1 and not args.no_others and args.workload == "unet3d":
+    if _dist_on(world) and not args.no_others and args.workload == "unet3d":
         # config 5 (cross teaching, the BASELINE configuration that is DEFINED on 8 GPUs: 16+16 images per GPU) behind the
         # default workload: two students, two gradient bucketers, the second student's backward on a side stream
         import copy
@@ -652,11 +659,11 @@ def main():
                                            per_rank_ms_per_step=r["per_rank_ms_per_step"],
                                            distributed=r["distributed"])}
     if rank == 0:
-        if world == 1 and not args.stub and not args.no_cpu_baseline and wl["cpu_sample"] is not None:
+        if not _dist_on(world) and not args.stub and not args.no_cpu_baseline and wl["cpu_sample"] is not None:
             out["cpu_baseline"] = cpu_baseline(args.workload, wl)
             out["gpu_over_cpu"] = round(out["value"] / out["cpu_baseline"]["value"], 2)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if _dist_on(world):
         torch.distributed.destroy_process_group()
 
 

@@ -174,3 +174,29 @@ def test_single_rank_rccl_group_bucketed_step_is_bit_identical(tmp_path, kind):
     assert len(a) == len(b) >= 2
     for x, y in zip(a, b):
         assert torch.isfinite(x).all() and torch.equal(x, y)
+
+
+@pytest.mark.timeout(1200)
+def test_bench_multi_gpu_code_path_on_a_single_rank_rccl_group():
+    """``bench.py``'s N > 1 path -- RCCL group with a timeout, weight broadcast, barrier + all-gathered timings, the bit
+    fingerprint of the weights, the blocking / no-exchange regions, cross teaching behind the default workload -- executed in
+    a process group of one rank on the one GPU (MIS_BENCH_DIST_AT_WORLD1), gradient bucketers forced on: what the driver's
+    2 / 4 / 8-GPU launches run, minus the peers."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(MIS_BENCH_DIST_AT_WORLD1="1", MIS_FORCE_BUCKETER="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()),
+               RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1",
+                        "--no-kernel-events"], capture_output=True, text=True, timeout=1100, env=env)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    out = json.loads(lines[0])
+    d = out["distributed"]
+    assert out["n_gpus"] == 1 and out["value"] > 0 and d["backend"] == "nccl (RCCL)" and d["params_identical"] is True
+    assert d["blocking_allreduce_ms_per_step"] > 0 and d["no_exchange_ms_per_step"] > 0
+    assert all(v == v for v in out["losses_last_step"].values())            # finite losses after the extra regions
+    c = out["others"]["cross"]
+    assert c["value"] > 0 and c["distributed"]["params_identical"] is True and c["distributed"]["blocking_allreduce_ms_per_step"] > 0
+    assert "cpu_baseline" not in out
