@@ -700,6 +700,289 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     wg_finish(acc, lds, a.ws + (long long)task * (27 * 256), tid, wave, lt, lc);
 }
 
+// =====================================================================================================================
+// z-ring form for rows of 24 voxels (the 24^3 level: conv3 / up_concat3 of unet_3D, block_three / block_seven of V-Net;
+// round 4).  24 does not split into the 16- or 32-voxel columns of the kernels above, and a column of 8 x 24 voxels is 48
+// tiles = 12 chunks: THREE MFMA runs per wave and stage instead of two.  What changes with it:
+//   * planes of 10 rows x 16 channels x 36 floats (32 + one pad group: a channel stride of 32 floats would put the 16 channel
+//     lanes of a patch read on two LDS banks) = 23 KB; a ring of 6 slots (138 KB) -- the new plane pair of stage s + 1 is
+//     issued in the first run of stage s into the slots stage s - 1 freed, one stage (three runs) ahead of its first read;
+//   * dy does not pass through LDS (no room for a double buffer): the lane loads the 2 x 2 x 2 patch of its (co, tile) with four
+//     buffer_load_dwordx2 in the first slots of the run BEFORE the one that consumes it, as the flat kernel does -- inline
+//     asm, so that the vmcnt bookkeeping stays in one place (hipcc does not see the asm DMAs and would wait for vmcnt(0));
+//   * one barrier per stage (after the second run: every wave has read stage s, every wave's new planes have landed).
+template <int TY_, int TX_>
+struct Wr3Cfg {
+    static constexpr int TY = TY_, TX = TX_;
+    static constexpr int OY = 2 * TY, OX = 2 * TX, HY = OY + 2;
+    static constexpr int NQ = (OX + 8) / 4 + 1, RX = NQ * 4;              // x rows hold [x0 - 4, x0 + OX + 4) + one pad group
+    static constexpr int PLG = HY * 16 * NQ;                              // 16-byte groups of one z plane of 16 channels
+    static constexpr int PP = (PLG + 63) / 64, PLF = PP * 256, PLB = PLF * 4;   // whole DMA pieces: the slot is padded
+    static constexpr int PW = (PP + 3) / 4;
+    static constexpr int R = 6;
+    static constexpr int NRUN = TY * TX / 16;
+    static constexpr int CX = TX / 4;
+    static constexpr int LDS_BYTES = R * PLB;
+    static_assert(NRUN == 3 && TX % 4 == 0, "48 tiles: three chunks per wave");
+    static_assert(LDS_BYTES <= 160 * 1024, "LDS");
+    static_assert(4 * 27 * 256 * 4 <= LDS_BYTES, "the final cross-wave sum reuses the ring");
+    static_assert(4 * (2 * PW) + 2 < 64, "DMA slots of the first run");
+};
+
+template <class C>
+struct Wr3State {
+    unsigned e_vo[C::PW];           // per lane: DMA byte offset of the lane's group in a plane (piece slot e), faces applied
+    unsigned e_off[C::PW];          // LDS byte offset of the slot's piece inside its plane
+    unsigned d_vo[C::NRUN];         // per lane: byte offset of the dy patch of (co = lane & 15, tile lane >> 4 of chunk h)
+    i32x4 rxa, rxb, rd, rdn;        // x of the first / second new plane of the fill; dy of this stage / of the next (0: beyond)
+    unsigned full, hw_bytes, w_bytes, lds0;
+    unsigned dst_a, qa, soff_a;     // fill cursor: LDS address / ring slot / byte offset of the first new plane
+    unsigned dsoff;                 // dy byte offset of the stage being computed
+    int f, f_bz, cnt, sz;           // the stage the NEXT fill is for (segment-relative), its z index
+
+    __device__ __forceinline__ void next_fill() {
+        ++f; ++f_bz;
+        soff_a += 2u * hw_bytes;
+        qa = qa + 2u >= 6u ? qa + 2u - 6u : qa + 2u;
+        dst_a = lds0 + qa * (unsigned)C::PLB;
+        rxa[2] = (int)(f < cnt ? full : 0u);
+        rxb[2] = (int)((f < cnt && f_bz < sz - 1) ? full : 0u);       // plane 3 of the column's last stage: below the volume
+    }
+};
+
+// the lane's four dy pairs (z, y) of one chunk: buffer_load_dwordx2, scalar offsets for the plane / row steps
+template <class C, int K>
+__device__ __forceinline__ void wr3_dy(f32x2& r, unsigned vo, const i32x4& rsrc, unsigned base, const Wr3State<C>& st) {
+    const unsigned so = base + (K / 2 ? st.hw_bytes : 0u) + (K % 2 ? st.w_bytes : 0u);
+    asm volatile("buffer_load_dwordx2 %0, %1, %2, %3 offen" : "=v"(r) : "v"(vo), "s"(rsrc), "s"(so) : "memory");
+}
+
+// One run: 64 MFMAs of the current chunk; the LDS reads of the next chunk's x patch (planes x0..x3); in the first four slots
+// the dy loads of the next chunk.  RUN = 0: the 2 PW plane pieces of the next stage (M0 at K = 4 e + 1, DMA at 4 e + 2);
+// RUN = 1: the fill cursor moves on (K = 62).
+template <class C, int RUN, int K>
+__device__ __forceinline__ void wr3_slots(f32x2 (&u)[32], const f32x2 (&v)[16], f32x4 (&acc)[64], f32x2 (&rn)[4],
+                                          const float* __restrict__ x0, const float* __restrict__ x1,
+                                          const float* __restrict__ x2, const float* __restrict__ x3,
+                                          unsigned dvo, const i32x4& drs, unsigned dbase, Wr3State<C>& st, float (&av)[4]) {
+    if constexpr (K < 64) {
+        if constexpr (K % 4 == 0) {
+            const f32x2 p = v[K / 4];
+            f32x2 pm;
+            asm volatile("v_pk_add_f32 %0, %1, %1 op_sel:[0,1] op_sel_hi:[0,1] neg_hi:[0,1]" : "=v"(pm) : "v"(p));
+            av[0] = p[0]; av[1] = pm[0]; av[2] = pm[1]; av[3] = f_sub(0.f, p[1]);
+        }
+        // asm with the accumulator tied to an AGPR tuple: with three unrolled runs hipcc's allocator otherwise parks
+        // accumulator tuples in VGPRs and moves them back and forth (1200 v_accvgpr_* in the loop)
+        asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+a"(acc[K]) : "v"(av[K % 4]), "v"(u[K / 2][K % 2]));
+        {
+            constexpr int z = K / 16, y = (K / 4) % 4, xx = K % 4;
+            const float* __restrict__ xs = z == 0 ? x0 : z == 1 ? x1 : z == 2 ? x2 : x3;
+            u[K / 2][K % 2] = ((const volatile __attribute__((address_space(3))) float*)xs)[y * 16 * C::RX + xx];
+        }
+        if constexpr (K < 4) wr3_dy<C, K>(rn[K], dvo, drs, dbase, st);
+        if constexpr (RUN == 0) {
+            constexpr int E = (K - 1) / 4;                                 // slots 0 .. PW-1: first new plane, PW .. 2 PW - 1: second
+            if constexpr (K >= 5 && K % 4 == 1 && E - 1 < 2 * C::PW)
+                set_m0((E - 1) < C::PW ? st.dst_a : st.dst_a + (unsigned)C::PLB, st.e_off[(E - 1) % C::PW]);
+            if constexpr (K >= 6 && K % 4 == 2 && E - 1 < 2 * C::PW)
+                dma_x4_m0(st.e_vo[(E - 1) % C::PW], (E - 1) < C::PW ? st.soff_a : st.soff_a + st.hw_bytes,
+                          (E - 1) < C::PW ? st.rxa : st.rxb);
+        } else if constexpr (RUN == 1) {
+            if constexpr (K == 62) st.next_fill();
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        wr3_slots<C, RUN, K + 1>(u, v, acc, rn, x0, x1, x2, x3, dvo, drs, dbase, st, av);
+    }
+}
+
+template <class C>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void wino_wgrad_ring3_kernel(const WgArgs a) {
+    float* const lds = mis_wgw_lds;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lt = lane >> 4, lc = lane & 15;
+    const long long S = (long long)a.D * a.H * a.W;
+    const unsigned s_bytes = (unsigned)S * 4u;
+    const int HW = a.H * a.W;
+
+    // workgroup -> (channel-block pair, XCD, j) and its units / stage range: as wino_wgrad_ring_kernel
+    const int pairs = a.ci_blocks * a.co_blocks, nt = a.splits / MIS_NUM_XCD;
+    const int xcd = blockIdx.x % MIS_NUM_XCD, local = blockIdx.x / MIS_NUM_XCD;
+    const int pair = local % pairs, j = local / pairs;
+    const int cib = pair % a.ci_blocks, cob = pair / a.ci_blocks;
+    const int task = pair * a.splits + xcd * nt + j;
+    const bool by_units = a.seg > 0;
+    const int per8 = (a.n_stage + MIS_NUM_XCD - 1) / MIS_NUM_XCD;
+    const int u_begin = xcd * per8 + j, u_lim = (xcd + 1) * per8 < a.n_stage ? (xcd + 1) * per8 : a.n_stage;
+    const int chunk = xcd * nt + j;
+    long long g = (long long)a.n_stage * chunk / a.splits;
+    const long long g_end = (long long)a.n_stage * (chunk + 1) / a.splits;
+    int unit = u_begin;
+
+    Wr3State<C> st;
+    st.hw_bytes = (unsigned)HW * 4u;
+    st.w_bytes = (unsigned)a.W * 4u;
+    st.sz = a.sz;
+    st.lds0 = lds_addr(lds);
+    const unsigned x_bias = (unsigned)(HW + a.W + 4) * 4u;
+    st.full = 17u * s_bytes + x_bias;
+
+    // ---- per-lane DMA geometry of a plane (see the ring kernel above): group g = (row, channel, 16-byte group) ----
+    unsigned e_rel[C::PW], e_cls = 0;
+#pragma unroll
+    for (int e = 0; e < C::PW; ++e) {
+        const int pin = wave + 4 * e < C::PP ? wave + 4 * e : C::PP - 1;       // surplus slot: the plane's last piece again
+        const int gg = pin * 64 + lane;
+        const int hy = gg / (16 * C::NQ), rem = gg - hy * (16 * C::NQ), ci = rem / C::NQ, q = rem - ci * C::NQ;
+        unsigned rel = (unsigned)((hy * a.W + 4 * q) * 4) + (unsigned)ci * s_bytes;
+        if (gg >= C::PLG || q == C::NQ - 1 || cib * 16 + ci >= a.Cin) rel = OOB;       // slot padding, pad group, channels past Cin
+        e_rel[e] = rel;
+        e_cls |= ((hy == 0 ? 1u : 0u) | (hy == C::HY - 1 ? 2u : 0u) | (q == 0 ? 4u : 0u) | (q == C::NQ - 2 ? 8u : 0u)) << (4 * e);
+        st.e_off[e] = (unsigned)pin * 1024u;
+    }
+
+    // ---- this wave's three chunks (c = wave, wave + 4, wave + 8) and this lane's patches inside them ----
+    int xoff[C::NRUN];
+#pragma unroll
+    for (int h = 0; h < C::NRUN; ++h) {
+        const int c = wave + 4 * h;
+        const int cx = c % C::CX, cy = c / C::CX;
+        const int tx = 4 * cx + lt;
+        xoff[h] = (2 * cy) * 16 * C::RX + lc * C::RX + 3 + 2 * tx;
+        st.d_vo[h] = cob * 16 + lc < a.Cout ? (unsigned)lc * s_bytes + (unsigned)(((2 * cy) * a.W + 2 * tx) * 4) : OOB;
+    }
+
+    f32x4 acc[64];
+    const f32x2 zero = {0.f, 0.f};
+    {
+        float z0 = 0.f;
+        asm volatile("" : "+v"(z0));
+#pragma unroll
+        for (int i = 0; i < 64; ++i)
+            acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(z0, z0, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+    }
+    f32x2 u[32], v[16], rn[4];
+    float av[4];
+    auto land = [&]() {             // the asm loads' destinations hold data from here on
+#pragma unroll
+        for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(rn[i]));
+    };
+
+    while (by_units ? unit < u_lim : g < g_end) {
+        // ---- a column segment: stages bz0 .. bz0 + cnt - 1 of column (n, by, bx) ----
+        int bx, by, n, bz0, cnt;
+        if (by_units) {
+            int t = unit;
+            bx = t % a.sx; t /= a.sx;
+            by = t % a.sy; t /= a.sy;
+            const int zs = t % a.nseg;
+            n = t / a.nseg; bz0 = zs * a.seg; cnt = a.seg;
+            unit += nt;
+        } else {
+            const int col = (int)(g / a.sz);
+            bz0 = (int)(g - (long long)col * a.sz);
+            cnt = (int)((long long)(a.sz - bz0) < g_end - g ? (long long)(a.sz - bz0) : g_end - g);
+            g += cnt;
+            int t = col;
+            bx = t % a.sx; t /= a.sx;
+            by = t % a.sy; n = t / a.sy;
+        }
+        const unsigned flags = (by == 0 ? 1u : 0u) | (by == a.sy - 1 ? 2u : 0u) | (bx == 0 ? 4u : 0u) | (bx == a.sx - 1 ? 8u : 0u);
+#pragma unroll
+        for (int e = 0; e < C::PW; ++e) st.e_vo[e] = (((e_cls >> (4 * e)) & 15u) & flags) ? OOB : e_rel[e];
+        st.rxa = make_rsrc(reinterpret_cast<const char*>(a.x + (long long)n * a.x_bs + (long long)cib * 16 * S) - x_bias, st.full);
+        st.rxb = st.rxa;
+        st.rd = make_rsrc(a.dy + (long long)n * a.dy_bs + (long long)cob * 16 * S, 16u * s_bytes);
+        st.rdn = st.rd;
+        st.cnt = cnt;
+        // byte offset of the column origin at the segment's first stage: x plane 0 (input plane 2 bz0 - 1, biased by the
+        // descriptor base) and the first dy plane
+        const unsigned soff0 = (unsigned)(((2 * bz0) * a.H + by * C::OY) * a.W + bx * C::OX) * 4u;
+        st.dsoff = soff0;
+
+        // ---- prologue (not overlapped): the four planes of stage bz0 and the dy patch of its first chunk ----
+        vmwait<0>::go();
+        __syncthreads();            // the previous segment's last LDS reads are done before the ring is written again
+        {
+            i32x4 r = st.rxa;
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt) {
+                const int zp = 2 * bz0 - 1 + tt;
+                r[2] = (int)((zp >= 0 && zp < a.D) ? st.full : 0u);
+#pragma unroll
+                for (int e = 0; e < C::PW; ++e) {
+                    set_m0(st.lds0 + (unsigned)(tt * C::PLB), st.e_off[e]);
+                    asm volatile("s_nop 0");
+                    dma_x4_m0(st.e_vo[e], soff0 + (unsigned)tt * st.hw_bytes, r);
+                }
+            }
+            wr3_dy<C, 0>(rn[0], st.d_vo[0], st.rd, st.dsoff, st);
+            wr3_dy<C, 1>(rn[1], st.d_vo[0], st.rd, st.dsoff, st);
+            wr3_dy<C, 2>(rn[2], st.d_vo[0], st.rd, st.dsoff, st);
+            wr3_dy<C, 3>(rn[3], st.d_vo[0], st.rd, st.dsoff, st);
+        }
+        // fill cursor: the first fill is stage bz0 + 1 (its planes 2, 3 -> ring slots 4, 5)
+        st.f = 1; st.f_bz = bz0 + 1;
+        st.qa = 4u; st.dst_a = st.lds0 + 4u * (unsigned)C::PLB;
+        st.soff_a = soff0 + 4u * st.hw_bytes;
+        st.rxa[2] = (int)(st.f < cnt ? st.full : 0u);
+        st.rxb[2] = (int)((st.f < cnt && st.f_bz < a.sz - 1) ? st.full : 0u);
+        vmwait<0>::go();
+        land();
+        __syncthreads();
+
+        unsigned jb = 0;                // ring slot of plane 0 of the stage being computed
+        auto plane_ptr = [&](unsigned slot, int z, int h) -> const float* {
+            unsigned q = slot + (unsigned)z;
+            q = q >= 6u ? q - 6u : q;
+            return lds + q * (unsigned)C::PLF + xoff[h];
+        };
+        {
+#pragma unroll
+            for (int k = 0; k < 64; ++k) {
+                const int z = k / 16, y = (k / 4) % 4, xx = k % 4;
+                u[k / 2][k % 2] = plane_ptr(0, z, 0)[y * 16 * C::RX + xx];
+            }
+            in_units<0, 24>(u);
+            vzy_transform(rn, v, zero);
+        }
+        for (int s = 0; s < cnt; ++s) {
+            st.rdn[2] = (int)(s + 1 < cnt ? 16u * s_bytes : 0u);
+            // first run: chunk 0; x patch and dy of chunk 1; the new plane pair of stage s + 1
+            wr3_slots<C, 0, 0>(u, v, acc, rn, plane_ptr(jb, 0, 1), plane_ptr(jb, 1, 1), plane_ptr(jb, 2, 1), plane_ptr(jb, 3, 1),
+                               st.d_vo[1], st.rd, st.dsoff, st, av);
+            in_units<0, 24>(u);
+            vmwait<2 * C::PW>::go();    // dy of chunk 1 (older than the plane pieces just issued)
+            land();
+            vzy_transform(rn, v, zero);
+            // second run: chunk 1; x patch and dy of chunk 2; the fill cursor moves on
+            wr3_slots<C, 1, 0>(u, v, acc, rn, plane_ptr(jb, 0, 2), plane_ptr(jb, 1, 2), plane_ptr(jb, 2, 2), plane_ptr(jb, 3, 2),
+                               st.d_vo[2], st.rd, st.dsoff, st, av);
+            in_units<0, 24>(u);
+            vmwait<0>::go();            // dy of chunk 2; the planes of stage s + 1 (mine) ...
+            land();
+            vzy_transform(rn, v, zero);
+            __syncthreads();            // ... and everyone's; every wave has read stage s completely
+            // third run: chunk 2; x patch and dy of chunk 0 of stage s + 1 (after the last stage: stale planes, zero dy -- unused)
+            jb = jb + 2u >= 6u ? jb + 2u - 6u : jb + 2u;
+            wr3_slots<C, 2, 0>(u, v, acc, rn, plane_ptr(jb, 0, 0), plane_ptr(jb, 1, 0), plane_ptr(jb, 2, 0), plane_ptr(jb, 3, 0),
+                               st.d_vo[0], st.rdn, st.dsoff + 2u * st.hw_bytes, st, av);
+            in_units<0, 24>(u);
+            vmwait<0>::go();
+            land();
+            vzy_transform(rn, v, zero);
+            st.dsoff += 2u * st.hw_bytes;
+        }
+    }
+    vmwait<0>::go();
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");       // the last (asm) MFMAs have left the pipe before their AGPRs are read
+    __syncthreads();
+
+    // ---- G^T . G: 64 points -> 27 taps for the lane's 4 (co, ci) pairs, two accumulator rows at a time ----
+    wg_finish(acc, lds, a.ws + (long long)task * (27 * 256), tid, wave, lt, lc);
+}
+
 // dw[co][ci][tap] (+)= sum over the splits of the task partials [pair][split][27][16 co][16 ci].  A workgroup owns 64
 // consecutive elements of a pair's 27 x 256 partial; thread (e = tid & 63, g = tid >> 6) sums the splits k = g, g + 4, ... in
 // ascending order -- every load of a wave is 256 contiguous bytes -- and the four groups are combined in a fixed order through
@@ -977,6 +1260,7 @@ using WgV1 = WgCfg<2, 2, 8>;      // stages of 4 x 4 x 16 voxels (W a multiple o
 using WgV2 = WgCfg<4, 2, 4, 0>;   // stages of 8 x 4 x 8 voxels (W a multiple of 8: the 24^3 level); no dy pad group: LDS
 using WrV3 = WrCfg<2, 16>;        // z-ring, stages of 2 x 4 x 32 voxels (W a multiple of 32, H of 4): the 96^3 level
 using WrV4 = WrCfg<4, 8>;         // z-ring, stages of 2 x 8 x 16 voxels (W a multiple of 16, H of 8): the 48^3 level
+using Wr3V = Wr3Cfg<4, 12>;       // z-ring of three runs, stages of 2 x 8 x 24 voxels (W a multiple of 24, H of 8): the 24^3 level
 
 // z-ring geometry: units = (image, z segment, y, x) with x fastest, `seg` stages each.  The segment count and the workgroups
 // per (pair, XCD) come from a small model of the busiest workgroup: units per workgroup x (seg + the cost of a unit start --
@@ -1034,6 +1318,19 @@ int launch_ring(WgArgs a, float* dw, int accumulate, hipStream_t stream) {
     return mis_launch_status();
 }
 
+template <class C>
+int launch_ring3(WgArgs a, float* dw, int accumulate, hipStream_t stream) {
+    ring_geometry<C>(a);
+    static std::atomic<unsigned long long> attr_done{0};
+    if (mis_set_lds_attr(reinterpret_cast<const void*>(&wino_wgrad_ring3_kernel<C>), C::LDS_BYTES, attr_done) != MIS_OK)
+        return MIS_ERR_LAUNCH;
+    const int tasks = a.ci_blocks * a.co_blocks * a.splits;
+    hipLaunchKernelGGL(wino_wgrad_ring3_kernel<C>, dim3(tasks), dim3(256), C::LDS_BYTES, stream, a);
+    hipLaunchKernelGGL(wino_wgrad_reduce_kernel, dim3(a.ci_blocks * a.co_blocks * 108), dim3(256), 0, stream, a.ws, dw, a.Cout, a.Cin,
+                       a.ci_blocks, a.splits, accumulate);
+    return mis_launch_status();
+}
+
 unsigned long long* g_wr_prof = nullptr;
 
 // MIS_WGRAD_RING=0: the box kernels of round 2 for every level (A/B switch)
@@ -1049,6 +1346,7 @@ bool variant_fits(int variant, int D, int H, int W) {
         case 2: return W % 8 == 0 && H % 4 == 0 && D % 8 == 0;
         case 3: return W % 32 == 0 && H % 4 == 0 && D % 2 == 0;
         case 4: return W % 16 == 0 && H % 8 == 0 && D % 2 == 0;
+        case 6: return W % 24 == 0 && H % 8 == 0 && D % 2 == 0;
     }
     return false;
 }
@@ -1063,22 +1361,24 @@ bool flat_enabled() {
 // kernel name of a weight-gradient variant as rocprofv3 prints it (minus the anonymous-namespace prefix), for bench.py
 extern "C" int mis_conv3d_wino_wgrad_kernel_name(int variant, char* name, int name_len) {
     if (!name || name_len <= 0) return MIS_ERR_ARG;
-    static const char* const names[6] = {"wino_wgrad_kernel<WgCfg<1, 2, 16, 1> >", "wino_wgrad_kernel<WgCfg<2, 2, 8, 1> >",
+    static const char* const names[7] = {"wino_wgrad_kernel<WgCfg<1, 2, 16, 1> >", "wino_wgrad_kernel<WgCfg<2, 2, 8, 1> >",
                                          "wino_wgrad_kernel<WgCfg<4, 2, 4, 0> >", "wino_wgrad_ring_kernel<WrCfg<2, 16, 1> >",
-                                         "wino_wgrad_ring_kernel<WrCfg<4, 8, 1> >", "wino_wgrad_flat_kernel<12, 12>"};
-    if (variant < 0 || variant > 5) return MIS_ERR_UNSUPPORTED;
+                                         "wino_wgrad_ring_kernel<WrCfg<4, 8, 1> >", "wino_wgrad_flat_kernel<12, 12>",
+                                         "wino_wgrad_ring3_kernel<Wr3Cfg<4, 12> >"};
+    if (variant < 0 || variant > 6) return MIS_ERR_UNSUPPORTED;
     snprintf(name, name_len, "%s", names[variant]);
     return MIS_OK;
 }
 
 // Which variant serves the weight gradient of this 3x3x3 'same' convolution, or -1 (use mis_conv_wgrad).
-// 3 / 4: the z-ring kernels (96^3 / 48^3 levels), 0 / 1 / 2: the box kernels
+// 3 / 4 / 6: the z-ring kernels (96^3 / 48^3 / 24^3 levels), 0 / 1 / 2: the box kernels, 5: the flat form (12^3)
 extern "C" int mis_conv3d_wino_wgrad_select(int N, int Cin, int Cout, int D, int H, int W) {
     if (N <= 0 || Cin < 8 || Cout < 8 || D <= 0 || H <= 0 || W <= 0) return -1;
     if (((long long)17 * D * H * W + (long long)H * W + W + 64) * 4 >= (1LL << 31)) return -1;
     if (ring_enabled()) {
         if (variant_fits(3, D, H, W)) return 3;
         if (variant_fits(4, D, H, W)) return 4;
+        if (variant_fits(6, D, H, W)) return 6;
     }
     for (int v = 0; v < 3; ++v)
         if (variant_fits(v, D, H, W)) return v;
@@ -1093,11 +1393,11 @@ extern "C" long long mis_conv3d_wino_wgrad_workspace_bytes(int N, int Cin, int C
         const FlatGeo g = flat_geometry(N, Cin, Cout, D, H, W);
         return g.part_bytes + g.pad_bytes;
     }
-    if (variant < 0 || variant > 4 || !variant_fits(variant, D, H, W)) return MIS_ERR_UNSUPPORTED;
+    if (variant < 0 || variant > 6 || !variant_fits(variant, D, H, W)) return MIS_ERR_UNSUPPORTED;
     WgArgs a{};
     a.N = N; a.Cin = Cin; a.Cout = Cout; a.D = D; a.H = H; a.W = W;
     if (variant == 0) geometry<WgV0>(a); else if (variant == 1) geometry<WgV1>(a); else if (variant == 2) geometry<WgV2>(a);
-    else if (variant == 3) ring_geometry<WrV3>(a); else ring_geometry<WrV4>(a);
+    else if (variant == 3) ring_geometry<WrV3>(a); else if (variant == 4) ring_geometry<WrV4>(a); else ring_geometry<Wr3V>(a);
     return (long long)a.ci_blocks * a.co_blocks * a.splits * 27 * 256 * 4;
 }
 
@@ -1115,7 +1415,8 @@ extern "C" int mis_conv3d_wino_wgrad(const float* x, long long x_bs, const float
         if (workspace_bytes < mis_conv3d_wino_wgrad_workspace_bytes(N, Cin, Cout, D, H, W, 5)) return MIS_ERR_WORKSPACE;
         return launch_flat<12, 12>(x, x_bs, dy, dy_bs, dw, workspace, N, Cin, Cout, D, accumulate, stream);
     }
-    if (variant < 0 || variant > 4 || !variant_fits(variant, D, H, W)) return MIS_ERR_UNSUPPORTED;
+    if (variant < 0 || variant > 6 || !variant_fits(variant, D, H, W)) return MIS_ERR_UNSUPPORTED;
+    if (variant == 6 && (((uintptr_t)dy & 7) || dy_bs % 2)) return MIS_ERR_UNSUPPORTED;
     if (((uintptr_t)x & 15) || ((uintptr_t)dy & 15) || x_bs % 4 || dy_bs % 4 || W % 4) return MIS_ERR_UNSUPPORTED;
     if (workspace_bytes < mis_conv3d_wino_wgrad_workspace_bytes(N, Cin, Cout, D, H, W, variant)) return MIS_ERR_WORKSPACE;
     WgArgs a{};
@@ -1126,6 +1427,7 @@ extern "C" int mis_conv3d_wino_wgrad(const float* x, long long x_bs, const float
     if (variant == 2) return launch_wg<WgV2>(a, dw, accumulate, stream);
     a.prof = g_wr_prof;
     if (variant == 3) return launch_ring<WrV3>(a, dw, accumulate, stream);
+    if (variant == 6) return launch_ring3<Wr3V>(a, dw, accumulate, stream);
     return launch_ring<WrV4>(a, dw, accumulate, stream);
 }
 

@@ -109,9 +109,12 @@ def wgrad_main():
             print(f"wgrad N{N} {Cin}->{Cout} {S}^3: flat {ta:8.1f} us ({fl / ta / 1e6:6.1f} TF eq)   direct {tb:8.1f} us ({fl / tb / 1e6:6.1f} TF)"
                   f"  x{tb / ta:.2f}  rel diff {err:.2e}", flush=True)
         return
-    if "ab" in sys.argv[1:]:        # box kernels (0 / 1) against the z-ring kernels (3 / 4) on the config-3 / V-Net layers
-        for (N, Cin, Cout, S, va, vb) in [(8, 16, 16, 96, 0, 3), (8, 48, 16, 96, 0, 3), (8, 32, 32, 48, 1, 4),
-                                          (8, 96, 32, 48, 1, 4), (8, 16, 32, 48, 1, 4), (8, 32, 32, 48, 0, 4)]:
+    if "ab" in sys.argv[1:]:        # box kernels (0 / 1 / 2) against the z-ring kernels (3 / 4 / 6) on the config-3 / V-Net layers
+        cases = [(8, 16, 16, 96, 0, 3), (8, 48, 16, 96, 0, 3), (8, 32, 32, 48, 1, 4), (8, 96, 32, 48, 1, 4), (8, 16, 32, 48, 1, 4),
+                 (8, 32, 32, 48, 0, 4), (8, 64, 64, 24, 2, 6), (8, 192, 64, 24, 2, 6), (8, 32, 64, 24, 2, 6), (4, 64, 64, 24, 2, 6)]
+        if "24" in sys.argv[1:]:
+            cases = [c for c in cases if c[3] == 24]
+        for (N, Cin, Cout, S, va, vb) in cases:
             x = torch.randn(N, Cin, S, S, S, device="cuda")
             dy = torch.randn(N, Cout, S, S, S, device="cuda")
             fl = 2.0 * N * Cout * Cin * 27 * S ** 3

@@ -79,7 +79,7 @@ MT_CASES = {
                                "wino:WinoCfg<1, 4, 4, 4, 1, 1, 1, 4, 1, 0>",       # 24^3, 6^3: 8 x 8 x 8 boxes
                                "wino:WinoCfg<3, 3, 6, 1, 1, 1, 1, 4, 1, 1>",       # 12^3: 6 x 6 x 12 boxes, 54 tiles
                                "tag:wino_wgrad:v3@96", "tag:wino_wgrad:v4@48",     # weight gradients: z-ring at 96^3 / 48^3,
-                               "tag:wino_wgrad:v2@24", "tag:wino_wgrad:v5@12",     # boxes at 24^3, the flat form at 12^3,
+                               "tag:wino_wgrad:v6@24", "tag:wino_wgrad:v5@12",     # three-run ring at 24^3, the flat form at 12^3,
                                "tag:direct_wgrad:k333@6"]),                        # the direct kernel at 6^3
     "config4_swin_24+24_224": ("swin", (48, 1, 224, 224), 24, 4, torch.uint8, 1200, 1000, []),
     # BASELINE configs[2] says "3D UNet (vnet-style)": the reference's other 3-D backbone on the same 4+4 @ 96^3 batch.
@@ -93,7 +93,7 @@ MT_CASES = {
                              "tag:k2s2_up:32x16@48", "tag:k2s2_up:64x32@24",            # ConvTranspose3d(k2s2) forward
                              "tag:k2s2_wgrad:16x32@48", "tag:k2s2_wgrad:32x64@24",
                              "tag:wino_wgrad:v3@96", "tag:wino_wgrad:v4@48",            # z-ring weight gradients
-                             "tag:wino_wgrad:v2@24", "tag:wino_wgrad:v5@12"]),          # 8 x 4 x 8 boxes; the flat form at 12^3
+                             "tag:wino_wgrad:v6@24", "tag:wino_wgrad:v5@12"]),          # three-run ring at 24^3; the flat form at 12^3
 }
 
 

@@ -162,7 +162,15 @@ WGRAD_CASES = [
     (1, 48, 16, 8, 4, 48),
     (3, 8, 8, 4, 4, 16),
     (2, 32, 16, 8, 4, 8),         # stages of 8 x 4 x 8 voxels (24^3 level)
-    (1, 64, 64, 8, 12, 24),
+    (1, 64, 64, 8, 12, 24),       # (W = 24, H = 12: box kernel -- the three-run ring needs H % 8)
+    # z-ring of three runs per stage (round 4: W % 24 / H % 8 -> 2 x 8 x 24-voxel stages, the 24^3 level): planes in a ring of 6,
+    # dy straight into registers
+    (1, 16, 16, 2, 8, 24),        # one stage
+    (1, 16, 16, 4, 8, 24),        # two stages: prologue + one fill
+    (2, 24, 40, 6, 16, 24),       # ragged channel blocks, two columns along y, three stages (the ring wraps once)
+    (1, 16, 32, 24, 24, 24),      # a whole 24^3 volume: 12 stages per column, the ring wraps four times, all y faces
+    (3, 32, 16, 10, 8, 48 + 24),  # W = 72: three columns along x (every x face class), 5 stages
+    (8, 64, 64, 24, 24, 24),      # unet_3D conv3.conv2 at the full batch
     # z-ring kernels (round 4: W % 32 / H % 4 -> 2 x 4 x 32-voxel stages, W % 16 / H % 8 -> 2 x 8 x 16); a workgroup owns a
     # contiguous range of the (image, y, x, z) stage sequence
     (1, 16, 16, 4, 4, 32),        # two stages, eight workgroups: single-stage and empty ranges
@@ -225,9 +233,10 @@ import sys, torch, torch.nn.functional as F
 sys.path.insert(0, %r); sys.path.insert(0, %r)
 from mis_hip import ops, lib
 cases = [(1, 16, 16, 4, 4, 32), (8, 16, 16, 4, 4, 32), (1, 16, 16, 64, 4, 32), (2, 16, 16, 12, 8, 32), (3, 16, 16, 16, 16, 64),
-         (1, 24, 40, 8, 8, 32), (2, 32, 32, 8, 16, 48), (1, 16, 48, 20, 8, 16), (1, 16, 16, 2, 4, 32)]
+         (1, 24, 40, 8, 8, 32), (2, 32, 32, 8, 16, 48), (1, 16, 48, 20, 8, 16), (1, 16, 16, 2, 4, 32),
+         (1, 16, 16, 2, 8, 24), (2, 24, 40, 6, 16, 24), (1, 16, 32, 24, 24, 24), (3, 32, 16, 10, 8, 72)]
 for N, Cin, Cout, D, H, W in cases:
-    assert lib.load().mis_conv3d_wino_wgrad_select(N, Cin, Cout, D, H, W) in (3, 4)
+    assert lib.load().mis_conv3d_wino_wgrad_select(N, Cin, Cout, D, H, W) in (3, 4, 6)
     g = torch.Generator().manual_seed(N * 1000 + D)
     x = torch.randn(N, Cin, D, H, W, generator=g, dtype=torch.float64)
     dy = torch.randn(N, Cout, D, H, W, generator=g, dtype=torch.float64)
@@ -267,7 +276,8 @@ def test_wino_select_and_refusal():
     assert L.mis_conv3d_wino_wgrad_select(1, 16, 16, 6, 6, 30) == -1
     wsel = L.mis_conv3d_wino_wgrad_select
     assert wsel(8, 16, 16, 96, 96, 96) == 3 and wsel(8, 32, 32, 48, 48, 48) == 4      # z-ring kernels
-    assert wsel(8, 64, 64, 24, 24, 24) == 2 and wsel(1, 16, 16, 2, 4, 32) == 3          # box kernel at 24^3
+    assert wsel(8, 64, 64, 24, 24, 24) == 6 and wsel(1, 16, 16, 2, 4, 32) == 3          # three-run ring at 24^3
+    assert wsel(1, 64, 64, 8, 12, 24) == 2 and wsel(2, 32, 16, 8, 4, 8) == 2            # box kernel: H % 8 != 0 / W = 8
     assert wsel(1, 16, 16, 6, 4, 16) == -1 and wsel(1, 16, 16, 4, 4, 16) == 1           # 2 x 8 x 16 stages need H % 8
     assert wsel(1, 16, 16, 3, 4, 32) == -1                                              # odd depth: no stage of two planes
     assert wsel(8, 128, 128, 12, 12, 12) == 5 and wsel(2, 16, 32, 4, 12, 12) == 5       # flat form: 12 x 12 planes
