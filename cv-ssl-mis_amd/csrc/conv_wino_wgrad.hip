@@ -509,16 +509,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // 3.07 GB from HBM instead of 1.7: every halo came from HBM again), and all channel-block pairs of a unit share x or dy there
     const int pairs = a.ci_blocks * a.co_blocks, nt = a.splits / MIS_NUM_XCD;
     const int xcd = blockIdx.x % MIS_NUM_XCD, local = blockIdx.x / MIS_NUM_XCD;
-    const int pair = local % pairs, j = local / pairs;
-    const int cib = pair % a.ci_blocks, cob = pair / a.ci_blocks;
-    const int task = pair * a.splits + xcd * nt + j;
     // a.seg == 0 (the smaller levels: tensors that the 256 MB infinity cache holds, short columns): one CONTIGUOUS range of the
     // (image, y, x, z) stage sequence per workgroup instead -- perfect balance, a prologue only where the range crosses a
-    // column end (48^3 level: 178 us against 188 us with units; at 96^3 the other way round, 367 against 386 us)
+    // column end (48^3 level: 178 us against 188 us with units; at 96^3 the other way round, 367 against 386 us).  There
+    // a.splits is ANY count (the host picks the one that fills whole rounds of 256 workgroups): the (range, pair) list, pair
+    // fastest, is cut into 8 contiguous pieces, one per XCD -- all channel-block pairs of a range share x or dy in one L2
+    // (one pair per XCD instead: 32 -> 32 at 48^3 171 -> 195 us)
     const bool by_units = a.seg > 0;
+    int pair, j = 0, chunk;
+    if (by_units) {
+        pair = local % pairs; j = local / pairs; chunk = xcd * nt + j;
+    } else {
+        const int total = pairs * a.splits, per = (total + MIS_NUM_XCD - 1) / MIS_NUM_XCD, t = xcd * per + local;
+        if (local >= per || t >= total) return;
+        chunk = t / pairs; pair = t - chunk * pairs;
+    }
+    const int cib = pair % a.ci_blocks, cob = pair / a.ci_blocks;
+    const int task = pair * a.splits + chunk;
     const int per8 = (a.n_stage + MIS_NUM_XCD - 1) / MIS_NUM_XCD;      // a.n_stage: UNITS (by_units) or stages of the launch
     const int u_begin = xcd * per8 + j, u_lim = (xcd + 1) * per8 < a.n_stage ? (xcd + 1) * per8 : a.n_stage;
-    const int chunk = xcd * nt + j;
     long long g = (long long)a.n_stage * chunk / a.splits;
     const long long g_end = (long long)a.n_stage * (chunk + 1) / a.splits;
     int unit = u_begin;
@@ -809,13 +818,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // workgroup -> (channel-block pair, XCD, j) and its units / stage range: as wino_wgrad_ring_kernel
     const int pairs = a.ci_blocks * a.co_blocks, nt = a.splits / MIS_NUM_XCD;
     const int xcd = blockIdx.x % MIS_NUM_XCD, local = blockIdx.x / MIS_NUM_XCD;
-    const int pair = local % pairs, j = local / pairs;
-    const int cib = pair % a.ci_blocks, cob = pair / a.ci_blocks;
-    const int task = pair * a.splits + xcd * nt + j;
     const bool by_units = a.seg > 0;
+    int pair, j = 0, chunk;
+    if (by_units) {
+        pair = local % pairs; j = local / pairs; chunk = xcd * nt + j;
+    } else {
+        const int total = pairs * a.splits, per = (total + MIS_NUM_XCD - 1) / MIS_NUM_XCD, t = xcd * per + local;
+        if (local >= per || t >= total) return;
+        chunk = t / pairs; pair = t - chunk * pairs;
+    }
+    const int cib = pair % a.ci_blocks, cob = pair / a.ci_blocks;
+    const int task = pair * a.splits + chunk;
     const int per8 = (a.n_stage + MIS_NUM_XCD - 1) / MIS_NUM_XCD;
     const int u_begin = xcd * per8 + j, u_lim = (xcd + 1) * per8 < a.n_stage ? (xcd + 1) * per8 : a.n_stage;
-    const int chunk = xcd * nt + j;
     long long g = (long long)a.n_stage * chunk / a.splits;
     const long long g_end = (long long)a.n_stage * (chunk + 1) / a.splits;
     int unit = u_begin;
@@ -1277,11 +1292,17 @@ void ring_geometry(WgArgs& a) {
     static const int forced = getenv("MIS_WGRAD_RING_UNITS") ? atoi(getenv("MIS_WGRAD_RING_UNITS")) : 0;
     if (forced == 2 || (forced != 1 && (a.sz < 32 || bytes <= (256LL << 20)))) {
         a.n_stage = cols * a.sz;
-        const int nt1 = 256 / (MIS_NUM_XCD * pairs), nt2 = 512 / (MIS_NUM_XCD * pairs);
-        int nt = (nt1 >= 1 && MIS_NUM_XCD * pairs * nt1 * 10 >= 256 * 9) ? nt1 : (nt2 >= 1 ? nt2 : 1);
-        const int cap = a.n_stage / (MIS_NUM_XCD * 4);                  // at least ~4 stages per workgroup
-        if (nt > cap) nt = cap < 1 ? 1 : cap;
-        a.splits = MIS_NUM_XCD * nt;
+        // ranges per pair: the count that minimises rounds of 256 resident workgroups x (stages per range + ~3 stages of
+        // prologue / final transform); e.g. 48 pairs (192 -> 64 at 24^3): 5 ranges = 240 workgroups in one round, where 8 ranges
+        // = 384 workgroups took two rounds with the second half empty (305 -> 262 us)
+        double best = 1e300;
+        int best_s = 1;
+        for (int sp = 1; sp <= 128 && sp * 4 <= (a.n_stage > 4 ? a.n_stage : 4); ++sp) {
+            const long long wgs = (long long)pairs * sp;
+            const double t = (double)((wgs + 255) / 256) * ((a.n_stage + sp - 1) / sp + 3.0);
+            if (t < best - 1e-9) { best = t; best_s = sp; }
+        }
+        a.splits = best_s;
         a.seg = a.nseg = 0;
         return;
     }
@@ -1311,7 +1332,8 @@ int launch_ring(WgArgs a, float* dw, int accumulate, hipStream_t stream) {
     if (mis_set_lds_attr(reinterpret_cast<const void*>(&wino_wgrad_ring_kernel<C>), C::LDS_BYTES, attr_done) != MIS_OK)
         return MIS_ERR_LAUNCH;
     const int tasks = a.ci_blocks * a.co_blocks * a.splits;
-    hipLaunchKernelGGL(wino_wgrad_ring_kernel<C>, dim3(tasks), dim3(256), C::LDS_BYTES, stream, a);
+    const int grid = a.seg > 0 ? tasks : (int)(mis_cdiv(tasks, MIS_NUM_XCD) * MIS_NUM_XCD);      // contiguous ranges: 8 equal pieces
+    hipLaunchKernelGGL(wino_wgrad_ring_kernel<C>, dim3(grid), dim3(256), C::LDS_BYTES, stream, a);
 
     hipLaunchKernelGGL(wino_wgrad_reduce_kernel, dim3(a.ci_blocks * a.co_blocks * 108), dim3(256), 0, stream, a.ws, dw, a.Cout, a.Cin,
                        a.ci_blocks, a.splits, accumulate);
@@ -1325,7 +1347,8 @@ int launch_ring3(WgArgs a, float* dw, int accumulate, hipStream_t stream) {
     if (mis_set_lds_attr(reinterpret_cast<const void*>(&wino_wgrad_ring3_kernel<C>), C::LDS_BYTES, attr_done) != MIS_OK)
         return MIS_ERR_LAUNCH;
     const int tasks = a.ci_blocks * a.co_blocks * a.splits;
-    hipLaunchKernelGGL(wino_wgrad_ring3_kernel<C>, dim3(tasks), dim3(256), C::LDS_BYTES, stream, a);
+    const int grid = a.seg > 0 ? tasks : (int)(mis_cdiv(tasks, MIS_NUM_XCD) * MIS_NUM_XCD);
+    hipLaunchKernelGGL(wino_wgrad_ring3_kernel<C>, dim3(grid), dim3(256), C::LDS_BYTES, stream, a);
     hipLaunchKernelGGL(wino_wgrad_reduce_kernel, dim3(a.ci_blocks * a.co_blocks * 108), dim3(256), 0, stream, a.ws, dw, a.Cout, a.Cin,
                        a.ci_blocks, a.splits, accumulate);
     return mis_launch_status();
