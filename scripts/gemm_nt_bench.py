@@ -40,5 +40,9 @@ for M, N, K in shapes:
     err = (c[:512].double() - ref).abs().max().item() / ref.abs().max().item()
     fl = 2.0 * M * N * K
     tot += t
-    print(f"M={M:7d} N={N:5d} K={K:5d}: {t:8.1f} us  {fl / t / 1e6:6.1f} TF ({fl / t / 1e6 / 157.3:.3f})  rel err {err:.1e}", flush=True)
+    # the two floors of this shape: the fp32 matrix pipe at 2.4 GHz, and A + C (+ W once) over HBM at 5 TB/s (what the
+    # streaming passes of this code reach)
+    t_mfma, t_hbm = fl / 157.3e6, (M * K + M * N + N * K) * 4 / 5e6
+    print(f"M={M:7d} N={N:5d} K={K:5d}: {t:8.1f} us  {fl / t / 1e6:6.1f} TF ({fl / t / 1e6 / 157.3:.3f})  floors: pipe {t_mfma:6.1f} us, "
+          f"HBM {t_hbm:6.1f} us -> {t / max(t_mfma, t_hbm):.2f}x the larger, {t / (t_mfma + t_hbm):.2f}x their sum  rel err {err:.1e}", flush=True)
 print(f"sum {tot:.1f} us")
