@@ -54,6 +54,10 @@ struct WinoArgs {
     const float* xn; long long xn_bs;
     const float* thr;
     float slope;
+    // SPLIT instantiation (few boxes: the 6^3 level, half batches at 12^3): the input channels are cut into `ks` slices of
+    // nci4 / ks chunks, a (box, slice) pair is one entry of the workgroups' walk; y then points at the partial outputs
+    // [ks][N][...] (slice stride y_ks floats), no bias, no statistics: mis_wino_split_reduce finishes
+    int ks; long long y_ks;
 };
 
 // group = GZ x GY x GX tiles (16) per wave; workgroup = WZ x WY x WX groups x COB blocks of 16 output channels (4 waves)
@@ -192,8 +196,8 @@ __device__ __forceinline__ void slots(const f32x4* __restrict__ wl, const f32x4*
 // DMAs, so that chunk's closing vmcnt wait covers them (vmcnt retires in order: loads issued in the epilogue itself
 // would wait for every DMA in flight).  The thresholds of all (n, c) sit in the LDS bias table (a data gradient has
 // no bias): N * Cout <= MAX_COUT.
-template <class C, bool NB = false>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void wino_fwd_kernel(const WinoArgs a) {
+template <class C, bool NB, bool SPLIT>
+__device__ __forceinline__ void wino_fwd_body(const WinoArgs& a) {
     float* const lds = mis_wino_lds;
     // persistent: XCD x owns the boxes [x * per, (x + 1) * per); its workgroups walk them 32 apart, so the 32 resident
     // workgroups of an XCD always work on neighbouring boxes (shared halos and filter points in one L2)
@@ -221,12 +225,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const long long S = (long long)a.D * a.H * a.W;
     const unsigned s_bytes = (unsigned)S * 4u;
     const unsigned lds0 = lds_addr(lds);
-    const int nst = a.nci4;
+    const int nst = SPLIT ? a.nci4 / a.ks : a.nci4;      // chunks per entry of the walk
 
-    // box coordinates (channel group fastest, then x, y, z, image).  Decoded by division once; the walk L += nslot then
+    // box coordinates (channel group fastest, then [SPLIT: contraction slice,] x, y, z, image).  Decoded by division once; the walk L += nslot then
     // advances them by the decoded stride with carries (a scalar division is a ~100-cycle dependent chain, and a lone
     // wave per SIMD cannot hide it: 4 divisions per box were 0.5 us of the 2.9 us a box costs outside its MFMAs)
-    struct Box { int cg, bx, by, bz, n, z0, y0, x0; long long idx; };
+    struct Box { int cg, kz, bx, by, bz, n, z0, y0, x0; long long idx; };
     auto finish = [&](Box& b) {
         b.z0 = b.bz * C::OZ; b.y0 = b.by * C::OY; b.x0 = b.bx * C::OX;
         b.idx = ((long long)b.bz * a.boxes_y + b.by) * a.boxes_x + b.bx;
@@ -235,6 +239,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         Box b;
         unsigned t = L;
         b.cg = t % a.co_groups; t /= a.co_groups;
+        b.kz = 0;
+        if constexpr (SPLIT) { b.kz = t % a.ks; t /= a.ks; }
         b.bx = t % a.boxes_x;   t /= a.boxes_x;
         b.by = t % a.boxes_y;   t /= a.boxes_y;
         b.bz = t % a.boxes_z;   t /= a.boxes_z;
@@ -246,6 +252,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     auto advance = [&](Box b) {
         int c;
         b.cg += stride.cg;     c = b.cg >= a.co_groups; b.cg -= c ? a.co_groups : 0;
+        if constexpr (SPLIT) { b.kz += stride.kz + c; c = b.kz >= a.ks; b.kz -= c ? a.ks : 0; }
         b.bx += stride.bx + c; c = b.bx >= a.boxes_x;   b.bx -= c ? a.boxes_x : 0;
         b.by += stride.by + c; c = b.by >= a.boxes_y;   b.by -= c ? a.boxes_y : 0;
         b.bz += stride.bz + c; c = b.bz >= a.boxes_z;   b.bz -= c ? a.boxes_z : 0;
@@ -256,13 +263,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
     // ---- DMA issue cursor: (box, chunk) of the next stage to issue; runs NBUF-1 stages ahead of the compute ----
     Issue<C> is;
-    is.rw = make_rsrc(a.wt, (unsigned)a.co_groups * C::COB * (unsigned)nst * 16384u);
+    is.rw = make_rsrc(a.wt, (unsigned)a.co_groups * C::COB * (unsigned)a.nci4 * 16384u);
 #pragma unroll
     for (int i = 0; i < C::WPW; ++i) {
         const int j = wave + 4 * i, b = j / 16, pp = j % 16;
-        is.wvoff[i] = (unsigned)((b * nst) * 4096 + pp * 256 + lane * 4) * 4u;
+        is.wvoff[i] = (unsigned)((b * a.nci4) * 4096 + pp * 256 + lane * 4) * 4u;
     }
-    int icg = 0;                 // channel group of the cursor's box
+    int icg = 0, ikz = 0;        // channel group (and contraction slice) of the cursor's box
     // per-lane geometry of the DMA pieces, packed (hz | hy << 4 | q << 9 | valid << 14), kept in LDS: as registers
     // hipcc spills these box-invariant values to scratch, and a scratch reload waits on vmcnt(0) -- on the DMAs in flight
     unsigned* const s_geo = reinterpret_cast<unsigned*>(lds + C::NBUF * C::STAGE + 128 + C::MAX_COUT);
@@ -279,7 +286,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     auto cursor_box = [&](const Box& b_in, bool live) {     // per-lane offsets and descriptors of box b (all OOB past the end)
         Box b = b_in;
         if (DBG & 2048) { b.n = 0; b.z0 = 0; b.y0 = 0; b.x0 = 0; }      // ablation: every box reads the first box's input (L2-hot)
-        icg = b.cg;
+        icg = b.cg; ikz = b.kz;
         is.rx = make_rsrc(a.x + (long long)b.n * a.x_bs, live ? (unsigned)a.Cin * s_bytes : 0u);
         unsigned geo[C::NCH];
 #pragma unroll
@@ -297,8 +304,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     };
     auto cursor_set = [&](unsigned gs_issue, int istage) {      // uniform parts of the stage about to be issued
         is.st = lds0 + (gs_issue % C::NBUF) * (unsigned)(C::STAGE * 4);
+        if constexpr (SPLIT) istage += ikz * nst;                        // the slice's first chunk
         is.cbase = (unsigned)(istage * 4 + wave) * s_bytes;              // channel >= Cin: beyond the descriptor
-        is.wbase = (unsigned)(icg * C::COB * nst + istage) * 16384u;
+        is.wbase = (unsigned)(icg * C::COB * a.nci4 + istage) * 16384u;
     };
 
     // this lane's patch: tile (tz, ty, tx) of the box, channel lk of the chunk
@@ -423,7 +431,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         const bool ok = lane_live && oz < a.D && oy < a.H && ox < a.W;
         const int co0 = (bb.cg * C::COB + cb) * 16;
         const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(
-            (void*)(a.y + (long long)bb.n * a.y_bs + (long long)co0 * S), 0, (int)(16u * s_bytes), 0x00020000);
+            (void*)(a.y + (SPLIT ? (long long)bb.kz * a.y_ks : 0LL) + (long long)bb.n * a.y_bs + (long long)co0 * S), 0,
+            (int)(16u * s_bytes), 0x00020000);
         const unsigned vo = ok && !(DBG & 1) ? (unsigned)(lk * 4) * s_bytes + (unsigned)((oz * a.H + oy) * a.W + ox) * 4u : OOB;
         // Two of the lane's four channel rows at a time (register pairs: packed adds), one (x, y) column of points at a
         // time, folded into the y and x sums as it is read.  Few live registers (the next box's first chunk is already
@@ -536,21 +545,88 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 }
 
 template <class C, bool NB = false>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void wino_fwd_kernel(const WinoArgs a) {
+    wino_fwd_body<C, NB, false>(a);
+}
+// (box, contraction slice) entries, partial outputs: see WinoArgs::ks
+template <class C>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void wino_fwd_split_kernel(const WinoArgs a) {
+    wino_fwd_body<C, false, true>(a);
+}
+
+template <class C, bool NB = false, bool SPLIT = false>
 int launch_wino(WinoArgs a, hipStream_t stream) {
     a.boxes_z = (int)mis_cdiv(a.D, C::OZ);
     a.boxes_y = (int)mis_cdiv(a.H, C::OY);
     a.boxes_x = (int)mis_cdiv(a.W, C::OX);
     a.co_groups = a.Cout / (16 * C::COB);
-    const long long nb = (long long)a.N * a.boxes_z * a.boxes_y * a.boxes_x * a.co_groups;
+    const long long nb = (long long)a.N * a.boxes_z * a.boxes_y * a.boxes_x * a.co_groups * (SPLIT ? a.ks : 1);
     if (nb <= 0 || nb > 0x7fffffffLL) return MIS_ERR_ARG;
     a.n_blocks = (unsigned)nb;
     a.n_blocks_padded = (unsigned)(mis_cdiv(nb, MIS_NUM_XCD) * MIS_NUM_XCD);
     static std::atomic<unsigned long long> attr_done{0};
-    if (mis_set_lds_attr(reinterpret_cast<const void*>(&wino_fwd_kernel<C, NB>), C::LDS_BYTES, attr_done) != MIS_OK)
-        return MIS_ERR_LAUNCH;
     const unsigned grid = a.n_blocks_padded < 256u ? a.n_blocks_padded : 256u;      // persistent: one workgroup per CU
-    hipLaunchKernelGGL((wino_fwd_kernel<C, NB>), dim3(grid), dim3(256), C::LDS_BYTES, stream, a);
+    if constexpr (SPLIT) {
+        if (mis_set_lds_attr(reinterpret_cast<const void*>(&wino_fwd_split_kernel<C>), C::LDS_BYTES, attr_done) != MIS_OK)
+            return MIS_ERR_LAUNCH;
+        hipLaunchKernelGGL((wino_fwd_split_kernel<C>), dim3(grid), dim3(256), C::LDS_BYTES, stream, a);
+    } else {
+        if (mis_set_lds_attr(reinterpret_cast<const void*>(&wino_fwd_kernel<C, NB>), C::LDS_BYTES, attr_done) != MIS_OK)
+            return MIS_ERR_LAUNCH;
+        hipLaunchKernelGGL((wino_fwd_kernel<C, NB>), dim3(grid), dim3(256), C::LDS_BYTES, stream, a);
+    }
     return mis_launch_status();
+}
+
+using WinoV2 = WinoCfg<1, 4, 4, 4, 1, 1, 1, 4, 1>;
+using WinoV3 = WinoCfg<3, 3, 6, 1, 1, 1, 1, 4, 1, 1>;
+
+// Contraction slices for a launch with too few (box, channel group) entries for the chip (the 6^3 level: 8 ... 128 entries of
+// 32 ... 64 chunks each; half batches at 12^3): the smallest count that brings the entries to >= 192, slices of an even
+// number >= 8 of chunks.  Variants 2 / 3 only (the levels where it happens); 1 = no split.
+int wino_splits(int N, int Cin, int Cout, int D, int H, int W, int variant) {
+    static const bool on = [] { const char* e = getenv("MIS_WINO_SPLIT"); return !(e && e[0] == '0'); }();
+    if (!on || (variant != 2 && variant != 3)) return 1;
+    // variant 2 only on partly filled boxes (the 6^3 level): whole 8 x 8 x 8 boxes with few entries only occur at input sizes
+    // below the benchmarked 96^3 (the 8^3 level of a 64^3 input), and the GroupNorm fixture of that size sits on a
+    // discontinuity there (tests/test_parity_gpu.py, F64_GN) -- left on the arithmetic the goldens were judged with
+    if (variant == 2 && D % 8 == 0 && H % 8 == 0 && W % 8 == 0) return 1;
+    const long long boxes = variant == 2 ? mis_cdiv(D, 8) * mis_cdiv(H, 8) * mis_cdiv(W, 8) : (long long)(D / 6) * (H / 6) * (W / 12);
+    const long long entries = (long long)N * boxes * (Cout / 16);
+    const int nst = (Cin + 3) / 4;
+    int ks = 1;
+    while (entries * ks < 192 && ks < 8 && nst % (2 * ks) == 0 && nst / (2 * ks) >= 8 && (nst / (2 * ks)) % 2 == 0) ks *= 2;
+    return ks;
+}
+
+// y[n][c][v] = bias[c] + sum_k part[k][n][c][v] (fixed order), and the (sum, sum of squares) of y per (n, c) into the first
+// statistics tile of the image (zeros into the others): what the unsplit launch's epilogue leaves.  One workgroup per (n, c).
+__global__ __launch_bounds__(256) void wino_split_reduce_kernel(const float* __restrict__ part, long long part_ks, long long part_bs,
+                                                                const float* __restrict__ bias, float* __restrict__ y,
+                                                                long long y_bs, int Cout, int S, int ks, float2* stat,
+                                                                long long stat_sc, long long stat_sn, int tiles) {
+    __shared__ float2 red[256];
+    const int n = blockIdx.x / Cout, c = blockIdx.x - n * Cout;
+    const float* __restrict__ p = part + (long long)n * part_bs + (long long)c * S;
+    float* __restrict__ o = y + (long long)n * y_bs + (long long)c * S;
+    const float b = bias ? bias[c] : 0.f;
+    float s1 = 0.f, s2 = 0.f;
+    for (int v = threadIdx.x; v < S; v += 256) {
+        float acc = p[v];
+        for (int k = 1; k < ks; ++k) acc += p[(long long)k * part_ks + v];
+        acc += b;
+        o[v] = acc;
+        s1 += acc; s2 = fmaf(acc, acc, s2);
+    }
+    if (!stat) return;
+    red[threadIdx.x] = make_float2(s1, s2);
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) { red[threadIdx.x].x += red[threadIdx.x + w].x; red[threadIdx.x].y += red[threadIdx.x + w].y; }
+        __syncthreads();
+    }
+    for (int t = threadIdx.x; t < tiles; t += 256)
+        stat[(long long)c * stat_sc + (long long)n * stat_sn + t] = t == 0 ? red[0] : make_float2(0.f, 0.f);
 }
 
 }  // namespace
@@ -570,12 +646,15 @@ extern "C" int mis_conv3d_wino_select(int N, int Cin, int Cout, int D, int H, in
     if (W % 8 == 0 && D % 8 == 0 && H % 8 == 0 && Cin >= 32) return 2;      // the 24^3 level: boxes of 8 x 8 x 8
     // the 12^3 level: 4 boxes of 54 tiles per 12^3 volume (when the launch has enough boxes for the serial walk over the
     // input channels to pay: the direct kernel spreads a small problem over more workgroups)
-    if (W == 12 && D % 6 == 0 && H % 6 == 0 && Cin >= 32 && (long long)N * (D / 6) * (H / 6) * (Cout / 16) >= 64) return 3;
+    // (entries of the workgroups' walk: with few boxes mis_conv3d_wino_fwd_ws cuts the contraction into slices)
+    if (W == 12 && D % 6 == 0 && H % 6 == 0 && Cin >= 32 &&
+        (long long)N * (D / 6) * (H / 6) * (Cout / 16) * wino_splits(N, Cin, Cout, D, H, W, 3) >= 64) return 3;
     if (Cin >= 32) {
         // partly filled 8 x 8 x 8 boxes (the 12^3 level: 42 % of the box volume is output) still beat the direct kernel
         // 1.3 - 1.8x when there are enough boxes for the 256 CUs; out-of-range tiles are not stored and not counted
         const long long boxes = mis_cdiv(D, 8) * mis_cdiv(H, 8) * mis_cdiv(W, 8);
-        if ((long long)D * H * W * 5 >= boxes * 512 * 2 && (long long)N * boxes * (Cout / 16) >= 128) return 2;
+        if ((long long)D * H * W * 5 >= boxes * 512 * 2 && (long long)N * boxes * (Cout / 16) * wino_splits(N, Cin, Cout, D, H, W, 2) >= 128)
+            return 2;
     }
     return -1;
 }
@@ -633,6 +712,50 @@ extern "C" int mis_conv3d_wino_fwd(const float* x, long long x_bs, const float* 
         return launch_wino<WinoCfg<3, 3, 6, 1, 1, 1, 1, 4, 1, 1>>(a, stream);
     }
     return MIS_ERR_UNSUPPORTED;
+}
+
+// Contraction slices mis_conv3d_wino_fwd_ws cuts this launch into (1: none) and the floats of workspace it then needs.
+extern "C" int mis_conv3d_wino_fwd_splits(int N, int Cin, int Cout, int D, int H, int W, int variant) {
+    if (N <= 0 || Cin <= 0 || Cout <= 0 || D <= 0 || H <= 0 || W <= 0 || variant < 0 || variant > 3) return MIS_ERR_ARG;
+    return wino_splits(N, Cin, Cout, D, H, W, variant);
+}
+extern "C" long long mis_conv3d_wino_fwd_workspace_bytes(int N, int Cin, int Cout, int D, int H, int W, int variant) {
+    const int ks = mis_conv3d_wino_fwd_splits(N, Cin, Cout, D, H, W, variant);
+    if (ks < 0) return ks;
+    return ks > 1 ? (long long)ks * N * Cout * D * H * W * 4 : 0;
+}
+
+// mis_conv3d_wino_fwd with the contraction cut into slices when the launch has too few boxes for the chip (the 6^3 level of
+// unet_3D / V-Net, half batches at 12^3): (box, slice) entries fill the CUs, the slices' partial outputs go to `workspace`
+// and a second launch sums them in a fixed order, adds the bias and leaves the same statistics partials.  Same result as
+// the unsplit launch up to the association of the sum over input channels.
+extern "C" int mis_conv3d_wino_fwd_ws(const float* x, long long x_bs, const float* wt, const float* bias, float* y,
+                                      long long y_bs, int N, int Cin, int Cout, int D, int H, int W, float* stat,
+                                      long long stat_sc, long long stat_sn, int variant, float* workspace,
+                                      long long workspace_bytes, hipStream_t stream) {
+    const int ks = mis_conv3d_wino_fwd_splits(N, Cin, Cout, D, H, W, variant);
+    if (ks < 0) return ks;
+    if (ks == 1)
+        return mis_conv3d_wino_fwd(x, x_bs, wt, bias, y, y_bs, N, Cin, Cout, D, H, W, stat, stat_sc, stat_sn, variant, stream);
+    if (!x || !wt || !y || !workspace) return MIS_ERR_ARG;
+    const long long S = (long long)D * H * W;
+    if (x_bs < (long long)Cin * S || y_bs < (long long)Cout * S) return MIS_ERR_ARG;
+    if (Cout % 16 || Cout > 384 || Cin % 8 || Cin < 16 || D % 2 || H % 2 || W % 2 || ((uintptr_t)workspace & 15) || ((uintptr_t)wt & 15))
+        return MIS_ERR_UNSUPPORTED;
+    if (variant == 3 && (W != 12 || D % 6 || H % 6)) return MIS_ERR_UNSUPPORTED;
+    if (((long long)Cin + 32) * S * 4 >= (1LL << 30)) return MIS_ERR_UNSUPPORTED;
+    if (workspace_bytes < (long long)ks * N * Cout * S * 4) return MIS_ERR_WORKSPACE;
+    WinoArgs a{};
+    a.x = x; a.x_bs = x_bs; a.wt = wt; a.bias = nullptr; a.y = workspace; a.y_bs = (long long)Cout * S;
+    a.N = N; a.Cin = Cin; a.Cout = Cout; a.D = D; a.H = H; a.W = W;
+    a.nci4 = (Cin + 3) / 4;
+    a.ks = ks; a.y_ks = (long long)N * Cout * S;
+    const int st = variant == 2 ? launch_wino<WinoV2, false, true>(a, stream) : launch_wino<WinoV3, false, true>(a, stream);
+    if (st) return st;
+    const int tiles = (int)mis_conv3d_wino_stat_tiles(D, H, W, variant);
+    hipLaunchKernelGGL(wino_split_reduce_kernel, dim3((unsigned)(N * Cout)), dim3(256), 0, stream, workspace, a.y_ks, a.y_bs, bias, y,
+                       y_bs, Cout, (int)S, ks, reinterpret_cast<float2*>(stat), stat_sc, stat_sn, tiles);
+    return mis_launch_status();
 }
 
 // The data gradient of mis_conv3d_wino_fwd (dy -> da, transformed filter of pack mode 5) for a convolution whose input

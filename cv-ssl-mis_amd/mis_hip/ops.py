@@ -271,8 +271,16 @@ def conv_fwd(x, wp, bias, y, Cin, Cout, ksize, stat=None, wino=-1):
                                        _l.ptr(st[0]), st[1], st[2], wino - WINO2D, _l.stream_ptr()), "mis_conv2d_wino_fwd")
     elif wino >= 0:
         st = stat if stat is not None else (None, 0, 0)
-        _l.check(L.mis_conv3d_wino_fwd(_l.ptr(x), xbs, _l.ptr(wp), _l.ptr(bias), _l.ptr(y), ybs, N, Cin, Cout, D, H, W,
-                                       _l.ptr(st[0]), st[1], st[2], wino, _l.stream_ptr()), "mis_conv3d_wino_fwd")
+        # few boxes (the 6^3 level, half batches at 12^3): the contraction is cut into slices, partials in scratch
+        nb = L.mis_conv3d_wino_fwd_workspace_bytes(N, Cin, Cout, D, H, W, wino)
+        if nb < 0:
+            _l.check(nb, "mis_conv3d_wino_fwd_workspace_bytes")
+        ws = scratch(nb, "wino_fwd") if nb > 0 else None
+        if ws is not None:
+            _tag(f"wino_fwd_split:v{wino}@{W}")
+        _l.check(L.mis_conv3d_wino_fwd_ws(_l.ptr(x), xbs, _l.ptr(wp), _l.ptr(bias), _l.ptr(y), ybs, N, Cin, Cout, D, H, W,
+                                          _l.ptr(st[0]), st[1], st[2], wino, _l.ptr(ws), nb, _l.stream_ptr()),
+                 "mis_conv3d_wino_fwd_ws")
     elif stat is not None:
         _l.check(L.mis_conv_fwd_stats(_l.ptr(x), xbs, _l.ptr(wp), _l.ptr(bias), _l.ptr(y), ybs, N, Cin, Cout, D, H, W,
                                       kd, kh, kw, _l.ptr(stat[0]), stat[1], stat[2], _l.stream_ptr()),

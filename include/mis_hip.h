@@ -102,6 +102,15 @@ int mis_conv3d_wino_kernel_name(int variant, char* name, int name_len);
 int mis_conv3d_wino_fwd(const float* x, long long x_bs, const float* wt, const float* bias, float* y, long long y_bs,
                         int N, int Cin, int Cout, int D, int H, int W, float* stat, long long stat_sc,
                         long long stat_sn, int variant, mis_stream_t stream);
+/* The same convolution with the contraction over the input channels cut into slices when the launch has too few boxes to
+ * fill the chip (the 6^3 level, half batches at 12^3; variants 2 / 3): (box, slice) entries instead of boxes, partial
+ * outputs in `workspace` (mis_conv3d_wino_fwd_workspace_bytes; 0 = this launch is not split and needs none), summed in a
+ * fixed order by a second launch that also adds the bias and leaves the statistics partials.  _splits: the slice count. */
+int mis_conv3d_wino_fwd_splits(int N, int Cin, int Cout, int D, int H, int W, int variant);
+long long mis_conv3d_wino_fwd_workspace_bytes(int N, int Cin, int Cout, int D, int H, int W, int variant);
+int mis_conv3d_wino_fwd_ws(const float* x, long long x_bs, const float* wt, const float* bias, float* y, long long y_bs,
+                           int N, int Cin, int Cout, int D, int H, int W, float* stat, long long stat_sc, long long stat_sn,
+                           int variant, float* workspace, long long workspace_bytes, mis_stream_t stream);
 /* The data gradient (dy -> da, filter of pack mode 5) of a conv whose input a = act(InstanceNorm(xn)) -- no affine, no
  * dropout, read by nothing else -- with the first stage of that normalisation's backward in its epilogue: per (n, channel)
  * and run of boxes part = (sum dz, sum dz * xn), dz = da * (xn > mean ? 1 : slope), in the layout of the forward's

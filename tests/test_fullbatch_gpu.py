@@ -73,7 +73,8 @@ MT_CASES = {
                                   "wino2d:W2Cfg<8, 8, 2, 3>"]),               # 32 and more
     "config3_unet3d_4+4_96": ("unet3d", (8, 1, 96, 96, 96), 4, 2, torch.int64, 1200, 0,
                               ["name:conv_fwd_cin1_kernel<3>",                     # first layer (1 input channel): taps as K
-                               "Cfg<3, 3, 3, 2, 8, 8, 16, 4, 2>",                  # 6^3 level of the teacher's 4 volumes: direct
+                               "tag:wino_fwd_split:v2@6",                          # 6^3 level: few boxes, contraction in slices
+                               "tag:wino_fwd_split:v3@12",                         # 12^3 level of the teacher's 4 volumes
                                "wino:WinoCfg<1, 1, 16, 2, 2, 1, 1, 4, 0, 0>",      # 96^3: Winograd, 4 x 4 x 32 boxes
                                "wino:WinoCfg<1, 2, 8, 2, 2, 1, 1, 4, 0, 0>",       # 48^3: 4 x 8 x 16 boxes
                                "wino:WinoCfg<1, 4, 4, 4, 1, 1, 1, 4, 1, 0>",       # 24^3, 6^3: 8 x 8 x 8 boxes
@@ -93,7 +94,8 @@ MT_CASES = {
                              "tag:k2s2_up:32x16@48", "tag:k2s2_up:64x32@24",            # ConvTranspose3d(k2s2) forward
                              "tag:k2s2_wgrad:16x32@48", "tag:k2s2_wgrad:32x64@24",
                              "tag:wino_wgrad:v3@96", "tag:wino_wgrad:v4@48",            # z-ring weight gradients
-                             "tag:wino_wgrad:v6@24", "tag:wino_wgrad:v5@12"]),          # three-run ring at 24^3; the flat form at 12^3
+                             "tag:wino_wgrad:v6@24", "tag:wino_wgrad:v5@12",            # three-run ring at 24^3; the flat form at 12^3
+                             "tag:wino_fwd_split:v2@6", "tag:wino_fwd_split:v3@12"]),   # few boxes: contraction in slices
 }
 
 

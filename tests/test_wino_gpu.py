@@ -48,8 +48,16 @@ FWD_CASES = [
     (4, 32, 128, 18, 6, 12, 3),
     (2, 128, 384, 12, 12, 12, 3),
     (8, 32, 64, 12, 8, 20, 2),      # partly filled 8 x 8 x 8 boxes (tiles outside the volume are not stored)
-    (8, 128, 256, 6, 6, 6, 2),
+    (8, 128, 256, 6, 6, 6, 2),      # 128 (box, channel group) entries: the contraction is cut into 2 slices (conv_wino.hip SPLIT)
+    (8, 256, 256, 6, 6, 6, 2),      # unet_3D center.conv2 / V-Net block five: 2 slices of 32 chunks
+    (4, 256, 256, 6, 6, 6, 2),      # the teacher's half batch: 4 slices
+    (4, 128, 128, 12, 12, 12, 3),   # 12^3, half batch: 2 slices of the 3 x 3 x 6-tile boxes
+    (2, 64, 128, 6, 6, 6, -1),      # too few entries even when split: direct kernel
 ]
+# (N, Cin, Cout, D, H, W) -> contraction slices mis_conv3d_wino_fwd_ws uses
+SPLITS = {(8, 128, 256, 6, 6, 6): 2, (8, 256, 256, 6, 6, 6): 2, (4, 256, 256, 6, 6, 6): 4, (4, 128, 128, 12, 12, 12): 2,
+          (4, 64, 128, 12, 12, 12): 2, (2, 128, 384, 12, 12, 12): 1, (1, 32, 32, 8, 8, 8): 1, (2, 64, 48, 8, 16, 24): 1,      # whole boxes: never split
+          (8, 32, 64, 12, 8, 20): 1}
 
 
 @pytest.mark.parametrize("case", FWD_CASES)
@@ -57,6 +65,11 @@ def test_wino_forward_and_data_gradient(case):
     ops = _ops()
     N, Cin, Cout, D, H, W, variant = case
     assert ops.conv_wino_select(N, Cin, Cout, D, H, W, (3, 3, 3)) == variant
+    if variant < 0:
+        return
+    if case[:6] in SPLITS:
+        from mis_hip import lib
+        assert lib.load().mis_conv3d_wino_fwd_splits(N, Cin, Cout, D, H, W, variant) == SPLITS[case[:6]]
     x = _rand(N, Cin, D, H, W, seed=1).requires_grad_(True)
     w = _rand(Cout, Cin, 3, 3, 3, seed=2, scale=0.2).requires_grad_(True)
     b = _rand(Cout, seed=3)
@@ -84,7 +97,10 @@ def test_wino_forward_and_data_gradient(case):
 
 @pytest.mark.parametrize("N,Cin,Cout,D,H,W,per_sample", [(2, 16, 16, 4, 8, 32, True), (3, 32, 32, 4, 8, 16, False),
                                                          (2, 48, 16, 8, 4, 64, True), (4, 64, 128, 12, 12, 12, True),
-                                                         (4, 32, 64, 12, 12, 12, False)])
+                                                         (4, 32, 64, 12, 12, 12, False),
+                                                         # split contraction: the statistics come from the reduction launch
+                                                         (8, 128, 256, 6, 6, 6, True), (8, 256, 256, 6, 6, 6, False),
+                                                         (4, 128, 128, 12, 12, 12, False)])
 def test_wino_fused_statistics(N, Cin, Cout, D, H, W, per_sample):
     """The per-box (sum, sumsq) partials of the Winograd epilogue + mis_norm_stats_finalize == the statistics of the
     InstanceNorm / BatchNorm that follows the conv (reference utils.py:104-107: Conv3d -> norm -> ReLU)."""
@@ -137,6 +153,32 @@ def test_wino_channel_slices_of_concat_buffers():
     wr = w.cpu().double().requires_grad_(True)
     F.conv3d(cat[:, C0:].cpu().double(), wr, padding=1).backward(dy[:, 16:].cpu().double())
     _close(dw, wr.grad, rtol=3e-4, atol=1e-4)
+
+
+def test_split_forward_on_channel_slices_of_concat_buffers():
+    """The split-contraction launch (6^3 level) with input / output views of wider buffers: the partial outputs live in the
+    workspace, the reduction writes through the output's batch stride."""
+    ops = _ops()
+    N, C0, Cin, Cout, S = 8, 32, 128, 256, 6
+    cat = _rand(N, C0 + Cin, S, S, S, seed=25).float().cuda()
+    w = _rand(Cout, Cin, 3, 3, 3, seed=26, scale=0.2).float().cuda()
+    b = _rand(Cout, seed=27).float().cuda()
+    ycat = torch.zeros(N, 16 + Cout, S, S, S, device="cuda")
+    v = ops.conv_wino_select(N, Cin, Cout, S, S, S, (3, 3, 3))
+    assert v == 2
+    keep, ops.DISPATCH = ops.DISPATCH, set()
+    try:
+        ops.conv_fwd(cat[:, C0:], ops.conv_pack(w, 4), b, ycat[:, 16:], Cin, Cout, (3, 3, 3), wino=v)
+        assert "wino_fwd_split:v2@6" in ops.DISPATCH
+    finally:
+        ops.DISPATCH = keep
+    ref = F.conv3d(cat[:, C0:].cpu().double(), w.cpu().double(), b.cpu().double(), padding=1)
+    _close(ycat[:, 16:], ref)
+    assert ycat[:, :16].abs().max().item() == 0.0
+    # deterministic
+    y2 = torch.zeros_like(ycat)
+    ops.conv_fwd(cat[:, C0:], ops.conv_pack(w, 4), b, y2[:, 16:], Cin, Cout, (3, 3, 3), wino=v)
+    assert torch.equal(ycat, y2)
 
 
 def test_flat_weight_gradient_from_channel_slices():
@@ -265,7 +307,8 @@ def test_wino_select_and_refusal():
     assert sel(2, 16, 2, 96, 96, 96) == -1          # Cout not a multiple of 16
     assert sel(2, 64, 64, 24, 24, 24) == 2
     assert sel(4, 128, 128, 12, 12, 12) == 3        # 12^3: 6 x 6 x 12 boxes, when there are enough of them
-    assert sel(1, 32, 16, 12, 12, 12) == -1 and sel(8, 128, 256, 6, 6, 6) == 2 and sel(4, 128, 256, 6, 6, 6) == -1
+    assert sel(1, 32, 16, 12, 12, 12) == -1 and sel(8, 128, 256, 6, 6, 6) == 2
+    assert sel(4, 128, 256, 6, 6, 6) == 2 and sel(1, 128, 256, 6, 6, 6) == -1      # 64 entries x 2 contraction slices; 16 x 4
     assert sel(2, 16, 16, 6, 6, 30) == -1
     assert ops.conv_wino_select(2, 16, 16, 1, 64, 64, (3, 3)) == ops.WINO2D          # 2-D: conv_wino2d.hip
     x = torch.zeros(1, 16, 6, 6, 30, device="cuda")
