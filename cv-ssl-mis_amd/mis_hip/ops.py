@@ -208,6 +208,40 @@ WINO_MIN_W = int(_os.environ.get("MIS_WINO_MIN_W", "0"))
 WINO2D = 10       # ids >= WINO2D: variant id - WINO2D of the 2-D kernels (conv_wino2d.hip); below: 3-D (conv_wino.hip)
 
 
+# 1x1x1 convolutions of small volumes with many channels (the space-to-depth form of V-Net's deep kernel-2 / stride-2 layers):
+# batched GEMM instead of the spatially tiled direct kernel (conv1x1_gemm.hip).  MIS_CONV1X1_GEMM=0 switches it off
+CONV1X1_GEMM = _os.environ.get("MIS_CONV1X1_GEMM", "1") != "0"
+CONV1X1_GEMM_MAX_S = 4096
+
+
+def conv1x1_gemm_eligible(x, y, cin, cout):
+    """x / y: 5-D NCDHW views with dense (C, D, H, W); few voxels, many channels, sizes the GEMM's float4 rows need."""
+    if not CONV1X1_GEMM:
+        return False
+    try:
+        _, _, _, _, _, S, xbs = _geom(x)
+        _, _, _, _, _, _, ybs = _geom(y)
+    except RuntimeError:
+        return False
+    return (S <= CONV1X1_GEMM_MAX_S and S % 4 == 0 and cout % 4 == 0 and cin >= 64 and xbs % 4 == 0 and ybs % 4 == 0 and
+            x.data_ptr() % 16 == 0 and y.data_ptr() % 16 == 0)
+
+
+def conv1x1_gemm(x, wt, bias, y, accumulate=False):
+    """y[n][co][s] (+)= bias[co] + sum_ci wt[ci][co] x[n][ci][s] (mis_conv1x1_gemm); ``wt`` = the weights [Cin][Cout]."""
+    L = _l.load()
+    N, Cin, D, H, W, S, xbs = _geom(x)
+    _, Cout, _, _, _, _, ybs = _geom(y)
+    assert wt.dim() == 2 and wt.shape == (Cin, Cout) and wt.stride(1) == 1, (wt.shape, Cin, Cout)
+    nb = L.mis_conv1x1_gemm_workspace_bytes(N, Cin, Cout, S)
+    if nb < 0:
+        _l.check(nb, "mis_conv1x1_gemm_workspace_bytes")
+    ws = scratch(nb, "conv1x1") if nb > 0 else None
+    _tag(f"conv1x1_gemm:{Cin}x{Cout}@{W}")
+    _l.check(L.mis_conv1x1_gemm(_l.ptr(x), xbs, _l.ptr(wt), wt.stride(0), _l.ptr(bias), _l.ptr(y), ybs, N, Cin, Cout, S,
+                                int(accumulate), _l.ptr(ws), nb, _l.stream_ptr()), "mis_conv1x1_gemm")
+
+
 def conv_wino_select(N, Cin, Cout, D, H, W, ksize):
     """Winograd variant serving this convolution (mis_conv3d_wino_select / mis_conv2d_wino_select), or -1: use the
     direct kernel."""

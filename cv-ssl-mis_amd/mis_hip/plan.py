@@ -360,6 +360,7 @@ class DownConvOp:
         self._xs_valid = False
         self.dxs = None
         self.wp = self.wpd = None
+        self._wT = None
 
     def _new_xs(self):
         N, Cin, D, H, W = self.in_shape
@@ -372,6 +373,14 @@ class DownConvOp:
             return
         ops.space_to_depth2(self.x.t, self._xs, self.in_shape, True)
         self._xs_valid = True
+        if ops.conv1x1_gemm_eligible(self._xs, self.y.t, self.cin8, self.cout):
+            # few voxels, many channels (the 12^3 / 6^3 levels): a batched GEMM with the weights contraction-major
+            from . import tops
+            if self._wT is None:
+                self._wT = torch.empty((self.cin8, self.cout), dtype=torch.float32, device="cuda")
+            tops.transpose(self.w.data.view(self.cout, self.cin8), self._wT)
+            ops.conv1x1_gemm(self._xs, self._wT, None if self.b is None else self.b.data, self.y.t)
+            return
         self.wp = ops.conv_pack_raw(self.w.data, self.cout, self.cin8, 1, 0, out=self.wp)
         ops.conv_fwd(self._xs, self.wp, None if self.b is None else self.b.data, self.y.t, self.cin8, self.cout, (1, 1, 1))
 
@@ -398,8 +407,12 @@ class DownConvOp:
             return
         if self.dxs is None:
             self.dxs = self._new_xs()
-        self.wpd = ops.conv_pack_raw(self.w.data, self.cout, self.cin8, 1, 1, out=self.wpd)
-        ops.conv_fwd(dy, self.wpd, None, self.dxs, self.cout, self.cin8, (1, 1, 1))
+        if ops.conv1x1_gemm_eligible(dy, self.dxs, self.cout, self.cin8):
+            # dxs[8 Cin][S] = W[Cout][8 Cin]^T . dy[Cout][S]: the parameter is already contraction-major for this product
+            ops.conv1x1_gemm(dy, self.w.data.view(self.cout, self.cin8), None, self.dxs)
+        else:
+            self.wpd = ops.conv_pack_raw(self.w.data, self.cout, self.cin8, 1, 1, out=self.wpd)
+            ops.conv_fwd(dy, self.wpd, None, self.dxs, self.cout, self.cin8, (1, 1, 1))
         ops.space_to_depth2(self.dxs, self.x.grad(), self.in_shape, False, accumulate=self.x.written)
         self.x.mark_written()
 
@@ -420,6 +433,7 @@ class UpConvOp:
         self.dy8 = None
         self.dw8 = None
         self.wp = self.wpd = None
+        self._wT = None
 
     def _new_y8(self):
         N, _, d, h, wd = self.x.shape
@@ -431,8 +445,12 @@ class UpConvOp:
             return
         if self.y8 is None:
             self.y8 = self._new_y8()
-        self.wp = ops.conv_pack_raw(self.w.data, self.cout8, self.cin, 1, 2, out=self.wp)
-        ops.conv_fwd(self.x.t, self.wp, None, self.y8, self.cin, self.cout8, (1, 1, 1))
+        if ops.conv1x1_gemm_eligible(self.x.t, self.y8, self.cin, self.cout8):
+            # y8[8 Cout][S] = W[Cin][8 Cout]^T . x[Cin][S]: the parameter's own layout is contraction-major
+            ops.conv1x1_gemm(self.x.t, self.w.data.view(self.cin, self.cout8), None, self.y8)
+        else:
+            self.wp = ops.conv_pack_raw(self.w.data, self.cout8, self.cin, 1, 2, out=self.wp)
+            ops.conv_fwd(self.x.t, self.wp, None, self.y8, self.cin, self.cout8, (1, 1, 1))
         ops.space_to_depth2(self.y8, self.y.t, self.y.shape, False, bias=None if self.b is None else self.b.data)
 
     def bwd(self, ctx):
@@ -454,8 +472,15 @@ class UpConvOp:
             ops.conv_k2s2_down(self.y.grad(), self.w.data, None, self.x.grad())
             self.x.mark_written()
             return
-        self.wpd = ops.conv_pack_raw(self.w.data, self.cout8, self.cin, 1, 3, out=self.wpd)
-        ops.conv_fwd(self.dy8, self.wpd, None, self.x.grad(), self.cout8, self.cin, (1, 1, 1))
+        if ops.conv1x1_gemm_eligible(self.dy8, self.x.grad(), self.cout8, self.cin):
+            # dx[Cin][S] = W[Cin][8 Cout] . dy8[8 Cout][S]: needs the parameter transposed
+            if self._wT is None:
+                self._wT = torch.empty((self.cout8, self.cin), dtype=torch.float32, device="cuda")
+            tops.transpose(self.w.data.view(self.cin, self.cout8), self._wT)
+            ops.conv1x1_gemm(self.dy8, self._wT, None, self.x.grad())
+        else:
+            self.wpd = ops.conv_pack_raw(self.w.data, self.cout8, self.cin, 1, 3, out=self.wpd)
+            ops.conv_fwd(self.dy8, self.wpd, None, self.x.grad(), self.cout8, self.cin, (1, 1, 1))
         self.x.mark_written()
 
 

@@ -608,6 +608,19 @@ int mis_win3d_attn_bwd(const float* qkv, long long ldq, const float* out, const 
                        int accumulate_table, int BW, int nW, int n, int nH, void* workspace, long long workspace_bytes,
                        mis_stream_t stream);
 
+/* ---- 1x1x1 convolution of channel-major volumes with few voxels and many channels as a batched GEMM (csrc/conv1x1_gemm.hip)
+ * The contraction inside nn.Conv3d(C, 2C, 2, stride=2) / nn.ConvTranspose3d(2C, C, 2, stride=2) on V-Net's deep levels
+ * (reference code/networks/vnet.py:73, :100) once the 2x2x2 taps are folded into channels (mis_space_to_depth2):
+ *   y[n][co][s] (+)= bias[co] + sum_ci wt[ci][co] x[n][ci][s],   s over the S voxels of the coarse volume,
+ * weights CONTRACTION-major ([Cin][Cout], row stride ldw); x / y NCDHW views (channel stride S, batch strides x_bs / y_bs).
+ * Split over the input channels when (image, tile) entries would not fill the chip: partials in `workspace`
+ * (mis_conv1x1_gemm_workspace_bytes; 0 = none needed), fixed-order reduction.  S, Cout and the strides multiples of 4, 16-byte
+ * aligned pointers; same result as mis_conv_fwd(k = 1) up to fp32 summation order. */
+long long mis_conv1x1_gemm_workspace_bytes(int N, int Cin, int Cout, long long S);
+int mis_conv1x1_gemm(const float* x, long long x_bs, const float* wt, long long ldw, const float* bias, float* y, long long y_bs,
+                     int N, int Cin, int Cout, long long S, int accumulate, float* workspace, long long workspace_bytes,
+                     mis_stream_t stream);
+
 /* Test support (never on the product path): fills the LDS of every CU with NaNs so that a kernel reading LDS it did not write
  * fails deterministically instead of depending on the previous launch.  sink: any device float (or NULL). */
 int mis_debug_poison_lds(float* sink, mis_stream_t stream);

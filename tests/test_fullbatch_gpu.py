@@ -95,7 +95,10 @@ MT_CASES = {
                              "tag:k2s2_wgrad:16x32@48", "tag:k2s2_wgrad:32x64@24",
                              "tag:wino_wgrad:v3@96", "tag:wino_wgrad:v4@48",            # z-ring weight gradients
                              "tag:wino_wgrad:v6@24", "tag:wino_wgrad:v5@12",            # three-run ring at 24^3; the flat form at 12^3
-                             "tag:wino_fwd_split:v2@6", "tag:wino_fwd_split:v3@12"]),   # few boxes: contraction in slices
+                             "tag:wino_fwd_split:v2@6", "tag:wino_fwd_split:v3@12",     # few boxes: contraction in slices
+                             # the deep kernel-2 / stride-2 layers (space-to-depth + batched GEMM, conv1x1_gemm.hip)
+                             "tag:conv1x1_gemm:512x128@12", "tag:conv1x1_gemm:1024x256@6",
+                             "tag:conv1x1_gemm:256x1024@6", "tag:conv1x1_gemm:128x512@12"]),
 }
 
 
