@@ -276,7 +276,11 @@ int launch_w2(W2Args a, hipStream_t stream) {
     return mis_launch_status();
 }
 
-using W2V0 = W2Cfg<8, 8, 1, 4>;      // 16 x 16 pixel boxes, one block of 16 output channels
+#ifndef MIS_W2V0_NBUF
+#define MIS_W2V0_NBUF 3        // ring of 3: 34 KB of LDS, four workgroups per CU (the register limit).  These launches (16 output
+#endif                         // channels: the 256^2 level) are bound by the bytes in flight, not by the pipe: 150 -> 142 us (16 -> 16,
+                               // 48 slices), 197 -> 188 us (32 -> 16) against a ring of 4 (scripts/w2_nbuf_ab.sh)
+using W2V0 = W2Cfg<8, 8, 1, MIS_W2V0_NBUF>;      // 16 x 16 pixel boxes, one block of 16 output channels
 using W2V1 = W2Cfg<8, 8, 2, 3>;      // ... two blocks (Cout a multiple of 32): the transform is shared.  Ring of 3: 47 KB
                                      // of LDS, three workgroups per CU (a ring of 4 is 10 % slower)
 
@@ -299,7 +303,7 @@ extern "C" long long mis_conv2d_wino_stat_tiles(int H, int W, int variant) {
 
 extern "C" int mis_conv2d_wino_kernel_name(int variant, char* name, int name_len) {
     if (!name || name_len <= 0) return MIS_ERR_ARG;
-    if (variant == 0) snprintf(name, name_len, "wino2d_fwd_kernel<W2Cfg<8, 8, 1, 4>>");
+    if (variant == 0) snprintf(name, name_len, "wino2d_fwd_kernel<W2Cfg<8, 8, 1, %d>>", MIS_W2V0_NBUF);
     else if (variant == 1) snprintf(name, name_len, "wino2d_fwd_kernel<W2Cfg<8, 8, 2, 3>>");
     else return MIS_ERR_UNSUPPORTED;
     return MIS_OK;
