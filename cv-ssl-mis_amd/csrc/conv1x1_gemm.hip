@@ -157,6 +157,146 @@ __global__ __launch_bounds__(256) void conv1x1_reduce_kernel(const C1Args a) {
     *reinterpret_cast<float4*>(p) = s;
 }
 
+// ------------------------------------------------------------------------------------------------ weight gradient
+// dw[m][n] (+)= sum_b sum_s A[b][m][s] B[b][n][s]: the weight gradient of the same layers (A = dy or x, B = the other one), an NT
+// product whose contraction runs over images x voxels.  Both operands are contraction-MINOR here (a row = one channel's voxels),
+// so the tiles are transposed on their way into LDS: thread (row r fastest, k quad q) loads A[b][m0 + r][s0 + 4 q ..] as a float4
+// and stores its four floats to sA[4 q + j][r] -- lanes of a wave hold consecutive rows, i.e. consecutive banks (the loads
+// themselves touch one 16-byte piece per row: these tensors live in L2 / the infinity cache).  Slices = (image, voxel chunk).
+struct W1Args {
+    const float* A; long long a_bs;            // [batch][M][S]
+    const float* B; long long b_bs;            // [batch][N][S]
+    float* C; long long ldc;                   // [M][N]
+    float* ws;                                 // partials [slice][M][N]
+    int M, N, S, batch, SJ, schunk, accumulate;
+    int tiles_m, tiles_n;
+    unsigned n_blocks, n_blocks_padded;
+};
+
+template <int BT>
+__global__ __launch_bounds__(256) void conv1x1_wgrad_kernel(const W1Args a) {
+    constexpr int LD = BT + 16;
+    constexpr int NI = BT / 32;
+    constexpr int QK = BK1 / 4;        // float4 per row and k-step
+    __shared__ __attribute__((aligned(16))) float sA[BK1 * LD];
+    __shared__ __attribute__((aligned(16))) float sB[BK1 * LD];
+
+    const unsigned L = mis_xcd_remap(blockIdx.x, a.n_blocks_padded);
+    if (L >= a.n_blocks) return;
+    const unsigned tiles = (unsigned)(a.tiles_n * a.tiles_m);
+    const int slice = L / tiles;
+    const unsigned tl = L - slice * tiles;
+    const int tn = tl % a.tiles_n, tm = tl / a.tiles_n;
+    const int b = slice / a.SJ, sj = slice - b * a.SJ;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lk = lane >> 4, lj = lane & 15;
+    const int wm = (wave >> 1) * (BT / 2), wn = (wave & 1) * (BT / 2);
+    const int m0 = tm * BT, n0 = tn * BT;
+    const int sbeg = sj * a.schunk;
+    const int send = sbeg + a.schunk < a.S ? sbeg + a.schunk : a.S;
+    const float* __restrict__ Ap = a.A + (long long)b * a.a_bs;
+    const float* __restrict__ Bp = a.B + (long long)b * a.b_bs;
+
+    f32x4 acc[NI][NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    constexpr int NLD = BT * QK / 256;
+    float4 ra[NLD], rb[NLD];
+    auto fetch = [&](int s0) {
+#pragma unroll
+        for (int it = 0; it < NLD; ++it) {
+            const int e = tid + it * 256;
+            const int r = e % BT, q = e / BT;
+            const int sp = s0 + 4 * q;
+            {
+                const bool ok = sp < send && m0 + r < a.M;
+                ra[it] = *reinterpret_cast<const float4*>(Ap + (ok ? (long long)(m0 + r) * a.S + sp : 0));
+                if (!ok) ra[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            {
+                const bool ok = sp < send && n0 + r < a.N;
+                rb[it] = *reinterpret_cast<const float4*>(Bp + (ok ? (long long)(n0 + r) * a.S + sp : 0));
+                if (!ok) rb[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+    };
+    fetch(sbeg);
+    for (int s0 = sbeg; s0 < send; s0 += BK1) {
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < NLD; ++it) {
+            const int e = tid + it * 256;
+            const int r = e % BT, q = e / BT;
+            sA[(4 * q + 0) * LD + r] = ra[it].x; sA[(4 * q + 1) * LD + r] = ra[it].y;
+            sA[(4 * q + 2) * LD + r] = ra[it].z; sA[(4 * q + 3) * LD + r] = ra[it].w;
+            sB[(4 * q + 0) * LD + r] = rb[it].x; sB[(4 * q + 1) * LD + r] = rb[it].y;
+            sB[(4 * q + 2) * LD + r] = rb[it].z; sB[(4 * q + 3) * LD + r] = rb[it].w;
+        }
+        if (s0 + BK1 < send) fetch(s0 + BK1);
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < BK1 / 4; ++s) {
+            float af[NI], bf[NI];
+#pragma unroll
+            for (int i = 0; i < NI; ++i) af[i] = sA[(s * 4 + lk) * LD + wm + i * 16 + lj];
+#pragma unroll
+            for (int j = 0; j < NI; ++j) bf[j] = sB[(s * 4 + lk) * LD + wn + j * 16 + lj];
+#pragma unroll
+            for (int i = 0; i < NI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    float* __restrict__ out = a.ws + (long long)slice * a.M * a.N;
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            const int n = n0 + wn + j * 16 + lj;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + wm + i * 16 + lk * 4 + r;
+                if (m < a.M && n < a.N) out[(long long)m * a.N + n] = acc[i][j][r];
+            }
+        }
+}
+
+// C[m][n] (+)= sum over the slices, ascending (deterministic)
+__global__ __launch_bounds__(256) void conv1x1_wgrad_reduce_kernel(const W1Args a) {
+    const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long total = (long long)a.M * a.N;
+    if (e >= total) return;
+    const int slices = a.batch * a.SJ;
+    float s0 = 0.f, s1 = 0.f;
+    int k = 0;
+    for (; k + 1 < slices; k += 2) { s0 += a.ws[(long long)k * total + e]; s1 += a.ws[(long long)(k + 1) * total + e]; }
+    if (k < slices) s0 += a.ws[(long long)k * total + e];
+    const int m = (int)(e / a.N), n = (int)(e - (long long)m * a.N);
+    float* p = a.C + (long long)m * a.ldc + n;
+    const float s = s0 + s1;
+    *p = a.accumulate ? *p + s : s;
+}
+
+void wplan(W1Args& a) {
+    a.tiles_m = (int)mis_cdiv(a.M, 128);
+    a.tiles_n = (int)mis_cdiv(a.N, 128);
+    const long long tiles = (long long)a.tiles_m * a.tiles_n;
+    // (image, voxel chunk) slices: ~ 1.5 resident workgroups per CU, chunks of >= 4 k-steps
+    long long sj = 384 / (tiles * a.batch);
+    const long long sjmax = mis_cdiv(a.S, 4 * BK1);
+    if (sj > sjmax) sj = sjmax;
+    if (sj < 1) sj = 1;
+    a.schunk = (int)(mis_cdiv(mis_cdiv(a.S, sj), BK1) * BK1);
+    a.SJ = (int)mis_cdiv(a.S, a.schunk);
+    const long long nb = tiles * a.batch * a.SJ;
+    a.n_blocks = (unsigned)nb;
+    a.n_blocks_padded = (unsigned)(mis_cdiv(nb, MIS_NUM_XCD) * MIS_NUM_XCD);
+}
+
 constexpr int BT1 = 128;
 
 // slices over the channels: (image, slice, tile) entries ~ 1.5 resident workgroups per CU, >= 4 k-steps per slice
@@ -212,5 +352,34 @@ extern "C" int mis_conv1x1_gemm(const float* x, long long x_bs, const float* wt,
         const long long q = (long long)N * Cout * S / 4;
         hipLaunchKernelGGL(conv1x1_reduce_kernel, dim3((unsigned)mis_cdiv(q, 256)), dim3(256), 0, stream, a);
     }
+    return mis_launch_status();
+}
+
+// Workspace (bytes) of mis_conv1x1_wgrad: the per-slice partials.
+extern "C" long long mis_conv1x1_wgrad_workspace_bytes(int N, int M, int Nc, long long S) {
+    if (N <= 0 || M <= 0 || Nc <= 0 || S <= 0 || S > 0x7fffffffLL) return MIS_ERR_ARG;
+    W1Args a{};
+    a.M = M; a.N = Nc; a.S = (int)S; a.batch = N;
+    wplan(a);
+    return (long long)N * a.SJ * M * Nc * 4;
+}
+
+// dw[m][n] (+)= sum over the N images and the S voxels of a[img][m][s] * b[img][n][s]: the weight gradient of the 1x1x1
+// convolution above (a = dy, b = x gives [Cout][Cin]; swapped operands give the transposed parameter layout directly).
+// a / b: channel-major views (channel stride S, batch strides a_bs / b_bs); dw: row stride ldw.  S and the batch strides
+// multiples of 4, 16-byte aligned a / b.  Deterministic (fixed slices, fixed-order reduction).
+extern "C" int mis_conv1x1_wgrad(const float* av, long long a_bs, const float* bv, long long b_bs, float* dw, long long ldw, int N,
+                                 int M, int Nc, long long S, int accumulate, float* workspace, long long workspace_bytes,
+                                 hipStream_t stream) {
+    if (!av || !bv || !dw || !workspace || N <= 0 || M <= 0 || Nc <= 0 || S <= 0) return MIS_ERR_ARG;
+    if (a_bs < (long long)M * S || b_bs < (long long)Nc * S || ldw < Nc) return MIS_ERR_ARG;
+    if (S % 4 || a_bs % 4 || b_bs % 4 || !a16(av) || !a16(bv) || S > 0x7fffffffLL) return MIS_ERR_UNSUPPORTED;
+    W1Args a{};
+    a.A = av; a.a_bs = a_bs; a.B = bv; a.b_bs = b_bs; a.C = dw; a.ldc = ldw; a.ws = workspace;
+    a.M = M; a.N = Nc; a.S = (int)S; a.batch = N; a.accumulate = accumulate;
+    wplan(a);
+    if (workspace_bytes < (long long)N * a.SJ * M * Nc * 4) return MIS_ERR_WORKSPACE;
+    hipLaunchKernelGGL(conv1x1_wgrad_kernel<128>, dim3(a.n_blocks_padded), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL(conv1x1_wgrad_reduce_kernel, dim3((unsigned)mis_cdiv((long long)M * Nc, 256)), dim3(256), 0, stream, a);
     return mis_launch_status();
 }

@@ -52,6 +52,8 @@ PROTOTYPES = {
     "mis_conv3d_wino_fwd": (c_i, [c_p, c_ll, c_p, c_p, c_p, c_ll, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_ll, c_ll, c_i, c_p]),
     "mis_conv1x1_gemm_workspace_bytes": (c_ll, [c_i, c_i, c_i, c_ll]),
     "mis_conv1x1_gemm": (c_i, [c_p, c_ll, c_p, c_ll, c_p, c_p, c_ll, c_i, c_i, c_i, c_ll, c_i, c_p, c_ll, c_p]),
+    "mis_conv1x1_wgrad_workspace_bytes": (c_ll, [c_i, c_i, c_i, c_ll]),
+    "mis_conv1x1_wgrad": (c_i, [c_p, c_ll, c_p, c_ll, c_p, c_ll, c_i, c_i, c_i, c_ll, c_i, c_p, c_ll, c_p]),
     "mis_conv3d_wino_fwd_splits": (c_i, [c_i, c_i, c_i, c_i, c_i, c_i, c_i]),
     "mis_conv3d_wino_fwd_workspace_bytes": (c_ll, [c_i, c_i, c_i, c_i, c_i, c_i, c_i]),
     "mis_conv3d_wino_fwd_ws": (c_i, [c_p, c_ll, c_p, c_p, c_p, c_ll, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_ll, c_ll, c_i, c_p, c_ll,

@@ -242,6 +242,34 @@ def conv1x1_gemm(x, wt, bias, y, accumulate=False):
                                 int(accumulate), _l.ptr(ws), nb, _l.stream_ptr()), "mis_conv1x1_gemm")
 
 
+def conv1x1_wgrad_eligible(a, b):
+    """a / b: the two 5-D NCDHW operands of the weight gradient (same N, D, H, W)."""
+    if not CONV1X1_GEMM:
+        return False
+    try:
+        _, _, _, _, _, S, abs_ = _geom(a)
+        _, _, _, _, _, _, bbs = _geom(b)
+    except RuntimeError:
+        return False
+    return (S <= CONV1X1_GEMM_MAX_S and S % 4 == 0 and abs_ % 4 == 0 and bbs % 4 == 0 and a.data_ptr() % 16 == 0 and
+            b.data_ptr() % 16 == 0 and min(a.shape[1], b.shape[1]) >= 64)
+
+
+def conv1x1_wgrad(a, b, dw, accumulate=False):
+    """dw[M][Nc] (+)= sum_{image, voxel} a[.][m][s] * b[.][n][s] (mis_conv1x1_wgrad); dw: a 2-D view [a channels][b channels]."""
+    L = _l.load()
+    N, M, D, H, W, S, abs_ = _geom(a)
+    _, Nc, _, _, _, _, bbs = _geom(b)
+    assert dw.dim() == 2 and dw.shape == (M, Nc) and dw.stride(1) == 1, (dw.shape, M, Nc)
+    nb = L.mis_conv1x1_wgrad_workspace_bytes(N, M, Nc, S)
+    if nb < 0:
+        _l.check(nb, "mis_conv1x1_wgrad_workspace_bytes")
+    ws = scratch(nb, "conv1x1_wgrad")
+    _tag(f"conv1x1_wgrad:{M}x{Nc}@{W}")
+    _l.check(L.mis_conv1x1_wgrad(_l.ptr(a), abs_, _l.ptr(b), bbs, _l.ptr(dw), dw.stride(0), N, M, Nc, S, int(accumulate),
+                                 _l.ptr(ws), nb, _l.stream_ptr()), "mis_conv1x1_wgrad")
+
+
 def conv_wino_select(N, Cin, Cout, D, H, W, ksize):
     """Winograd variant serving this convolution (mis_conv3d_wino_select / mis_conv2d_wino_select), or -1: use the
     direct kernel."""

@@ -393,7 +393,10 @@ class DownConvOp:
                 if self._xs is None:
                     self._xs = self._new_xs()
                 ops.space_to_depth2(self.x.t, self._xs, self.in_shape, True)
-            ops.conv_wgrad(self._xs, dy, self.w.grad, (1, 1, 1))      # [Cout][8Cin] == [Cout][Cin][2][2][2] in memory
+            if ops.conv1x1_wgrad_eligible(dy, self._xs):
+                ops.conv1x1_wgrad(dy, self._xs, self.w.grad.view(self.cout, self.cin8))
+            else:
+                ops.conv_wgrad(self._xs, dy, self.w.grad, (1, 1, 1))      # [Cout][8Cin] == [Cout][Cin][2][2][2] in memory
         # bias gradient exactly 0 when the conv feeds a normalisation (see ConvOp)
         if self.bias_grad and self.b is not None:
             ops.channel_sum(dy, self.b.grad)
@@ -465,8 +468,12 @@ class UpConvOp:
                 self.dy8 = self._new_y8()
                 self.dw8 = torch.empty((self.cout8, self.cin), dtype=torch.float32, device="cuda")
             ops.space_to_depth2(dyf, self.dy8, self.y.shape, True)
-            ops.conv_wgrad(self.x.t, self.dy8, self.dw8, (1, 1, 1))                  # [8Cout][Cin]
-            tops.transpose(self.dw8, self.w.grad.view(self.cin, self.cout8))         # parameter is [Cin][8Cout]
+            if ops.conv1x1_wgrad_eligible(self.x.t, self.dy8):
+                # operands swapped: the result IS the parameter's input-major layout [Cin][8Cout]
+                ops.conv1x1_wgrad(self.x.t, self.dy8, self.w.grad.view(self.cin, self.cout8))
+            else:
+                ops.conv_wgrad(self.x.t, self.dy8, self.dw8, (1, 1, 1))                  # [8Cout][Cin]
+                tops.transpose(self.dw8, self.w.grad.view(self.cin, self.cout8))         # parameter is [Cin][8Cout]
         assert not self.x.written
         if self.direct_dx:       # dX = Conv3d(k2s2)(dy) with the parameter read as [M = Cin][K = 8 Cout]
             ops.conv_k2s2_down(self.y.grad(), self.w.data, None, self.x.grad())

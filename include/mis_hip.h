@@ -620,6 +620,12 @@ long long mis_conv1x1_gemm_workspace_bytes(int N, int Cin, int Cout, long long S
 int mis_conv1x1_gemm(const float* x, long long x_bs, const float* wt, long long ldw, const float* bias, float* y, long long y_bs,
                      int N, int Cin, int Cout, long long S, int accumulate, float* workspace, long long workspace_bytes,
                      mis_stream_t stream);
+/* Its weight gradient: dw[m][n] (+)= sum over the N images and S voxels of a[img][m][s] * b[img][n][s] (a = dy, b = x gives
+ * [Cout][Cin]; swapped operands give the transposed layout directly -- ConvTranspose3d's parameter is input-major).  Slices over
+ * (image, voxel chunk), partials in `workspace` (always needed), fixed-order reduction.  S, a_bs, b_bs multiples of 4. */
+long long mis_conv1x1_wgrad_workspace_bytes(int N, int M, int Nc, long long S);
+int mis_conv1x1_wgrad(const float* a, long long a_bs, const float* b, long long b_bs, float* dw, long long ldw, int N, int M, int Nc,
+                      long long S, int accumulate, float* workspace, long long workspace_bytes, mis_stream_t stream);
 
 /* Test support (never on the product path): fills the LDS of every CU with NaNs so that a kernel reading LDS it did not write
  * fails deterministically instead of depending on the previous launch.  sink: any device float (or NULL). */

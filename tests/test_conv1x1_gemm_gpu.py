@@ -81,3 +81,49 @@ def test_conv1x1_gemm_refusals():
         ops.conv1x1_gemm(x, torch.zeros(64, 64, device="cuda"), None, y)
     big = torch.zeros(1, 64, 32, 32, 32, device="cuda")     # many voxels: the spatially tiled kernel's job
     assert not ops.conv1x1_gemm_eligible(big, big, 64, 64)
+
+
+# N, M (channels of a), Nc (channels of b), (D, H, W)
+WGRAD_CASES = [
+    (8, 128, 512, (12, 12, 12)),      # V-Net block_three_dw: dw[Cout][8 Cin]
+    (8, 256, 1024, (6, 6, 6)),        # block_four_dw
+    (8, 256, 1024, (6, 6, 6)),
+    (8, 128, 512, (12, 12, 12)),
+    (4, 1024, 256, (6, 6, 6)),
+    (3, 72, 100, (5, 6, 4)),          # ragged tiles, one chunk of 120 voxels
+    (2, 64, 200, (8, 8, 8)),
+]
+
+
+@pytest.mark.parametrize("N,M,Nc,sp", WGRAD_CASES)
+def test_conv1x1_wgrad_matches_reference(N, M, Nc, sp):
+    from mis_hip import ops
+    a = _rand(N, M, *sp, seed=11)
+    b = _rand(N, Nc, *sp, seed=12)
+    ref = torch.einsum("nmdhw,nkdhw->mk", a, b)
+    ad, bd = a.float().cuda(), b.float().cuda()
+    assert ops.conv1x1_wgrad_eligible(ad, bd)
+    dw = torch.full((M, Nc), float("nan"), device="cuda")
+    ops.conv1x1_wgrad(ad, bd, dw)
+    _close(dw, ref, rtol=1e-5, atol=1e-6)
+    dw2 = torch.empty_like(dw)
+    ops.conv1x1_wgrad(ad, bd, dw2)
+    assert torch.equal(dw, dw2)                       # fixed slices, fixed-order reduction
+    ops.conv1x1_wgrad(ad, bd, dw2, accumulate=True)
+    _close(dw2, 2 * ref, rtol=1e-5, atol=1e-6)
+    # the spatially tiled kernel agrees (a = dy, b = x: dw[Cout][Cin])
+    dwd = torch.empty(M, Nc, 1, 1, 1, device="cuda")
+    ops.conv_wgrad(bd, ad, dwd, (1, 1, 1))
+    _close(dw, dwd.view(M, Nc), rtol=1e-5, atol=1e-6)
+
+
+def test_conv1x1_wgrad_on_channel_slices_into_a_wider_gradient():
+    from mis_hip import ops
+    N, sp = 4, (6, 6, 6)
+    abuf = _rand(N, 32 + 128, *sp, seed=21).float().cuda()
+    bbuf = _rand(N, 256 + 16, *sp, seed=22).float().cuda()
+    wide = torch.zeros(128, 256 + 64, device="cuda")
+    ops.conv1x1_wgrad(abuf[:, 32:], bbuf[:, :256], wide[:, 64:])
+    ref = torch.einsum("nmdhw,nkdhw->mk", abuf[:, 32:].cpu().double(), bbuf[:, :256].cpu().double())
+    _close(wide[:, 64:], ref, rtol=1e-5, atol=1e-6)
+    assert wide[:, :64].abs().max().item() == 0.0

@@ -98,7 +98,8 @@ MT_CASES = {
                              "tag:wino_fwd_split:v2@6", "tag:wino_fwd_split:v3@12",     # few boxes: contraction in slices
                              # the deep kernel-2 / stride-2 layers (space-to-depth + batched GEMM, conv1x1_gemm.hip)
                              "tag:conv1x1_gemm:512x128@12", "tag:conv1x1_gemm:1024x256@6",
-                             "tag:conv1x1_gemm:256x1024@6", "tag:conv1x1_gemm:128x512@12"]),
+                             "tag:conv1x1_gemm:256x1024@6", "tag:conv1x1_gemm:128x512@12",
+                             "tag:conv1x1_wgrad:128x512@12", "tag:conv1x1_wgrad:256x1024@6"]),       # ... and their weight gradients
 }
 
 
