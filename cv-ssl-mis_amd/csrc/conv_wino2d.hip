@@ -18,6 +18,7 @@
 #include "common.h"
 #include "wino.h"
 #include <stdio.h>
+#include <stdlib.h>
 
 // Prototype of review item 5 (round 4), off in the product build: -DMIS_W2_NORM=1 applies BatchNorm scale / shift +
 // LeakyReLU on the LDS -> register read of the patch (the raw convolution output of the previous layer would then be the only
@@ -284,6 +285,13 @@ using W2V0 = W2Cfg<8, 8, 1, MIS_W2V0_NBUF>;      // 16 x 16 pixel boxes, one blo
 using W2V1 = W2Cfg<8, 8, 2, 3>;      // ... two blocks (Cout a multiple of 32): the transform is shared.  Ring of 3: 47 KB
                                      // of LDS, three workgroups per CU (a ring of 4 is 10 % slower)
 
+// Wide boxes (round 4): 4 x 16 tiles = 8 x 32 pixels instead of 16 x 16.  Same tile count, same LDS, but a box row is 128 bytes
+// of output (one store instruction of a wave = 16 lanes x 8 contiguous bytes) and 160 bytes of input instead of 64 / 96:
+// scripts/ubench/hbm_pieces.hip -- a copy in 64-byte pieces gets 3.1 TB/s from HBM, in 128-byte pieces 4.4, in streams 5.1 --
+// and the 256^2 level of the 2-D UNet, whose launches move 400 MB for 41 us of matrix-pipe work, ran at exactly that 2.85 TB/s.
+using W2V2 = W2Cfg<4, 16, 1, MIS_W2V0_NBUF>;
+using W2V3 = W2Cfg<4, 16, 2, 3>;
+
 }  // namespace
 
 // Which variant serves this 3x3 'same' convolution (D = 1), or -1 (use the direct kernel, mis_conv_fwd):
@@ -291,20 +299,24 @@ using W2V1 = W2Cfg<8, 8, 2, 3>;      // ... two blocks (Cout a multiple of 32): 
 //   W % 4 == 0, and whole 16 x 16 boxes (the fused statistics need them, and ragged boxes waste the matrix pipe).
 extern "C" int mis_conv2d_wino_select(int N, int Cin, int Cout, int H, int W) {
     if (N <= 0 || Cin < 8 || Cin % 4 || Cout <= 0 || Cout % 16 || H <= 0 || W <= 0) return -1;
-    if (H % 16 || W % 16) return -1;
     if (((long long)Cin + 32) * H * W * 4 >= (1LL << 30)) return -1;
+    static const bool wide = [] { const char* e = getenv("MIS_W2_WIDE"); return !(e && e[0] == '0'); }();
+    if (wide && H % 8 == 0 && W % 32 == 0) return Cout % 32 == 0 ? 3 : 2;      // 8 x 32-pixel boxes: 128-byte output rows
+    if (H % 16 || W % 16) return -1;
     return Cout % 32 == 0 ? 1 : 0;
 }
 
 extern "C" long long mis_conv2d_wino_stat_tiles(int H, int W, int variant) {
-    if (H <= 0 || W <= 0 || variant < 0 || variant > 1) return MIS_ERR_ARG;
-    return mis_cdiv(H, 16) * mis_cdiv(W, 16);
+    if (H <= 0 || W <= 0 || variant < 0 || variant > 3) return MIS_ERR_ARG;
+    return variant >= 2 ? mis_cdiv(H, 8) * mis_cdiv(W, 32) : mis_cdiv(H, 16) * mis_cdiv(W, 16);
 }
 
 extern "C" int mis_conv2d_wino_kernel_name(int variant, char* name, int name_len) {
     if (!name || name_len <= 0) return MIS_ERR_ARG;
     if (variant == 0) snprintf(name, name_len, "wino2d_fwd_kernel<W2Cfg<8, 8, 1, %d>>", MIS_W2V0_NBUF);
     else if (variant == 1) snprintf(name, name_len, "wino2d_fwd_kernel<W2Cfg<8, 8, 2, 3>>");
+    else if (variant == 2) snprintf(name, name_len, "wino2d_fwd_kernel<W2Cfg<4, 16, 1, %d>>", MIS_W2V0_NBUF);
+    else if (variant == 3) snprintf(name, name_len, "wino2d_fwd_kernel<W2Cfg<4, 16, 2, 3>>");
     else return MIS_ERR_UNSUPPORTED;
     return MIS_OK;
 }
@@ -316,8 +328,9 @@ extern "C" int mis_conv2d_wino_fwd(const float* x, long long x_bs, const float* 
     if (!x || !wt || !y || N <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0) return MIS_ERR_ARG;
     const long long S = (long long)H * W;
     if (x_bs < (long long)Cin * S || y_bs < (long long)Cout * S) return MIS_ERR_ARG;
-    if (mis_conv2d_wino_select(N, Cin, Cout, H, W) < 0 || (variant == 1 && Cout % 32) || variant < 0 || variant > 1)
+    if (mis_conv2d_wino_select(N, Cin, Cout, H, W) < 0 || ((variant & 1) && Cout % 32) || variant < 0 || variant > 3)
         return MIS_ERR_UNSUPPORTED;
+    if (variant >= 2 ? (H % 8 || W % 32) : (H % 16 || W % 16)) return MIS_ERR_UNSUPPORTED;
     if (y_bs % 2 || ((uintptr_t)y & 7) || ((uintptr_t)wt & 15) || ((uintptr_t)x & 15) || x_bs % 4) return MIS_ERR_UNSUPPORTED;
     W2Args a{};
     a.x = x; a.x_bs = x_bs; a.wt = wt; a.bias = bias; a.y = y; a.y_bs = y_bs;
@@ -328,6 +341,8 @@ extern "C" int mis_conv2d_wino_fwd(const float* x, long long x_bs, const float* 
     a.nrm = g_w2_nrm; a.slope = g_w2_slope;
     if (a.nrm && Cin > 512) return MIS_ERR_UNSUPPORTED;
 #endif
+    if (variant == 2) return launch_w2<W2V2>(a, stream);
+    if (variant == 3) return launch_w2<W2V3>(a, stream);
     return variant == 0 ? launch_w2<W2V0>(a, stream) : launch_w2<W2V1>(a, stream);
 }
 

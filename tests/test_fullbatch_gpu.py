@@ -69,8 +69,9 @@ MT_CASES = {
     #        full batch reaches)
     "config2_unet2d_24+24_256": ("unet2d", (48, 1, 256, 256), 24, 4, torch.uint8, 1200, 1000,
                                  ["name:conv_fwd_cin1_kernel<1>",             # first layer (1 input channel): taps as K
-                                  "wino2d:W2Cfg<8, 8, 1, 3>",                 # 16 output channels: Winograd F(2x2, 3x3)
-                                  "wino2d:W2Cfg<8, 8, 2, 3>"]),               # 32 and more
+                                  "wino2d:W2Cfg<4, 16, 1, 3>",                # 16 output channels: Winograd F(2x2, 3x3), 8 x 32 boxes
+                                  "wino2d:W2Cfg<4, 16, 2, 3>",                # 32 and more
+                                  "wino2d:W2Cfg<8, 8, 2, 3>"]),               # the 16^2 level: 16 x 16 boxes
     "config3_unet3d_4+4_96": ("unet3d", (8, 1, 96, 96, 96), 4, 2, torch.int64, 1200, 0,
                               ["name:conv_fwd_cin1_kernel<3>",                     # first layer (1 input channel): taps as K
                                "tag:wino_fwd_split:v2@6",                          # 6^3 level: few boxes, contraction in slices

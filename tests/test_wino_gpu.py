@@ -310,7 +310,9 @@ def test_wino_select_and_refusal():
     assert sel(1, 32, 16, 12, 12, 12) == -1 and sel(8, 128, 256, 6, 6, 6) == 2
     assert sel(4, 128, 256, 6, 6, 6) == 2 and sel(1, 128, 256, 6, 6, 6) == -1      # 64 entries x 2 contraction slices; 16 x 4
     assert sel(2, 16, 16, 6, 6, 30) == -1
-    assert ops.conv_wino_select(2, 16, 16, 1, 64, 64, (3, 3)) == ops.WINO2D          # 2-D: conv_wino2d.hip
+    assert ops.conv_wino_select(2, 16, 16, 1, 64, 64, (3, 3)) == ops.WINO2D + 2      # 2-D: conv_wino2d.hip, 8 x 32-pixel boxes
+    assert ops.conv_wino_select(2, 16, 32, 1, 64, 64, (3, 3)) == ops.WINO2D + 3 and ops.conv_wino_select(2, 16, 16, 1, 48, 48, (3, 3)) == ops.WINO2D
+    assert ops.conv_wino_select(2, 16, 32, 1, 16, 16, (3, 3)) == ops.WINO2D + 1 and ops.conv_wino_select(2, 16, 16, 1, 24, 32, (3, 3)) == ops.WINO2D + 2
     x = torch.zeros(1, 16, 6, 6, 30, device="cuda")
     y = torch.zeros(1, 16, 6, 6, 30, device="cuda")
     wt = ops.conv_pack(torch.zeros(16, 16, 3, 3, 3, device="cuda"), 4)
@@ -376,7 +378,9 @@ def test_first_layer_weight_gradient(N, D, H, W):
 
 # N, Cin, Cout, H, W
 W2D_CASES = [(1, 16, 16, 16, 16), (2, 16, 32, 32, 48), (3, 32, 16, 16, 32), (2, 64, 64, 32, 32), (1, 8, 16, 48, 16),
-             (2, 12, 48, 16, 64)]
+             (2, 12, 48, 16, 64),
+             # 8 x 32-pixel boxes (W % 32 == 0, H % 8 == 0): heights that are not multiples of 16, several boxes in both directions
+             (2, 16, 16, 24, 96), (3, 32, 64, 8, 32), (2, 16, 16, 64, 256), (1, 24, 32, 40, 64)]
 
 
 @pytest.mark.parametrize("case", W2D_CASES)
@@ -397,7 +401,7 @@ def test_wino2d_forward_and_data_gradient(case):
     wd, bd = w.detach().float().cuda(), b.float().cuda()
     dyd = dy.float().cuda().unsqueeze(2).contiguous()
     T = ops.conv_stat_tiles(N, Cin, Cout, 1, H, W, (3, 3), wino=v)
-    assert T == (H // 16) * (W // 16)
+    assert T == ((H // 8) * (W // 32) if v >= ops.WINO2D + 2 else (H // 16) * (W // 16))
     part = torch.full((Cout * N * T, 2), float("nan"), device="cuda")
     y = torch.full((N, Cout, 1, H, W), float("nan"), device="cuda")
     ops.conv_fwd(xd, ops.conv_pack(wd, 6), bd, y, Cin, Cout, (3, 3), stat=(part, N * T, T), wino=v)
