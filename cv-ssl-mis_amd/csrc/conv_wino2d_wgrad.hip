@@ -16,6 +16,7 @@
 // (16 -> 9) in registers, waves summed through LDS, partials summed in a fixed order by a second kernel (deterministic).
 #include "common.h"
 #include "wino.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -31,9 +32,9 @@ struct Wg2Args {
     int ci_blocks, co_groups, splits;   // tasks = co_groups * ci_blocks * splits, splits = 8 * nt
 };
 
-template <int COB_>
+template <int COB_, int TY_ = 4, int TX_ = 8>
 struct Wg2Cfg {
-    static constexpr int COB = COB_, TY = 4, TX = 8;                 // stage = 4 x 8 tiles: 8 chunks of 4 x-adjacent tiles
+    static constexpr int COB = COB_, TY = TY_, TX = TX_;             // stage = 4 x 8 (or 2 x 16) tiles: 8 chunks of 4 x-adjacent tiles
     static constexpr int OY = 2 * TY, OX = 2 * TX, HY = OY + 2;
     static constexpr int NQ = (OX + 8) / 4, RX = NQ * 4;             // x rows hold [x0 - 4, x0 + OX + 4)
     static constexpr int XG = HY * 16 * NQ, XF = XG * 4;
@@ -46,6 +47,7 @@ struct Wg2Cfg {
     static constexpr int RED = 9 * DC * 16;                          // floats of one wave's transformed partial
     static constexpr int LDS_FLOATS = 2 * STAGE > 4 * RED ? 2 * STAGE : 4 * RED;
     static constexpr int LDS_BYTES = LDS_FLOATS * 4;
+    static_assert(TY * TX == 32 && TX % 4 == 0, "32 tiles per stage");
     static_assert(XG % 64 == 0 && DG % 64 == 0, "whole DMA pieces");
     static_assert(LDS_BYTES <= 80 * 1024, "two workgroups per CU");
     static_assert(PW <= 10 && PW <= (COB == 1 ? 8 : 10), "class bits: 5 pieces per register, 2 registers; DMA slots");
@@ -193,6 +195,14 @@ __global__ __launch_bounds__(256, 2) void wino2d_wgrad_kernel(const Wg2Args a) {
             vy[b][2] = pk_sub(rn[b][0], rn[b][1]);
             vy[b][3] = pk_sub(zero, rn[b][1]);
         }
+        // The packed adds above are inline asm: hipcc does not know they are VALU writes and inserts no wait states between one
+        // of them and an MFMA that reads its result.  Left alone it hoisted the run's first MFMA to TWO instructions behind the
+        // v_pk_add_f32 that produces its B operand (Wg2Cfg<1, 2, 16>): lanes 48 - 63 -- the last pass of the wave -- then read the
+        // register before it was written, timing-dependent (found as errors in tap (0, 0) only, i.e. transform point 0).  Every
+        // operand of the run passes through this statement, which sits behind all the adds and carries the wait states.
+        asm volatile("s_nop 3" : "+v"(u[0]), "+v"(u[1]), "+v"(u[2]), "+v"(u[3]), "+v"(u[4]), "+v"(u[5]), "+v"(u[6]), "+v"(u[7]));
+#pragma unroll
+        for (int b = 0; b < C::COB; ++b) asm volatile("" : "+v"(vy[b][0]), "+v"(vy[b][1]), "+v"(vy[b][2]), "+v"(vy[b][3]));
     };
 
     if (s_begin < s_end) {
@@ -320,13 +330,22 @@ int launch_wg2(Wg2Args a, float* dw, int accumulate, hipStream_t stream) {
     return mis_launch_status();
 }
 
+// wide stages (round 4): 2 x 16 tiles = 4 x 32 pixels: dy rows of 128 bytes, x rows of 160 instead of 64 / 96 (the same halo
+// ratio and LDS; scripts/ubench/hbm_pieces.hip: HBM gives 64-byte pieces 3.1 TB/s, 128-byte pieces 4.4)
+using Wg2W1 = Wg2Cfg<1, 2, 16>;
+using Wg2W2 = Wg2Cfg<2, 2, 16>;
+
 }  // namespace
 
 // variant serving the weight gradient of this 3x3 'same' convolution (D = 1): 0 = one block of 16 output channels per
-// workgroup, 1 = two; -1 = use mis_conv_wgrad.  Needs whole stages (H % 8, W % 16) and Cin, Cout >= 8.
+// workgroup, 1 = two (stages of 8 x 16 pixels: H % 8, W % 16); 2 / 3 = the same with stages of 4 x 32 pixels (H % 4, W % 32);
+// -1 = use mis_conv_wgrad.  Cin, Cout >= 8.
 extern "C" int mis_conv2d_wino_wgrad_select(int N, int Cin, int Cout, int H, int W) {
-    if (N <= 0 || Cin < 8 || Cout < 8 || H <= 0 || W <= 0 || H % 8 || W % 16) return -1;
+    if (N <= 0 || Cin < 8 || Cout < 8 || H <= 0 || W <= 0) return -1;
     if (((long long)33 * H * W + W + 64) * 4 >= (1LL << 31)) return -1;
+    static const bool wide = [] { const char* e = getenv("MIS_W2_WIDE"); return !(e && e[0] == '0'); }();
+    if (wide && H % 4 == 0 && W % 32 == 0) return Cout > 16 ? 3 : 2;
+    if (H % 8 || W % 16) return -1;
     return Cout > 16 ? 1 : 0;
 }
 
@@ -336,6 +355,8 @@ extern "C" long long mis_conv2d_wino_wgrad_workspace_bytes(int N, int Cin, int C
     a.N = N; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W;
     if (variant == 0) { geometry2<Wg2Cfg<1>>(a); return (long long)a.ci_blocks * a.co_groups * a.splits * Wg2Cfg<1>::RED * 4; }
     if (variant == 1) { geometry2<Wg2Cfg<2>>(a); return (long long)a.ci_blocks * a.co_groups * a.splits * Wg2Cfg<2>::RED * 4; }
+    if (variant == 2) { geometry2<Wg2W1>(a); return (long long)a.ci_blocks * a.co_groups * a.splits * Wg2W1::RED * 4; }
+    if (variant == 3) { geometry2<Wg2W2>(a); return (long long)a.ci_blocks * a.co_groups * a.splits * Wg2W2::RED * 4; }
     return MIS_ERR_UNSUPPORTED;
 }
 
@@ -346,11 +367,14 @@ extern "C" int mis_conv2d_wino_wgrad(const float* x, long long x_bs, const float
     if (!x || !dy || !dw || !workspace || N <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0) return MIS_ERR_ARG;
     const long long S = (long long)H * W;
     if (x_bs < (long long)Cin * S || dy_bs < (long long)Cout * S) return MIS_ERR_ARG;
-    if (mis_conv2d_wino_wgrad_select(N, Cin, Cout, H, W) < 0 || variant < 0 || variant > 1) return MIS_ERR_UNSUPPORTED;
+    if (mis_conv2d_wino_wgrad_select(N, Cin, Cout, H, W) < 0 || variant < 0 || variant > 3) return MIS_ERR_UNSUPPORTED;
+    if (variant >= 2 ? (H % 4 || W % 32) : (H % 8 || W % 16)) return MIS_ERR_UNSUPPORTED;
     if (((uintptr_t)x & 15) || ((uintptr_t)dy & 15) || x_bs % 4 || dy_bs % 4) return MIS_ERR_UNSUPPORTED;
     if (workspace_bytes < mis_conv2d_wino_wgrad_workspace_bytes(N, Cin, Cout, H, W, variant)) return MIS_ERR_WORKSPACE;
     Wg2Args a{};
     a.x = x; a.x_bs = x_bs; a.dy = dy; a.dy_bs = dy_bs; a.ws = workspace;
     a.N = N; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W;
+    if (variant == 2) return launch_wg2<Wg2W1>(a, dw, accumulate, stream);
+    if (variant == 3) return launch_wg2<Wg2W2>(a, dw, accumulate, stream);
     return variant == 0 ? launch_wg2<Wg2Cfg<1>>(a, dw, accumulate, stream) : launch_wg2<Wg2Cfg<2>>(a, dw, accumulate, stream);
 }

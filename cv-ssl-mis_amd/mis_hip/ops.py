@@ -446,7 +446,7 @@ def _conv_wgrad_launch(L, x, dy, dw, N, Cin, Cout, D, H, W, xbs, dbs, kd, kh, kw
         ws = scratch(nb, "wgrad")
         _l.check(L.mis_conv2d_wino_wgrad(_l.ptr(x), xbs, _l.ptr(dy), dbs, _l.ptr(dw), _l.ptr(ws), ws.numel(), N, Cin, Cout,
                                          H, W, int(accumulate), wino2, _l.stream_ptr()), "mis_conv2d_wino_wgrad")
-        return f"wino2d_wgrad_kernel<Wg2Cfg<{wino2 + 1}> >"
+        return "wino2d_wgrad_kernel<Wg2Cfg<%d, %s> >" % (wino2 % 2 + 1, "2, 16" if wino2 >= 2 else "4, 8")
     nb = L.mis_conv_wgrad_workspace_bytes(N, Cin, Cout, D, H, W, kd, kh, kw)
     if nb < 0:
         _l.check(nb, "mis_conv_wgrad_workspace_bytes")

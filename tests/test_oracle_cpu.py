@@ -396,3 +396,15 @@ def test_surface_metrics_against_brute_force(shape, spacing, seed):
     inter = np.count_nonzero(a & b)
     assert abs(metrics.dc(a, b) - 2.0 * inter / (a.sum() + b.sum())) < 1e-12
     assert abs(metrics.ravd(a, b) - (a.sum() - b.sum()) / b.sum()) < 1e-12
+
+
+@pytest.mark.timeout(900)
+def test_no_mfma_reads_an_inline_asm_valu_result_too_early():
+    """hipcc does not insert wait states between an inline-asm vector instruction and an MFMA that reads its result (round 4: a
+    hoisted MFMA two instructions behind the packed add producing its B operand gave wrong weight gradients on lanes 48 - 63).
+    scripts/check_mfma_hazard.py compiles the kernels that mix the two to gfx950 ISA and looks for such pairs."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("check_mfma_hazard", os.path.join(ROOT, "scripts", "check_mfma_hazard.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert mod.main([]) == 0

@@ -424,7 +424,9 @@ def test_wino2d_forward_and_data_gradient(case):
 
 
 @pytest.mark.parametrize("N,Cin,Cout,H,W", [(1, 16, 16, 8, 16), (2, 16, 32, 32, 48), (3, 24, 40, 16, 32), (2, 64, 64, 32, 32),
-                                            (1, 8, 16, 48, 16), (2, 32, 48, 24, 64)])
+                                            (1, 8, 16, 48, 16), (2, 32, 48, 24, 64),
+                                            # stages of 4 x 32 pixels (W % 32 == 0): H not a multiple of 8, many stages, ragged blocks
+                                            (2, 16, 16, 12, 96), (5, 16, 16, 64, 256), (1, 40, 24, 20, 32)])
 def test_wino2d_weight_gradient(N, Cin, Cout, H, W):
     """F(2x2, 3x3) weight gradient (conv_wino2d_wgrad.hip) behind ops.conv_wgrad for the 2-D UNet's 3x3 convs, against
     torch fp64 and the direct kernel; ragged channel blocks; deterministic; `accumulate` adds."""
