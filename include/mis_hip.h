@@ -123,14 +123,19 @@ int mis_conv3d_wino_dgrad_norm(const float* dy, long long dy_bs, const float* wt
                                int variant, mis_stream_t stream);
 /* ---- Winograd F(2x2, 3x3) form of the stride-1 'same' 3x3 convolution of the 2-D UNet (csrc/conv_wino2d.hip) ----
  * reference: nn.Conv2d(k=3, padding=1) of ConvBlock (code/networks/unet.py:30-45).  Same contract as the 3-D entry
- * points above with D = 1; filter transformed by pack modes 6 (forward) / 7 (data gradient). */
+ * points above with D = 1; filter transformed by pack modes 6 (forward) / 7 (data gradient).
+ * _select: 0 / 1 = boxes of 16 x 16 pixels with one / two blocks of 16 output channels per wave (H, W multiples of 16),
+ * 2 / 3 = the same with boxes of 8 x 32 pixels (H % 8 == 0, W % 32 == 0: 128-byte output rows; preferred), -1 = use mis_conv_fwd.
+ * _stat_tiles: statistics partials per image (= boxes) of that variant. */
 int mis_conv2d_wino_select(int N, int Cin, int Cout, int H, int W);
 long long mis_conv2d_wino_stat_tiles(int H, int W, int variant);
 int mis_conv2d_wino_kernel_name(int variant, char* name, int name_len);
 int mis_conv2d_wino_fwd(const float* x, long long x_bs, const float* wt, const float* bias, float* y, long long y_bs,
                         int N, int Cin, int Cout, int H, int W, float* stat, long long stat_sc, long long stat_sn,
                         int variant, mis_stream_t stream);
-/* ... and its weight gradient (csrc/conv_wino2d_wgrad.hip): dw[Cout][Cin][9], deterministic; _select: variant or -1 */
+/* ... and its weight gradient (csrc/conv_wino2d_wgrad.hip): dw[Cout][Cin][9], deterministic; _select: 0 / 1 = stages of
+ * 8 x 16 pixels (H % 8, W % 16), 2 / 3 = stages of 4 x 32 pixels (H % 4, W % 32; preferred), odd = two blocks of 16 output
+ * channels per workgroup, -1 = use mis_conv_wgrad */
 int mis_conv2d_wino_wgrad_select(int N, int Cin, int Cout, int H, int W);
 long long mis_conv2d_wino_wgrad_workspace_bytes(int N, int Cin, int Cout, int H, int W, int variant);
 int mis_conv2d_wino_wgrad(const float* x, long long x_bs, const float* dy, long long dy_bs, float* dw, float* workspace,
