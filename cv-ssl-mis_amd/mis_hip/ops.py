@@ -211,7 +211,7 @@ WINO2D = 10       # ids >= WINO2D: variant id - WINO2D of the 2-D kernels (conv_
 # 1x1x1 convolutions of small volumes with many channels (the space-to-depth form of V-Net's deep kernel-2 / stride-2 layers):
 # batched GEMM instead of the spatially tiled direct kernel (conv1x1_gemm.hip).  MIS_CONV1X1_GEMM=0 switches it off
 CONV1X1_GEMM = _os.environ.get("MIS_CONV1X1_GEMM", "1") != "0"
-CONV1X1_GEMM_MAX_S = 4096
+CONV1X1_GEMM_MAX_S = int(_os.environ.get("MIS_CONV1X1_GEMM_MAX_S", "4096"))
 
 
 def conv1x1_gemm_eligible(x, y, cin, cout):

@@ -37,5 +37,7 @@ for H, nH, shift in ((56, 3, 0), (56, 3, 3), (28, 6, 3), (14, 12, 3), (7, 24, 0)
     tb = timeit(lambda: tops.window_attention_bwd(qkv, dout, dqkv, table, dtable, B, H, H, nH, shift, scale))
     units = B * (H // 7) ** 2 * nH
     fl = units * 2 * 2 * 49 * 49 * 32
-    print(f"H={H:3d} nH={nH:2d} shift={shift} units={units:6d}  fwd {tf:8.1f} us ({fl / tf / 1e6:6.2f} TF alg)   "
-          f"bwd {tb:8.1f} us ({2.5 * fl / tb / 1e6:6.2f} TF alg)")
+    # HBM floors at 5 TB/s: forward reads qkv, writes out; backward reads qkv and d(out), writes d(qkv)
+    bf, bb = (M * 4 * C) * 4 / 5e6, (M * 7 * C) * 4 / 5e6
+    print(f"H={H:3d} nH={nH:2d} shift={shift} units={units:6d}  fwd {tf:8.1f} us ({fl / tf / 1e6:6.2f} TF alg, {tf / bf:.2f}x its HBM floor)   "
+          f"bwd {tb:8.1f} us ({2.5 * fl / tb / 1e6:6.2f} TF alg, {tb / bb:.2f}x its HBM floor)")
