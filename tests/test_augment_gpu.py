@@ -129,3 +129,45 @@ def test_two_stream_loader_feeds_a_training_step():
     assert n == 9
     losses = tr.losses()
     assert all(np.isfinite(v) for v in losses.values())
+
+
+import os  # noqa: E402
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def test_random_generator_matches_the_reference_class():
+    """aug2d.npz: pixels produced by the REAL dataloaders.dataset.RandomGenerator (code/dataloaders/dataset.py:406-425) on
+    seeded slices (oracle/gen_golden_io.py); the device pipeline must give the same bytes and leave both host generators
+    where the reference leaves them."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(GOLD), "..", "oracle"))
+    from dataloaders.dataset import DeviceSlicePool, RandomGenerator, augment_batch
+    from oracle.gen_golden_io import AUG2D, aug2d_slices
+    g = np.load(os.path.join(GOLD, "aug2d.npz"))
+    slices = aug2d_slices()
+    assert abs(sum(float(s[0].astype(np.float64).sum()) for s in slices) - float(g["input_sum"])) < 1e-9
+    pool = DeviceSlicePool(slices)
+    for c, size in enumerate(AUG2D["out"]):
+        random.seed(500 + c), np.random.seed(600 + c)
+        image, label = augment_batch(pool, list(range(len(slices))), RandomGenerator(size))
+        tail = (random.random(), int(np.random.randint(1 << 30)))
+        assert np.array_equal(image.cpu().numpy(), g[f"image{c}"])
+        assert np.array_equal(label.cpu().numpy(), g[f"label{c}"])
+        assert tail == (float(g[f"tail_random{c}"]), int(g[f"tail_np{c}"]))
+
+
+def test_rot_flip_crop_matches_the_reference_transforms():
+    """aug3d.npz: the REAL RandomRotFlip -> RandomCrop -> ToTensor chain of code/dataloaders/brats2019.py (:134-147, :84-131,
+    :196-208; order of train_mean_teacher_3D.py:102-106), including volumes smaller than the patch."""
+    from dataloaders.brats2019 import DeviceVolumePool, RandomRotFlipCrop, crop_batch
+    from oracle.gen_golden_io import aug3d_volumes
+    g = np.load(os.path.join(GOLD, "aug3d.npz"))
+    vols, idx = aug3d_volumes()
+    assert idx == [int(i) for i in g["idx"]]
+    pool = DeviceVolumePool(vols)
+    np.random.seed(700)
+    image, label = crop_batch(pool, idx, RandomRotFlipCrop(tuple(int(v) for v in g["patch"])))
+    assert int(np.random.randint(1 << 30)) == int(g["tail_np"])
+    assert np.array_equal(image.cpu().numpy(), g["image"])
+    assert np.array_equal(label.cpu().numpy().astype(np.uint8), g["label"]) and label.dtype == torch.int64

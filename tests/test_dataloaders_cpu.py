@@ -104,3 +104,47 @@ def test_base_datasets_read_npz_cases(tmp_path):
     (b / "train.txt").write_text("case_a,extra\n")
     ds = BraTS2019(base_dir=str(b), split="train")
     assert len(ds) == 1 and ds[0]["label"].dtype == np.uint8 and ds[0]["image"].shape == (4, 5, 6)
+
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def test_two_stream_sampler_matches_the_reference_class():
+    """sampler.npz: index streams of the REAL TwoStreamBatchSampler (code/dataloaders/dataset.py:247-294 and its
+    brats2019.py twin) over several epochs, and where they leave np.random (oracle/gen_golden_io.py)."""
+    from dataloaders import brats2019, dataset
+    g = np.load(os.path.join(GOLD, "sampler.npz"))
+    for c in range(int(g["cases"])):
+        primary, secondary, batch, sbs, seed, epochs = (int(v) for v in g[f"cfg{c}"])
+        prim, sec = list(range(primary)), list(range(primary, primary + secondary))
+        for mod in (dataset, brats2019):
+            s = mod.TwoStreamBatchSampler(prim, sec, batch, sbs)
+            np.random.seed(seed)
+            got = np.stack([np.array(b) for _ in range(epochs) for b in s])
+            assert len(s) == int(g[f"len{c}"])
+            assert np.array_equal(got, g[f"batches{c}"])
+            assert int(np.random.randint(1 << 30)) == int(g[f"tail_np{c}"])
+
+
+def test_oracle_augmentations_match_the_reference_goldens():
+    """oracle/augment.py against the pixels of the REAL RandomGenerator / RandomRotFlip + RandomCrop + ToTensor
+    (aug2d.npz, aug3d.npz): the restatement the GPU tests sweep with is pinned to the reference itself."""
+    sys.path.insert(0, ROOT)
+    from oracle.augment import random_generator, rot_flip_crop
+    from oracle.gen_golden_io import AUG2D, aug2d_slices, aug3d_volumes
+    g = np.load(os.path.join(GOLD, "aug2d.npz"))
+    slices = aug2d_slices()
+    for c, size in enumerate(AUG2D["out"]):
+        random.seed(500 + c), np.random.seed(600 + c)
+        for n, (img, lab) in enumerate(slices):
+            oi, ol, draws = random_generator(img, lab, size)
+            assert np.array_equal(oi, g[f"image{c}"][n]) and np.array_equal(ol, g[f"label{c}"][n])
+            assert draws[0] == int(g[f"modes{c}"][n])
+        assert (random.random(), int(np.random.randint(1 << 30))) == (float(g[f"tail_random{c}"]), int(g[f"tail_np{c}"]))
+    g3 = np.load(os.path.join(GOLD, "aug3d.npz"))
+    vols, idx = aug3d_volumes()
+    np.random.seed(700)
+    for n, i in enumerate(idx):
+        oi, ol = rot_flip_crop(vols[i][0], vols[i][1], tuple(int(v) for v in g3["patch"]))
+        assert np.array_equal(oi, g3["image"][n]) and np.array_equal(ol.astype(np.uint8), g3["label"][n])
+    assert int(np.random.randint(1 << 30)) == int(g3["tail_np"])
