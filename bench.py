@@ -264,8 +264,11 @@ def run_workload(name, args, rank, world, kernel_events=True):
         if not stub:
             torch.cuda.synchronize()
 
+    enqueue = []
+
     def timed(steps):
-        """`steps` steps between barrier + device sync on both sides; this rank's seconds."""
+        """`steps` steps between barrier + device sync on both sides; this rank's seconds.  The host's share -- the time
+        the Python loop needs to ENQUEUE the steps (no wait for the device inside it) -- is kept in `enqueue`."""
         sync()
         if _dist_on(world):
             tdist.barrier()
@@ -273,6 +276,7 @@ def run_workload(name, args, rank, world, kernel_events=True):
         t0 = time.perf_counter()
         for _ in range(steps):
             tr.step(vol, lab)
+        enqueue.append((time.perf_counter() - t0, steps))
         sync()
         if _dist_on(world):
             tdist.barrier()
@@ -287,6 +291,7 @@ def run_workload(name, args, rank, world, kernel_events=True):
     for _ in range(args.warmup):
         tr.step(vol, lab)
     dt_local = timed(args.steps)
+    host_enqueue_ms = enqueue[-1][0] / enqueue[-1][1] * 1e3
     dt, per_rank = dt_local, [dt_local]
     if _dist_on(world):
         t = torch.tensor([dt_local], device=dev, dtype=torch.float64)
@@ -322,11 +327,12 @@ def run_workload(name, args, rank, world, kernel_events=True):
     roofline = None
     if prof:
         per = {}
-        for kname, flops, e0, e1 in prof:
-            d = per.setdefault(kname, [0.0, 0.0, 0])
+        for kname, flops, e0, e1, nbytes in prof:
+            d = per.setdefault(kname, [0.0, 0.0, 0, 0.0])
             d[0] += flops
             d[1] += e0.elapsed_time(e1) * 1e-3
             d[2] += 1
+            d[3] += nbytes
         def reduction(k):
             """Winograd F(2x2x2, 3x3x3) / F(2x2, 3x3): 64 (16) multiplies per 2x2x2 (2x2) outputs instead of 216 (36)."""
             return (3.375 if k.startswith(("wino_fwd_kernel", "wino_wgrad_")) else
@@ -339,11 +345,11 @@ def run_workload(name, args, rank, world, kernel_events=True):
         red = reduction(dom)
         alg_tf = per[dom][0] / per[dom][1] / 1e12           # direct-convolution (algorithmic) flops over time
         achieved = alg_tf / red                             # flops the matrix pipe executes over time: <= peak
-        # HBM bytes per launch need the PMC counters (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes,
-        # scripts/pmc_traffic.py): they cannot be read from inside this process, so `traffic` of THIS run is null; the
-        # figure of the last committed PMC pass of this same command is quoted beside it, labelled as such
+        # HBM bytes per launch come from the PMC counters (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes): main()
+        # re-executes this command under rocprofv3 for them and fills `traffic` (inrun_traffic); the figure of the last
+        # committed PMC pass stays beside it, labelled as such
         traffic_prof = None
-        for rnd in ("r04", "r03", "r02", "r01"):
+        for rnd in ("r05", "r04", "r03", "r02", "r01"):
             tfile = os.path.join(ROOT, "profiles", f"{rnd}_{name}_pmc_traffic.json")
             if os.path.exists(tfile):
                 with open(tfile) as f:
@@ -364,6 +370,7 @@ def run_workload(name, args, rank, world, kernel_events=True):
                         traffic=None, traffic_from_profiles=traffic_prof,
                         launches=per[dom][2], avg_launch_ms=round(per[dom][1] / per[dom][2] * 1e3, 4),
                         algorithmic_flops_per_launch_avg=per[dom][0] / per[dom][2],
+                        algorithmic_bytes_per_launch_avg=per[dom][3] / per[dom][2],
                         executed_flops_per_launch_avg=per[dom][0] / per[dom][2] / red,
                         family=dict(kernel="all event-timed MFMA launches (wino*_fwd_kernel<*> / conv_fwd_kernel<*> forward + "
                                            "data gradient, wino*_wgrad_kernel<*> / conv_wgrad_kernel<*> weight gradient; "
@@ -390,8 +397,11 @@ def run_workload(name, args, rank, world, kernel_events=True):
         exec_frac = fam_exec / serial_steps / step_s / (PEAK_FP32_MFMA_TFLOPS * 1e12)
         roofline["executed_step_flops"] = fam_exec / serial_steps
         roofline["executed_step_frac"] = round(exec_frac, 4)
-    res = dict(value=round(shape[0] * world * args.steps / dt, 3), unit=UNIT.get(name, "images/s"),
+    grad_bytes = [] if stub else [int(m.flat_param.numel()) * 4 for m in
+                                  (getattr(tr, a, None) for a in ("model", "model1", "model2")) if m is not None]
+    res = dict(value=round(shape[0] * world * args.steps / dt, 3), unit=UNIT.get(name, "images/s"), grad_bytes=grad_bytes,
                ms_per_step=round(step_s * 1e3, 3), step_flop_frac=round(step_frac, 4),
+               host_enqueue_ms_per_step=round(host_enqueue_ms, 3),
                executed_step_frac=None if exec_frac is None else round(exec_frac, 4), roofline=roofline,
                losses={k: round(v, 6) for k, v in losses.items()},
                per_rank_ms_per_step=[round(t / args.steps * 1e3, 3) for t in per_rank], distributed=dist_info)
@@ -455,6 +465,18 @@ def _distributed_checks(tr, timed, args, rank, world, dev, stub, dt_overlap):
     return out
 
 
+def _predicted_exchange(res, world):
+    """The exchange MODEL of mis_hip/dist.py for this workload's gradient buffers, at the run's world size (at N = 1: for
+    8 GPUs, the node the scaling run uses), with the backward time it would have to hide in."""
+    try:
+        from mis_hip import dist as _mdist
+        pred = _mdist.predict_exchange(res.get("grad_bytes") or [], world if world > 1 else 8)
+        pred["step_ms_without_exchange"] = res["ms_per_step"] if world == 1 else None
+        return pred
+    except Exception as e:      # a model line must never fail a measurement
+        return {"error": f"{type(e).__name__}: {e}"[:200]}
+
+
 # ------------------------------------------------------------------------------------------------ CPU baseline
 def _physical_cores():
     try:
@@ -477,11 +499,12 @@ def _physical_cores():
     return os.cpu_count() or 1
 
 
-def cpu_baseline(kind, wl, timed=3, warm=1, budget_s=150.0):
+def cpu_baseline(kind, wl, timed=5, warm=2, budget_s=150.0, cands=(16, 32, 64)):
     """The oracle step (reference arithmetic on stock torch CPU ops, dropout + noise active) on this host's cores.
-    ``torch.set_num_threads`` is swept over {8,16,32,64,physical cores} on the reduced batch ``wl["cpu_sample"]`` of the
-    same geometry (1 warm-up + 1 timed step each); the best count then times the reduced batch (median of 3) and the
-    FULL batch of the GPU line (``warm`` + ``timed`` steps, median) -- ``value`` is the full-batch figure."""
+    ``torch.set_num_threads`` is swept over ``cands`` on the reduced batch ``wl["cpu_sample"]`` of the same geometry
+    (1 warm-up + 1 timed step each; 8 and the physical core count lost every sweep of rounds 2-4 and are no longer
+    tried); the best count then times the FULL batch of the GPU line: ``warm`` warm-up + ``timed`` timed steps
+    (2 + >= 5), median -- ``value`` is that full-batch figure."""
     import torch
     from oracle.nets import OracleUNet2D, OracleUNet3D, OracleVNet
     from oracle.step import mean_teacher_step
@@ -524,7 +547,7 @@ def cpu_baseline(kind, wl, timed=3, warm=1, budget_s=150.0):
     small, full = make(Bs, Ls), make(Bf, Lf)
     logical, physical = os.cpu_count() or 1, _physical_cores()
     default_threads = torch.get_num_threads()
-    cands = sorted({n for n in (8, 16, 32, 64, physical) if 1 <= n <= logical})
+    cands = sorted({n for n in cands if 1 <= n <= logical}) or [min(logical, 16)]
     sweep, t_start = {}, time.perf_counter()
     for n in cands:
         torch.set_num_threads(n)
@@ -534,14 +557,15 @@ def cpu_baseline(kind, wl, timed=3, warm=1, budget_s=150.0):
             break
     best = min(sweep, key=sweep.get)
     torch.set_num_threads(best)
-    ts = sorted(small() for _ in range(3))[1]
+    ts = sweep[best]
     for _ in range(warm):
         full()
     times = sorted(full() for _ in range(timed))
     t = times[len(times) // 2]
     torch.set_num_threads(default_threads)
     sp = "x".join(map(str, wl["shape"][2:]))
-    return dict(value=Bf / t, unit=UNIT.get(kind, "images/s"), cores=best, kind="port",
+    return dict(value=Bf / t, unit=UNIT.get(kind, "images/s"), cores=best, kind="port", warmup_steps=warm, timed_steps=timed,
+                s_per_step_all=[round(x, 3) for x in times],
                 host=dict(logical_cpus=logical, physical_cores=physical),
                 thread_sweep_s_per_step={str(k): round(v, 3) for k, v in sweep.items()},
                 reduced_batch=dict(batch=f"{Ls}+{Bs - Ls}", value=Bs / ts, s_per_step=round(ts, 3)),
@@ -549,6 +573,75 @@ def cpu_baseline(kind, wl, timed=3, warm=1, budget_s=150.0):
                        f"{timed} timed steps, median {t:.3f} s/step, at {best} threads (torch.set_num_threads swept over "
                        f"{sorted(sweep)} on the reduced batch {Ls}+{Bs - Ls}: {ts:.3f} s/step there), torch "
                        f"{torch.__version__} CPU")
+
+
+# ------------------------------------------------------------------------------------------------ in-run HBM traffic
+def _short_kernel_name(name):
+    """rocprofv3's kernel name -> the short form ops.py / the *_kernel_name functions use (scripts/pmc_traffic.py)."""
+    import re
+    n = re.sub(r"\(anonymous namespace\)::", "", name)
+    n = re.sub(r"^void ", "", n)
+    n = re.sub(r"\(.*$", "", n)
+    return n.replace(" >", ">").strip()
+
+
+def inrun_traffic(workload, dom, alg_bytes, budget_s=90.0):
+    """HBM bytes per launch of the dominant kernel from the PMC counters, collected BY THIS RUN: bench.py re-executes
+    itself for 1 warm-up + 2 steps (side streams off) under ``rocprofv3 --kernel-trace --pmc FETCH_SIZE`` and again
+    under ``--pmc WRITE_SIZE`` (the two counters do not fit one pass; no other trace domain is enabled), as
+    MI355X_MICROARCH.md "HBM" prescribes: both counters are in KiB; on gfx950 FETCH_SIZE tallies the 128-byte requests
+    of wide coalesced reads at 64 bytes, so read bytes = FETCH_SIZE x 1024 x 2; WRITE_SIZE x 1024 at face value.
+    Bounded by ``budget_s`` and failure-tolerant: returns (dict | None, reason | None)."""
+    import csv
+    import glob
+    import shutil
+    import tempfile
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if exe is None:
+        return None, "rocprofv3 is not on PATH"
+    t_start = time.perf_counter()
+    tmp = tempfile.mkdtemp(prefix="mis_bench_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    want = dom.replace(" >", ">")
+    got = {}
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            left = budget_s - (time.perf_counter() - t_start)
+            if left < 20:
+                return None, f"time budget ({budget_s:.0f} s) spent before the {counter} pass"
+            out = os.path.join(tmp, counter)
+            cmd = [exe, "--pmc", counter, "--kernel-trace", "-d", out, "-o", "pmc", "--output-format", "csv", "--",
+                   sys.executable, os.path.abspath(__file__), "--workload", workload, "--serial", "--steps", "2",
+                   "--warmup", "1", "--no-cpu-baseline", "--no-others", "--no-kernel-events", "--no-traffic"]
+            try:
+                p = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True,
+                                   errors="replace", timeout=left)
+            except subprocess.TimeoutExpired:
+                return None, f"the {counter} pass exceeded the time budget ({budget_s:.0f} s for both passes)"
+            files = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
+            if p.returncode != 0 or not files:
+                return None, f"the {counter} pass failed (exit {p.returncode}): " + " | ".join(_stderr_digest(p.stderr, 4))[:400]
+            n = tot = 0
+            for fn in files:
+                with open(fn, newline="") as f:
+                    for row in csv.DictReader(f):
+                        if row.get("Counter_Name") == counter and _short_kernel_name(row["Kernel_Name"]) == want:
+                            n += 1
+                            tot += float(row["Counter_Value"])
+            if n == 0:
+                return None, f"kernel {dom!r} has no {counter} rows in the counter collection"
+            got[counter] = (n, tot)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    rd = got["FETCH_SIZE"][1] * 1024 * 2 / got["FETCH_SIZE"][0]
+    wr = got["WRITE_SIZE"][1] * 1024 / got["WRITE_SIZE"][0]
+    return dict(hbm_bytes_per_launch=round(rd + wr), read_bytes_per_launch=round(rd), write_bytes_per_launch=round(wr),
+                launches_sampled=got["FETCH_SIZE"][0], algorithmic_bytes_per_launch=round(alg_bytes),
+                over_algorithmic=round((rd + wr) / alg_bytes, 3) if alg_bytes else None,
+                method="this run: bench.py re-executed for 1 warm-up + 2 serial steps under rocprofv3 --kernel-trace --pmc "
+                       "FETCH_SIZE, then --pmc WRITE_SIZE (separate passes); read = FETCH_SIZE KiB x 1024 x 2 (gfx950 "
+                       "half-count of wide reads), written = WRITE_SIZE KiB x 1024; averaged over the kernel's launches",
+                seconds=round(time.perf_counter() - t_start, 1)), None
 
 
 # ------------------------------------------------------------------------------------------------ main
@@ -561,6 +654,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-others", action="store_true", help="skip the 'others' block (the other single-GPU configs)")
     ap.add_argument("--no-kernel-events", action="store_true", help="skip the per-launch HIP events")
+    ap.add_argument("--no-traffic", action="store_true",
+                    help="skip the two rocprofv3 PMC passes of this command that fill roofline.traffic (N=1 only)")
     ap.add_argument("--serial", action="store_true",
                     help="side streams off in the timed region too (MIS_TWO_STREAM=0 MIS_WGRAD_STREAM=0): every kernel has "
                          "the chip to itself -- what the rocprofv3 kernel statistics under profiles/ are collected with")
@@ -580,6 +675,13 @@ def main():
     backend = None
     if not args.stub:
         torch.cuda.set_device(local_rank)
+    affinity = None
+    if world > 1:
+        # this rank's threads next to its GPU's PCIe root: its share of the cores of the device's NUMA node (mis_hip/dist.py)
+        from mis_hip import dist as _mdist
+        local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+        ids = [] if args.stub else _mdist.device_bus_ids(min(local_world, torch.cuda.device_count()))
+        affinity = _mdist.pin_rank_to_numa(local_rank, local_world, ids)
     nccl_logs = None
     if _dist_on(world):
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -624,7 +726,10 @@ def main():
                        "teacher_forward": "side stream (beside the student forward)" if two_stream else "same stream",
                        "weight_gradients": "side stream (beside the data-gradient chain)" if wgrad_stream else "same stream"},
             "distributed": dict(res["distributed"] or {"world_size_seen": 1}, backend=backend,
-                                per_rank_ms_per_step=res["per_rank_ms_per_step"], max_ms_per_step=res["ms_per_step"]),
+                                per_rank_ms_per_step=res["per_rank_ms_per_step"], max_ms_per_step=res["ms_per_step"],
+                                affinity_rank0=affinity, predicted=_predicted_exchange(res, world)),
+            "host_enqueue_ms_per_step": res["host_enqueue_ms_per_step"],
+            "host_enqueue_frac": round(res["host_enqueue_ms_per_step"] / res["ms_per_step"], 3),
             "losses_last_step": res["losses"],
             "roofline": res["roofline"],
         }
@@ -641,6 +746,9 @@ def main():
             rf = r["roofline"] or {}
             others[name] = dict(workload=WORKLOADS[name]["config"], value=r["value"], unit=r["unit"],
                                 ms_per_step=r["ms_per_step"], steps=oargs.steps,
+                                host_enqueue_ms_per_step=r["host_enqueue_ms_per_step"],
+                                serial_ms_per_step=rf.get("serial_ms_per_step"),
+                                grad_bytes=r["grad_bytes"],
                                 executed_step_frac=r["executed_step_frac"],          # matrix-pipe flops executed: <= 1
                                 algorithmic_step_flop_frac=r["step_flop_frac"],      # direct-convolution flops: may exceed 1
                                 dominant_kernel=rf.get("kernel"), dominant_kernel_frac=rf.get("frac"),
@@ -657,11 +765,29 @@ def main():
             out["others"] = {"cross": dict(workload=WORKLOADS["cross"]["config"], value=r["value"], unit=r["unit"],
                                            ms_per_step=r["ms_per_step"], steps=oargs.steps, n_gpus=world,
                                            per_rank_ms_per_step=r["per_rank_ms_per_step"],
-                                           distributed=r["distributed"])}
+                                           host_enqueue_ms_per_step=r["host_enqueue_ms_per_step"],
+                                           distributed=dict(r["distributed"] or {},
+                                                            predicted=_predicted_exchange(r, world)))}
     if rank == 0:
-        if not _dist_on(world) and not args.stub and not args.no_cpu_baseline and wl["cpu_sample"] is not None:
+        single = not _dist_on(world) and not args.stub
+        if single and not args.no_traffic and not args.no_kernel_events and out["roofline"]:
+            # HBM bytes of the dominant kernel from the PMC counters, collected by re-executing this command (before the
+            # CPU baseline occupies the host's cores)
+            torch.cuda.synchronize()
+            torch.cuda.empty_cache()
+            rf = out["roofline"]
+            tr, why = inrun_traffic(args.workload, rf["kernel"], rf["algorithmic_bytes_per_launch_avg"])
+            rf["traffic"] = tr
+            if tr is None:
+                rf["traffic_unavailable"] = why
+        if single and not args.no_cpu_baseline and wl["cpu_sample"] is not None:
             out["cpu_baseline"] = cpu_baseline(args.workload, wl)
             out["gpu_over_cpu"] = round(out["value"] / out["cpu_baseline"]["value"], 2)
+            if "others" in out and "unet2d" in out["others"] and args.workload == "unet3d":
+                # the ACDC figure the north star asks for beside the BraTS one: the same oracle step on config 2's batch
+                o2 = out["others"]["unet2d"]
+                o2["cpu_baseline"] = cpu_baseline("unet2d", WORKLOADS["unet2d"], budget_s=60.0)
+                o2["gpu_over_cpu"] = round(o2["value"] / o2["cpu_baseline"]["value"], 2)
         print(json.dumps(out), flush=True)
     if _dist_on(world):
         torch.distributed.destroy_process_group()

@@ -21,6 +21,7 @@
 // share of a tile back to back and waits once, instead of ~10 serialised register-staged batches
 // (61 floats per lane per tile), and halo / channel padding is the descriptor's range check.
 // With NBUF = 2 the DMA of the next tile overlaps the MFMAs of the current one.
+#include <cstdio>
 #include "common.h"
 #include <stdlib.h>
 
@@ -421,11 +422,14 @@ int run(WgradArgs a, float* dw, long long ws_bytes, int accumulate, hipStream_t 
 #endif
 
 // mode 0: workspace query (returns floats through *out_ws), mode 1: run
+#define MIS_WG_STR2(...) #__VA_ARGS__
+#define MIS_WG_STR(...) MIS_WG_STR2(__VA_ARGS__)
 int dispatch(WgradArgs a, int kd, int kh, int kw, float* dw, long long ws_bytes, int accumulate,
-             hipStream_t stream, long long* out_ws) {
+             hipStream_t stream, long long* out_ws, const char** out_name = nullptr) {
 #define MIS_WG(...)                                                              \
     do {                                                                         \
         using C_ = WCfg<__VA_ARGS__>;                                            \
+        if (out_name) { *out_name = "conv_wgrad_kernel<WCfg<" MIS_WG_STR(__VA_ARGS__) "> >"; return MIS_OK; } \
         if (out_ws) { *out_ws = ws_floats<C_>(a) * 4; return MIS_OK; }           \
         return run<C_>(a, dw, ws_bytes, accumulate, stream);                     \
     } while (0)
@@ -483,6 +487,22 @@ extern "C" long long mis_conv_wgrad_workspace_bytes(int N, int Cin, int Cout, in
     long long out = 0;
     int st = dispatch(a, kd, kh, kw, nullptr, 0, 0, nullptr, &out);
     return st ? st : out;
+}
+
+// kernel mis_conv_wgrad launches for this geometry as rocprofv3 prints it (minus the anonymous-namespace prefix)
+extern "C" int mis_conv_wgrad_kernel_name(int N, int Cin, int Cout, int D, int H, int W, int kd, int kh, int kw, char* name,
+                                          int name_len) {
+    if (!name || name_len <= 0 || N <= 0 || Cin <= 0 || Cout <= 0 || D <= 0 || H <= 0 || W <= 0) return MIS_ERR_ARG;
+    if (mis_wgrad_cin1_eligible(N, Cin, Cout, D, H, W, kd, kh, kw)) {
+        snprintf(name, name_len, "wgrad_cin1_kernel<%d, false>", kd == 1 ? 1 : 3);
+        return MIS_OK;
+    }
+    WgradArgs a = make_args(nullptr, 0, nullptr, 0, nullptr, N, Cin, Cout, D, H, W);
+    const char* n = nullptr;
+    const int st = dispatch(a, kd, kh, kw, nullptr, 0, 0, nullptr, nullptr, &n);
+    if (st) return st;
+    snprintf(name, name_len, "%s", n);
+    return MIS_OK;
 }
 
 extern "C" int mis_conv_wgrad(const float* x, long long x_bs, const float* dy, long long dy_bs, float* dw,

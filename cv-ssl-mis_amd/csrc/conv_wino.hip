@@ -583,14 +583,10 @@ using WinoV3 = WinoCfg<3, 3, 6, 1, 1, 1, 1, 4, 1, 1>;
 
 // Contraction slices for a launch with too few (box, channel group) entries for the chip (the 6^3 level: 8 ... 128 entries of
 // 32 ... 64 chunks each; half batches at 12^3): the smallest count that brings the entries to >= 192, slices of an even
-// number >= 8 of chunks.  Variants 2 / 3 only (the levels where it happens); 1 = no split.
+// number >= 8 of chunks.  Variants 2 / 3 only (the levels where it happens); 1 = no split.  Chosen on the entry count alone.
 int wino_splits(int N, int Cin, int Cout, int D, int H, int W, int variant) {
     static const bool on = [] { const char* e = getenv("MIS_WINO_SPLIT"); return !(e && e[0] == '0'); }();
     if (!on || (variant != 2 && variant != 3)) return 1;
-    // variant 2 only on partly filled boxes (the 6^3 level): whole 8 x 8 x 8 boxes with few entries only occur at input sizes
-    // below the benchmarked 96^3 (the 8^3 level of a 64^3 input), and the GroupNorm fixture of that size sits on a
-    // discontinuity there (tests/test_parity_gpu.py, F64_GN) -- left on the arithmetic the goldens were judged with
-    if (variant == 2 && D % 8 == 0 && H % 8 == 0 && W % 8 == 0) return 1;
     const long long boxes = variant == 2 ? mis_cdiv(D, 8) * mis_cdiv(H, 8) * mis_cdiv(W, 8) : (long long)(D / 6) * (H / 6) * (W / 12);
     const long long entries = (long long)N * boxes * (Cout / 16);
     const int nst = (Cin + 3) / 4;

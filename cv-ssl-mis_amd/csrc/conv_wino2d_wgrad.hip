@@ -14,6 +14,7 @@
 // run under another's MFMAs.  x (haloed, 16 channels) and dy stages are double-buffered by LDS-DMA; the LDS image is
 // linear in (row, channel, 16-byte group).  XCD-aware interleaved stage order as in the 3-D kernel.  At the end G^T . G
 // (16 -> 9) in registers, waves summed through LDS, partials summed in a fixed order by a second kernel (deterministic).
+#include <cstdio>
 #include "common.h"
 #include "wino.h"
 #include <stdlib.h>
@@ -347,6 +348,17 @@ extern "C" int mis_conv2d_wino_wgrad_select(int N, int Cin, int Cout, int H, int
     if (wide && H % 4 == 0 && W % 32 == 0) return Cout > 16 ? 3 : 2;
     if (H % 8 || W % 16) return -1;
     return Cout > 16 ? 1 : 0;
+}
+
+// kernel a variant launches as rocprofv3 prints it (minus the anonymous-namespace prefix): bench.py keys its flop
+// attribution (the 2.25x Winograd factor) on this string
+extern "C" int mis_conv2d_wino_wgrad_kernel_name(int variant, char* name, int name_len) {
+    if (!name || name_len <= 0) return MIS_ERR_ARG;
+    static const char* const names[4] = {"wino2d_wgrad_kernel<Wg2Cfg<1, 4, 8> >", "wino2d_wgrad_kernel<Wg2Cfg<2, 4, 8> >",
+                                         "wino2d_wgrad_kernel<Wg2Cfg<1, 2, 16> >", "wino2d_wgrad_kernel<Wg2Cfg<2, 2, 16> >"};
+    if (variant < 0 || variant > 3) return MIS_ERR_UNSUPPORTED;
+    snprintf(name, name_len, "%s", names[variant]);
+    return MIS_OK;
 }
 
 extern "C" long long mis_conv2d_wino_wgrad_workspace_bytes(int N, int Cin, int Cout, int H, int W, int variant) {

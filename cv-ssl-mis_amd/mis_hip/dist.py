@@ -35,6 +35,144 @@ def sync_gradients(flat_grad, group=None):
     return 1.0 / w
 
 
+def default_bucket_bytes(grad_bytes, bucket_bytes=None):
+    """max(16 MiB, a quarter of the buffer) unless given / MIS_BUCKET_MB: at most ~4 collectives (+ the small tail) per
+    model and step."""
+    if bucket_bytes is None:
+        if "MIS_BUCKET_MB" in os.environ:
+            bucket_bytes = int(float(os.environ["MIS_BUCKET_MB"]) * (1 << 20))
+        else:
+            bucket_bytes = max(16 << 20, -(-int(grad_bytes) // 4))
+    return int(bucket_bytes)
+
+
+def bucket_layout(numel, esize, bucket_bytes):
+    """(lo, hi) element ranges of the all-reduce buckets, in the order they are issued (descending offsets): cut from
+    the END of the flat buffer (the part the backward finishes first), the first bucket takes the remainder; the bucket
+    at offset 0 is complete only when the backward is -- its all-reduce is the exposed one -- so it is kept small (2 MiB:
+    a latency-bound ring step) by splitting the remainder.  A pure function of the sizes: every rank cuts the same."""
+    n, per = int(numel), max(1, int(bucket_bytes) // int(esize))
+    cuts = list(range(n, 0, -per)) + [0]
+    buckets = [(cuts[i + 1], cuts[i]) for i in range(len(cuts) - 1)]
+    tail = max(1, (2 << 20) // int(esize))
+    lo, hi = buckets[-1]
+    if hi - lo > 2 * tail:
+        buckets[-1:] = [(lo + tail, hi), (lo, lo + tail)]
+    return buckets
+
+
+XGMI_LINK_GBPS = 153.0        # per direction-pair and link, 7 links per GPU (MI355X_MICROARCH.md / the task's figure)
+
+
+def predict_exchange(grad_bytes, world, bucket_bytes=None, link_gbps=XGMI_LINK_GBPS, latency_us=25.0):
+    """A MODEL (not a measurement) of the gradient exchange of one step at ``world`` GPUs of one node, to read the
+    driver's scaling numbers against.  ``grad_bytes``: flat gradient bytes of every model that is exchanged.  An
+    all-reduce of B bytes moves 2 (N-1)/N B per GPU; xGMI is a point-to-point mesh (N-1 peers, one ~153 GB/s link each):
+    ``ring`` = one ring, every hop on ONE link (per-link bound); ``direct`` = the N-1 peers' links used at once
+    (reduce-scatter + all-gather straight to the peers).  Each collective adds ``latency_us`` x 2 (N-1) ring steps
+    (``ring``) or x 2 (``direct``).  ``exposed``: only the 2 MiB tail bucket of every model cannot hide behind the
+    backward; everything else overlaps if total <= the backward's duration."""
+    world = int(world)
+    out = dict(world=world, link_GBps=link_gbps, latency_us_per_step=latency_us, models=[],
+               model="all-reduce bytes per GPU = 2 (N-1)/N x bucket; ring: / one link; direct: / (N-1) links; + latency per "
+                     "ring step; a model, not a measurement")
+    if world < 2:
+        return out
+    f = 2.0 * (world - 1) / world
+    tot_ring = tot_direct = exp_ring = exp_direct = 0.0
+    for gb in grad_bytes:
+        lay = bucket_layout(int(gb) // 4, 4, default_bucket_bytes(gb, bucket_bytes))
+        sizes = [(hi - lo) * 4 for lo, hi in lay]
+        ring = [f * b / (link_gbps * 1e9) * 1e3 + 2 * (world - 1) * latency_us * 1e-3 for b in sizes]
+        direct = [f * b / ((world - 1) * link_gbps * 1e9) * 1e3 + 2 * latency_us * 1e-3 for b in sizes]
+        out["models"].append(dict(grad_bytes=int(gb), bucket_bytes=sizes, ring_ms=[round(t, 4) for t in ring],
+                                  direct_ms=[round(t, 4) for t in direct]))
+        tot_ring, tot_direct = tot_ring + sum(ring), tot_direct + sum(direct)
+        exp_ring, exp_direct = exp_ring + ring[-1], exp_direct + direct[-1]
+    out.update(total_ring_ms=round(tot_ring, 4), total_direct_ms=round(tot_direct, 4),
+               exposed_tail_ring_ms=round(exp_ring, 4), exposed_tail_direct_ms=round(exp_direct, 4))
+    return out
+
+
+def _parse_cpulist(text):
+    cpus = []
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        a, _, b = part.partition("-")
+        cpus += list(range(int(a), int(b or a) + 1))
+    return cpus
+
+
+def _numa_node_of(bus_id, sysfs):
+    if not bus_id:
+        return -1
+    bid = bus_id.lower()
+    if len(bid.split(":")) == 2:
+        bid = "0000:" + bid
+    try:
+        with open(os.path.join(sysfs, "bus/pci/devices", bid, "numa_node")) as f:
+            return int(f.read().strip())
+    except (OSError, ValueError):
+        return -1
+
+
+def device_bus_ids(n):
+    """PCI bus ids ("dddd:bb:dd.0") of HIP devices 0..n-1 as torch reports them, None where it does not."""
+    out = []
+    for i in range(n):
+        try:
+            p = torch.cuda.get_device_properties(i)
+            out.append("%04x:%02x:%02x.0" % (p.pci_domain_id, p.pci_bus_id, p.pci_device_id))
+        except Exception:
+            out.append(None)
+    return out
+
+
+def pin_rank_to_numa(local_rank, local_world, pci_bus_ids=None, sysfs="/sys", apply=True):
+    """CPU affinity of this rank := its share of the cores of the NUMA node its GPU hangs off (one process per GPU: the
+    launch thread, the c10d watchdog and the input pipeline stay next to the device's PCIe root; 8 Python processes
+    enqueue 300-700 launches per step each).  ``pci_bus_ids[i]`` = bus id of local rank i's GPU (``device_bus_ids``);
+    the node comes from ``<sysfs>/bus/pci/devices/<id>/numa_node``, its cores from
+    ``<sysfs>/devices/system/node/node<k>/cpulist``.  Ranks whose GPUs share a node split its cores evenly in local-rank
+    order -- every rank evaluates every rank's node, so the shares are disjoint without any communication.  Unknown node
+    (-1 / no sysfs entry / no bus id): the cores this process may run on are split evenly over ``local_world``.
+    MIS_PIN_NUMA=0 leaves the affinity alone.  Returns a dict for the log; never raises."""
+    local_rank, local_world = int(local_rank), max(1, int(local_world))
+    info = dict(local_rank=local_rank, local_world=local_world, numa_node=None, cpus=None, n_cpus=None, applied=False)
+    try:
+        allowed = sorted(os.sched_getaffinity(0))
+        ids = list(pci_bus_ids) if pci_bus_ids else []
+        ids += [None] * (local_world - len(ids))
+        nodes = [_numa_node_of(b, sysfs) for b in ids[:local_world]]
+        node = nodes[local_rank] if local_rank < len(nodes) else -1
+        info["pci_bus_id"], info["numa_node"] = ids[local_rank] if local_rank < len(ids) else None, node
+        pool = None
+        if node >= 0:
+            try:
+                with open(os.path.join(sysfs, "devices/system/node", f"node{node}", "cpulist")) as f:
+                    ok = set(allowed)
+                    pool = [c for c in _parse_cpulist(f.read()) if c in ok] or None
+            except (OSError, ValueError):
+                pool = None
+        if pool is not None:
+            sharers = [r for r in range(local_world) if nodes[r] == node]
+        else:
+            pool, sharers = allowed, list(range(local_world))
+        slot = sharers.index(local_rank) if local_rank in sharers else 0
+        per = max(1, len(pool) // len(sharers))
+        mine = pool[slot * per:(slot + 1) * per] or pool
+        info["sharers"], info["n_cpus"] = len(sharers), len(mine)
+        info["cpus"] = (f"{mine[0]}-{mine[-1]}" if mine == list(range(mine[0], mine[-1] + 1)) else
+                        ",".join(map(str, mine)))
+        if apply and os.environ.get("MIS_PIN_NUMA", "1") != "0":
+            os.sched_setaffinity(0, mine)
+            info["applied"] = True
+    except Exception as e:       # affinity is an optimisation: never fail a run over it
+        info["error"] = f"{type(e).__name__}: {e}"[:200]
+    return info
+
+
 class GradBucketer:
     """Overlap of the gradient exchange with the backward pass.
 
@@ -54,12 +192,7 @@ class GradBucketer:
     step plus the small tail bucket below.  MIS_BUCKET_MB overrides."""
 
     def __init__(self, flat_grad, group=None, bucket_bytes=None, defer_tail=False):
-        if bucket_bytes is None:
-            if "MIS_BUCKET_MB" in os.environ:
-                bucket_bytes = int(float(os.environ["MIS_BUCKET_MB"]) * (1 << 20))
-            else:       # at most ~4 collectives (+ the small tail) per model and step
-                bucket_bytes = max(16 << 20, -(-flat_grad.numel() * flat_grad.element_size() // 4))
-        bucket_bytes = int(bucket_bytes)
+        bucket_bytes = default_bucket_bytes(flat_grad.numel() * flat_grad.element_size(), bucket_bytes)
         if world_size(group) > 1:
             # the cut points must be the same on every rank (MIS_BUCKET_MB is a per-process environment variable): ranks
             # that disagree would issue collectives of different sizes and counts -- a hang or silently wrong sums
@@ -75,16 +208,7 @@ class GradBucketer:
         # does.  For a backward whose collectives are ENQUEUED before another network's (cross teaching: the side-stream
         # student): the in-order RCCL stream would otherwise hold the other network's early buckets behind this tail
         self.defer_tail = bool(defer_tail)
-        n, per = flat_grad.numel(), max(1, bucket_bytes // flat_grad.element_size())
-        # cut from the end (the part that finishes first); the first bucket takes the remainder
-        cuts = list(range(n, 0, -per)) + [0]
-        self.buckets = [(cuts[i + 1], cuts[i]) for i in range(len(cuts) - 1)]     # (lo, hi), descending
-        # the bucket at offset 0 is complete only when the backward is: its all-reduce is the exposed one.  Keep it small
-        # (2 MiB: a latency-bound ring step) by splitting the remainder
-        tail = max(1, (2 << 20) // flat_grad.element_size())
-        lo, hi = self.buckets[-1]
-        if hi - lo > 2 * tail:
-            self.buckets[-1:] = [(lo + tail, hi), (lo, lo + tail)]
+        self.buckets = bucket_layout(flat_grad.numel(), flat_grad.element_size(), bucket_bytes)
         self._next, self._works = 0, []
 
     def begin(self):

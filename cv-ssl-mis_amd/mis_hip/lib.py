@@ -69,6 +69,7 @@ PROTOTYPES = {
     "mis_conv2d_wino_kernel_name": (c_i, [c_i, ctypes.c_char_p, c_i]),
     "mis_conv2d_wino_fwd": (c_i, [c_p, c_ll, c_p, c_p, c_p, c_ll, c_i, c_i, c_i, c_i, c_i, c_p, c_ll, c_ll, c_i, c_p]),
     "mis_conv2d_wino_wgrad_select": (c_i, [c_i, c_i, c_i, c_i, c_i]),
+    "mis_conv2d_wino_wgrad_kernel_name": (c_i, [c_i, ctypes.c_char_p, c_i]),
     "mis_conv2d_wino_wgrad_workspace_bytes": (c_ll, [c_i, c_i, c_i, c_i, c_i, c_i]),
     "mis_conv2d_wino_wgrad": (c_i, [c_p, c_ll, c_p, c_ll, c_p, c_p, c_ll, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
     "mis_conv3d_wino_wgrad_select": (c_i, [c_i, c_i, c_i, c_i, c_i, c_i]),
@@ -76,6 +77,7 @@ PROTOTYPES = {
     "mis_conv3d_wino_wgrad_workspace_bytes": (c_ll, [c_i, c_i, c_i, c_i, c_i, c_i, c_i]),
     "mis_conv3d_wino_wgrad": (c_i, [c_p, c_ll, c_p, c_ll, c_p, c_p, c_ll, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
     "mis_conv_wgrad_workspace_bytes": (c_ll, [c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i]),
+    "mis_conv_wgrad_kernel_name": (c_i, [c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, ctypes.c_char_p, c_i]),
     "mis_conv_wgrad": (c_i, [c_p, c_ll, c_p, c_ll, c_p, c_p, c_ll, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i,
                              c_i, c_p]),
     "mis_norm_workspace_bytes": (c_ll, [c_i, c_i, c_ll, c_i]),

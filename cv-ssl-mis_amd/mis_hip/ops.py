@@ -359,11 +359,13 @@ def conv_fwd(x, wp, bias, y, Cin, Cout, ksize, stat=None, wino=-1):
             L.mis_conv3d_wino_kernel_name(wino, buf, 128)
         else:
             L.mis_conv_fwd_kernel_name(N, Cin, Cout, D, H, W, kd, kh, kw, buf, 128)
-        prof.append((buf.value.decode(), 2.0 * N * Cout * Cin * kd * kh * kw * S, e0, e1))
+        prof.append((buf.value.decode(), 2.0 * N * Cout * Cin * kd * kh * kw * S, e0, e1,
+                     4.0 * (N * (Cin + Cout) * S + Cout * Cin * kd * kh * kw)))
 
 
 # When set to a list, conv_fwd brackets every launch with HIP events on the launch stream and appends
-# (kernel name, algorithmic FLOPs, start event, end event): bench.py's live roofline measurement.
+# (kernel name, algorithmic FLOPs, start event, end event, algorithmic bytes = operands read once + result written once):
+# bench.py's live roofline measurement.
 PROFILE = None
 
 
@@ -390,7 +392,8 @@ def conv_dgrad_norm(dy, wpd, da, Cin, Cout, xn, mean, slope, part, wino):
         e1.record()
         buf = _ctypes.create_string_buffer(128)
         L.mis_conv3d_wino_kernel_name(wino, buf, 128)
-        prof.append((buf.value.decode().replace(", false>", ", true>"), 2.0 * N * Cout * Cin * 27 * S, e0, e1))
+        prof.append((buf.value.decode().replace(", false>", ", true>"), 2.0 * N * Cout * Cin * 27 * S, e0, e1,
+                     4.0 * (N * (Cin + 2 * Cout) * S + Cout * Cin * 27)))     # + the norm input it reads
     return tiles
 
 
@@ -420,7 +423,8 @@ def conv_wgrad(x, dy, dw, ksize, accumulate=False):
     name = _conv_wgrad_launch(L, x, dy, dw, N, Cin, Cout, D, H, W, xbs, dbs, kd, kh, kw, accumulate)
     if prof is not None:       # bench.py's live roofline: the weight gradients count towards the executed step flops
         e1.record()
-        prof.append((name, 2.0 * N * Cout * Cin * kd * kh * kw * S, e0, e1))
+        prof.append((name, 2.0 * N * Cout * Cin * kd * kh * kw * S, e0, e1,
+                     4.0 * (N * (Cin + Cout) * S + Cout * Cin * kd * kh * kw)))
 
 
 def _conv_wgrad_launch(L, x, dy, dw, N, Cin, Cout, D, H, W, xbs, dbs, kd, kh, kw, accumulate):
@@ -446,7 +450,9 @@ def _conv_wgrad_launch(L, x, dy, dw, N, Cin, Cout, D, H, W, xbs, dbs, kd, kh, kw
         ws = scratch(nb, "wgrad")
         _l.check(L.mis_conv2d_wino_wgrad(_l.ptr(x), xbs, _l.ptr(dy), dbs, _l.ptr(dw), _l.ptr(ws), ws.numel(), N, Cin, Cout,
                                          H, W, int(accumulate), wino2, _l.stream_ptr()), "mis_conv2d_wino_wgrad")
-        return "wino2d_wgrad_kernel<Wg2Cfg<%d, %s> >" % (wino2 % 2 + 1, "2, 16" if wino2 >= 2 else "4, 8")
+        buf = _ctypes.create_string_buffer(96)
+        _l.check(L.mis_conv2d_wino_wgrad_kernel_name(wino2, buf, 96), "mis_conv2d_wino_wgrad_kernel_name")
+        return buf.value.decode()
     nb = L.mis_conv_wgrad_workspace_bytes(N, Cin, Cout, D, H, W, kd, kh, kw)
     if nb < 0:
         _l.check(nb, "mis_conv_wgrad_workspace_bytes")
@@ -454,7 +460,9 @@ def _conv_wgrad_launch(L, x, dy, dw, N, Cin, Cout, D, H, W, xbs, dbs, kd, kh, kw
     _tag(f"direct_wgrad:k{kd}{kh}{kw}@{W}")
     _l.check(L.mis_conv_wgrad(_l.ptr(x), xbs, _l.ptr(dy), dbs, _l.ptr(dw), _l.ptr(ws), ws.numel(), N, Cin, Cout,
                               D, H, W, kd, kh, kw, int(accumulate), _l.stream_ptr()), "mis_conv_wgrad")
-    return f"conv_wgrad_kernel<k{kd}{kh}{kw}>"
+    buf = _ctypes.create_string_buffer(96)
+    _l.check(L.mis_conv_wgrad_kernel_name(N, Cin, Cout, D, H, W, kd, kh, kw, buf, 96), "mis_conv_wgrad_kernel_name")
+    return buf.value.decode()
 
 
 # ------------------------------------------------------- norm + act + dropout

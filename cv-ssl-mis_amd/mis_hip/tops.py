@@ -63,7 +63,7 @@ def gemm(A, B, C, bias=None, trans=False, accumulate=False):
             name = _tn_name(L, A, lda, B, ldb, C, ldc, M, N, K)
         else:
             name = _nt_name(L, M, N, K, 0)
-        prof.append((name, 2.0 * M * N * K, e0, e1))
+        prof.append((name, 2.0 * M * N * K, e0, e1, 4.0 * (M * K + N * K + M * N)))
 
 
 def gemm_dw(dy, x, dW, db, accumulate=False):
@@ -83,7 +83,7 @@ def gemm_dw(dy, x, dW, db, accumulate=False):
                            _l.ptr(ws), ws.numel() if ws is not None else 0, _l.stream_ptr()), "mis_gemm_dw")
     if prof is not None:
         e1.record()
-        prof.append((_tn_name(L, dy, lddy, x, ldx, dW, ldw, M, N, K), 2.0 * M * N * K, e0, e1))
+        prof.append((_tn_name(L, dy, lddy, x, ldx, dW, ldw, M, N, K), 2.0 * M * N * K, e0, e1, 4.0 * (M * K + N * K + M * N)))
 
 
 EP_GELU_FWD, EP_GELU_BWD, EP_RESIDUAL = 1, 2, 3
@@ -115,7 +115,7 @@ def gemm_ex(A, B, C, epilogue, bias=None, E1=None, C2=None, rowscale=None, rows_
     if prof is not None:
         e1.record()
         # (split-K shapes run the plain instantiation + the reduce kernel; the label keeps the requested epilogue)
-        prof.append((_nt_name(L, M, N, K, epilogue), 2.0 * M * N * K, e0, e1))
+        prof.append((_nt_name(L, M, N, K, epilogue), 2.0 * M * N * K, e0, e1, 4.0 * (M * K + N * K + M * N)))
     return True
 
 
@@ -142,7 +142,7 @@ def gemm_expand(x, w, out, B, H, W, P, c):
     _l.check(st, "mis_gemm_expand")
     if prof is not None:
         e1.record()
-        prof.append((_nt_name(L, M, N, K, 0), 2.0 * M * N * K, e0, e1))
+        prof.append((_nt_name(L, M, N, K, 0), 2.0 * M * N * K, e0, e1, 4.0 * (M * K + N * K + M * N)))
     return True
 
 

@@ -107,6 +107,13 @@ def setup_distributed():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local_rank)
+    if world > 1:
+        # this rank's threads next to its GPU's PCIe root: its share of the cores of the device's NUMA node
+        from . import dist as _dist
+        local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+        pin = _dist.pin_rank_to_numa(local_rank, local_world, _dist.device_bus_ids(min(local_world,
+                                                                                         torch.cuda.device_count())))
+        logging.info("rank %d: CPU affinity %s", rank, pin)
     if world > 1 and not torch.distributed.is_initialized():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", local_rank))

@@ -137,6 +137,8 @@ int mis_conv2d_wino_fwd(const float* x, long long x_bs, const float* wt, const f
  * 8 x 16 pixels (H % 8, W % 16), 2 / 3 = stages of 4 x 32 pixels (H % 4, W % 32; preferred), odd = two blocks of 16 output
  * channels per workgroup, -1 = use mis_conv_wgrad */
 int mis_conv2d_wino_wgrad_select(int N, int Cin, int Cout, int H, int W);
+/* the kernel a variant launches, as a profiler names it (bench.py's flop attribution keys on it) */
+int mis_conv2d_wino_wgrad_kernel_name(int variant, char* name, int name_len);
 long long mis_conv2d_wino_wgrad_workspace_bytes(int N, int Cin, int Cout, int H, int W, int variant);
 int mis_conv2d_wino_wgrad(const float* x, long long x_bs, const float* dy, long long dy_bs, float* dw, float* workspace,
                           long long workspace_bytes, int N, int Cin, int Cout, int H, int W, int accumulate, int variant,
@@ -152,6 +154,9 @@ int mis_conv3d_wino_wgrad(const float* x, long long x_bs, const float* dy, long 
                           long long workspace_bytes, int N, int Cin, int Cout, int D, int H, int W, int accumulate,
                           int variant, mis_stream_t stream);
 long long mis_conv_wgrad_workspace_bytes(int N, int Cin, int Cout, int D, int H, int W, int kd, int kh, int kw);
+/* the kernel mis_conv_wgrad launches for this geometry, as a profiler names it */
+int mis_conv_wgrad_kernel_name(int N, int Cin, int Cout, int D, int H, int W, int kd, int kh, int kw, char* name,
+                               int name_len);
 /* dw[Cout][Cin][taps] (+)= sum_{n,p} dy[n][co][p] * x[n][ci][p + tap - pad]  (autograd weight gradient) */
 int mis_conv_wgrad(const float* x, long long x_bs, const float* dy, long long dy_bs, float* dw, float* workspace,
                    long long workspace_bytes, int N, int Cin, int Cout, int D, int H, int W, int kd, int kh,

@@ -199,20 +199,62 @@ def reference_step(kind, model, ema_model, optimizer, volume, label, noise, iter
                 teacher_logits=ema_output.detach(), grads=grads)
 
 
-def reference_grads64(kind, cfg, sd0, tsd0, drop_s, drop_t, volume, label, noise, iter_num):
+def reference_grads64(kind, cfg, sd0, tsd0, drop_s, drop_t, volume, label, noise, iter_num, flips=0):
     """The same loop body with the reference modules in float64: measures the reference's own fp32
-    rounding noise per gradient tensor (the tolerance envelope of the gradient-level parity tests)."""
+    rounding noise per gradient tensor (the tolerance envelope of the gradient-level parity tests).
+
+    ``flips`` > 0: also returns the FLIP ENVELOPE.  At the deepest levels (<= 4^3 voxels per channel) some ReLU
+    pre-activation of the student always lies within ~1e-6 (relative) of zero -- measured over ten input draws: 1.6e-7 ...
+    5.9e-6 -- i.e. within the rounding error of ANY fp32 convolution: which side of the discontinuity an implementation
+    lands on is a coin toss, and one flipped element moves a whole weight-gradient tensor of that level.  The float64 step
+    is therefore re-evaluated with the sign of each of the ``flips`` smallest such pre-activations reversed (one at a
+    time); the largest change per gradient tensor, relative to the tensor's maximum, is what a single legitimate flip
+    costs on this fixture.  Returns (grads, flip_relerr per tensor, the margins that were flipped)."""
     C = cfg["num_classes"]
     m64, e64 = build_reference(kind, 1, C).double(), build_reference(kind, 1, C).double()
-    m64.load_state_dict({k: (v.double() if v.is_floating_point() else v) for k, v in sd0.items()})
-    e64.load_state_dict({k: (v.double() if v.is_floating_point() else v) for k, v in tsd0.items()})
-    m64.train(); e64.train()
     to64 = lambda d: d if d == "off" else {k: v.double() for k, v in d.items()}
-    set_reference_dropout(m64, kind, to64(drop_s), None)
-    set_reference_dropout(e64, kind, to64(drop_t), None)
-    opt = torch.optim.SGD(m64.parameters(), lr=0.0)
-    ref = reference_step(kind, m64, e64, opt, volume.double(), label, noise.double(), iter_num, cfg)
-    return ref["grads"]
+
+    def run(hook_factory=None):
+        m64.load_state_dict({k: (v.double() if v.is_floating_point() else v) for k, v in sd0.items()})
+        e64.load_state_dict({k: (v.double() if v.is_floating_point() else v) for k, v in tsd0.items()})
+        m64.train(); e64.train()
+        set_reference_dropout(m64, kind, to64(drop_s), None)
+        set_reference_dropout(e64, kind, to64(drop_t), None)
+        opt = torch.optim.SGD(m64.parameters(), lr=0.0)
+        relus = [m for m in m64.modules() if isinstance(m, torch.nn.ReLU)]
+        hooks = [m.register_forward_pre_hook(hook_factory(i)) for i, m in enumerate(relus)] if hook_factory else []
+        ref = reference_step(kind, m64, e64, opt, volume.double(), label, noise.double(), iter_num, cfg)
+        for h in hooks:
+            h.remove()
+        return [g.clone() for g in ref["grads"]]
+
+    if not flips:
+        return run()
+    cands = []          # (margin relative to the layer's largest |x|, relu index, flat element index)
+
+    def probe(i):
+        def pre(mod, inp):
+            x = inp[0].detach()
+            if x.dim() >= 4 and int(np.prod(x.shape[2:])) <= 64:
+                a = x.abs().flatten()
+                k = torch.topk(a, min(flips, a.numel()), largest=False)
+                cands.extend((float(v / a.max()), i, int(j)) for v, j in zip(k.values, k.indices))
+        return pre
+
+    g64 = run(probe)
+    cands.sort()
+    env = [0.0] * len(g64)
+    for margin, ri, j in cands[:flips]:
+        def flip(i, ri=ri, j=j):
+            def pre(mod, inp):
+                if i == ri:
+                    x = inp[0].clone()
+                    x.view(-1)[j] = -x.view(-1)[j]
+                    return (x,)
+            return pre
+        gf = run(flip)
+        env = [max(e, float((a - b).abs().max() / (b.abs().max() + 1e-300))) for e, a, b in zip(env, gf, g64)]
+    return g64, env, [c[0] for c in cands[:flips]]
 
 
 def rel_close(a, b, tol, what):
@@ -227,10 +269,11 @@ def rel_close(a, b, tol, what):
 def make_inputs(kind, cfg):
     B = cfg["batch_size"]
     sp = tuple(cfg["spatial"])
-    volume = filler.image((B, cfg.get("in_channels", 1)) + sp, "volume")
+    tag = cfg.get("tag", "")          # another draw of the closed-form inputs for the same geometry
+    volume = filler.image((B, cfg.get("in_channels", 1)) + sp, "volume" + tag)
     ldt = torch.uint8 if kind in ("unet2d", "swin", "swin_w8") else torch.int64
     label = filler.labels((B,) + sp, cfg["num_classes"], ldt)
-    noise = filler.noise((B - cfg["labeled_bs"], cfg.get("in_channels", 1)) + sp, "noise")
+    noise = filler.noise((B - cfg["labeled_bs"], cfg.get("in_channels", 1)) + sp, "noise" + tag)
     return volume, label, noise
 
 
@@ -333,7 +376,15 @@ def run_case(name, kind, cfg, iters, drop_mode, eval_logits=False):
         for k, v in tensor_summary(ref["teacher_logits"]).items():
             out[pre + "teacher_logits_" + k] = np.asarray(v)
         out[pre + "grad_norms"] = np.array([float(g.double().norm()) for g in ref["grads"]])
-        g64 = reference_grads64(kind, cfg, sd0, tsd0, drop_s, drop_t, volume, label, noise, it)
+        if cfg.get("flips"):
+            g64, flip_env, margins = reference_grads64(kind, cfg, sd0, tsd0, drop_s, drop_t, volume, label, noise, it,
+                                                       flips=cfg["flips"])
+            out[pre + "grad_flip_relerr"] = np.array(flip_env)
+            out[pre + "flip_margins"] = np.array(margins)
+            print(f"{name} it{it}: flip envelope over {len(margins)} pre-activations with margins "
+                  f"{', '.join('%.1e' % m for m in margins)}: largest per-tensor change {max(flip_env):.2e}")
+        else:
+            g64 = reference_grads64(kind, cfg, sd0, tsd0, drop_s, drop_t, volume, label, noise, it)
         out[pre + "grad_norms64"] = np.array([float(g.norm()) for g in g64])
         out[pre + "grad_max64"] = np.array([float(g.abs().max()) for g in g64])
         out[pre + "grad_relerr32"] = np.array([float((a.double() - b).abs().max() / (b.abs().max() + 1e-300))
@@ -910,8 +961,9 @@ def main():
         # conv + InstanceNorm3d + ReLU, conv + ReLU
         ("vnet_gn_64_dropoff", "vnet_groupnorm", dict(CFG3D, batch_size=2, labeled_bs=1, spatial=[64, 64, 64]), [0, 7],
          "off", True),
-        ("vnet_gn_64_masks", "vnet_groupnorm", dict(CFG3D, batch_size=2, labeled_bs=1, spatial=[64, 64, 64]), [450],
-         "masks", False),
+        # flips=4: the float64 gate's flip envelope (reference_grads64): this fixture has a 4^3-level ReLU within rounding of 0
+        ("vnet_gn_64_masks", "vnet_groupnorm", dict(CFG3D, batch_size=2, labeled_bs=1, spatial=[64, 64, 64], flips=4),
+         [450], "masks", False),
         ("vnet_in_64_dropoff", "vnet_instancenorm", dict(CFG3D, batch_size=2, labeled_bs=1, spatial=[64, 64, 64]), [7],
          "off", False),
         ("vnet_none_64_masks", "vnet_none", dict(CFG3D, batch_size=2, labeled_bs=1, spatial=[64, 64, 64]), [450],

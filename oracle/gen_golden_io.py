@@ -231,6 +231,7 @@ def gen_aug2d():
         out[f"size{c}"], out[f"tail_random{c}"], out[f"tail_np{c}"] = np.array(size), tail[0], tail[1]
         out[f"modes{c}"] = np.array(modes)
         print(f"aug2d {size}: modes {np.bincount(modes)}  tail {tail}")
+    out["oracle_vs_reference_worst_rel"] = 0.0       # oracle/augment.py asserted bit-equal above
     np.savez_compressed(os.path.join(GOLD, "aug2d.npz"), **out)
 
 
@@ -255,7 +256,7 @@ def gen_aug3d():
         assert np.array_equal(oi, ri) and np.array_equal(ol, rl)
     assert tail == int(np.random.randint(1 << 30))
     np.savez_compressed(os.path.join(GOLD, "aug3d.npz"), image=np.stack(imgs), label=np.stack(labs), idx=np.array(idx),
-                        patch=np.array(patch), tail_np=tail,
+                        patch=np.array(patch), tail_np=tail, oracle_vs_reference_worst_rel=0.0,
                         input_sum=float(sum(float(v[0].astype(np.float64).sum()) for v in vols)))
     print(f"aug3d: {len(idx)} crops of {patch}, tail {tail}")
 

@@ -69,10 +69,11 @@ def _inputs(kind, cfg):
     from oracle import filler
     B, sp = cfg["batch_size"], tuple(cfg["spatial"])
     ch = cfg.get("in_channels", 1)
-    volume = filler.image((B, ch) + sp, "volume")
+    tag = cfg.get("tag", "")
+    volume = filler.image((B, ch) + sp, "volume" + tag)
     label = filler.labels((B,) + sp, cfg["num_classes"],
                           torch.uint8 if kind in ("unet2d", "swin", "swin_w8") else torch.int64)
-    noise = filler.noise((B - cfg["labeled_bs"], ch) + sp, "noise")
+    noise = filler.noise((B - cfg["labeled_bs"], ch) + sp, "noise" + tag)
     return volume, label, noise
 
 
@@ -349,13 +350,16 @@ F64_MEDIAN_RATIO = 2.0
 # error of the whole layer, amplified by every normalisation below it.  The transform now runs in double and is rounded
 # once: worst tensor 3.1x the reference's error (was 21x), better than the direct kernels (4.3x), medians 1.3.
 # -> GroupNorm nets are held to the SAME gate as every other net (measured: worst tensor 3.3x, medians 1.3 / 1.6)
-# What this gate cannot tell apart (round 4, measured): `vnet_gn_64_masks` sits on a DISCONTINUITY.  Changing the arithmetic of
-# the 8^3 level in ANY way -- its convolutions on the direct kernels (MIS_WINO_MIN_W=16), or on the split-contraction Winograd
-# launch, whose outputs are MORE accurate than the unsplit ones (scripts/split_err.py: rms 2.4e-7 against 4.2e-7) -- gives the
-# same error to three digits, 2.84e-4 at block_five.conv.3.weight = 22x the reference's own, median 2.55; both levels on the
-# direct kernels (MIS_WINO_MIN_W=32) give max 1.65x, median 1.09.  Identical errors from unrelated perturbations are one ReLU
-# whose pre-activation is within rounding of zero at the 4^3 level: a coin toss for every fp32 implementation, the reference's
-# included.  The split launch is therefore not applied to whole 8 x 8 x 8 boxes (no benchmarked shape needs it there).
+# What the reference's own noise e32 cannot tell (rounds 4-5, measured): at the 4^3 level some ReLU pre-activation of EVERY
+# fixture lies within 1e-7 .. 6e-6 (relative) of zero (ten input draws, oracle/gen_golden.py::reference_grads64) -- inside the
+# rounding error of any fp32 convolution.  Which side an implementation lands on is a coin toss, and one flipped element of
+# `vnet_gn_64_masks` (margin 4e-7) moves block_five.conv.3.weight by 32 % of its maximum and every tensor above it by 3-8 %:
+# exactly the "22x the reference's own error, same to three digits whatever is changed at the 8^3 level" of round 4.  The
+# golden now carries the FLIP ENVELOPE (the float64 step with the sign of each of the 4 smallest such pre-activations
+# reversed, largest change per tensor); a tensor may deviate by F64_FLIP x that, and the median ratio is taken against
+# max(e32, flip).  The gate no longer depends on which kernel serves the 8^3 level, and the split-contraction launch is
+# chosen on performance alone (conv_wino.hip::wino_splits).
+F64_FLIP = 1.5
 F64_GN = dict(K=F64_K, median=F64_MEDIAN_RATIO)
 
 
@@ -418,16 +422,18 @@ def test_step_gradients_match_float64_oracle(name, it):
     # oracle/gen_golden.py::reference_grads64: these fixtures are ill-conditioned through the normalisation layers
     # (no-norm V-Net: 1e-7; BatchNorm / GroupNorm / InstanceNorm nets: 1e-2 .. 1e-1 for ANY fp32 implementation)
     ref32 = z[f"it{it}_grad_relerr32"]
+    fkey = f"it{it}_grad_flip_relerr"
+    flip = z[fkey] if fkey in z.files else np.zeros_like(ref32)       # what ONE legitimate ReLU flip costs (see above)
     rows, ratios = [], []
     for i, (n, g) in enumerate(model.named_flat(model.flat_grad)):
         ref = orc["grads"][n]
         gmax = float(ref.abs().max())
         err = (g.cpu().double() - ref).abs().max().item()
         K = F64_GN["K"] if "groupnorm" in kind else F64_K
-        tol = max(K * float(ref32[i]), F64_REL) * gmax + F64_ABS * gscale
+        tol = max(K * float(ref32[i]), F64_FLIP * float(flip[i]), F64_REL) * gmax + F64_ABS * gscale
         rows.append((err / tol, n, err, gmax))
         if gmax > 1e-4 * gscale:
-            ratios.append((err / gmax) / max(float(ref32[i]), 1e-3))
+            ratios.append((err / gmax) / max(float(ref32[i]), float(flip[i]), 1e-3))
     worst = max(rows)
     if os.environ.get("MIS_PRINT_GRAD_ROWS"):
         for r in sorted(rows, reverse=True)[:12]:
