@@ -24,8 +24,10 @@ TOL_LOGIT, TOL_LOSS = 1e-3, 2e-4          # the north-star bar on logits; scalar
 # cross teaching 2.0e-2 on the CNN / inside the absolute term on the Transformer) -- the fixture-size envelope of
 # test_parity_gpu.py (6 x the reference's own fp32 noise + 2e-3), not a dispatch-only bound
 GRAD_REL, GRAD_ABS = 0.1, 2e-3
-GRAD_REL_CASE = {"config2_unet2d_24+24_256": 0.03, "config3_unet3d_4+4_96": 0.015, "config4_swin_24+24_224": 0.01,
-                 "config3_vnet_4+4_96": 0.08}       # V-Net: 1.5e-2 measured (round 4), x5
+# round 5: 3x the values measured at the full batch (1.3e-3, 1.0e-3, inside the absolute term, 2.4e-2) -- a wrong halo row in
+# one box of one layer moves a tensor by far more than that
+GRAD_REL_CASE = {"config2_unet2d_24+24_256": 0.004, "config3_unet3d_4+4_96": 0.003, "config4_swin_24+24_224": 0.003,
+                 "config3_vnet_4+4_96": 0.07}
 
 
 def _states(onet, tag=""):
@@ -154,6 +156,10 @@ def test_mean_teacher_step_at_full_batch(name):
         assert (v.cpu() - teacher[n]).abs().max().item() <= 1e-6 + (1 - alpha) * orc["lr"] * gscale, n
 
 
+# (CNN, Transformer) per geometry: 3x the measured 2.0e-2 / 7.9e-3 on the CNN; the Transformer stays inside the absolute term
+CROSS_GRAD_REL = {224: (0.06, 0.003), 256: (0.024, 0.003)}
+
+
 @pytest.mark.timeout(1500)
 @pytest.mark.parametrize("size,window", [(224, 7), (256, 8)], ids=["224_w7", "256_w8"])
 def test_cross_teaching_step_at_full_batch(size, window):
@@ -207,7 +213,7 @@ def test_cross_teaching_step_at_full_batch(size, window):
         assert abs(got[f"pseudo_supervision{m + 1}"] - ps) <= TOL_LOSS
         lg = models[m]._last[0].out.t.cpu().reshape(r[f"logits{m + 1}"].shape)
         assert (lg - r[f"logits{m + 1}"]).abs().max().item() <= TOL_LOGIT
-        _check_grads_and_params(models[m], r["grads"][m], osd[m], r["lr"], f"model{m + 1}", 0.08 if m == 0 else 0.01)
+        _check_grads_and_params(models[m], r["grads"][m], osd[m], r["lr"], f"model{m + 1}", CROSS_GRAD_REL[size][m])
 
 
 @pytest.mark.timeout(2400)
@@ -258,7 +264,7 @@ def test_uamt_3d_step_at_full_batch():
     mp = tr._mean_probs.cpu().reshape((B - L, C) + sp)
     unc = -1.0 * torch.sum(mp * torch.log(mp + 1e-6), dim=1, keepdim=True)
     assert (unc - orc["uncertainty"]).abs().max().item() <= 1e-3
-    _check_grads_and_params(model, orc["grads"], student, orc["lr"], "uamt3d", 0.005)       # 9.3e-4 measured, x5
+    _check_grads_and_params(model, orc["grads"], student, orc["lr"], "uamt3d", 0.003)       # 9.7e-4 measured, x3
 
 
 @pytest.mark.timeout(1500)
@@ -295,4 +301,4 @@ def test_cnn_meet_vit_step_at_full_batch():
     for m in range(2):
         assert abs(got[f"pseudo_supervision{m + 1}"] - r["parts"][m][2]) <= TOL_LOSS
         assert abs(got[f"consistency_loss{m + 1}"] - r["parts"][m][3]) <= TOL_LOSS
-        _check_grads_and_params(models[m], r["grads"][m], sds[m], r["lr"], f"cnnvit model{m + 1}", 0.08 if m == 0 else 0.01)
+        _check_grads_and_params(models[m], r["grads"][m], sds[m], r["lr"], f"cnnvit model{m + 1}", 0.043 if m == 0 else 0.003)   # 3x measured (1.4e-2; Transformer inside the absolute term)

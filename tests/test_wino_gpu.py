@@ -56,7 +56,8 @@ FWD_CASES = [
 ]
 # (N, Cin, Cout, D, H, W) -> contraction slices mis_conv3d_wino_fwd_ws uses
 SPLITS = {(8, 128, 256, 6, 6, 6): 2, (8, 256, 256, 6, 6, 6): 2, (4, 256, 256, 6, 6, 6): 4, (4, 128, 128, 12, 12, 12): 2,
-          (4, 64, 128, 12, 12, 12): 2, (2, 128, 384, 12, 12, 12): 1, (1, 32, 32, 8, 8, 8): 1, (2, 64, 48, 8, 16, 24): 1,      # whole boxes: never split
+          (4, 64, 128, 12, 12, 12): 2, (2, 128, 384, 12, 12, 12): 1, (1, 32, 32, 8, 8, 8): 1,
+          (2, 64, 48, 8, 16, 24): 2,      # whole 8 x 8 x 8 boxes split like partly filled ones (entry count alone decides)
           (8, 32, 64, 12, 8, 20): 1}
 
 
