@@ -617,6 +617,12 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const GemmArgs a) {
 // The 4 waves of a workgroup take 4 consecutive row ranges of the same tile and sum their tiles through LDS (fixed tree:
 // deterministic), so a launch writes tiles x workgroup-slices partials, summed by gemm_reduce_kernel as before.
 // The bias gradient (column sums of A) rides on the waves of the first tile column: 3 packed adds per group.
+// The zeros past a wave's row range rest on the GFX9-family raw-buffer range check, which INCLUDES soffset (the row advance
+// is carried there): an architecture that excludes it would return the next wave's rows -- silently wrong dW.  This file is
+// built for gfx950 only; refuse anything else at compile time (tests/test_token_kernels_gpu.py puts NaNs behind the range).
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "gemm_tn_reg_kernel: buffer range check with soffset is verified for gfx950 only"
+#endif
 constexpr int RT = 96;                 // wave tile edge
 constexpr int RD = 4;                  // groups (of 4 rows) in flight
 

@@ -120,6 +120,24 @@ def setup_distributed():
     return rank, world, local_rank
 
 
+def broadcast_model_state(*models, src=0):
+    """Every rank starts from (or resumes with) rank ``src``'s state: the flat parameter buffer AND the floating-point
+    buffers (BatchNorm running statistics -- per-rank during training, rank 0's are the canonical ones a checkpoint holds)."""
+    for m in models:
+        if m is None:
+            continue
+        torch.distributed.broadcast(m.flat_param, src)
+        bufs = [b for b in m.buffers() if b.is_floating_point() and b.numel()]
+        if bufs:
+            flat = torch.cat([b.detach().reshape(-1).float() for b in bufs])
+            torch.distributed.broadcast(flat, src)
+            off = 0
+            with torch.no_grad():
+                for b in bufs:
+                    b.copy_(flat[off:off + b.numel()].view_as(b))
+                    off += b.numel()
+
+
 def _init_conv_weights(model, init_fn):
     """Shared body of the reference's ``kaiming_normal_init_weight`` / ``xavier_normal_init_weight``
     (train_cross_pseudo_supervision_3D.py:79-96, train_cross_pseudo_supervision_2D.py:85-102): ``init_fn`` on the
@@ -184,8 +202,10 @@ class Validator:
     single-GPU) shard the validation cases over the ranks (``cases[rank::world]``) and all-reduce the metric sums: no
     rank waits in the next step's gradient all-reduce for a whole validation pass on rank 0 (RCCL's watchdog would
     abort a long 3-D one).  Every rank holds identical weights; the BatchNorm running statistics -- per-rank, there is
-    no SyncBN -- are taken from rank 0 for the scoring, as the checkpoint is.  Scalars, logs and checkpoints are
-    rank 0's.  When the validation list file is missing (the synthetic runs) nothing is scored and ``finish`` writes
+    no SyncBN -- are taken from rank 0 for the scoring, as the checkpoint is, and every rank's OWN running statistics are
+    put back afterwards: validation never changes the training state, the ranks' running statistics evolve independently for the
+    whole run (standard DDP without SyncBN) and rank 0 is canonical -- its buffers are what checkpoints hold and what
+    ``resume`` broadcasts (train_common.broadcast_model_state).  Scalars, logs and checkpoints are rank 0's.  When the validation list file is missing (the synthetic runs) nothing is scored and ``finish`` writes
     the final weights under the best-model name, so that the inference CLIs always find their checkpoint."""
 
     def __init__(self, args, snapshot_path, scalars=None, rank=0, world=1, process_group=None):
@@ -221,14 +241,21 @@ class Validator:
                     for b in bufs:
                         b.copy_(flat[off:off + b.numel()].view_as(b))
                         off += b.numel()
+        err = None
         try:
             total, count = self._score_shard(model)
+        except Exception as e:       # keep the collective below symmetric: the other ranks must not wait for this one
+            if self.world <= 1:
+                raise
+            err, total, count = e, np.zeros((args.num_classes - 1, 2)), 0
         finally:
             if saved is not None:
                 with torch.no_grad():
                     for b, v in zip(bufs, saved):
                         b.copy_(v)
-        m = self._reduce(total, count)
+        m = self._reduce(total, count, failed=err is not None)
+        if err is not None:
+            raise err
         return float(np.mean(m, axis=0)[0]), float(np.mean(m, axis=0)[1]), m
 
     def _score_shard(self, model):
@@ -250,14 +277,19 @@ class Validator:
                 count += 1
         return total, count
 
-    def _reduce(self, total, count):
-        """Mean over all ranks' cases: all-reduce (sum) of the metric sums and the case count."""
+    def _reduce(self, total, count, failed=False):
+        """Mean over all ranks' cases: all-reduce (sum) of the metric sums, the case count and an error flag -- a rank whose
+        shard raised still takes part, and EVERY rank then fails (instead of the others blocking in this all-reduce until
+        the process group's timeout)."""
         if self.world > 1:
-            t = torch.tensor(np.append(np.asarray(total, dtype=np.float64).ravel(), float(count)), dtype=torch.float64,
+            t = torch.tensor(np.concatenate([np.asarray(total, dtype=np.float64).ravel(), [float(count), float(failed)]]),
+                             dtype=torch.float64,
                              device="cuda" if torch.distributed.get_backend(self.pg) == "nccl" else "cpu")
             torch.distributed.all_reduce(t, group=self.pg)
             t = t.cpu().numpy()
-            total, count = t[:-1].reshape(np.shape(total)), t[-1]
+            if t[-1] > 0 and not failed:
+                raise RuntimeError(f"validation failed on {int(t[-1])} other rank(s); see their logs")
+            total, count = t[:-2].reshape(np.shape(total)), t[-2]
         return np.asarray(total, dtype=np.float64) / max(count, 1)
 
     def __call__(self, iter_num, models):
@@ -330,15 +362,14 @@ def run_cross_teaching(args, make_model1, make_model2, log_every=1, label_dtype=
         init_fns[1](model2)
     ema_model = make_ema() if make_ema is not None else None
     if world > 1:
-        torch.distributed.broadcast(model1.flat_param, 0)
-        torch.distributed.broadcast(model2.flat_param, 0)
+        broadcast_model_state(model1, model2)
     model1.train()
     model2.train()
     if ema_model is not None:
         for p in ema_model.parameters():
             p.detach_()
         if world > 1:
-            torch.distributed.broadcast(ema_model.flat_param, 0)
+            broadcast_model_state(ema_model)
         ema_model.train()
         trainer = CnnMeetVitTrainer(model1, model2, ema_model, labeled_bs=args.labeled_bs,
                                     num_classes=args.num_classes, base_lr=args.base_lr,
@@ -408,9 +439,8 @@ def run_training(args, make_model, *, label_dtype, cons_start_iter, save_ema, lo
     ema_model = make_model()
     for p in ema_model.parameters():       # create_model(ema=True): teacher params are detached
         p.detach_()
-    if world > 1:                          # every rank starts from rank 0's weights
-        torch.distributed.broadcast(model.flat_param, 0)
-        torch.distributed.broadcast(ema_model.flat_param, 0)
+    if world > 1:                          # every rank starts from rank 0's weights and running statistics
+        broadcast_model_state(model, ema_model)
     model.train()
     ema_model.train()
 

@@ -311,3 +311,60 @@ def test_deferred_tail_bucket_and_rank_agreement_on_the_layout(tmp_path):
     for r in range(world):
         res = torch.load(os.path.join(tmp_path, f"layout{r}.pt"))
         assert res["sum_ok"] and res["mismatch_raised"], res
+
+
+def test_bucket_layout_and_exchange_model():
+    """bucket_layout is what GradBucketer cuts (a pure function of the sizes); predict_exchange prices those buckets."""
+    from mis_hip import dist as mdist
+    n = (100 << 20) // 4
+    lay = mdist.bucket_layout(n, 4, mdist.default_bucket_bytes(n * 4))
+    assert lay[0][1] == n and lay[-1] == (0, (2 << 20) // 4)                 # issued from the end; 2 MiB exposed tail
+    assert all(a[0] == b[1] for a, b in zip(lay, lay[1:]))                   # contiguous, descending
+    flat = torch.zeros(n // 64)                                              # small buffer: one bucket
+    b = mdist.GradBucketer(flat, bucket_bytes=1 << 30)
+    assert b.buckets == mdist.bucket_layout(flat.numel(), 4, 1 << 30) == [(0, flat.numel())]
+    p = mdist.predict_exchange([23536208, 108_000_000], 8)
+    assert p["world"] == 8 and len(p["models"]) == 2
+    m0 = p["models"][0]
+    assert sum(m0["bucket_bytes"]) == 23536208 and m0["bucket_bytes"][-1] == 2 << 20
+    f = 2 * 7 / 8
+    assert abs(m0["ring_ms"][0] - (f * m0["bucket_bytes"][0] / 153e9 * 1e3 + 14 * 25e-3)) < 1e-3
+    assert abs(m0["direct_ms"][0] - (f * m0["bucket_bytes"][0] / (7 * 153e9) * 1e3 + 2 * 25e-3)) < 1e-3
+    assert p["exposed_tail_ring_ms"] < p["total_ring_ms"] and p["total_direct_ms"] < p["total_ring_ms"]
+    assert mdist.predict_exchange([1000], 1)["models"] == []
+
+
+def test_rank_pinning_follows_the_gpus_numa_node(tmp_path):
+    """pin_rank_to_numa against a fabricated sysfs: ranks whose GPUs share a NUMA node split its cores in rank order,
+    shares are disjoint, an unknown node falls back to an even split of the allowed cores."""
+    from mis_hip import dist as mdist
+    allowed = sorted(os.sched_getaffinity(0))
+    if len(allowed) < 4:
+        pytest.skip("needs >= 4 usable cores")
+    half = len(allowed) // 2
+    nodes = {0: allowed[:half], 1: allowed[half:]}
+    for k, cpus in nodes.items():
+        d = tmp_path / "devices/system/node" / f"node{k}"
+        d.mkdir(parents=True)
+        (d / "cpulist").write_text(",".join(map(str, cpus)) + "\n")
+    ids = ["0000:05:00.0", "0000:15:00.0", "0000:85:00.0", "0000:95:00.0"]
+    for bid, node in zip(ids, (0, 0, 1, 1)):
+        d = tmp_path / "bus/pci/devices" / bid
+        d.mkdir(parents=True)
+        (d / "numa_node").write_text(f"{node}\n")
+    infos = [mdist.pin_rank_to_numa(r, 4, ids, sysfs=str(tmp_path), apply=False) for r in range(4)]
+    assert [i["numa_node"] for i in infos] == [0, 0, 1, 1] and all(i["sharers"] == 2 and not i["applied"] for i in infos)
+
+    def cpus_of(i):
+        return set(mdist._parse_cpulist(i["cpus"]))
+    sets = [cpus_of(i) for i in infos]
+    assert sets[0] | sets[1] <= set(nodes[0]) and sets[2] | sets[3] <= set(nodes[1])
+    assert all(not (sets[a] & sets[b]) for a in range(4) for b in range(a + 1, 4))
+    unknown = [mdist.pin_rank_to_numa(r, 2, None, sysfs=str(tmp_path), apply=False) for r in range(2)]
+    assert all(i["numa_node"] == -1 for i in unknown) and not (cpus_of(unknown[0]) & cpus_of(unknown[1]))
+    before = os.sched_getaffinity(0)
+    try:
+        i = mdist.pin_rank_to_numa(1, 4, ids, sysfs=str(tmp_path), apply=True)
+        assert i["applied"] and os.sched_getaffinity(0) == cpus_of(i)
+    finally:
+        os.sched_setaffinity(0, before)

@@ -96,6 +96,24 @@ def test_gemm_dw_weight_and_bias_gradient_in_one_pass(T, Cout, Cin):
     assert torch.equal(dW, dW3) and torch.equal(db, db3)
 
 
+@pytest.mark.parametrize("T", [1001, 1003, 2054, 9419])
+def test_register_only_tn_gemm_never_reads_past_its_row_range(T):
+    """gemm_tn_reg_kernel (widths % 96 == 0) keeps 4 row groups in flight and lets the buffer descriptor's range check
+    zero the loads past a wave's last row -- the K tail inside a group of 4 rows and the ring's surplus groups when
+    ngroups % 4 != 0.  The rows behind row T of the SAME allocations hold NaNs: a load that escapes the range poisons dW/db."""
+    tops = _t()
+    Cout, Cin, pad = 192, 96, 64
+    Xf = torch.full((T + pad, Cin), float("nan"), device="cuda")
+    Yf = torch.full((T + pad, Cout), float("nan"), device="cuda")
+    Xf[:T], Yf[:T] = _rand(T, Cin, seed=21).cuda(), (_rand(T, Cout, seed=22) + 0.25).cuda()
+    X, dY = Xf[:T], Yf[:T]
+    dW, db = torch.empty(Cout, Cin, device="cuda"), torch.empty(Cout, device="cuda")
+    tops.gemm_dw(dY, X, dW, db)
+    assert torch.isfinite(dW).all() and torch.isfinite(db).all()
+    _close(dW, dY.double().t() @ X.double(), rtol=3e-4)
+    assert (db.double() - dY.double().sum(0)).abs().max().item() <= 2e-5 * float(dY.double().sum(0).abs().max())
+
+
 @pytest.mark.parametrize("B,S,C,NC", [(2, 3136, 96, 4), (3, 1000, 96, 2), (1, 50, 128, 3), (2, 77, 36, 4)])
 def test_layernorm_and_output_head_in_one_pass(B, S, C, NC):
     """mis_ln_head_{fwd,bwd}: nn.LayerNorm(C) + the bias-free 1x1 output convolution of SwinUnet's tail (reference
