@@ -94,6 +94,34 @@ __global__ __launch_bounds__(256) void s2d8_kernel(const S2DArgs a) {
         }
 }
 
+// 2-D twin (nn.ConvTranspose2d(k=2, s=2) of the 2-D UNet's UpBlock(bilinear=False), reference networks/unet.py:76-78): fine
+// [N][C][H][W] <-> coarse [N][4C][H/2][W/2], coarse channel = c*4 + ky*2 + kx.  One thread per fine x-pair (float2);
+// grid (ceil(H*W/2 / 256), 1, N*C).
+__global__ __launch_bounds__(256) void s2d2d_kernel(const S2DArgs a) {
+    const int Wh = a.W >> 1, Hc = a.H >> 1;
+    const int pl = blockIdx.x * 256 + threadIdx.x;
+    if (pl >= a.H * Wh) return;
+    const int nc = blockIdx.z;
+    const int n = nc / a.C, c = nc - n * a.C;
+    const int y = pl / Wh, xc = pl - y * Wh;
+    const long long S = (long long)a.H * a.W, Sc = S >> 2;
+    const long long fine = (long long)c * S + (long long)y * a.W + 2 * xc;
+    const long long coarse0 = (long long)(c * 4 + (y & 1) * 2) * Sc + (long long)(y >> 1) * Wh + xc;
+    (void)Hc;
+    if (a.to_depth) {
+        const float2 v = *reinterpret_cast<const float2*>(a.src + (long long)n * a.src_bs + fine);
+        float* d = a.dst + (long long)n * a.dst_bs + coarse0;
+        if (a.accumulate) { d[0] += v.x; d[Sc] += v.y; } else { d[0] = v.x; d[Sc] = v.y; }
+    } else {
+        const float* s = a.src + (long long)n * a.src_bs + coarse0;
+        const float b = a.bias ? a.bias[c] : 0.f;
+        float2 v = make_float2(s[0] + b, s[Sc] + b);
+        float2* d = reinterpret_cast<float2*>(a.dst + (long long)n * a.dst_bs + fine);
+        if (a.accumulate) { const float2 o = *d; v.x += o.x; v.y += o.y; }
+        *d = v;
+    }
+}
+
 // out = a (+ b); dense (C, S), batch strides free; S % 4 == 0
 __global__ __launch_bounds__(256) void add_kernel(const float* __restrict__ a, long long a_bs,
                                                   const float* __restrict__ b, long long b_bs,
@@ -129,6 +157,20 @@ extern "C" int mis_space_to_depth2(const float* src, long long src_bs, float* ds
         return mis_launch_status();
     }
     hipLaunchKernelGGL(s2d_kernel, dim3((H * (W / 2) + 255) / 256, D, N * C), dim3(256), 0, stream, a);
+    return mis_launch_status();
+}
+
+// 2-D: to_depth = 1: fine [N][C][H][W] -> coarse [N][4C][H/2][W/2]; to_depth = 0: coarse -> fine (+ bias[C]).
+extern "C" int mis_space_to_depth2d(const float* src, long long src_bs, float* dst, long long dst_bs, const float* bias,
+                                    int N, int C, int H, int W, int to_depth, int accumulate, hipStream_t stream) {
+    if (!src || !dst || N <= 0 || C <= 0 || H <= 0 || W <= 0) return MIS_ERR_ARG;
+    if ((H | W) & 1) return MIS_ERR_UNSUPPORTED;
+    const float* fine = to_depth ? src : dst;
+    const long long fine_bs = to_depth ? src_bs : dst_bs;
+    if ((fine_bs & 1) || ((uintptr_t)fine & 7)) return MIS_ERR_UNSUPPORTED;
+    if ((long long)N * C > 65535) return MIS_ERR_UNSUPPORTED;
+    S2DArgs a{src, src_bs, dst, dst_bs, bias, N, C, 1, H, W, to_depth, accumulate};
+    hipLaunchKernelGGL(s2d2d_kernel, dim3((H * (W / 2) + 255) / 256, 1, N * C), dim3(256), 0, stream, a);
     return mis_launch_status();
 }
 

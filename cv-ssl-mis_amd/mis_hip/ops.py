@@ -115,6 +115,16 @@ def space_to_depth2(src, dst, fine_shape, to_depth, bias=None, accumulate=False)
                                    int(accumulate), _l.stream_ptr()), "mis_space_to_depth2")
 
 
+def space_to_depth2d(src, dst, fine_shape, to_depth, bias=None, accumulate=False):
+    """2-D: fine [N,C,1,H,W] <-> coarse [N,4C,1,H/2,W/2]; ``fine_shape`` = (N,C,1,H,W) of the fine tensor."""
+    L = _l.load()
+    N, C, D, H, W = fine_shape
+    assert D == 1
+    sbs, dbs = _geom(src)[6], _geom(dst)[6]
+    _l.check(L.mis_space_to_depth2d(_l.ptr(src), sbs, _l.ptr(dst), dbs, _l.ptr(bias), N, C, H, W, int(to_depth),
+                                    int(accumulate), _l.stream_ptr()), "mis_space_to_depth2d")
+
+
 def conv_k2s2_eligible(cin, cout, coarse, up):
     """(cin, cout) and the COARSE (Do, Ho, Wo) the in-place kernel-2 / stride-2 kernels serve (conv_k2s2.hip)."""
     return K2S2 and bool(_l.load().mis_conv_k2s2_eligible(int(cin), int(cout), *[int(v) for v in coarse], int(up)))

@@ -491,6 +491,44 @@ class UpConvOp:
         self.x.mark_written()
 
 
+class UpConv2dOp:
+    """nn.ConvTranspose2d(Cin, Cout, 2, stride=2) -- ``UpBlock(bilinear=False)`` of the 2-D UNet (reference
+    networks/unet.py:76-78, :81-84): windows of a kernel-2 / stride-2 transposed convolution do not overlap, so it is a 1x1
+    convolution to 4*Cout channels (the parameter [Cin][Cout][2][2] IS the input-major 1x1 weight [Cin][4 Cout]: pack modes
+    2 / 3 of the V-Net op) + the 2-D pixel shuffle (+ bias).  Backward: bias sums, un-shuffle of dy, then the 1x1
+    convolution's weight / data gradient on the MFMA kernels."""
+
+    def __init__(self, x, y, w, b, bias_grad=True):
+        self.x, self.y, self.w, self.b, self.bias_grad = x, y, w, b, bias_grad
+        N, Cin, d, h, wd = x.shape
+        assert d == 1
+        self.cin, self.cout4 = Cin, 4 * w.data.shape[1]
+        self.y4 = torch.empty((N, self.cout4, 1, h, wd), dtype=torch.float32, device="cuda")
+        self.dy4 = self.dw4 = None
+        self.wp = self.wpd = None
+
+    def fwd(self, ctx):
+        self.wp = ops.conv_pack_raw(self.w.data, self.cout4, self.cin, 1, 2, out=self.wp)
+        ops.conv_fwd(self.x.t, self.wp, None, self.y4, self.cin, self.cout4, (1, 1, 1))
+        ops.space_to_depth2d(self.y4, self.y.t, self.y.shape, False, bias=None if self.b is None else self.b.data)
+
+    def bwd(self, ctx):
+        from . import tops
+        dyf = self.y.grad()
+        if self.bias_grad and self.b is not None:
+            ops.channel_sum(dyf, self.b.grad)
+        if self.dy4 is None:
+            self.dy4 = torch.empty_like(self.y4)
+            self.dw4 = torch.empty((self.cout4, self.cin), dtype=torch.float32, device="cuda")
+        ops.space_to_depth2d(dyf, self.dy4, self.y.shape, True)
+        ops.conv_wgrad(self.x.t, self.dy4, self.dw4, (1, 1, 1))                      # [4Cout][Cin]
+        tops.transpose(self.dw4, self.w.grad.view(self.cin, self.cout4))             # the parameter is [Cin][4Cout]
+        assert not self.x.written
+        self.wpd = ops.conv_pack_raw(self.w.data, self.cout4, self.cin, 1, 3, out=self.wpd)
+        ops.conv_fwd(self.dy4, self.wpd, None, self.x.grad(), self.cout4, self.cin, (1, 1, 1))
+        self.x.mark_written()
+
+
 class AddOp:
     """out = a + b (the additive skips of V-Net, reference vnet.py:210-222)."""
 
@@ -587,6 +625,10 @@ class Plan:
 
     def up_conv(self, x, y, w, b, bias_grad=False):
         self.ops.append(UpConvOp(x, y, w, b, bias_grad))
+        return y
+
+    def up_conv2d(self, x, y, w, b, bias_grad=True):
+        self.ops.append(UpConv2dOp(x, y, w, b, bias_grad))
         return y
 
     def add(self, a, b, out=None, fuse=False):

@@ -9,7 +9,9 @@ Architecture as the reference *instantiates* it: featu
 [16,32,64,128,256]; every 3x3 conv is followed by BatchNorm2d + LeakyReLU(0.01); Dropout
 p = [.05,.1,.2,.3,.5] after the first activation of each encoder block; decoder blocks are
 1x1 conv -> bilinear x2 (align_corners=True) -> cat([skip, up]) -> ConvBlock(p=0); 3x3 out_conv.
-(UpBlock's ``bilinear`` defaults to True in the reference, unet.py:68-69,129-136.)
+(UpBlock's ``bilinear`` defaults to True in the reference, unet.py:68-69,129-136, and its Decoder never passes the flag.)
+``UNet(..., bilinear=False)`` builds the other branch of UpBlock (unet.py:76-78): ``decoder.up{i}.up`` =
+``nn.ConvTranspose2d(C1, C2, kernel_size=2, stride=2)`` in place of ``conv1x1`` + bilinear up-sampling.
 
 The layer graph is executed by ``mis_hip.plan``; nothing here computes on the CPU.
 """
@@ -35,9 +37,9 @@ def _conv_init(cout, cin, k):
 class UNet(HipNet):
     ndim_spatial = 2
 
-    def __init__(self, in_chns, class_num):
+    def __init__(self, in_chns, class_num, bilinear=True):
         super().__init__()
-        self.in_chns, self.class_num = in_chns, class_num
+        self.in_chns, self.class_num, self.bilinear = in_chns, class_num, bool(bilinear)
         ft = _FT
         self._blocks = []   # (prefix, cin, cout, dropout)
         self._declare_block("encoder.in_conv.conv_conv", in_chns, ft[0])
@@ -45,9 +47,16 @@ class UNet(HipNet):
             self._declare_block(f"encoder.down{i}.maxpool_conv.1.conv_conv", ft[i - 1], ft[i])
         for i in range(1, 5):
             c1, c2 = ft[5 - i], ft[4 - i]
-            w, b = _conv_init(c2, c1, (1, 1))
-            self._declare(f"decoder.up{i}.conv1x1.weight", w)
-            self._declare(f"decoder.up{i}.conv1x1.bias", b)
+            if self.bilinear:
+                w, b = _conv_init(c2, c1, (1, 1))
+                self._declare(f"decoder.up{i}.conv1x1.weight", w)
+                self._declare(f"decoder.up{i}.conv1x1.bias", b)
+            else:       # nn.ConvTranspose2d(c1, c2, 2, stride=2): weight [c1][c2][2][2]; torch's fan_in = size(1) * 4
+                w = torch.empty(c1, c2, 2, 2)
+                torch.nn.init.kaiming_uniform_(w, a=math.sqrt(5))
+                bound = 1.0 / math.sqrt(c2 * 4)
+                self._declare(f"decoder.up{i}.up.weight", w)
+                self._declare(f"decoder.up{i}.up.bias", torch.empty(c2).uniform_(-bound, bound))
             self._declare_block(f"decoder.up{i}.conv.conv_conv", 2 * c2, c2)
         w, b = _conv_init(class_num, ft[0], (3, 3))
         self._declare("decoder.out_conv.weight", w)
@@ -105,10 +114,13 @@ class UNet(HipNet):
         # decoder (UpBlock, unet.py:65-86)
         for i in range(1, 5):
             l = 4 - i
-            c1 = plan.new(ft[l], sp[l + 1])
-            plan.conv(x, c1, self.P(f"decoder.up{i}.conv1x1.weight"), self.P(f"decoder.up{i}.conv1x1.bias"),
-                      (1, 1), bias_grad=True)
-            plan.upsample(c1, upv[l], align_corners=True)
+            if self.bilinear:
+                c1 = plan.new(ft[l], sp[l + 1])
+                plan.conv(x, c1, self.P(f"decoder.up{i}.conv1x1.weight"), self.P(f"decoder.up{i}.conv1x1.bias"),
+                          (1, 1), bias_grad=True)
+                plan.upsample(c1, upv[l], align_corners=True)
+            else:
+                plan.up_conv2d(x, upv[l], self.P(f"decoder.up{i}.up.weight"), self.P(f"decoder.up{i}.up.bias"))
             x = self._conv_block(plan, f"decoder.up{i}.conv.conv_conv", cat[l], ft[l], sp[l], 0.0,
                                  plan.new(ft[l], sp[l]))
         plan.out = plan.new(self.class_num, sp[0])

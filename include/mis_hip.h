@@ -422,6 +422,10 @@ int mis_conv_k2s2_wgrad(const float* coarse, long long c_bs, const float* fine, 
  * coarse channel = c*8 + kz*4 + ky*2 + kx.  mis_add: out = a (+ b) -- the additive skips (:210-222). */
 int mis_space_to_depth2(const float* src, long long src_bs, float* dst, long long dst_bs, const float* bias, int N,
                         int C, int D, int H, int W, int to_depth, int accumulate, mis_stream_t stream);
+/* 2-D twin: fine [N][C][H][W] <-> coarse [N][4C][H/2][W/2] (coarse channel = c*4 + ky*2 + kx) around a 1x1 convolution =
+ * nn.ConvTranspose2d(C1, C2, kernel_size=2, stride=2) of UpBlock(bilinear=False) (reference code/networks/unet.py:76-78) */
+int mis_space_to_depth2d(const float* src, long long src_bs, float* dst, long long dst_bs, const float* bias, int N, int C,
+                         int H, int W, int to_depth, int accumulate, mis_stream_t stream);
 int mis_add(const float* a, long long a_bs, const float* b, long long b_bs, float* out, long long o_bs, int N, int C,
             long long S, mis_stream_t stream);
 

@@ -104,6 +104,15 @@ def build_reference(kind, in_chns, num_classes):
     if kind == "unet2d":
         from networks.unet import UNet
         return UNet(in_chns=in_chns, class_num=num_classes)
+    if kind == "unet2d_deconv":
+        # UpBlock(bilinear=False) (unet.py:76-78): the reference's Decoder never passes the flag (:129-136), so the real
+        # UNet is built and its four UpBlocks are replaced by real UpBlock(..., bilinear=False) modules of the same widths
+        from networks.unet import UNet, UpBlock
+        net = UNet(in_chns=in_chns, class_num=num_classes)
+        ft = net.decoder.ft_chns
+        for i in range(1, 5):
+            setattr(net.decoder, f"up{i}", UpBlock(ft[5 - i], ft[4 - i], ft[4 - i], dropout_p=0.0, bilinear=False))
+        return net
     if kind in ("swin", "swin_w8"):
         _install_timm_shim()
         from types import SimpleNamespace as NS
@@ -147,7 +156,7 @@ def set_reference_dropout(model, kind, drop, sites):
             else:
                 blk.drop_path = SeqScale([drop[2 * bi], drop[2 * bi + 1]])
         return
-    if kind == "unet2d":
+    if kind.startswith("unet2d"):
         blocks = [model.encoder.in_conv, model.encoder.down1.maxpool_conv[1], model.encoder.down2.maxpool_conv[1],
                   model.encoder.down3.maxpool_conv[1], model.encoder.down4.maxpool_conv[1]]
         for site, blk in enumerate(blocks):
@@ -271,7 +280,7 @@ def make_inputs(kind, cfg):
     sp = tuple(cfg["spatial"])
     tag = cfg.get("tag", "")          # another draw of the closed-form inputs for the same geometry
     volume = filler.image((B, cfg.get("in_channels", 1)) + sp, "volume" + tag)
-    ldt = torch.uint8 if kind in ("unet2d", "swin", "swin_w8") else torch.int64
+    ldt = torch.uint8 if kind in ("unet2d", "unet2d_deconv", "swin", "swin_w8") else torch.int64
     label = filler.labels((B,) + sp, cfg["num_classes"], ldt)
     noise = filler.noise((B - cfg["labeled_bs"], cfg.get("in_channels", 1)) + sp, "noise" + tag)
     return volume, label, noise
@@ -289,6 +298,8 @@ def run_case(name, kind, cfg, iters, drop_mode, eval_logits=False):
     elif kind.startswith("vnet"):
         from oracle.nets import OracleVNet
         onet = OracleVNet(C, 1, normalization=kind.split("_", 1)[1] if "_" in kind else "batchnorm")
+    elif kind == "unet2d_deconv":
+        onet = OracleUNet2D(1, C, bilinear=False)
     else:
         onet = OracleUNet2D(1, C) if kind == "unet2d" else OracleUNet3D(C, 1)
     model = build_reference(kind, 1, C)
@@ -949,6 +960,8 @@ def main():
     cases = [
         ("unet2d_64_dropoff", "unet2d", small2d, [0, 1000, 1001], "off", True),
         ("unet2d_64_masks", "unet2d", small2d, [1500], "masks", False),
+        # the transposed-convolution decoder: UpBlock(bilinear=False), nn.ConvTranspose2d(k=2, s=2) (unet.py:76-78)
+        ("unet2d_deconv_64_masks", "unet2d_deconv", small2d, [1500], "masks", True),
         ("unet3d_64_dropoff", "unet3d", small3d, [0, 7], "off", True),
         ("unet3d_64_masks", "unet3d", small3d, [450], "masks", False),
         # V-Net (--model vnet): BatchNorm3d + Dropout3d, stride-2 / transposed convolutions; batch 2+2 so that

@@ -29,8 +29,9 @@ class OracleUNet2D:
     FT = [16, 32, 64, 128, 256]
     DROPOUT = [0.05, 0.1, 0.2, 0.3, 0.5]   # unet.py:310
 
-    def __init__(self, in_chns, class_num):
-        self.in_chns, self.class_num = in_chns, class_num
+    def __init__(self, in_chns, class_num, bilinear=True):
+        # bilinear=False: UpBlock's other branch, nn.ConvTranspose2d(C1, C2, 2, stride=2) (unet.py:76-78, :81-84)
+        self.in_chns, self.class_num, self.bilinear = in_chns, class_num, bilinear
 
     def _block_keys(self, prefix, cin, cout):
         out = []
@@ -48,7 +49,10 @@ class OracleUNet2D:
             keys += self._block_keys(f"encoder.down{i}.maxpool_conv.1.conv_conv", ft[i - 1], ft[i])
         for i in range(1, 5):
             c1, c2 = ft[5 - i], ft[4 - i]
-            keys += [(f"decoder.up{i}.conv1x1.weight", (c2, c1, 1, 1)), (f"decoder.up{i}.conv1x1.bias", (c2,))]
+            if self.bilinear:
+                keys += [(f"decoder.up{i}.conv1x1.weight", (c2, c1, 1, 1)), (f"decoder.up{i}.conv1x1.bias", (c2,))]
+            else:
+                keys += [(f"decoder.up{i}.up.weight", (c1, c2, 2, 2)), (f"decoder.up{i}.up.bias", (c2,))]
             keys += self._block_keys(f"decoder.up{i}.conv.conv_conv", 2 * c2, c2)
         keys += [("decoder.out_conv.weight", (self.class_num, ft[0], 3, 3)),
                  ("decoder.out_conv.bias", (self.class_num,))]
@@ -98,8 +102,11 @@ class OracleUNet2D:
             feats.append(x)
         for i in range(1, 5):                                                        # UpBlock, unet.py:65-86
             skip = feats[4 - i]
-            x = F.conv2d(x, sd[f"decoder.up{i}.conv1x1.weight"], sd[f"decoder.up{i}.conv1x1.bias"])
-            x = F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=True)
+            if self.bilinear:
+                x = F.conv2d(x, sd[f"decoder.up{i}.conv1x1.weight"], sd[f"decoder.up{i}.conv1x1.bias"])
+                x = F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=True)
+            else:
+                x = F.conv_transpose2d(x, sd[f"decoder.up{i}.up.weight"], sd[f"decoder.up{i}.up.bias"], stride=2)
             x = torch.cat([skip, x], dim=1)
             x = self._conv_block(sd, f"decoder.up{i}.conv.conv_conv", x, 0.0, training, "off", -1)
         return F.conv2d(x, sd["decoder.out_conv.weight"], sd["decoder.out_conv.bias"], padding=1)

@@ -16,6 +16,7 @@ pytestmark = pytest.mark.gpu
 
 CASES = [
     ("unet2d", (2, 1, 64, 64), 4),
+    ("unet2d_deconv", (2, 1, 64, 64), 4),       # UpBlock(bilinear=False): UpConv2dOp owns the ConvTranspose2d parameters
     ("unet3d", (2, 1, 32, 32, 32), 2),
     ("unet3d", (2, 1, 96, 96, 96), 2),        # the BASELINE geometry: Winograd boxes + fused head + first-layer fusion
     ("vnet", (2, 1, 32, 32, 32), 2),

@@ -23,8 +23,8 @@ def _sample_idx(numel):
     return np.unique(np.linspace(0, numel - 1, 64).astype(np.int64))
 
 
-@pytest.mark.parametrize("name", ["unet2d_64_dropoff", "unet2d_64_masks", "unet3d_64_dropoff", "unet3d_64_masks",
-                                  "vnet_64_masks", "vnet_gn_64_masks"])
+@pytest.mark.parametrize("name", ["unet2d_64_dropoff", "unet2d_64_masks", "unet2d_deconv_64_masks", "unet3d_64_dropoff",
+                                  "unet3d_64_masks", "vnet_64_masks", "vnet_gn_64_masks"])
 def test_oracle_reproduces_reference_goldens(name):
     """oracle.step on the fixture inputs == numbers the real reference produced (gen_golden.py)."""
     from oracle import filler
@@ -33,7 +33,7 @@ def test_oracle_reproduces_reference_goldens(name):
     z, meta = _load(name)
     kind, cfg, iters, mode = meta["kind"], meta["cfg"], meta["iters"], meta["drop_mode"]
     C, L = cfg["num_classes"], cfg["labeled_bs"]
-    onet = {"unet2d": lambda: OracleUNet2D(1, C), "unet3d": lambda: OracleUNet3D(C, 1),
+    onet = {"unet2d": lambda: OracleUNet2D(1, C), "unet2d_deconv": lambda: OracleUNet2D(1, C, bilinear=False), "unet3d": lambda: OracleUNet3D(C, 1),
             "vnet": lambda: OracleVNet(C, 1),
             "vnet_groupnorm": lambda: OracleVNet(C, 1, normalization="groupnorm")}[kind]()
     sd0 = filler.fill_state_dict(onet.new_state())
@@ -41,7 +41,7 @@ def test_oracle_reproduces_reference_goldens(name):
     tsd0 = {k[2:]: v for k, v in tsd0.items()}
     B, sp = cfg["batch_size"], tuple(cfg["spatial"])
     volume = filler.image((B, 1) + sp, "volume")
-    label = filler.labels((B,) + sp, C, torch.uint8 if kind == "unet2d" else torch.int64)
+    label = filler.labels((B,) + sp, C, torch.uint8 if kind.startswith("unet2d") else torch.int64)
     noise = filler.noise((B - L, 1) + sp, "noise")
     if "eval_logits_samples" in z.files:
         lg = onet.forward({k: v.clone() for k, v in sd0.items()}, volume, training=False).double().flatten()

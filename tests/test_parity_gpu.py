@@ -44,6 +44,9 @@ def _build(kind, C):
     if kind == "unet2d":
         from networks.net_factory import net_factory
         return OracleUNet2D(1, C), (lambda: net_factory("unet", 1, C))
+    if kind == "unet2d_deconv":      # UpBlock(bilinear=False): nn.ConvTranspose2d(k=2, s=2) decoder (reference unet.py:76-78)
+        from networks.unet import UNet
+        return OracleUNet2D(1, C, bilinear=False), (lambda: UNet(1, C, bilinear=False).cuda())
     from networks.net_factory_3d import net_factory_3d
     if kind == "vnet":
         from oracle.nets import OracleVNet
@@ -72,7 +75,7 @@ def _inputs(kind, cfg):
     tag = cfg.get("tag", "")
     volume = filler.image((B, ch) + sp, "volume" + tag)
     label = filler.labels((B,) + sp, cfg["num_classes"],
-                          torch.uint8 if kind in ("unet2d", "swin", "swin_w8") else torch.int64)
+                          torch.uint8 if kind in ("unet2d", "unet2d_deconv", "swin", "swin_w8") else torch.int64)
     noise = filler.noise((B - cfg["labeled_bs"], ch) + sp, "noise" + tag)
     return volume, label, noise
 
@@ -87,7 +90,7 @@ def _check_summary(t, z, prefix, tol):
     assert abs(float(t.min()) - float(z[prefix + "min"])) <= tol
 
 
-CASES = ["unet2d_64_dropoff", "unet2d_64_masks", "unet3d_64_dropoff", "unet3d_64_masks", "unet2d_256_cfg1",
+CASES = ["unet2d_64_dropoff", "unet2d_64_masks", "unet2d_deconv_64_masks", "unet3d_64_dropoff", "unet3d_64_masks", "unet2d_256_cfg1",
          "unet3d_96_cfg3_b2", "swin_224_dropoff", "swin_224_masks", "vnet_64_dropoff", "vnet_64_masks",
          "vnet_gn_64_dropoff", "vnet_gn_64_masks", "vnet_in_64_dropoff", "vnet_none_64_masks",
          "swin_224_rgb", "swin_256_w8"]
@@ -332,7 +335,7 @@ def test_philox_dropout_trains_and_is_reproducible():
 # 1e-2..1e-1 (relative, per tensor) away from this truth for the deep layers; the HIP path has to be close to the
 # truth, not to that noise.
 # --------------------------------------------------------------------------------------------------------------
-F64_CASES = [("unet2d_64_dropoff", 1000), ("unet2d_64_masks", 1500), ("unet3d_64_dropoff", 7), ("vnet_64_dropoff", 7),
+F64_CASES = [("unet2d_64_dropoff", 1000), ("unet2d_64_masks", 1500), ("unet2d_deconv_64_masks", 1500), ("unet3d_64_dropoff", 7), ("vnet_64_dropoff", 7),
              ("vnet_gn_64_dropoff", 7), ("vnet_gn_64_masks", 450), ("vnet_none_64_masks", 450)]
 # per tensor: |g_hip - g_f64|_max <= max(F64_K * e32, F64_REL) * |g_f64|_max + F64_ABS * (largest |g_f64| of the net),
 # e32 = the reference's own fp32-vs-fp64 relative error of that tensor; and over all tensors the median of
