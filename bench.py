@@ -46,6 +46,7 @@ for p in (os.path.join(ROOT, "cv-ssl-mis_amd"), ROOT):
         sys.path.insert(0, p)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_*_f32 dense peak
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # same guide: bf16 MFMA, dense (the 5 PF headline includes 2:1 sparsity)
 
 # step_gflop: algorithmic FLOP of one step, SURVEY.md s.8d: F_fwd * (3*(L+U) + U) (student fwd+dgrad+wgrad, teacher
 # fwd); cross teaching: both students train on the whole batch.
@@ -338,13 +339,27 @@ def run_workload(name, args, rank, world, kernel_events=True):
             return (3.375 if k.startswith(("wino_fwd_kernel", "wino_wgrad_")) else
                     2.25 if k.startswith(("wino2d_fwd_kernel", "wino2d_wgrad_kernel")) else 1.0)
 
+        def bf3(k):
+            """The Linear GEMMs in their bf16x3 form (gemm.hip: last template argument 1): every algorithmic multiply-add is
+            six v_mfma_f32_16x16x32_bf16 piece products, priced against the dense bf16 matrix peak."""
+            return k.startswith("gemm_nt_kernel<") and k.rstrip(" >").endswith(", 1") or k.startswith("gemm_tn_reg_kernel<1")
+
+        def pipe_seconds(k, flops):
+            """Time the matrix pipe needs for this launch's EXECUTED flops at its peak."""
+            if bf3(k):
+                return flops * 6.0 / (PEAK_BF16_MFMA_TFLOPS * 1e12)
+            return flops / reduction(k) / (PEAK_FP32_MFMA_TFLOPS * 1e12)
+
         fam_alg = sum(d[0] for d in per.values())
-        fam_exec = sum(d[0] / reduction(k) for k, d in per.items())
+        fam_exec = sum(d[0] * (6.0 if bf3(k) else 1.0 / reduction(k)) for k, d in per.items())
+        fam_pipe_s = sum(pipe_seconds(k, d[0]) for k, d in per.items())
         fam_time = sum(d[1] for d in per.values())
         dom = max(per, key=lambda k: per[k][1])
         red = reduction(dom)
         alg_tf = per[dom][0] / per[dom][1] / 1e12           # direct-convolution (algorithmic) flops over time
-        achieved = alg_tf / red                             # flops the matrix pipe executes over time: <= peak
+        dom_bf3 = bool(bf3(dom))
+        peak = PEAK_BF16_MFMA_TFLOPS if dom_bf3 else PEAK_FP32_MFMA_TFLOPS
+        achieved = alg_tf * 6.0 if dom_bf3 else alg_tf / red  # flops the matrix pipe executes over time: <= its peak
         # HBM bytes per launch come from the PMC counters (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes): main()
         # re-executes this command under rocprofv3 for them and fills `traffic` (inrun_traffic); the figure of the last
         # committed PMC pass stays beside it, labelled as such
@@ -364,19 +379,21 @@ def run_workload(name, args, rank, world, kernel_events=True):
         # summed launch durations, against the fp32 MFMA peak: a fraction of the pipe, <= 1 by construction and the
         # quantity SQ_VALU_MFMA_BUSY_CYCLES measures (profiles/r03_*_pmc_mfma.csv).  The algorithmic rate (what a direct
         # convolution would have to sustain for the same time) is kept beside it.
-        roofline = dict(bound="mfma", kernel=dom, achieved=round(achieved, 3), peak=PEAK_FP32_MFMA_TFLOPS,
-                        unit="TFLOP/s", frac=round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
+        roofline = dict(bound="mfma", kernel=dom, achieved=round(achieved, 3), peak=peak,
+                        unit="TFLOP/s", frac=round(achieved / peak, 4),
                         algorithmic_tflops=round(alg_tf, 3), winograd_reduction=red,
+                        pipe=("bf16 MFMA (bf16x3: exact 3-way split of the fp32 operands, 6 piece products per multiply-add, fp32 "
+                              "accumulation; `achieved` = 6 x algorithmic)" if dom_bf3 else "fp32 MFMA"),
                         traffic=None, traffic_from_profiles=traffic_prof,
                         launches=per[dom][2], avg_launch_ms=round(per[dom][1] / per[dom][2] * 1e3, 4),
                         algorithmic_flops_per_launch_avg=per[dom][0] / per[dom][2],
                         algorithmic_bytes_per_launch_avg=per[dom][3] / per[dom][2],
-                        executed_flops_per_launch_avg=per[dom][0] / per[dom][2] / red,
+                        executed_flops_per_launch_avg=per[dom][0] / per[dom][2] * (6.0 if dom_bf3 else 1.0 / red),
                         family=dict(kernel="all event-timed MFMA launches (wino*_fwd_kernel<*> / conv_fwd_kernel<*> forward + "
                                            "data gradient, wino*_wgrad_kernel<*> / conv_wgrad_kernel<*> weight gradient; "
                                            "gemm_nt_kernel<*> / gemm_tn_reg_kernel / gemm_tn_kernel<*> for SwinUnet)",
                                     achieved=round(fam_exec / fam_time / 1e12, 3),
-                                    frac=round(fam_exec / fam_time / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
+                                    frac=round(fam_pipe_s / fam_time, 4),     # pipe-seconds at peak / seconds (fp32 and bf16 launches each against their own peak)
                                     algorithmic_tflops=round(fam_alg / fam_time / 1e12, 3),
                                     share_of_step_time=round(fam_time / serial_dt, 4)))
         roofline["measured_in"] = (f"a second region of {serial_steps} steps of this run with the side streams off (teacher "
@@ -394,7 +411,7 @@ def run_workload(name, args, rank, world, kernel_events=True):
         roofline["step_algorithmic_flop_frac"] = round(step_frac, 4)      # direct-convolution flops: may exceed 1
         # the flops the matrix pipe EXECUTES per step (every event-timed launch of the serial region, Winograd launches
         # at 1/3.375 resp. 1/2.25 of their direct-convolution count) over the TIMED region's step time: <= 1
-        exec_frac = fam_exec / serial_steps / step_s / (PEAK_FP32_MFMA_TFLOPS * 1e12)
+        exec_frac = fam_pipe_s / serial_steps / step_s
         roofline["executed_step_flops"] = fam_exec / serial_steps
         roofline["executed_step_frac"] = round(exec_frac, 4)
     grad_bytes = [] if stub else [int(m.flat_param.numel()) * 4 for m in
@@ -744,7 +761,22 @@ def main():
         for name in OTHERS:
             r = run_workload(name, oargs, rank, world, kernel_events=not args.no_kernel_events)
             rf = r["roofline"] or {}
-            others[name] = dict(workload=WORKLOADS[name]["config"], value=r["value"], unit=r["unit"],
+            extra = {}
+            if name in ("swin", "cross"):
+                # the nn.Linear GEMMs run as bf16x3 split products by default (gemm.hip): the same workload with them on
+                # the fp32 MFMA instruction, timed the same way, so that the line carries both
+                from mis_hip import tops as _tops
+                prev = _tops.set_split_precision(0)
+                try:
+                    r32 = run_workload(name, oargs, rank, world, kernel_events=False)
+                finally:
+                    _tops.set_split_precision(prev)
+                extra = dict(linear_gemm_arithmetic="bf16x3: every fp32 operand cut exactly into three bf16 pieces, six piece "
+                             "products per multiply-add on v_mfma_f32_16x16x32_bf16, fp32 accumulation -- error against float64 "
+                             "no larger than the fp32 MFMA kernels' (tests/test_token_kernels_gpu.py, both forms)",
+                             ms_per_step_fp32_mfma=r32["ms_per_step"], value_fp32_mfma=r32["value"],
+                             losses_fp32_mfma=r32["losses"], losses=r["losses"])
+            others[name] = dict(workload=WORKLOADS[name]["config"], value=r["value"], unit=r["unit"], **extra,
                                 ms_per_step=r["ms_per_step"], steps=oargs.steps,
                                 host_enqueue_ms_per_step=r["host_enqueue_ms_per_step"],
                                 serial_ms_per_step=rf.get("serial_ms_per_step"),

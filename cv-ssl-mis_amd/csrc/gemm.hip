@@ -27,6 +27,7 @@
 // per-workgroup loops and profit more from 4 resident workgroups per CU than from a double-buffered DMA stage:
 // 9.5 ms/step vs 13.1 ms/step on config 4), partial tiles in a caller workspace and a fixed-order reduction
 // (deterministic).  Workgroups are ordered XCD-aware over one linear (k-slice, tile) index.
+#include <atomic>
 #include "common.h"
 
 namespace {
@@ -75,6 +76,40 @@ extern __shared__ __attribute__((aligned(16))) float mis_gemm_lds[];
 // the k-loop, 4 no MFMAs, 8 no epilogue at all
 constexpr int GDBG = MIS_GEMM_DBG_CT;
 
+// ------------------------------------------------------------------------------------------------ split-precision products
+// PREC = 1 ("bf16x3", MIS_GEMM_BF3=1): an fp32 value is cut EXACTLY into three bf16 pieces by truncation, x = h + m + l (8 + 8 + 8
+// significant bits; the two subtractions are exact), and a product of two such values is the sum of the six piece products
+// hh + hm + mh + hl + lh + mm on v_mfma_f32_16x16x32_bf16 with fp32 accumulation -- what is dropped (ml + lm + ll) is below
+// 2^-24 of |a||b|, i.e. below the rounding of the fp32 fmaf chain it replaces (tests: error against float64 no larger than the
+// fp32 kernel's).  One K = 32 block costs 6 instructions of 18 cycles instead of 8 of 32 (scripts/ubench/pipe_share.hip:
+// 7.5 ns against 13.8 ns per instruction), and the 32-bit integer / fp32 ops of the split overlap a co-resident wave's bf16
+// MFMAs (v_add beside mfma_bf16: 2175 us together against 2967 serial), which packed fp32 ops and the fp32 MFMA do not.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void bf3_split_pair(float x0, float x1, unsigned& h, unsigned& m, unsigned& l) {
+    const unsigned u0 = __float_as_uint(x0), u1 = __float_as_uint(x1);
+    h = __builtin_amdgcn_perm(u1, u0, 0x07060302u);                   // {hi16(x1), hi16(x0)}: element 0 in the low half
+    const float r0 = x0 - __uint_as_float(u0 & 0xFFFF0000u), r1 = x1 - __uint_as_float(u1 & 0xFFFF0000u);
+    const unsigned v0 = __float_as_uint(r0), v1 = __float_as_uint(r1);
+    m = __builtin_amdgcn_perm(v1, v0, 0x07060302u);
+    const float t0 = r0 - __uint_as_float(v0 & 0xFFFF0000u), t1 = r1 - __uint_as_float(v1 & 0xFFFF0000u);
+    l = __builtin_amdgcn_perm(__float_as_uint(t1), __float_as_uint(t0), 0x07060302u);
+}
+
+__device__ __forceinline__ f32x4 bf3_mfma(const u32x4& a, const u32x4& b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+// Split-precision mask: bit 0 the NT GEMMs (forward, dX), bit 1 the register-only TN GEMM (dW) as bf16x3 products; 0 = fp32 MFMA
+// everywhere.  Default 3 (MIS_GEMM_BF3 overrides at load; mis_gemm_set_split_precision at run time: bench.py times both).
+std::atomic<int>& gemm_bf3_state() {
+    static std::atomic<int> m{[] { const char* e = getenv("MIS_GEMM_BF3"); return e ? atoi(e) & 3 : 3; }()};
+    return m;
+}
+bool gemm_bf3() { return gemm_bf3_state().load(std::memory_order_relaxed) & 1; }
+bool gemm_bf3_tn() { return gemm_bf3_state().load(std::memory_order_relaxed) & 2; }
+
 // ------------------------------------------------------------------------------------------------ NT
 template <int BMT, int BN>
 struct NtCfg {
@@ -95,7 +130,7 @@ struct NtCfg {
 // EP: compile-time epilogue (EP_NONE / EP_GELU_FWD / EP_GELU_BWD / EP_RESIDUAL).  The fused epilogues are separate
 // instantiations: compiled into the plain kernel they cost it 41 registers and one resident workgroup per CU
 // (measured: every Linear of the step slowed down, 38.5 -> 41.7 ms).
-template <int BMT, int BN, int EP>
+template <int BMT, int BN, int EP, int PREC = 0>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs a) {
     using G = NtCfg<BMT, BN>;
     float* const lds = mis_gemm_lds;
@@ -177,6 +212,46 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs a) {
         }
     };
 
+    // bf16x3 form of the same k-step (PREC = 1): the lane's 8 operand floats of a row -- the four float2 reads above, k = 8 s +
+    // 2 lk + {0, 1} -- ARE the 8 contraction elements of a v_mfma_f32_16x16x32_bf16 operand (any assignment of the 32 k to
+    // (lane group, slot) works as long as A and B share it): same LDS reads, 6 instructions per K = 32 block instead of 8
+    auto compute_bf3 = [&](const float* st) {
+        const float2* __restrict__ sA2 = reinterpret_cast<const float2*>(st);
+        const float2* __restrict__ sB2 = reinterpret_cast<const float2*>(st + G::A_FLOATS);
+        u32x4 ah[G::MI], am[G::MI], al[G::MI];
+#pragma unroll
+        for (int i = 0; i < G::MI; ++i)
+#pragma unroll
+            for (int s = 0; s < BK / 8; ++s) {
+                const float2 v = sA2[((wm + i * 16 + lj) * BK + ((s * 8 + 2 * lk) ^ swz)) >> 1];
+                unsigned h, m, l;
+                bf3_split_pair(v.x, v.y, h, m, l);
+                ah[i][s] = h; am[i][s] = m; al[i][s] = l;
+            }
+#pragma unroll
+        for (int j = 0; j < G::NJ; ++j) {
+            u32x4 bh, bm, bl;
+#pragma unroll
+            for (int s = 0; s < BK / 8; ++s) {
+                const float2 v = sB2[((wn + j * 16 + lj) * BK + ((s * 8 + 2 * lk) ^ swz)) >> 1];
+                unsigned h, m, l;
+                bf3_split_pair(v.x, v.y, h, m, l);
+                bh[s] = h; bm[s] = m; bl[s] = l;
+            }
+#pragma unroll
+            for (int i = 0; i < G::MI; ++i) {
+                f32x4 c = acc[i][j];
+                c = bf3_mfma(al[i], bh, c);
+                c = bf3_mfma(ah[i], bl, c);
+                c = bf3_mfma(am[i], bm, c);
+                c = bf3_mfma(am[i], bh, c);
+                c = bf3_mfma(ah[i], bm, c);
+                c = bf3_mfma(ah[i], bh, c);
+                acc[i][j] = c;
+            }
+        }
+    };
+
     // ---- software pipeline over k-steps: DMA(s+1) || MFMA(s) ----
     stage(0, kbeg);
     dma_wait();
@@ -184,7 +259,8 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs a) {
     int s = 0;
     for (int k0 = kbeg; k0 < kend; k0 += BK, ++s) {
         if (k0 + BK < kend && !(GDBG & 2)) stage((s + 1) & 1, k0 + BK);
-        if constexpr (!(GDBG & 4)) compute(lds + (s & 1) * G::STAGE);
+        if constexpr (PREC == 1) compute_bf3(lds + (s & 1) * G::STAGE);
+        else if constexpr (!(GDBG & 4)) compute(lds + (s & 1) * G::STAGE);
         dma_wait();
         __syncthreads();   // k-step s+1 landed in the other buffer; everyone is done reading this one
     }
@@ -660,9 +736,84 @@ __device__ __forceinline__ void tn_reg_loop(f32x4 (&acc)[6][6], float2 (&bs)[3],
     }
 }
 
+// bf16x3 form of the same loop (PREC = 1, see bf3_split_pair): a v_mfma_f32_16x16x32_bf16 operand is 8 contraction elements per
+// lane -- here the lane's own row (kk) of 8 consecutive groups of 4 rows, i.e. a SUPER-GROUP of 32 token rows: slot j of the
+// operand = group j, for A and B alike, so the values stay in the registers they were loaded into and only get cut into their
+// bf16 pieces (2 x 24 pairs x 11 integer / fp32 ops per super-group beside 216 MFMAs of 18 cycles; the fp32 form: 288 of 32).
+// A is split for all six tiles first and its next super-group is requested at once; B is split tile by tile between the MFMAs,
+// and the rows of a column block t are requested again as soon as its two tiles are cut.
+template <bool COLSUM>
+__device__ __forceinline__ void tn_reg_loop_bf3(f32x4 (&acc)[6][6], float2 (&bs)[3], __amdgpu_buffer_rsrc_t rA, __amdgpu_buffer_rsrc_t rB,
+                                                int va, int vb, unsigned sa, unsigned sb, unsigned step_a, unsigned step_b, int ngroups) {
+    float2 ra[8][3], rb[8][3];
+#pragma unroll
+    for (int d = 0; d < 8; ++d)
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            ra[d][t] = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(rA, va + t * 128, (int)(sa + d * step_a), 0));
+            rb[d][t] = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(rB, vb + t * 128, (int)(sb + d * step_b), 0));
+        }
+    sa += 8 * step_a; sb += 8 * step_b;
+    for (int g = 0; g < ngroups; g += 8) {
+        u32x4 ah[6], am[6], al[6];
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                unsigned h, m, l;
+                bf3_split_pair(ra[2 * s][t].x, ra[2 * s + 1][t].x, h, m, l);
+                ah[2 * t][s] = h; am[2 * t][s] = m; al[2 * t][s] = l;
+                bf3_split_pair(ra[2 * s][t].y, ra[2 * s + 1][t].y, h, m, l);
+                ah[2 * t + 1][s] = h; am[2 * t + 1][s] = m; al[2 * t + 1][s] = l;
+            }
+            if constexpr (COLSUM) {
+#pragma unroll
+                for (int d = 0; d < 8; ++d) { bs[t].x += ra[d][t].x; bs[t].y += ra[d][t].y; }
+            }
+        }
+#pragma unroll
+        for (int d = 0; d < 8; ++d)
+#pragma unroll
+            for (int t = 0; t < 3; ++t)
+                ra[d][t] = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(rA, va + t * 128, (int)(sa + d * step_a), 0));
+        sa += 8 * step_a;
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                u32x4 bh, bm, bl;
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    unsigned h, m, l;
+                    if (c == 0) bf3_split_pair(rb[2 * s][t].x, rb[2 * s + 1][t].x, h, m, l);
+                    else bf3_split_pair(rb[2 * s][t].y, rb[2 * s + 1][t].y, h, m, l);
+                    bh[s] = h; bm[s] = m; bl[s] = l;
+                }
+                const int j = 2 * t + c;
+#pragma unroll
+                for (int i = 0; i < 6; ++i) {
+                    f32x4 v = acc[i][j];
+                    v = bf3_mfma(al[i], bh, v);
+                    v = bf3_mfma(ah[i], bl, v);
+                    v = bf3_mfma(am[i], bm, v);
+                    v = bf3_mfma(am[i], bh, v);
+                    v = bf3_mfma(ah[i], bm, v);
+                    v = bf3_mfma(ah[i], bh, v);
+                    acc[i][j] = v;
+                }
+            }
+#pragma unroll
+            for (int d = 0; d < 8; ++d)
+                rb[d][t] = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(rB, vb + t * 128, (int)(sb + d * step_b), 0));
+        }
+        sb += 8 * step_b;
+    }
+}
+
 #ifndef MIS_TN_REG_WAVES
 #define MIS_TN_REG_WAVES 1
 #endif
+template <int PREC>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MIS_TN_REG_WAVES, MIS_TN_REG_WAVES))) void gemm_tn_reg_kernel(const GemmArgs a) {
     float* const lds = mis_gemm_lds;                   // 2 x 36 KiB: the in-workgroup sum of the 4 waves' tiles
     const unsigned L = mis_xcd_remap(blockIdx.x, a.n_blocks_padded);
@@ -694,8 +845,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MIS_TN_REG_
         for (int j = 0; j < 6; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     float2 bs[3] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
     const bool colsum = a.dbias != nullptr && tn == 0;          // workgroup-uniform
-    if (colsum) tn_reg_loop<true>(acc, bs, rA, rB, va, vb, sa, sb, (unsigned)(a.lda * 16), (unsigned)(a.ldb * 16), ngroups);
-    else tn_reg_loop<false>(acc, bs, rA, rB, va, vb, sa, sb, (unsigned)(a.lda * 16), (unsigned)(a.ldb * 16), ngroups);
+    if constexpr (PREC == 1) {
+        if (colsum) tn_reg_loop_bf3<true>(acc, bs, rA, rB, va, vb, sa, sb, (unsigned)(a.lda * 16), (unsigned)(a.ldb * 16), ngroups);
+        else tn_reg_loop_bf3<false>(acc, bs, rA, rB, va, vb, sa, sb, (unsigned)(a.lda * 16), (unsigned)(a.ldb * 16), ngroups);
+    } else {
+        if (colsum) tn_reg_loop<true>(acc, bs, rA, rB, va, vb, sa, sb, (unsigned)(a.lda * 16), (unsigned)(a.ldb * 16), ngroups);
+        else tn_reg_loop<false>(acc, bs, rA, rB, va, vb, sa, sb, (unsigned)(a.lda * 16), (unsigned)(a.ldb * 16), ngroups);
+    }
 
     // ---- sum of the 4 waves: (w2 -> w0, w3 -> w1), then w1 -> w0; fixed order ----
     f32x4* const l4 = reinterpret_cast<f32x4*>(lds);
@@ -815,8 +971,14 @@ void tn_reg_plan(GemmArgs& a) {
 int launch_tn_reg(GemmArgs& a, hipStream_t stream) {
     constexpr int LDSB = 2 * 36 * 64 * 16 + 2 * 64 * 6 * 4;
     static std::atomic<unsigned long long> attr_done{0};
-    if (mis_set_lds_attr(reinterpret_cast<const void*>(&gemm_tn_reg_kernel), LDSB, attr_done) != MIS_OK) return MIS_ERR_LAUNCH;
-    hipLaunchKernelGGL(gemm_tn_reg_kernel, dim3(a.n_blocks_padded), dim3(256), LDSB, stream, a);
+    if (gemm_bf3_tn()) {
+        static std::atomic<unsigned long long> attr_done1{0};
+        if (mis_set_lds_attr(reinterpret_cast<const void*>(&gemm_tn_reg_kernel<1>), LDSB, attr_done1) != MIS_OK) return MIS_ERR_LAUNCH;
+        hipLaunchKernelGGL(gemm_tn_reg_kernel<1>, dim3(a.n_blocks_padded), dim3(256), LDSB, stream, a);
+        return mis_launch_status();
+    }
+    if (mis_set_lds_attr(reinterpret_cast<const void*>(&gemm_tn_reg_kernel<0>), LDSB, attr_done) != MIS_OK) return MIS_ERR_LAUNCH;
+    hipLaunchKernelGGL(gemm_tn_reg_kernel<0>, dim3(a.n_blocks_padded), dim3(256), LDSB, stream, a);
     return mis_launch_status();
 }
 
@@ -944,14 +1106,19 @@ bool a16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 // works because ITS operands are contraction-major and a lane group reads 128 contiguous bytes.  The NT GEMMs need the transpose
 // that the LDS stage provides.  Removed; scripts/gemm_nt_bench.py is the measurement.)
 
-template <int BMT, int BN, int EP>
-int launch_nt_ep(const GemmArgs& a, hipStream_t stream) {
+template <int BMT, int BN, int EP, int PREC>
+int launch_nt_prec(const GemmArgs& a, hipStream_t stream) {
     static std::atomic<unsigned long long> attr_done{0};   // per instantiation, one bit per device
     using G = NtCfg<BMT, BN>;
-    if (mis_set_lds_attr(reinterpret_cast<const void*>(&gemm_nt_kernel<BMT, BN, EP>), G::LDS_BYTES, attr_done) != MIS_OK)
+    if (mis_set_lds_attr(reinterpret_cast<const void*>(&gemm_nt_kernel<BMT, BN, EP, PREC>), G::LDS_BYTES, attr_done) != MIS_OK)
         return MIS_ERR_LAUNCH;
-    hipLaunchKernelGGL((gemm_nt_kernel<BMT, BN, EP>), dim3(a.n_blocks_padded), dim3(256), G::LDS_BYTES, stream, a);
+    hipLaunchKernelGGL((gemm_nt_kernel<BMT, BN, EP, PREC>), dim3(a.n_blocks_padded), dim3(256), G::LDS_BYTES, stream, a);
     return mis_launch_status();
+}
+
+template <int BMT, int BN, int EP>
+int launch_nt_ep(const GemmArgs& a, hipStream_t stream) {
+    return gemm_bf3() ? launch_nt_prec<BMT, BN, EP, 1>(a, stream) : launch_nt_prec<BMT, BN, EP, 0>(a, stream);
 }
 
 // split-K slices write raw partials (the epilogue runs in gemm_reduce_kernel): always the plain instantiation
@@ -976,6 +1143,7 @@ int nt_tile_m(int M, int N, int K) {
 bool nt_short(const GemmArgs& a) {
     static const int force = getenv("MIS_GEMM_SHORT") ? atoi(getenv("MIS_GEMM_SHORT")) : -1;
     if (force == 0 || a.KS > 1 || !a.vec4 || a.ex_P || a.K % 4) return false;
+    if (gemm_bf3() && force != 1) return false;      // prototype: the split-precision form lives in the general kernel only
     if (force == 1) return true;
     return a.K <= 192 && mis_cdiv(a.M, 64) * mis_cdiv(a.N, nt_tile_n(a.N)) >= 1536;
 }
@@ -1020,6 +1188,16 @@ int launch_nt(GemmArgs& a, hipStream_t stream) {
 
 }  // namespace
 
+// Arithmetic of the nn.Linear GEMMs: mask bit 0 = forward / dX (NT), bit 1 = dW (TN, widths % 96 == 0) as bf16x3 split
+// products on v_mfma_f32_16x16x32_bf16 (exact 3-way split of the fp32 operands, six piece products, fp32 accumulation: error
+// against float64 no larger than the fp32 MFMA kernels'); 0 = v_mfma_f32_16x16x4_f32 everywhere.  Returns the previous mask;
+// mask < 0 only queries.
+extern "C" int mis_gemm_set_split_precision(int mask) {
+    const int prev = gemm_bf3_state().load();
+    if (mask >= 0) gemm_bf3_state().store(mask & 3);
+    return prev;
+}
+
 // NT kernel instantiation mis_gemm / mis_gemm_ex run this shape with (16-byte aligned operands, N % 4 == 0), as
 // rocprofv3 prints it minus the anonymous-namespace prefix: for bench.py's attribution
 extern "C" int mis_gemm_nt_kernel_name(int M, int N, int K, int epilogue, char* name, int name_len) {
@@ -1028,7 +1206,7 @@ extern "C" int mis_gemm_nt_kernel_name(int M, int N, int K, int epilogue, char* 
     a.M = M; a.N = N; a.K = K; a.vec4 = N % 4 == 0; a.KS = pick_ks(M, N, K, 0);
     const int bn = nt_tile_n(N);
     if (nt_short(a)) snprintf(name, name_len, "gemm_nt_short_kernel<%d, %d>", bn, epilogue);
-    else snprintf(name, name_len, "gemm_nt_kernel<%d, %d, %d>", nt_tile_m(M, N, K), bn, a.KS > 1 ? 0 : epilogue);
+    else snprintf(name, name_len, "gemm_nt_kernel<%d, %d, %d, %d>", nt_tile_m(M, N, K), bn, a.KS > 1 ? 0 : epilogue, gemm_bf3() ? 1 : 0);
     return MIS_OK;
 }
 
@@ -1038,7 +1216,7 @@ extern "C" int mis_gemm_tn_kernel_name(const float* A, long long lda, const floa
                                        long long ldc, int M, int N, int K, char* name, int name_len) {
     if (M <= 0 || N <= 0 || K <= 0 || !name || name_len <= 0) return MIS_ERR_ARG;
     if (tn_reg_ok(A, lda, B, ldb, C, ldc, M, N, K) && (long long)K * lda * 4 < (1LL << 31) && (long long)K * ldb * 4 < (1LL << 31))
-        snprintf(name, name_len, "gemm_tn_reg_kernel");
+        snprintf(name, name_len, "gemm_tn_reg_kernel<%d>", gemm_bf3_tn() ? 1 : 0);
     else snprintf(name, name_len, "gemm_tn_kernel<%d>", tn_tile(M, N));
     return MIS_OK;
 }

@@ -150,6 +150,7 @@ PROTOTYPES = {
     "mis_gemm_workspace_bytes": (c_ll, [c_i, c_i, c_i, c_i]),
     "mis_gemm_dw_workspace_bytes": (c_ll, [c_i, c_i, c_i]),
     "mis_gemm_dw": (c_i, [c_p, c_ll, c_p, c_ll, c_p, c_ll, c_p, c_i, c_i, c_i, c_i, c_p, c_ll, c_p]),
+    "mis_gemm_set_split_precision": (c_i, [c_i]),
     "mis_gemm_nt_kernel_name": (c_i, [c_i, c_i, c_i, c_i, ctypes.c_char_p, c_i]),
     "mis_gemm_tn_kernel_name": (c_i, [c_p, c_ll, c_p, c_ll, c_p, c_ll, c_i, c_i, c_i, ctypes.c_char_p, c_i]),
     "mis_gemm_expand": (c_i, [c_p, c_ll, c_p, c_ll, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),

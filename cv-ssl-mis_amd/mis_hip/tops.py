@@ -66,6 +66,12 @@ def gemm(A, B, C, bias=None, trans=False, accumulate=False):
         prof.append((name, 2.0 * M * N * K, e0, e1, 4.0 * (M * K + N * K + M * N)))
 
 
+def set_split_precision(mask):
+    """Arithmetic of the nn.Linear GEMMs (mis_gemm_set_split_precision): bit 0 forward + dX, bit 1 dW as bf16x3 products
+    (exact 3-way bf16 split of the fp32 operands, fp32 accumulation); 0 = fp32 MFMA.  Returns the previous mask; < 0 queries."""
+    return int(_l.load().mis_gemm_set_split_precision(int(mask)))
+
+
 def gemm_dw(dy, x, dW, db, accumulate=False):
     """dW[M,N] (+)= dy[K,M]^T @ x[K,N] and db[M] (+)= dy.sum(0) in one pass over dy (mis_gemm_dw)."""
     L = _l.load()

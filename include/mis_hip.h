@@ -447,6 +447,13 @@ int mis_gemm_dw(const float* dy, long long lddy, const float* x, long long ldx, 
                 int N, int K, int accumulate, float* workspace, long long workspace_bytes, hipStream_t stream);
 /* the NT kernel instantiation mis_gemm / mis_gemm_ex run this shape with (aligned operands), as a profiler names it */
 int mis_gemm_nt_kernel_name(int M, int N, int K, int epilogue, char* name, int name_len);
+/* Arithmetic of the nn.Linear GEMMs (mis_gemm / mis_gemm_ex / mis_gemm_dw / mis_gemm_expand): bit 0 forward + dX, bit 1 dW as
+ * "bf16x3" products -- each fp32 operand is cut EXACTLY into three bf16 pieces (x = h + m + l) and the product is the sum of the
+ * six piece products hh + hm + mh + hl + lh + mm on v_mfma_f32_16x16x32_bf16 with fp32 accumulation (the dropped ml + lm + ll
+ * are < 2^-24 |a||b|): the result is as close to exact arithmetic as the fp32 fmaf chain of v_mfma_f32_16x16x4_f32, on a
+ * pipe that is 2.4x faster per product.  mask 0 = fp32 MFMA everywhere; default 3 (environment MIS_GEMM_BF3 at load time).
+ * Returns the previous mask; mask < 0 only queries. */
+int mis_gemm_set_split_precision(int mask);
 /* the TN kernel mis_gemm(trans = 1) / mis_gemm_dw run this shape and these operands with, as a profiler names it */
 int mis_gemm_tn_kernel_name(const float* A, long long lda, const float* B, long long ldb, const float* C, long long ldc,
                             int M, int N, int K, char* name, int name_len);

@@ -18,6 +18,16 @@ def _rand(*shape, seed=0, scale=1.0):
     return (torch.rand(*shape, generator=g) * 2 - 1) * scale
 
 
+@pytest.fixture(params=[0, 3], ids=["fp32mfma", "bf16x3"])
+def prec(request):
+    """Arithmetic of the Linear GEMMs (mis_gemm_set_split_precision): 0 = v_mfma_f32_16x16x4_f32, 3 = bf16x3 split products
+    (the default).  Both must meet the same bounds against float64."""
+    tops = _t()
+    prev = tops.set_split_precision(request.param)
+    yield request.param
+    tops.set_split_precision(prev)
+
+
 def _close(a, b, rtol=2e-4, atol=1e-5):
     a, b = a.detach().cpu().double(), b.detach().cpu().double()
     err = (a - b).abs().max().item()
@@ -31,7 +41,7 @@ def _close(a, b, rtol=2e-4, atol=1e-5):
                                    # short contraction over many rows: gemm_nt_short_kernel (64-row tiles, ragged last)
                                    (50000, 288, 96), (33000, 384, 192),
                                    (16401, 576, 1536)])          # long K over many ragged row tiles
-def test_gemm_nt_and_tn(M, N, K):
+def test_gemm_nt_and_tn(M, N, K, prec):
     tops = _t()
     A, B, bias = _rand(M, K, seed=1), _rand(N, K, seed=2), _rand(N, seed=3)
     ref = (A.double() @ B.double().t() + bias.double())
@@ -39,7 +49,10 @@ def test_gemm_nt_and_tn(M, N, K):
     from mis_hip import lib
     name = ctypes.create_string_buffer(96)
     assert lib.load().mis_gemm_nt_kernel_name(M, N, K, 0, name, 96) == 0
-    assert name.value.decode().startswith("gemm_nt_short_kernel<") == (M >= 33000)
+    # the short-contraction kernel exists in the fp32 form only; the bf16x3 form runs the general kernel (4th template argument 1)
+    assert name.value.decode().startswith("gemm_nt_short_kernel<") == (M >= 33000 and not prec & 1)
+    if not name.value.decode().startswith("gemm_nt_short_kernel<"):
+        assert name.value.decode().endswith(", %d>" % (prec & 1))
     C = torch.empty(M, N, device="cuda")
     tops.gemm(Ad, Bd, C, bias=bias.cuda())
     _close(C, ref)
@@ -61,7 +74,7 @@ def test_gemm_nt_and_tn(M, N, K):
         _close(dW, 2 * refw, rtol=3e-4)
 
 
-def test_gemm_tn_split_k_large():
+def test_gemm_tn_split_k_large(prec):
     tops = _t()
     M, N, K = 20000, 96, 288     # M = tokens (contraction), small output -> many K slices
     X, dY = _rand(M, K, seed=5), _rand(M, N, seed=6)
@@ -75,7 +88,7 @@ def test_gemm_tn_split_k_large():
 
 @pytest.mark.parametrize("T,Cout,Cin", [(20000, 96, 288), (150528, 288, 96), (2352, 768, 3072), (49, 1536, 768),
                                         (3137, 100, 36), (9408, 1536, 384)])
-def test_gemm_dw_weight_and_bias_gradient_in_one_pass(T, Cout, Cin):
+def test_gemm_dw_weight_and_bias_gradient_in_one_pass(T, Cout, Cin, prec):
     """mis_gemm_dw: dW = dy^T x and db = dy.sum(0) from one read of dy (nn.Linear backward), split-K and direct forms,
     ragged tiles, accumulate; bit-identical dW to the plain TN form and deterministic."""
     tops = _t()
@@ -97,7 +110,7 @@ def test_gemm_dw_weight_and_bias_gradient_in_one_pass(T, Cout, Cin):
 
 
 @pytest.mark.parametrize("T", [1001, 1003, 2054, 9419])
-def test_register_only_tn_gemm_never_reads_past_its_row_range(T):
+def test_register_only_tn_gemm_never_reads_past_its_row_range(T, prec):
     """gemm_tn_reg_kernel (widths % 96 == 0) keeps 4 row groups in flight and lets the buffer descriptor's range check
     zero the loads past a wave's last row -- the K tail inside a group of 4 rows and the ring's surplus groups when
     ngroups % 4 != 0.  The rows behind row T of the SAME allocations hold NaNs: a load that escapes the range poisons dW/db."""
@@ -329,7 +342,7 @@ def test_window_attention(B, H, W, nH, shift, ws):
 
 
 @pytest.mark.parametrize("B,H,K,P,c", [(2, 56, 96, 4, 96), (24, 28, 192, 2, 96), (3, 14, 384, 2, 192), (2, 7, 768, 2, 384)])
-def test_gemm_expand_equals_gemm_plus_pixel_shuffle(B, H, K, P, c):
+def test_gemm_expand_equals_gemm_plus_pixel_shuffle(B, H, K, P, c, prec):
     """mis_gemm_expand (PatchExpand / FinalPatchExpand_X4: Linear + 'b h w (p1 p2 c) -> b (h p1) (w p2) c') is
     bit-identical to mis_gemm followed by mis_token_rearrange; shapes mis_gemm would split over K are refused."""
     tops = _t()
@@ -354,7 +367,7 @@ def test_gemm_expand_equals_gemm_plus_pixel_shuffle(B, H, K, P, c):
 @pytest.mark.parametrize("M,N,K", [(6272, 384, 96), (6272, 96, 384), (200, 96, 48), (98, 3072, 768), (98, 768, 3072),
                                    (33000, 384, 96), (65570, 96, 96),       # the short-contraction kernel's epilogues
                                    (20000, 768, 192), (16400, 192, 768)])   # many row tiles, ragged last one, K = 192 / 768
-def test_gemm_fused_epilogues(M, N, K):
+def test_gemm_fused_epilogues(M, N, K, prec):
     """mis_gemm_ex: GELU forward / backward and DropPath + residual add in the NT GEMM's epilogue (also through the
     split-K reduction for the deep-stage shapes) against torch in float64."""
     tops = _t()
