@@ -230,7 +230,7 @@ def reference_grads64(kind, cfg, sd0, tsd0, drop_s, drop_t, volume, label, noise
         set_reference_dropout(m64, kind, to64(drop_s), None)
         set_reference_dropout(e64, kind, to64(drop_t), None)
         opt = torch.optim.SGD(m64.parameters(), lr=0.0)
-        relus = [m for m in m64.modules() if isinstance(m, torch.nn.ReLU)]
+        relus = [m for m in m64.modules() if isinstance(m, (torch.nn.ReLU, torch.nn.LeakyReLU))]
         hooks = [m.register_forward_pre_hook(hook_factory(i)) for i, m in enumerate(relus)] if hook_factory else []
         ref = reference_step(kind, m64, e64, opt, volume.double(), label, noise.double(), iter_num, cfg)
         for h in hooks:
@@ -961,7 +961,7 @@ def main():
         ("unet2d_64_dropoff", "unet2d", small2d, [0, 1000, 1001], "off", True),
         ("unet2d_64_masks", "unet2d", small2d, [1500], "masks", False),
         # the transposed-convolution decoder: UpBlock(bilinear=False), nn.ConvTranspose2d(k=2, s=2) (unet.py:76-78)
-        ("unet2d_deconv_64_masks", "unet2d_deconv", small2d, [1500], "masks", True),
+        ("unet2d_deconv_64_masks", "unet2d_deconv", dict(small2d, flips=4), [1500], "masks", True),
         ("unet3d_64_dropoff", "unet3d", small3d, [0, 7], "off", True),
         ("unet3d_64_masks", "unet3d", small3d, [450], "masks", False),
         # V-Net (--model vnet): BatchNorm3d + Dropout3d, stride-2 / transposed convolutions; batch 2+2 so that
