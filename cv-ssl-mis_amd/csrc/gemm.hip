@@ -422,7 +422,12 @@ struct NsCfg {
     static constexpr int LDS_BYTES = LDS_FLOATS * 4;
 };
 
-template <int BN, int EP>
+typedef short bf16x4s __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+// PREC = 1: the k-step of 16 as bf16x3 products on v_mfma_f32_16x16x16_bf16 (4 contraction elements per lane = the lane's two
+// float2 reads of the step)
+template <int BN, int EP, int PREC = 0>
 __global__ __launch_bounds__(256) void gemm_nt_short_kernel(const GemmArgs a) {
     using G = NsCfg<BN>;
     constexpr int BKS = G::BKS;
@@ -495,13 +500,54 @@ __global__ __launch_bounds__(256) void gemm_nt_short_kernel(const GemmArgs a) {
         }
     };
 
+    auto mfma16 = [](const u32x2& x, const u32x2& y, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(bf16x4s, x), __builtin_bit_cast(bf16x4s, y), c, 0, 0, 0);
+    };
+    auto compute_bf3 = [&](const float* st) {
+        const float2* __restrict__ sA2 = reinterpret_cast<const float2*>(st);
+        const float2* __restrict__ sB2 = reinterpret_cast<const float2*>(st + G::A_FLOATS);
+        u32x2 ah[2], am[2], al[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int s = 0; s < BKS / 8; ++s) {
+                const float2 v = sA2[((wm + i * 16 + lj) * BKS + (((2 * s + (lk >> 1)) ^ swz) * 4 + (lk & 1) * 2)) >> 1];
+                unsigned h, m, l;
+                bf3_split_pair(v.x, v.y, h, m, l);
+                ah[i][s] = h; am[i][s] = m; al[i][s] = l;
+            }
+#pragma unroll
+        for (int j = 0; j < G::NJ; ++j) {
+            u32x2 bh, bm, bl;
+#pragma unroll
+            for (int s = 0; s < BKS / 8; ++s) {
+                const float2 v = sB2[((wn + j * 16 + lj) * BKS + (((2 * s + (lk >> 1)) ^ swz) * 4 + (lk & 1) * 2)) >> 1];
+                unsigned h, m, l;
+                bf3_split_pair(v.x, v.y, h, m, l);
+                bh[s] = h; bm[s] = m; bl[s] = l;
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                f32x4 c = acc[i][j];
+                c = mfma16(al[i], bh, c);
+                c = mfma16(ah[i], bl, c);
+                c = mfma16(am[i], bm, c);
+                c = mfma16(am[i], bh, c);
+                c = mfma16(ah[i], bm, c);
+                c = mfma16(ah[i], bh, c);
+                acc[i][j] = c;
+            }
+        }
+    };
+
     stage(0, 0);
     dma_wait();
     __syncthreads();
     int s = 0;
     for (int k0 = 0; k0 < a.K; k0 += BKS, ++s) {
         if (k0 + BKS < a.K) stage((s + 1) & 1, k0 + BKS);
-        compute(lds + (s & 1) * G::STAGE);
+        if constexpr (PREC == 1) compute_bf3(lds + (s & 1) * G::STAGE);
+        else compute(lds + (s & 1) * G::STAGE);
         dma_wait();
         __syncthreads();
     }
@@ -1143,7 +1189,9 @@ int nt_tile_m(int M, int N, int K) {
 bool nt_short(const GemmArgs& a) {
     static const int force = getenv("MIS_GEMM_SHORT") ? atoi(getenv("MIS_GEMM_SHORT")) : -1;
     if (force == 0 || a.KS > 1 || !a.vec4 || a.ex_P || a.K % 4) return false;
-    if (gemm_bf3() && force != 1) return false;      // prototype: the split-precision form lives in the general kernel only
+    // bf16x3: the K = 32 products of the general kernel win from K = 192 on (72 vs 75 us at 37632 x 576 x 192); at K = 96 the
+    // short kernel's residency still pays (150528 x 384 x 96: 120 vs 132 us, x 288: 93 vs 92, scripts/gemm_nt_bench.py)
+    if (gemm_bf3() && force != 1 && a.K > 96) return false;
     if (force == 1) return true;
     return a.K <= 192 && mis_cdiv(a.M, 64) * mis_cdiv(a.N, nt_tile_n(a.N)) >= 1536;
 }
@@ -1152,9 +1200,16 @@ template <int BN, int EP>
 int launch_nt_short_ep(const GemmArgs& a, hipStream_t stream) {
     using G = NsCfg<BN>;
     static std::atomic<unsigned long long> attr_done{0};
-    if (mis_set_lds_attr(reinterpret_cast<const void*>(&gemm_nt_short_kernel<BN, EP>), G::LDS_BYTES, attr_done) != MIS_OK)
+    if (gemm_bf3()) {
+        static std::atomic<unsigned long long> attr_done1{0};
+        if (mis_set_lds_attr(reinterpret_cast<const void*>(&gemm_nt_short_kernel<BN, EP, 1>), G::LDS_BYTES, attr_done1) != MIS_OK)
+            return MIS_ERR_LAUNCH;
+        hipLaunchKernelGGL((gemm_nt_short_kernel<BN, EP, 1>), dim3(a.n_blocks_padded), dim3(256), G::LDS_BYTES, stream, a);
+        return mis_launch_status();
+    }
+    if (mis_set_lds_attr(reinterpret_cast<const void*>(&gemm_nt_short_kernel<BN, EP, 0>), G::LDS_BYTES, attr_done) != MIS_OK)
         return MIS_ERR_LAUNCH;
-    hipLaunchKernelGGL((gemm_nt_short_kernel<BN, EP>), dim3(a.n_blocks_padded), dim3(256), G::LDS_BYTES, stream, a);
+    hipLaunchKernelGGL((gemm_nt_short_kernel<BN, EP, 0>), dim3(a.n_blocks_padded), dim3(256), G::LDS_BYTES, stream, a);
     return mis_launch_status();
 }
 
@@ -1205,7 +1260,7 @@ extern "C" int mis_gemm_nt_kernel_name(int M, int N, int K, int epilogue, char* 
     GemmArgs a{};
     a.M = M; a.N = N; a.K = K; a.vec4 = N % 4 == 0; a.KS = pick_ks(M, N, K, 0);
     const int bn = nt_tile_n(N);
-    if (nt_short(a)) snprintf(name, name_len, "gemm_nt_short_kernel<%d, %d>", bn, epilogue);
+    if (nt_short(a)) snprintf(name, name_len, "gemm_nt_short_kernel<%d, %d, %d>", bn, epilogue, gemm_bf3() ? 1 : 0);
     else snprintf(name, name_len, "gemm_nt_kernel<%d, %d, %d, %d>", nt_tile_m(M, N, K), bn, a.KS > 1 ? 0 : epilogue, gemm_bf3() ? 1 : 0);
     return MIS_OK;
 }
