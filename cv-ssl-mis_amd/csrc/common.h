@@ -16,6 +16,53 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// ---- "bf16x3" split-precision products (gemm.hip has the full story): an fp32 value is cut EXACTLY into three bf16 pieces by
+// truncation (x = h + m + l, 8 + 8 + 8 significant bits, both subtractions exact) and a product of two fp32 values is the sum of
+// the six piece products hh + hm + mh + hl + lh + mm on v_mfma_f32_16x16x32_bf16 with fp32 accumulation (ml + lm + ll, below
+// 2^-24 |a||b|, are dropped).  A MisBf3 holds one matrix operand of that instruction per piece: 8 contraction elements per lane.
+typedef __bf16 mis_bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned mis_u32x4 __attribute__((ext_vector_type(4)));
+struct MisBf3 { mis_u32x4 h, m, l; };
+
+__device__ __forceinline__ void mis_bf3_split_pair(float x0, float x1, unsigned& h, unsigned& m, unsigned& l) {
+    const unsigned u0 = __float_as_uint(x0), u1 = __float_as_uint(x1);
+    h = __builtin_amdgcn_perm(u1, u0, 0x07060302u);                   // {hi16(x1), hi16(x0)}: element 0 in the low half
+    const float r0 = x0 - __uint_as_float(u0 & 0xFFFF0000u), r1 = x1 - __uint_as_float(u1 & 0xFFFF0000u);
+    const unsigned v0 = __float_as_uint(r0), v1 = __float_as_uint(r1);
+    m = __builtin_amdgcn_perm(v1, v0, 0x07060302u);
+    const float t0 = r0 - __uint_as_float(v0 & 0xFFFF0000u), t1 = r1 - __uint_as_float(v1 & 0xFFFF0000u);
+    l = __builtin_amdgcn_perm(__float_as_uint(t1), __float_as_uint(t0), 0x07060302u);
+}
+
+// operand from the lane's 8 contraction elements e0 .. e7
+__device__ __forceinline__ MisBf3 mis_bf3_from8(float e0, float e1, float e2, float e3, float e4, float e5, float e6, float e7) {
+    MisBf3 r;
+    unsigned h, m, l;
+    mis_bf3_split_pair(e0, e1, h, m, l); r.h[0] = h; r.m[0] = m; r.l[0] = l;
+    mis_bf3_split_pair(e2, e3, h, m, l); r.h[1] = h; r.m[1] = m; r.l[1] = l;
+    mis_bf3_split_pair(e4, e5, h, m, l); r.h[2] = h; r.m[2] = m; r.l[2] = l;
+    mis_bf3_split_pair(e6, e7, h, m, l); r.h[3] = h; r.m[3] = m; r.l[3] = l;
+    return r;
+}
+
+__device__ __forceinline__ f32x4 mis_bf3_mfma1(const mis_u32x4& a, const mis_u32x4& b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(mis_bf16x8, a), __builtin_bit_cast(mis_bf16x8, b), c, 0, 0, 0);
+}
+
+// c += A . B over the 32 contraction elements of the two operands (smallest piece products first)
+__device__ __forceinline__ f32x4 mis_bf3_dot(const MisBf3& a, const MisBf3& b, f32x4 c) {
+    c = mis_bf3_mfma1(a.l, b.h, c);
+    c = mis_bf3_mfma1(a.h, b.l, c);
+    c = mis_bf3_mfma1(a.m, b.m, c);
+    c = mis_bf3_mfma1(a.m, b.h, c);
+    c = mis_bf3_mfma1(a.h, b.m, c);
+    c = mis_bf3_mfma1(a.h, b.h, c);
+    return c;
+}
+
+// the split-precision mask of mis_gemm_set_split_precision (gemm.hip): bit 0 NT GEMMs, bit 1 TN dW GEMM, bit 2 window attention
+int mis_split_precision_mask();
+
 static inline int mis_launch_status() {
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? MIS_OK : MIS_ERR_LAUNCH;

@@ -84,27 +84,17 @@ constexpr int GDBG = MIS_GEMM_DBG_CT;
 // fp32 kernel's).  One K = 32 block costs 6 instructions of 18 cycles instead of 8 of 32 (scripts/ubench/pipe_share.hip:
 // 7.5 ns against 13.8 ns per instruction), and the 32-bit integer / fp32 ops of the split overlap a co-resident wave's bf16
 // MFMAs (v_add beside mfma_bf16: 2175 us together against 2967 serial), which packed fp32 ops and the fp32 MFMA do not.
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-
+typedef mis_u32x4 u32x4;
 __device__ __forceinline__ void bf3_split_pair(float x0, float x1, unsigned& h, unsigned& m, unsigned& l) {
-    const unsigned u0 = __float_as_uint(x0), u1 = __float_as_uint(x1);
-    h = __builtin_amdgcn_perm(u1, u0, 0x07060302u);                   // {hi16(x1), hi16(x0)}: element 0 in the low half
-    const float r0 = x0 - __uint_as_float(u0 & 0xFFFF0000u), r1 = x1 - __uint_as_float(u1 & 0xFFFF0000u);
-    const unsigned v0 = __float_as_uint(r0), v1 = __float_as_uint(r1);
-    m = __builtin_amdgcn_perm(v1, v0, 0x07060302u);
-    const float t0 = r0 - __uint_as_float(v0 & 0xFFFF0000u), t1 = r1 - __uint_as_float(v1 & 0xFFFF0000u);
-    l = __builtin_amdgcn_perm(__float_as_uint(t1), __float_as_uint(t0), 0x07060302u);
+    mis_bf3_split_pair(x0, x1, h, m, l);
 }
+__device__ __forceinline__ f32x4 bf3_mfma(const u32x4& a, const u32x4& b, f32x4 c) { return mis_bf3_mfma1(a, b, c); }
 
-__device__ __forceinline__ f32x4 bf3_mfma(const u32x4& a, const u32x4& b, f32x4 c) {
-    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
-}
-
-// Split-precision mask: bit 0 the NT GEMMs (forward, dX), bit 1 the register-only TN GEMM (dW) as bf16x3 products; 0 = fp32 MFMA
-// everywhere.  Default 3 (MIS_GEMM_BF3 overrides at load; mis_gemm_set_split_precision at run time: bench.py times both).
+// Split-precision mask: bit 0 the NT GEMMs (forward, dX), bit 1 the register-only TN GEMM (dW), bit 2 the window-attention
+// products (attention_impl.inc) as bf16x3 products; 0 = fp32 MFMA everywhere.  Default 7 (MIS_GEMM_BF3 overrides at load;
+// mis_gemm_set_split_precision at run time: bench.py times both).
 std::atomic<int>& gemm_bf3_state() {
-    static std::atomic<int> m{[] { const char* e = getenv("MIS_GEMM_BF3"); return e ? atoi(e) & 3 : 3; }()};
+    static std::atomic<int> m{[] { const char* e = getenv("MIS_GEMM_BF3"); return e ? atoi(e) & 7 : 7; }()};
     return m;
 }
 bool gemm_bf3() { return gemm_bf3_state().load(std::memory_order_relaxed) & 1; }
@@ -1243,13 +1233,15 @@ int launch_nt(GemmArgs& a, hipStream_t stream) {
 
 }  // namespace
 
+int mis_split_precision_mask() { return gemm_bf3_state().load(std::memory_order_relaxed); }
+
 // Arithmetic of the nn.Linear GEMMs: mask bit 0 = forward / dX (NT), bit 1 = dW (TN, widths % 96 == 0) as bf16x3 split
 // products on v_mfma_f32_16x16x32_bf16 (exact 3-way split of the fp32 operands, six piece products, fp32 accumulation: error
 // against float64 no larger than the fp32 MFMA kernels'); 0 = v_mfma_f32_16x16x4_f32 everywhere.  Returns the previous mask;
 // mask < 0 only queries.
 extern "C" int mis_gemm_set_split_precision(int mask) {
     const int prev = gemm_bf3_state().load();
-    if (mask >= 0) gemm_bf3_state().store(mask & 3);
+    if (mask >= 0) gemm_bf3_state().store(mask & 7);
     return prev;
 }
 

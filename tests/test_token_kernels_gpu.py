@@ -18,10 +18,10 @@ def _rand(*shape, seed=0, scale=1.0):
     return (torch.rand(*shape, generator=g) * 2 - 1) * scale
 
 
-@pytest.fixture(params=[0, 3], ids=["fp32mfma", "bf16x3"])
+@pytest.fixture(params=[0, 7], ids=["fp32mfma", "bf16x3"])
 def prec(request):
-    """Arithmetic of the Linear GEMMs (mis_gemm_set_split_precision): 0 = v_mfma_f32_16x16x4_f32, 3 = bf16x3 split products
-    (the default).  Both must meet the same bounds against float64."""
+    """Arithmetic of the Linear GEMMs and the window attention (mis_gemm_set_split_precision): 0 = v_mfma_f32_16x16x4_f32, 7 =
+    bf16x3 split products everywhere (the default).  Both must meet the same bounds against float64."""
     tops = _t()
     prev = tops.set_split_precision(request.param)
     yield request.param
@@ -49,8 +49,9 @@ def test_gemm_nt_and_tn(M, N, K, prec):
     from mis_hip import lib
     name = ctypes.create_string_buffer(96)
     assert lib.load().mis_gemm_nt_kernel_name(M, N, K, 0, name, 96) == 0
-    # the short-contraction kernel exists in the fp32 form only; the bf16x3 form runs the general kernel (4th template argument 1)
-    assert name.value.decode().startswith("gemm_nt_short_kernel<") == (M >= 33000 and not prec & 1)
+    # the short-contraction kernel (K = 16 steps) serves K <= 192 in the fp32 form and K <= 96 in the bf16x3 form, whose K = 32
+    # products of the general kernel win from K = 192 on (last template argument: 1 = bf16x3)
+    assert name.value.decode().startswith("gemm_nt_short_kernel<") == (M >= 33000 and (not prec & 1 or K <= 96))
     if not name.value.decode().startswith("gemm_nt_short_kernel<"):
         assert name.value.decode().endswith(", %d>" % (prec & 1))
     C = torch.empty(M, N, device="cuda")
@@ -321,7 +322,7 @@ def _ref_window_attention(qkv, table, B, H, W, nH, shift, scale, ws=7):
                                                 # window 8 (64 tokens: IMG_SIZE 256 / WINDOW_SIZE 8), shift 4
                                                 (2, 16, 16, 3, 0, 8), (3, 16, 24, 2, 4, 8), (2, 8, 8, 6, 0, 8),
                                                 (5, 64, 64, 3, 4, 8)])
-def test_window_attention(B, H, W, nH, shift, ws):
+def test_window_attention(B, H, W, nH, shift, ws, prec):
     tops = _t()
     C = nH * 32
     qkv = _rand(B * H * W, 3 * C, seed=22, scale=1.5).double().requires_grad_(True)
