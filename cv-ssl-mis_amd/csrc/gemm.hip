@@ -1099,8 +1099,11 @@ void nt_choice(int M, int N, int K, int& bm, int& ks) {
         if (s > kmax) s = kmax;
         if (s < 2) s = 1;
         const long long rounds = mis_cdiv(tiles * s, 256);
-        // units: one row of a tile over one k; 128 rows x 768 k = 40 us measured -> 2458 units / us
-        long long cost = rounds * ((long long)rows * mis_cdiv(K, s) + 128 * 96);
+        // units: one row of a tile over one k; 128 rows x 768 k = 40 us measured -> 2458 units / us.  bf16x3 products run the
+        // k-loop ~2x faster (MIS_GEMM_NT_BF3_SCALE percent of the fp32 k-loop cost), the fixed costs stay: fewer slices pay
+        static const int bf3_pct = getenv("MIS_GEMM_NT_BF3_SCALE") ? atoi(getenv("MIS_GEMM_NT_BF3_SCALE")) : 50;
+        const long long kloop = (long long)rows * mis_cdiv(K, s) * (gemm_bf3() ? bf3_pct : 100) / 100;
+        long long cost = rounds * (kloop + 128 * 96);
         if (s > 1) cost += 49152 + (long long)(0.0039 * (double)s * M * N);
         if (rows == 128) cost += cost / 12;      // near-ties go to 64 rows (per-shape A/B, scripts/gemm_shapes_ab.py)
         if (best < 0 || cost < best) { best = cost; bm = rows; ks = (int)s; }

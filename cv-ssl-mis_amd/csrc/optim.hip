@@ -228,6 +228,56 @@ __global__ __launch_bounds__(1024) void poison_lds_kernel(int floats, float* sin
 }
 }  // namespace
 
+namespace {
+// A register-light, LDS-free wave that keeps ONE execution pipe of its SIMD busy: the co-residency probe of
+// scripts/interference.py (does a foreign wave on the same SIMD change a kernel's results?).  kind 1: v_mfma_f32_16x16x32_bf16,
+// 2: v_mfma_f32_16x16x4_f32, 3: 32-bit integer / unpacked fp32 VALU (v_perm / v_and / v_sub), 4: v_pk_add_f32.
+typedef __bf16 dbg_bf16x8 __attribute__((ext_vector_type(8)));
+template <int KIND>
+__global__ __launch_bounds__(256) void debug_spin_kernel(int iters, float* sink) {
+    f32x4 acc[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    mis_u32x4 ua = {threadIdx.x, 1u, 2u, 3u}, ub = {5u, 6u, threadIdx.x, 8u};
+    float a = (float)threadIdx.x, b = 1.5f;
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    f32x2 v0 = {a, b}, v1 = {b, a};
+    unsigned w0 = threadIdx.x, w1 = 77u;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            if constexpr (KIND == 1) acc[m] = mis_bf3_mfma1(ua, ub, acc[m]);
+            if constexpr (KIND == 2) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[m], 0, 0, 0);
+            if constexpr (KIND == 3) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    asm volatile("v_perm_b32 %0, %0, %1, %2" : "+v"(w0) : "v"(w1), "v"(0x07060302u));
+                    asm volatile("v_and_b32 %0, %0, %1" : "+v"(w1) : "v"(w0));
+                    asm volatile("v_sub_f32 %0, %0, %1" : "+v"(a) : "v"(b));
+                }
+            }
+            if constexpr (KIND == 4) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(v0) : "v"(v1));
+            }
+        }
+    }
+    const float s = acc[0][0] + acc[1][1] + acc[2][2] + acc[3][3] + a + v0[0] + v0[1] + __uint_as_float(w0 ^ w1);
+    if (s == 12345.678f) sink[threadIdx.x] = s;
+}
+}  // namespace
+
+// diagnostics: `blocks` workgroups of 4 such waves on `stream` (see debug_spin_kernel); sink: any device float buffer >= 256
+extern "C" int mis_debug_spin(int kind, int blocks, int iters, float* sink, hipStream_t stream) {
+    if (!sink || blocks <= 0 || iters <= 0) return MIS_ERR_ARG;
+    switch (kind) {
+        case 1: hipLaunchKernelGGL(debug_spin_kernel<1>, dim3(blocks), dim3(256), 0, stream, iters, sink); break;
+        case 2: hipLaunchKernelGGL(debug_spin_kernel<2>, dim3(blocks), dim3(256), 0, stream, iters, sink); break;
+        case 3: hipLaunchKernelGGL(debug_spin_kernel<3>, dim3(blocks), dim3(256), 0, stream, iters, sink); break;
+        case 4: hipLaunchKernelGGL(debug_spin_kernel<4>, dim3(blocks), dim3(256), 0, stream, iters, sink); break;
+        default: return MIS_ERR_UNSUPPORTED;
+    }
+    return mis_launch_status();
+}
+
 extern "C" int mis_debug_poison_lds(float* sink, hipStream_t stream) {
     constexpr int BYTES = 160 * 1024;
     static std::atomic<unsigned long long> done{0};

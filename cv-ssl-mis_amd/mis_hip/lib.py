@@ -142,6 +142,7 @@ PROTOTYPES = {
     "mis_conv_k2s2_wgrad_workspace_bytes": (c_ll, [c_i, c_i]),
     "mis_conv_k2s2_wgrad": (c_i, [c_p, c_ll, c_p, c_ll, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_ll, c_p]),
     "mis_debug_poison_lds": (c_i, [c_p, c_p]),
+    "mis_debug_spin": (c_i, [c_i, c_i, c_i, c_p, c_p]),
     "mis_debug_wgrad_prof": (c_i, [c_p]),
     "mis_space_to_depth2": (c_i, [c_p, c_ll, c_p, c_ll, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
     "mis_space_to_depth2d": (c_i, [c_p, c_ll, c_p, c_ll, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),

@@ -651,6 +651,10 @@ int mis_conv1x1_wgrad(const float* a, long long a_bs, const float* b, long long 
 /* Test support (never on the product path): fills the LDS of every CU with NaNs so that a kernel reading LDS it did not write
  * fails deterministically instead of depending on the previous launch.  sink: any device float (or NULL). */
 int mis_debug_poison_lds(float* sink, mis_stream_t stream);
+/* diagnostics: `blocks` workgroups of 4 register-light, LDS-free waves that keep one execution pipe busy for `iters` rounds
+ * (kind 1 bf16 MFMA, 2 fp32 MFMA, 3 unpacked VALU, 4 packed fp32 VALU): a co-residency probe -- does a foreign wave on the
+ * same SIMD change another kernel's results? (scripts/interference.py) */
+int mis_debug_spin(int kind, int blocks, int iters, float* sink, mis_stream_t stream);
 /* Development support (never on the product path): a device buffer of 8 x uint64 per (workgroup, wave) that a -DMIS_WR_PROF=1
  * build of the z-ring Winograd weight-gradient kernel fills with the cycles of its loop phases (scripts/wgrad_prof.py); NULL
  * switches it off.  Returns MIS_ERR_UNSUPPORTED in the product build, which never writes the buffer. */

@@ -212,7 +212,9 @@ def test_cross_teaching_step_at_full_batch(size, window):
         assert abs(got[f"loss{m + 1}_ce"] - ce) <= TOL_LOSS and abs(got[f"loss{m + 1}_dice"] - dl) <= TOL_LOSS
         assert abs(got[f"pseudo_supervision{m + 1}"] - ps) <= TOL_LOSS
         lg = models[m]._last[0].out.t.cpu().reshape(r[f"logits{m + 1}"].shape)
-        assert (lg - r[f"logits{m + 1}"]).abs().max().item() <= TOL_LOGIT
+        lerr = (lg - r[f"logits{m + 1}"]).abs()
+        print(f"model{m + 1}: logits max err {lerr.max().item():.3e}, {int((lerr > TOL_LOGIT).sum())} of {lerr.numel()} beyond {TOL_LOGIT}")
+        assert lerr.max().item() <= TOL_LOGIT
         _check_grads_and_params(models[m], r["grads"][m], osd[m], r["lr"], f"model{m + 1}", CROSS_GRAD_REL[size][m])
 
 
