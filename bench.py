@@ -755,8 +755,7 @@ def main():
     if not _dist_on(world) and not args.stub and not args.no_others and args.workload == "unet3d":
         # the other single-GPU configurations of BASELINE.json, shorter runs of the same protocol
         import copy
-        oargs = copy.copy(args)
-        oargs.steps, oargs.warmup = max(5, args.steps // 2), min(args.warmup, 2)
+        oargs = copy.copy(args)      # the same protocol as the headline workload (a short warm-up leaves first-launch costs in the timed steps)
         others = {}
         for name in OTHERS:
             r = run_workload(name, oargs, rank, world, kernel_events=not args.no_kernel_events)

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Re-measure everything that DESIGN.md quotes, on the GPU box (run through gpurun from the repo root):
-#   gpurun --timeout 2400 -- 'bash scripts/refresh_profiles.sh r04'
+#   gpurun --timeout 2400 -- 'bash scripts/refresh_profiles.sh r05'
 # Writes gpurun_out/<tag>/: the default bench JSON line (config 3 + the "others" block + thread-swept CPU baseline),
 # the bench lines of the other workloads, rocprofv3 kernel-trace statistics (CSV), and the two PMC passes that
 # scripts/pmc_traffic.py turns into profiles/<tag>_<workload>_pmc_traffic.json.  PMC passes run without any trace
@@ -8,7 +8,7 @@
 # The bench lines time the product configuration (teacher forward and weight gradients on side streams); every rocprofv3
 # pass runs `bench.py --serial` (side streams off), where a launch's duration is the kernel's own -- the same condition as
 # the roofline region inside bench.py, so `AverageNs` of the dominant kernel agrees with `roofline.avg_launch_ms`.
-tag=${1:-r04}
+tag=${1:-r05}
 out=gpurun_out/$tag
 mkdir -p "$out"
 export TMPDIR=/tmp
