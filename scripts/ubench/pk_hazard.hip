@@ -23,36 +23,40 @@ __global__ __launch_bounds__(256) void spin(int iters, float* sink, int kind) {
 }
 
 #define FORMS(X) \
-    X(0, "v_pk_add_f32 %0, %1, %2") \
-    X(1, "v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]") \
-    X(2, "v_pk_add_f32 %0, %1, %2 op_sel_hi:[1,0] neg_lo:[0,1]") \
-    X(3, "v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[1,0]") \
-    X(4, "v_pk_add_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[0,1]") \
-    X(5, "v_pk_add_f32 %0, %1, %2 neg_lo:[0,1]") \
-    X(6, "v_pk_add_f32 %0, %1, %2 neg_hi:[1,0]") \
-    X(7, "v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[1,0]") \
-    X(8, "v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]") \
-    X(9, "v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]") \
-    X(10, "v_pk_add_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]") \
-    X(11, "v_pk_add_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1] neg_lo:[1,0] neg_hi:[0,1]") \
-    X(12, "v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1] neg_hi:[1,0]") \
-    X(13, "v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1]") \
-    X(14, "v_pk_add_f32 %0, %1, %2 neg_lo:[1,0] neg_hi:[0,1]") \
-    X(15, "v_pk_fma_f32 %0, %1, %2, %1 op_sel:[1,0,0] op_sel_hi:[1,1,1]") \
-    X(16, "v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1] neg_lo:[0,1]") \
-    X(17, "v_pk_add_f32 %0, %1, %1 op_sel:[0,1] op_sel_hi:[0,1] neg_hi:[0,1]") \
-    X(18, "v_pk_add_f32 %0, %1, %1 op_sel:[1,0] op_sel_hi:[1,0] neg_hi:[1,0]") \
-    X(19, "v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[0,1]") \
-    X(20, "v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0]") \
-    X(21, "v_pk_add_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,1]") \
-    X(22, "v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]") \
-    X(23, "v_pk_fma_f32 %0, %1, %2, %1 op_sel:[0,1,0] op_sel_hi:[1,1,1]") \
-    X(24, "v_pk_fma_f32 %0, %1, %2, %2 op_sel:[0,0,1] op_sel_hi:[1,1,1]")
+    X(0, "v_pk_add_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,0]") \
+    X(1, "v_pk_add_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]") \
+    X(2, "v_pk_add_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[1,0]") \
+    X(3, "v_pk_add_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[1,1]") \
+    X(4, "v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[0,0]") \
+    X(5, "v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[0,1]") \
+    X(6, "v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0]") \
+    X(7, "v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]") \
+    X(8, "v_pk_add_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[0,0]") \
+    X(9, "v_pk_add_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[0,1]") \
+    X(10, "v_pk_add_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,0]") \
+    X(11, "v_pk_add_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1]") \
+    X(12, "v_pk_add_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[0,0]") \
+    X(13, "v_pk_add_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[0,1]") \
+    X(14, "v_pk_add_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0]") \
+    X(15, "v_pk_add_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,1]") \
+    X(16, "v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,1,1]") \
+    X(17, "v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,1] op_sel_hi:[1,1,1]") \
+    X(18, "v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,1,1]") \
+    X(19, "v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,1,1]") \
+    X(20, "v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,1] op_sel_hi:[1,1,1]") \
+    X(21, "v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,1] op_sel_hi:[1,1,1]") \
+    X(22, "v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,1] op_sel_hi:[1,1,1]") \
+    X(23, "v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]") \
+    X(24, "v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1]") \
+    X(25, "v_pk_add_f32 %0, %1, %1 op_sel:[0,1] op_sel_hi:[0,1] neg_hi:[0,1]") \
+    X(26, "v_pk_add_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1] neg_lo:[1,0] neg_hi:[0,1]") \
+    X(27, "v_pk_add_f32 %0, %1, %2 op_sel_hi:[1,0] neg_lo:[0,1]")
 
 template <int FORM>
 __device__ __forceinline__ f32x2 form(f32x2 a, f32x2 b) {
+    const f32x2 c = {a[1] * 0.5f + 1.f, b[0] - 0.25f};      // third source of the fma forms: another register pair
     f32x2 r = {0.f, 0.f};
-#define X(N, STR) if (FORM == N) asm volatile(STR : "=v"(r) : "v"(a), "v"(b));
+#define X(N, STR) if (FORM == N) asm volatile(STR : "=v"(r) : "v"(a), "v"(b), "v"(c));
     FORMS(X)
 #undef X
     return r;
