@@ -17,20 +17,25 @@ Default workload = BASELINE.json configs[2], the north-star target: Mean-Teacher
 scaling; value = samples of all ranks / max-over-ranks time.
 
 Prints ONE JSON line (rank 0) with the contract fields plus
-  roofline     live HIP-event timing of the dominant kernel (the MFMA conv kernel): achieved / frac = the flops the
-               matrix pipe EXECUTES (algorithmic flops / winograd_reduction) / the launches' summed duration, against the
-               fp32 MFMA peak (<= 1); ``algorithmic_tflops`` = the direct-convolution rate of the same launches;
-               ``step_algorithmic_flop_frac`` = the algorithmic FLOPs of the WHOLE step / step time /
-               peak.  The timed region runs the product configuration (teacher forward and weight gradients on side
-               streams); the events are taken in a second region of the same run with the side streams off, where a
-               launch's duration is the kernel's own (``roofline.measured_in``, ``serial_ms_per_step``)
-  others       (N=1) the other single-GPU configurations of BASELINE.json -- configs[1] 2-D UNet, configs[3]
-               SwinUnet, configs[4] per-GPU cross teaching, and V-Net -- each with value, ms_per_step, step-level
-               flop_frac and dominant-kernel fraction
-  cpu_baseline the CPU oracle (a port of the reference arithmetic on stock torch CPU ops) timed on this host's
-               cores on the SAME batch as the GPU line (config 3: 4+4 volumes): thread count swept on the reduced 1+1
-               batch, then 1 warm-up + 3 timed steps of the full batch at the best count; the 1+1 figure is reported
-               beside it (rank 0, N=1 only)
+  roofline     live HIP-event timing of the dominant kernel: achieved / frac = the flops the matrix pipe EXECUTES over the
+               launches' summed duration against that pipe's peak (<= 1): fp32 MFMA 157.3 TF with Winograd launches at 1 / 3.375
+               (1 / 2.25) of their direct-convolution count; the Linear GEMMs / window attention of SwinUnet in their bf16x3 form
+               at 6 executed multiply-adds per algorithmic one against the 2.5 PF dense bf16 peak.  ``algorithmic_tflops`` = the
+               direct rate of the same launches; ``executed_step_frac`` = pipe-seconds at peak per step / step seconds.  The timed
+               region runs the product configuration (teacher forward and weight gradients on side streams); the events are
+               taken in a second region of the same run with the side streams off (``measured_in``, ``serial_ms_per_step``).
+               ``traffic`` = HBM bytes per launch of the dominant kernel from the PMC counters of THIS run: bench.py re-executes
+               itself for 1 + 2 serial steps under ``rocprofv3 --pmc FETCH_SIZE`` and again under ``WRITE_SIZE`` (N = 1, bounded
+               to 90 s, ``traffic_unavailable`` says why when it could not)
+  others       (N=1) the other single-GPU configurations of BASELINE.json -- configs[1] 2-D UNet (with its own CPU baseline),
+               configs[3] SwinUnet, configs[4] per-GPU cross teaching (both also timed with the GEMMs on the fp32 MFMA
+               instruction: ``ms_per_step_fp32_mfma``), and V-Net -- same protocol as the headline workload
+  cpu_baseline the CPU oracle (a port of the reference arithmetic on stock torch CPU ops) timed on this host's cores on the
+               SAME batch as the GPU line: thread count swept over {16, 32, 64} on a reduced batch, then 2 warm-up + 5 timed
+               steps of the full batch at the best count, median (rank 0, N=1 only)
+  host_enqueue_ms_per_step   the Python loop's time to ENQUEUE a step (no wait for the device inside it)
+  distributed  world size seen, per-rank times, ``affinity_rank0`` (NUMA pinning, N > 1), ``predicted`` = a MODEL of the gradient
+               exchange (mis_hip/dist.py::predict_exchange; at N = 1 for 8 GPUs), and at N > 1 the measured exchange figures
 """
 import argparse
 import json
