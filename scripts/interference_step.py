@@ -1,6 +1,6 @@
 """Co-residency probe at network level: forward + backward of a CNN beside mis_debug_spin waves (kind 1 bf16 MFMA, 2 fp32 MFMA,
 3 unpacked VALU, 4 packed fp32 VALU) on a second stream; logits and the flat gradient are compared bit for bit with a quiet run.
-    python scripts/interference_step.py unet2d|unet3d|vnet"""
+    python scripts/interference_step.py unet2d|unet3d|vnet|swin|unetr"""
 import os, sys
 import torch
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
@@ -12,6 +12,12 @@ torch.manual_seed(0)
 if kind == "unet2d":
     from networks.net_factory import net_factory
     net = net_factory("unet", 1, 4); x = torch.rand(32, 1, 256, 256, device="cuda")
+elif kind == "swin":
+    from networks.net_factory import net_factory
+    net = net_factory("ViT_Seg", 1, 4); x = torch.rand(16, 1, 224, 224, device="cuda")
+elif kind == "unetr":
+    from networks.net_factory_3d import net_factory_3d
+    net = net_factory_3d("unetr", 1, 2); x = torch.rand(2, 1, 96, 96, 96, device="cuda")
 else:
     from networks.net_factory_3d import net_factory_3d
     net = net_factory_3d("unet_3D" if kind == "unet3d" else "vnet", 1, 2); x = torch.rand(4, 1, 96, 96, 96, device="cuda")
