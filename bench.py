@@ -755,6 +755,14 @@ def main():
             "losses_last_step": res["losses"],
             "roofline": res["roofline"],
         }
+        if not args.stub and args.workload in ("swin", "cross", "cross224", "cnnvit", "unetr", "swinunetr"):
+            from mis_hip import tops as _tops
+            mask = _tops.set_split_precision(-1)
+            out["config"]["linear_gemm_arithmetic"] = (
+                "fp32 MFMA (v_mfma_f32_16x16x4_f32)" if mask == 0 else
+                f"bf16x3 (mask {mask}: exact 3-way bf16 split of the fp32 operands, 6 piece products per multiply-add on "
+                "v_mfma_f32_16x16x32_bf16, fp32 accumulation; error vs float64 not above the fp32 MFMA form's -- "
+                "mis_gemm_set_split_precision(0) / MIS_GEMM_BF3=0 selects the fp32 MFMA)")
         if args.stub:
             out["data"] = "stub (CPU/gloo launcher test, not a measurement)"
     if not _dist_on(world) and not args.stub and not args.no_others and args.workload == "unet3d":
