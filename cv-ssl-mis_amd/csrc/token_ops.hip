@@ -758,7 +758,10 @@ __global__ __launch_bounds__(256) void ln_head_bwd_kernel(const float* __restric
                                                           long long dl_bs, float* __restrict__ dx, long long lddx,
                                                           int accumulate, long long M, long long S, int C,
                                                           long long rows_per_slab, float2* __restrict__ pln,
-                                                          float* __restrict__ pw) {
+                                                          float* __restrict__ pw, int ex_P, int ex_H, int ex_W) {
+    // ex_P > 0: row r of x is token (b, h P + p1, w P + p2) of the pixel-shuffled grid of FinalPatchExpand_X4 ('b h w (p1 p2 c) ->
+    // b (h p1) (w p2) c'); its gradient row goes straight to the expand Linear's output layout dx[(b, h, w)][(p1 P + p2) C + c]
+    // (row stride lddx = P P C): the un-shuffle pass over the largest tensor of the network is gone
     __shared__ float4 red[256];
     const int lane = threadIdx.x & 31, rg = threadIdx.x >> 5;
     const int c = lane * 4;
@@ -810,7 +813,14 @@ __global__ __launch_bounds__(256) void ln_head_bwd_kernel(const float* __restric
             if (act) {
                 float4 o = make_float4(rs * (q0 - s1 - h0 * s2), rs * (q1 - s1 - h1 * s2), rs * (q2 - s1 - h2 * s2),
                                        rs * (q3 - s1 - h3 * s2));
-                float* const op = dx + row * lddx + c;
+                float* op = dx + row * lddx + c;
+                if (ex_P) {
+                    const long long bimg = row / S;                      // S = H P W P < 2^31 (checked by the launcher)
+                    const int WP = ex_W * ex_P, pix = (int)(row - bimg * S), yy = pix / WP, xx = pix - yy * WP;
+                    const int h = yy / ex_P, w_ = xx / ex_P;
+                    const int p1 = yy - h * ex_P, p2 = xx - w_ * ex_P;
+                    op = dx + ((bimg * ex_H + h) * ex_W + w_) * lddx + (p1 * ex_P + p2) * C + c;
+                }
                 if (accumulate) {
                     const float4 pv = *reinterpret_cast<const float4*>(op);
                     o.x += pv.x; o.y += pv.y; o.z += pv.z; o.w += pv.w;
@@ -1194,11 +1204,38 @@ extern "C" long long mis_ln_head_workspace_bytes(long long M, int C, int NC) {
 
 // Backward of mis_ln_head_fwd: dx [B*S][C] (+)= LayerNorm backward of dy = dlogits . w;  dgamma, dbeta [C] and dw [NC][C] (+)=
 // their column sums (accumulate_params).  Deterministic (per-slab partials, fixed-order sums).
+static int ln_head_bwd_impl(const float* x, long long ldx, const float* gamma, const float* beta, const float* w,
+                            const float* mean, const float* rstd, const float* dlogits, long long dl_bs, float* dx,
+                            long long lddx, int accumulate_dx, float* dgamma, float* dbeta, float* dw,
+                            int accumulate_params, int B, long long S, int C, int NC, void* workspace,
+                            long long workspace_bytes, int ex_P, int ex_H, int ex_W, hipStream_t stream);
+
 extern "C" int mis_ln_head_bwd(const float* x, long long ldx, const float* gamma, const float* beta, const float* w,
                                const float* mean, const float* rstd, const float* dlogits, long long dl_bs, float* dx,
                                long long lddx, int accumulate_dx, float* dgamma, float* dbeta, float* dw,
                                int accumulate_params, int B, long long S, int C, int NC, void* workspace,
                                long long workspace_bytes, hipStream_t stream) {
+    return ln_head_bwd_impl(x, ldx, gamma, beta, w, mean, rstd, dlogits, dl_bs, dx, lddx, accumulate_dx, dgamma, dbeta, dw,
+                            accumulate_params, B, S, C, NC, workspace, workspace_bytes, 0, 0, 0, stream);
+}
+
+// ... with the gradient rows stored through the inverse pixel shuffle of FinalPatchExpand_X4: x rows are the tokens of the
+// (H P) x (W P) grid (S = H P W P per image), dx is the expand Linear's output gradient [B H W][P P C] (lddx >= P P C)
+extern "C" int mis_ln_head_bwd_unshuffle(const float* x, long long ldx, const float* gamma, const float* beta, const float* w,
+                                         const float* mean, const float* rstd, const float* dlogits, long long dl_bs, float* dx,
+                                         long long lddx, int accumulate_dx, float* dgamma, float* dbeta, float* dw,
+                                         int accumulate_params, int B, int H, int W, int P, int C, int NC, void* workspace,
+                                         long long workspace_bytes, hipStream_t stream) {
+    if (H <= 0 || W <= 0 || P <= 0 || lddx < (long long)P * P * C || (long long)H * P * W * P > 0x7fffffffLL) return MIS_ERR_ARG;
+    return ln_head_bwd_impl(x, ldx, gamma, beta, w, mean, rstd, dlogits, dl_bs, dx, lddx, accumulate_dx, dgamma, dbeta, dw,
+                            accumulate_params, B, (long long)H * P * W * P, C, NC, workspace, workspace_bytes, P, H, W, stream);
+}
+
+static int ln_head_bwd_impl(const float* x, long long ldx, const float* gamma, const float* beta, const float* w,
+                            const float* mean, const float* rstd, const float* dlogits, long long dl_bs, float* dx,
+                            long long lddx, int accumulate_dx, float* dgamma, float* dbeta, float* dw,
+                            int accumulate_params, int B, long long S, int C, int NC, void* workspace,
+                            long long workspace_bytes, int ex_P, int ex_H, int ex_W, hipStream_t stream) {
     if (!x || !gamma || !beta || !w || !mean || !rstd || !dlogits || !dx || !dgamma || !dbeta || !dw || !workspace ||
         B <= 0 || S <= 0 || C <= 0)
         return MIS_ERR_ARG;
@@ -1210,7 +1247,7 @@ extern "C" int mis_ln_head_bwd(const float* x, long long ldx, const float* gamma
     float2* pln = reinterpret_cast<float2*>(workspace);
     float* pw = reinterpret_cast<float*>(pln + (long long)slabs * C);
 #define MIS_LNH_B(N_) hipLaunchKernelGGL(ln_head_bwd_kernel<N_>, dim3(slabs), dim3(256), 0, stream, x, ldx, gamma, beta, w, mean, \
-                                         rstd, dlogits, dl_bs, dx, lddx, accumulate_dx, M, S, C, (long long)COL_SLAB_ROWS, pln, pw)
+                                         rstd, dlogits, dl_bs, dx, lddx, accumulate_dx, M, S, C, (long long)COL_SLAB_ROWS, pln, pw, ex_P, ex_H, ex_W)
     switch (NC) {
         case 2: MIS_LNH_B(2); break;
         case 3: MIS_LNH_B(3); break;

@@ -184,6 +184,8 @@ PROTOTYPES = {
     "mis_ln_head_workspace_bytes": (c_ll, [c_ll, c_i, c_i]),
     "mis_ln_head_bwd": (c_i, [c_p, c_ll, c_p, c_p, c_p, c_p, c_p, c_p, c_ll, c_p, c_ll, c_i, c_p, c_p, c_p, c_i, c_i, c_ll,
                               c_i, c_i, c_p, c_ll, c_p]),
+    "mis_ln_head_bwd_unshuffle": (c_i, [c_p, c_ll, c_p, c_p, c_p, c_p, c_p, c_p, c_ll, c_p, c_ll, c_i, c_p, c_p, c_p, c_i, c_i, c_i,
+                                        c_i, c_i, c_i, c_i, c_p, c_ll, c_p]),
     "mis_head_fwd": (c_i, [c_p, c_ll, c_p, c_p, c_ll, c_i, c_ll, c_i, c_i, c_p]),
     "mis_head_workspace_bytes": (c_ll, [c_i, c_i]),
     "mis_head_bwd": (c_i, [c_p, c_ll, c_p, c_p, c_ll, c_p, c_ll, c_p, c_i, c_i, c_ll, c_i, c_i, c_p, c_ll, c_p]),

@@ -17,6 +17,7 @@ from .plan import Act
 # GEMM epilogue fusions (GELU into fc1 / fc2-dX, DropPath + residual add into proj / fc2); MIS_SWIN_FUSE=0 runs the
 # separate element-wise passes (A/B timing, and the reference point of the fusion tests)
 LN_HEAD = os.environ.get("MIS_LN_HEAD", "1") != "0"        # last LayerNorm + output head in one pass (LnHeadOp)
+UNSHUFFLE = os.environ.get("MIS_LN_HEAD_UNSHUFFLE", "1") != "0"   # ... whose backward stores dx through FinalPatchExpand_X4's inverse shuffle
 FUSE = int(os.environ.get("MIS_SWIN_FUSE", "7"))      # bit 0: GELU forward, bit 1: GELU backward, bit 2: residual
 
 
@@ -232,6 +233,7 @@ class ExpandLinearOp(LinearOp):
     def __init__(self, x, y, sh, w, geo):
         super().__init__(x, y, w, None)
         self.sh, self.geo = sh, geo            # geo = (B, H, W, c, P)
+        self.unshuffled_by_consumer = False    # set for one backward by the LnHeadOp that consumes ``sh``
 
     def fwd(self, ctx):
         B, H, W, c, P = self.geo
@@ -241,9 +243,12 @@ class ExpandLinearOp(LinearOp):
 
     def bwd(self, ctx):
         B, H, W, c, P = self.geo
-        assert not self.y.written
-        tops.token_rearrange(self.sh.grad(), self.y.grad(), B, H, W, c, P, 1, inverse=True)
-        self.y.mark_written()
+        if self.unshuffled_by_consumer:       # LnHeadOp stored its dx through the inverse shuffle: y.grad is complete
+            self.unshuffled_by_consumer = False
+        else:
+            assert not self.y.written
+            tops.token_rearrange(self.sh.grad(), self.y.grad(), B, H, W, c, P, 1, inverse=True)
+            self.y.mark_written()
         super().bwd(ctx)
 
 
@@ -297,6 +302,7 @@ class LnHeadOp:
         self.gw2 = w.grad.view(w.grad.shape[0], -1)
         self.mean = torch.empty(x.rows, dtype=torch.float32, device="cuda")
         self.rstd = torch.empty(x.rows, dtype=torch.float32, device="cuda")
+        self.expand = None
 
     @staticmethod
     def eligible(C, num_classes):
@@ -307,6 +313,16 @@ class LnHeadOp:
         assert ok
 
     def bwd(self, ctx):
+        e = self.expand           # the ExpandLinearOp whose pixel-shuffled output is this op's input (set by the plan), or None
+        if UNSHUFFLE and e is not None and not self.x.written and not e.y.written:
+            # dx goes straight into the gradient of the expand Linear's (un-shuffled) output: no rearrange pass
+            B, H, W, c, P = e.geo
+            tops.ln_head_bwd(self.x.t, self.g.data, self.b.data, self.w2, self.mean, self.rstd, self.logits.grad(),
+                             e.y.grad(), self.g.grad, self.b.grad, self.gw2, unshuffle=(H, W, P))
+            e.y.mark_written()
+            e.unshuffled_by_consumer = True
+            self.x.mark_written()
+            return
         tops.ln_head_bwd(self.x.t, self.g.data, self.b.data, self.w2, self.mean, self.rstd, self.logits.grad(),
                          self.x.grad(), self.g.grad, self.b.grad, self.gw2, accumulate_dx=self.x.written)
         self.x.mark_written()

@@ -321,12 +321,22 @@ def ln_head_fwd(x, gamma, beta, w, mean, rstd, logits5, eps=1e-5):
     return True
 
 
-def ln_head_bwd(x, gamma, beta, w, mean, rstd, dlogits5, dx, dgamma, dbeta, dw, accumulate_dx=False):
+def ln_head_bwd(x, gamma, beta, w, mean, rstd, dlogits5, dx, dgamma, dbeta, dw, accumulate_dx=False, unshuffle=None):
+    """``unshuffle = (H, W, P)``: ``x`` rows are the tokens of the pixel-shuffled (H P) x (W P) grid and ``dx`` is the gradient of
+    the expand Linear's OUTPUT [B H W, P P C]: the rows are stored through the inverse shuffle (mis_ln_head_bwd_unshuffle)."""
     L = _l.load()
     M, C, ldx = _mat(x)
     _, _, lddx = _mat(dx)
     B, NC = dlogits5.shape[0], dlogits5.shape[1]
     ws = scratch(L.mis_ln_head_workspace_bytes(M, C, NC), "head")
+    if unshuffle is not None:
+        H, W, P = unshuffle
+        assert M == B * H * P * W * P and dx.shape[0] == B * H * W and dx.shape[1] == P * P * C, (M, dx.shape, unshuffle)
+        _l.check(L.mis_ln_head_bwd_unshuffle(_l.ptr(x), ldx, _l.ptr(gamma), _l.ptr(beta), _l.ptr(w), _l.ptr(mean), _l.ptr(rstd),
+                                             _l.ptr(dlogits5), dlogits5.stride(0), _l.ptr(dx), lddx, int(accumulate_dx),
+                                             _l.ptr(dgamma), _l.ptr(dbeta), _l.ptr(dw), 0, B, H, W, P, C, NC, _l.ptr(ws),
+                                             ws.numel(), _l.stream_ptr()), "mis_ln_head_bwd_unshuffle")
+        return
     _l.check(L.mis_ln_head_bwd(_l.ptr(x), ldx, _l.ptr(gamma), _l.ptr(beta), _l.ptr(w), _l.ptr(mean), _l.ptr(rstd),
                                _l.ptr(dlogits5), dlogits5.stride(0), _l.ptr(dx), lddx, int(accumulate_dx), _l.ptr(dgamma),
                                _l.ptr(dbeta), _l.ptr(dw), 0, B, M // B, C, NC, _l.ptr(ws), ws.numel(), _l.stream_ptr()),

@@ -295,8 +295,11 @@ class SwinUnet(HipNet):
         plan.out = sp.new_logits(B, self.num_classes, H, W)
         if sp.LnHeadOp.eligible(E, self.num_classes):      # up.norm + output in one pass over the 16x expanded tokens
             sh = self._expand(plan, "swin_unet.up", xu, None, B, pr, E, 4, norm=False)
-            plan.add(sp.LnHeadOp(sh, Pn("swin_unet.up.norm.weight"), Pn("swin_unet.up.norm.bias"),
-                                 Pn("swin_unet.output.weight"), plan.out))
+            expand = plan.ops[-1]                           # the ExpandLinearOp that wrote `sh` through the pixel shuffle
+            head = sp.LnHeadOp(sh, Pn("swin_unet.up.norm.weight"), Pn("swin_unet.up.norm.bias"),
+                               Pn("swin_unet.output.weight"), plan.out)
+            head.expand = expand if isinstance(expand, sp.ExpandLinearOp) else None
+            plan.add(head)
         else:
             xf = self._expand(plan, "swin_unet.up", xu, None, B, pr, E, 4)
             plan.add(sp.HeadOp(xf, Pn("swin_unet.output.weight"), plan.out))

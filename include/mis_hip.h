@@ -540,6 +540,14 @@ int mis_ln_head_bwd(const float* x, long long ldx, const float* gamma, const flo
                     const float* rstd, const float* dlogits, long long dl_bs, float* dx, long long lddx, int accumulate_dx,
                     float* dgamma, float* dbeta, float* dw, int accumulate_params, int B, long long S, int C, int NC,
                     void* workspace, long long workspace_bytes, mis_stream_t stream);
+/* ... with dx stored through the INVERSE pixel shuffle of FinalPatchExpand_X4 (reference
+ * swin_transformer_unet_skip_expand_decoder_sys.py:401-408): x rows are the tokens of the (H P) x (W P) grid, dx is the gradient of the
+ * expand Linear's output [B H W][P P C] -- the separate un-shuffle pass over the network's largest tensor disappears */
+int mis_ln_head_bwd_unshuffle(const float* x, long long ldx, const float* gamma, const float* beta, const float* w,
+                              const float* mean, const float* rstd, const float* dlogits, long long dl_bs, float* dx,
+                              long long lddx, int accumulate_dx, float* dgamma, float* dbeta, float* dw, int accumulate_params,
+                              int B, int H, int W, int P, int C, int NC, void* workspace, long long workspace_bytes,
+                              mis_stream_t stream);
 /* (shifted-)window attention core (:115-150 with the roll/partition/reverse of :244-288 folded into the
  * token addressing): qkv [B*H*W][3*nH*32] in natural token order -> out [B*H*W][nH*32]; window 7x7,
  * head_dim 32; bias_table = relative_position_bias_table [169][nH]; shift in {0,3}. */

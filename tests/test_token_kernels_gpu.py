@@ -162,6 +162,41 @@ def test_layernorm_and_output_head_in_one_pass(B, S, C, NC):
     assert torch.equal(dg, dg2) and torch.equal(db, db2) and torch.equal(dw, dw2)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,H,W,P,C,NC", [(2, 7, 7, 4, 96, 4), (1, 5, 3, 4, 96, 4), (3, 4, 6, 2, 48, 2)])
+def test_output_head_backward_stores_through_the_inverse_pixel_shuffle(B, H, W, P, C, NC):
+    """mis_ln_head_bwd_unshuffle: dx rows go straight into the expand Linear's output gradient [B H W, P P C]
+    (FinalPatchExpand_X4's 'b h w (p1 p2 c) -> b (h p1) (w p2) c', reference
+    swin_transformer_unet_skip_expand_decoder_sys.py:390-409) — bit-identical to mis_ln_head_bwd followed by the inverse
+    mis_token_rearrange, parameter gradients untouched by the addressing, with and without accumulation."""
+    tops = _t()
+    M = B * H * P * W * P
+    x = (_rand(M, C, seed=31, scale=2.0) + 0.3).cuda()
+    g, b, w = (1 + 0.2 * _rand(C, seed=32)).cuda(), (0.1 * _rand(C, seed=33)).cuda(), _rand(NC, C, seed=34, scale=0.3).cuda()
+    mean, rstd = torch.empty(M, device="cuda"), torch.empty(M, device="cuda")
+    out = torch.empty(B, NC, 1, H * P, W * P, device="cuda")
+    assert tops.ln_head_fwd(x, g, b, w, mean, rstd, out)
+    dl = _rand(B, NC, 1, H * P, W * P, seed=35).cuda()
+
+    def params():
+        return torch.full((C,), float("nan"), device="cuda"), torch.full((C,), float("nan"), device="cuda"), \
+            torch.full((NC, C), float("nan"), device="cuda")
+    dx = torch.full((M, C), float("nan"), device="cuda")
+    dg, db, dw = params()
+    tops.ln_head_bwd(x, g, b, w, mean, rstd, dl, dx, dg, db, dw)
+    ref = torch.empty(B * H * W, P * P * C, device="cuda")
+    tops.token_rearrange(dx, ref, B, H, W, C, P, 1, inverse=True)
+    got = torch.full((B * H * W, P * P * C), float("nan"), device="cuda")
+    dg2, db2, dw2 = params()
+    tops.ln_head_bwd(x, g, b, w, mean, rstd, dl, got, dg2, db2, dw2, unshuffle=(H, W, P))
+    assert torch.equal(got, ref)
+    assert torch.equal(dg, dg2) and torch.equal(db, db2) and torch.equal(dw, dw2)
+    base = _rand(B * H * W, P * P * C, seed=36).cuda()
+    acc = base.clone()
+    tops.ln_head_bwd(x, g, b, w, mean, rstd, dl, acc, dg2, db2, dw2, accumulate_dx=True, unshuffle=(H, W, P))
+    assert torch.equal(acc, base + ref)
+
+
 @pytest.mark.parametrize("M,C", [(784, 96), (50, 1536), (3137, 384)])
 def test_layernorm(M, C):
     tops = _t()
