@@ -66,6 +66,35 @@ extern "C" int mis_window_attention_bwd_ws(const float* qkv, long long ldq, cons
     return MIS_ERR_UNSUPPORTED;
 }
 
+// mis_window_attention_bwd_ws in two halves for callers that keep the bias-table gradient off the data-gradient chain (the
+// token plans run the second half beside it, with a workspace of the layer's own): _parts_ws = dqkv and the per-unit dS partials,
+// _dtable_ws = the relative-position-bias-table gradient from them (reference ...sys.py:99-131: autograd's index_add through
+// relative_position_index).  Same workspace size as the one-call form; same results bit for bit.
+extern "C" int mis_window_attention_bwd_parts_ws(const float* qkv, long long ldq, const float* dout, long long ldo,
+                                                 float* dqkv, long long lddq, const float* bias_table, int B, int H, int W,
+                                                 int nH, int shift, float scale, int window, void* workspace,
+                                                 long long workspace_bytes, hipStream_t stream) {
+    if (window == 7)
+        return ws7::window_attention_bwd(qkv, ldq, dout, ldo, dqkv, lddq, bias_table, nullptr, 0, B, H, W, nH, shift, scale,
+                                         workspace, workspace_bytes, stream, 1);
+    if (window == 8)
+        return ws8::window_attention_bwd(qkv, ldq, dout, ldo, dqkv, lddq, bias_table, nullptr, 0, B, H, W, nH, shift, scale,
+                                         workspace, workspace_bytes, stream, 1);
+    return MIS_ERR_UNSUPPORTED;
+}
+
+extern "C" int mis_window_attention_dtable_ws(void* workspace, long long workspace_bytes, float* dbias_table,
+                                              int accumulate_table, int B, int H, int W, int nH, int window,
+                                              hipStream_t stream) {
+    if (window == 7)
+        return ws7::window_attention_bwd(nullptr, 0, nullptr, 0, nullptr, 0, nullptr, dbias_table, accumulate_table, B, H, W,
+                                         nH, 0, 0.f, workspace, workspace_bytes, stream, 2);
+    if (window == 8)
+        return ws8::window_attention_bwd(nullptr, 0, nullptr, 0, nullptr, 0, nullptr, dbias_table, accumulate_table, B, H, W,
+                                         nH, 0, 0.f, workspace, workspace_bytes, stream, 2);
+    return MIS_ERR_UNSUPPORTED;
+}
+
 // the window-7 entry points of ABI version 1
 extern "C" int mis_window_attention_fwd(const float* qkv, long long ldq, float* out, long long ldo,
                                         const float* bias_table, int B, int H, int W, int nH, int shift, float scale,

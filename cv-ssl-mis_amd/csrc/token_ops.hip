@@ -989,18 +989,19 @@ extern "C" long long mis_colreduce_workspace_bytes(long long M, int C) {
     return mis_cdiv(M, COL_SLAB_ROWS) * C * (long long)sizeof(float2);
 }
 
-extern "C" int mis_layernorm_bwd(const float* x, long long ldx, const float* dy, long long lddy, float* dx,
-                                 long long lddx, const float* gamma, const float* mean, const float* rstd,
-                                 float* dgamma, float* dbeta, long long M, int C, int accumulate_dx,
-                                 int accumulate_affine, void* workspace, long long workspace_bytes,
-                                 hipStream_t stream) {
+// The data-gradient half of mis_layernorm_bwd: dx (+)= ..., and (affine) the per-slab partials of dgamma / dbeta into
+// `workspace`.  mis_layernorm_bwd_final turns the partials into dgamma / dbeta -- on any stream ordered behind this one: the
+// token plans run it beside the data-gradient chain (nothing downstream reads the affine gradients).
+static int layernorm_bwd_parts(const float* x, long long ldx, const float* dy, long long lddy, float* dx, long long lddx,
+                               const float* gamma, const float* mean, const float* rstd, long long M, int C,
+                               int accumulate_dx, bool affine, void* workspace, long long workspace_bytes,
+                               hipStream_t stream) {
     if (!x || !dy || !dx || !gamma || !mean || !rstd || !workspace || M <= 0 || C <= 0) return MIS_ERR_ARG;
     if (C % 4 || ldx % 4 || lddy % 4 || lddx % 4 || !a16(x) || !a16(dy) || !a16(dx) || !a16(gamma))
         return MIS_ERR_UNSUPPORTED;
     if (workspace_bytes < mis_colreduce_workspace_bytes(M, C)) return MIS_ERR_WORKSPACE;
     float2* part = reinterpret_cast<float2*>(workspace);
     const int slabs = (int)mis_cdiv(M, COL_SLAB_ROWS);
-    const bool affine = dgamma || dbeta;
     // C <= 1536: one pass, the slab kernel writes dx and the per-slab affine partials together
 #define MIS_LN_BWD(LPR, NV)                                                                                     \
     hipLaunchKernelGGL((ln_bwd_dx_reg_kernel<LPR, NV>), dim3(slabs), dim3(256), 0, stream, x, ldx, dy, lddy, dx, \
@@ -1020,10 +1021,36 @@ extern "C" int mis_layernorm_bwd(const float* x, long long ldx, const float* dy,
                            dx, lddx, gamma, mean, rstd, M, C, accumulate_dx);
     }
 #undef MIS_LN_BWD
-    if (affine)
-        hipLaunchKernelGGL(col_final_kernel, dim3((C + 31) / 32), dim3(1024), 0, stream, part, slabs, C, dgamma, dbeta,
-                           accumulate_affine);
     return mis_launch_status();
+}
+
+extern "C" int mis_layernorm_bwd_parts(const float* x, long long ldx, const float* dy, long long lddy, float* dx,
+                                       long long lddx, const float* gamma, const float* mean, const float* rstd,
+                                       long long M, int C, int accumulate_dx, void* workspace, long long workspace_bytes,
+                                       hipStream_t stream) {
+    return layernorm_bwd_parts(x, ldx, dy, lddy, dx, lddx, gamma, mean, rstd, M, C, accumulate_dx, true, workspace,
+                               workspace_bytes, stream);
+}
+
+extern "C" int mis_layernorm_bwd_final(const void* workspace, long long workspace_bytes, long long M, int C, float* dgamma,
+                                       float* dbeta, int accumulate_affine, hipStream_t stream) {
+    if (!workspace || M <= 0 || C <= 0 || (!dgamma && !dbeta)) return MIS_ERR_ARG;
+    if (workspace_bytes < mis_colreduce_workspace_bytes(M, C)) return MIS_ERR_WORKSPACE;
+    hipLaunchKernelGGL(col_final_kernel, dim3((C + 31) / 32), dim3(1024), 0, stream, reinterpret_cast<const float2*>(workspace),
+                       (int)mis_cdiv(M, COL_SLAB_ROWS), C, dgamma, dbeta, accumulate_affine);
+    return mis_launch_status();
+}
+
+extern "C" int mis_layernorm_bwd(const float* x, long long ldx, const float* dy, long long lddy, float* dx,
+                                 long long lddx, const float* gamma, const float* mean, const float* rstd,
+                                 float* dgamma, float* dbeta, long long M, int C, int accumulate_dx,
+                                 int accumulate_affine, void* workspace, long long workspace_bytes,
+                                 hipStream_t stream) {
+    const bool affine = dgamma || dbeta;
+    const int st = layernorm_bwd_parts(x, ldx, dy, lddy, dx, lddx, gamma, mean, rstd, M, C, accumulate_dx, affine, workspace,
+                                       workspace_bytes, stream);
+    if (st != MIS_OK || !affine) return st;
+    return mis_layernorm_bwd_final(workspace, workspace_bytes, M, C, dgamma, dbeta, accumulate_affine, stream);
 }
 
 // out[c] (+)= sum_rows x[row][c]   (nn.Linear bias gradient)

@@ -174,6 +174,8 @@ PROTOTYPES = {
     "mis_colreduce_workspace_bytes": (c_ll, [c_ll, c_i]),
     "mis_layernorm_bwd": (c_i, [c_p, c_ll, c_p, c_ll, c_p, c_ll, c_p, c_p, c_p, c_p, c_p, c_ll, c_i, c_i, c_i, c_p,
                                 c_ll, c_p]),
+    "mis_layernorm_bwd_parts": (c_i, [c_p, c_ll, c_p, c_ll, c_p, c_ll, c_p, c_p, c_p, c_ll, c_i, c_i, c_p, c_ll, c_p]),
+    "mis_layernorm_bwd_final": (c_i, [c_p, c_ll, c_ll, c_i, c_p, c_p, c_i, c_p]),
     "mis_colsum": (c_i, [c_p, c_ll, c_ll, c_i, c_p, c_i, c_p, c_ll, c_p]),
     "mis_gelu": (c_i, [c_p, c_p, c_p, c_ll, c_i, c_p]),
     "mis_residual_droppath": (c_i, [c_p, c_ll, c_p, c_ll, c_p, c_ll, c_p, c_ll, c_ll, c_i, c_ll, c_f, c_u, c_p, c_p,
@@ -198,6 +200,9 @@ PROTOTYPES = {
     "mis_window_attention_workspace_bytes_ws": (c_ll, [c_i, c_i, c_i, c_i, c_i]),
     "mis_window_attention_bwd_ws": (c_i, [c_p, c_ll, c_p, c_ll, c_p, c_ll, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_f,
                                           c_i, c_p, c_ll, c_p]),
+    "mis_window_attention_bwd_parts_ws": (c_i, [c_p, c_ll, c_p, c_ll, c_p, c_ll, c_p, c_i, c_i, c_i, c_i, c_i, c_f, c_i, c_p,
+                                                c_ll, c_p]),
+    "mis_window_attention_dtable_ws": (c_i, [c_p, c_ll, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
     "mis_full_attention_fwd": (c_i, [c_p, c_ll, c_p, c_ll, c_p, c_i, c_i, c_i, c_f, c_p]),
     "mis_full_attention_workspace_bytes": (c_ll, [c_i, c_i, c_i]),
     "mis_full_attention_bwd": (c_i, [c_p, c_ll, c_p, c_ll, c_p, c_ll, c_p, c_i, c_i, c_i, c_f, c_p, c_ll, c_p]),

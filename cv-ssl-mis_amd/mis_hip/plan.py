@@ -147,6 +147,7 @@ class ConvOp:
         if side is not None:
             side.wait_stream(torch.cuda.current_stream())     # dy is final
             with torch.cuda.stream(side):
+                run_deferred(ctx)
                 ops.conv_wgrad(self.x.t, dy, self.w.grad, self.ksize)
                 if self.b is not None and self.bias_grad:
                     ops.channel_sum(dy, self.b.grad)
@@ -794,9 +795,12 @@ class Plan:
                 self._wgrad_stream = torch.cuda.Stream()
             side = self._wgrad_stream
         ctx.wgrad_stream = side
+        ctx.deferred = [] if side is not None else None      # see defer(): finishing launches queued for the side stream
         if on_progress is None:
             for op in reversed(self.ops):
                 op.bwd(ctx)
+            flush_deferred(ctx)
+            ctx.deferred = None
             if side is not None:
                 main.wait_stream(side)      # every weight gradient is in the flat buffer before the optimizer reads it
             return
@@ -807,7 +811,10 @@ class Plan:
         for i in range(len(self.ops) - 1, -1, -1):
             self.ops[i].bwd(ctx)
             if i == 0 or self._progress[i] != self._progress[i - 1] or i == len(self.ops) - 1:
+                flush_deferred(ctx)         # a reported gradient range is complete on (main, side): finish what was queued
                 report(self._progress[i])
+        flush_deferred(ctx)
+        ctx.deferred = None
         if side is not None:
             main.wait_stream(side)          # every weight gradient is in the flat buffer before the optimizer reads it
 
@@ -818,6 +825,37 @@ class Plan:
     def drop_site_shape(self, site):
         """Activation shape an explicit ``net.drop_masks[site]`` tensor must have."""
         return next(op.y.shape for op in self.ops if isinstance(op, NormActOp) and op.site == site)
+
+
+# Gradients nothing downstream reads (LayerNorm's dgamma / dbeta, the relative-position-bias-table gradient) are finished on
+# the weight-gradient side stream: the data-gradient chain only runs the half that produces dx and the partials, into a
+# workspace of the op's own; the finishing launches ride on the next side-stream section.  MIS_DEFER_FINALS=0: all on one stream.
+DEFER = os.environ.get("MIS_DEFER_FINALS", "1") != "0"
+
+
+def defer(ctx, fn):
+    """Queue ``fn`` for the side stream (False: there is none in this pass and the caller runs the one-stream form)."""
+    if not DEFER or getattr(ctx, "wgrad_stream", None) is None or getattr(ctx, "deferred", None) is None:
+        return False
+    ctx.deferred.append(fn)
+    return True
+
+
+def run_deferred(ctx):
+    """Called with the side stream current and ordered behind everything enqueued on the compute stream so far."""
+    pend = getattr(ctx, "deferred", None)
+    if pend:
+        for fn in pend:
+            fn()
+        del pend[:]
+
+
+def flush_deferred(ctx):
+    side = getattr(ctx, "wgrad_stream", None)
+    if side is not None and getattr(ctx, "deferred", None):
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            run_deferred(ctx)
 
 
 def progress_reporter(on_progress, main, side):

@@ -12,7 +12,7 @@ import os
 import torch
 
 from . import tops
-from .plan import Act
+from .plan import Act, defer, run_deferred, flush_deferred
 
 # GEMM epilogue fusions (GELU into fc1 / fc2-dX, DropPath + residual add into proj / fc2); MIS_SWIN_FUSE=0 runs the
 # separate element-wise passes (A/B timing, and the reference point of the fusion tests)
@@ -116,6 +116,7 @@ class LinearOp:
         if side is not None:
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
+                run_deferred(ctx)
                 self._wgrad(dy)
         else:
             self._wgrad(dy)
@@ -139,14 +140,24 @@ class LayerNormOp:
         self.x, self.y, self.g, self.b = x, y, g, b
         self.mean = torch.empty(x.rows, dtype=torch.float32, device="cuda")
         self.rstd = torch.empty(x.rows, dtype=torch.float32, device="cuda")
+        self._ws = None
 
     def fwd(self, ctx):
         tops.layernorm_fwd(self.x.t, self.y.t, self.g.data, self.b.data, self.mean, self.rstd)
 
     def bwd(self, ctx):
-        tops.layernorm_bwd(self.x.t, self.y.grad(), self.x.grad(), self.g.data, self.mean, self.rstd, self.g.grad,
-                           self.b.grad, accumulate_dx=self.x.written)
+        if (self.g.grad is not None or self.b.grad is not None) and defer(ctx, self._final):
+            if self._ws is None:
+                self._ws = tops.colreduce_workspace(self.x.rows, self.x.t.shape[1])
+            tops.layernorm_bwd_parts(self.x.t, self.y.grad(), self.x.grad(), self.g.data, self.mean, self.rstd, self._ws,
+                                     accumulate_dx=self.x.written)
+        else:
+            tops.layernorm_bwd(self.x.t, self.y.grad(), self.x.grad(), self.g.data, self.mean, self.rstd, self.g.grad,
+                               self.b.grad, accumulate_dx=self.x.written)
         self.x.mark_written()
+
+    def _final(self):
+        tops.layernorm_bwd_final(self._ws, self.x.rows, self.x.t.shape[1], self.g.grad, self.b.grad)
 
 
 class GeluOp:
@@ -175,15 +186,25 @@ class AttnOp:
         self.geo = (B, H, W, nH, shift)
         self.scale = 32 ** -0.5
         self.window = window
+        self._ws = None
 
     def fwd(self, ctx):
         tops.window_attention_fwd(self.qkv.t, self.out.t, self.table.data, *self.geo, self.scale, window=self.window)
 
     def bwd(self, ctx):
         assert not self.qkv.written
-        tops.window_attention_bwd(self.qkv.t, self.out.grad(), self.qkv.grad(), self.table.data, self.table.grad,
-                                  *self.geo, self.scale, window=self.window)
+        if defer(ctx, self._dtable):
+            if self._ws is None:
+                self._ws = tops.window_attention_workspace(*self.geo[:4], window=self.window)
+            tops.window_attention_bwd_parts(self.qkv.t, self.out.grad(), self.qkv.grad(), self.table.data, self._ws,
+                                            *self.geo, self.scale, window=self.window)
+        else:
+            tops.window_attention_bwd(self.qkv.t, self.out.grad(), self.qkv.grad(), self.table.data, self.table.grad,
+                                      *self.geo, self.scale, window=self.window)
         self.qkv.mark_written()
+
+    def _dtable(self):
+        tops.window_attention_dtable(self._ws, self.table.grad, *self.geo[:4], window=self.window)
 
 
 class ResidualOp:
@@ -568,9 +589,12 @@ class SwinPlan:
                 self._wgrad_stream = torch.cuda.Stream()
             side = self._wgrad_stream
         ctx.wgrad_stream = side
+        ctx.deferred = [] if side is not None else None
         if on_progress is None:
             for op in reversed(self.ops):
                 op.bwd(ctx)
+            flush_deferred(ctx)
+            ctx.deferred = None
             if side is not None:
                 main.wait_stream(side)
             return
@@ -581,7 +605,10 @@ class SwinPlan:
         for i in range(len(self.ops) - 1, -1, -1):      # see mis_hip.plan.Plan.backward
             self.ops[i].bwd(ctx)
             if i == 0 or self._progress[i] != self._progress[i - 1] or i == len(self.ops) - 1:
+                flush_deferred(ctx)      # a reported gradient range is complete on (main, side): finish what was queued
                 report(self._progress[i])
+        flush_deferred(ctx)
+        ctx.deferred = None
         if side is not None:
             main.wait_stream(side)
 

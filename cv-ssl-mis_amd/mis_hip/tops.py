@@ -242,6 +242,28 @@ def layernorm_bwd(x, dy, dx, gamma, mean, rstd, dgamma, dbeta, accumulate_dx=Fal
              "mis_layernorm_bwd")
 
 
+def layernorm_bwd_parts(x, dy, dx, gamma, mean, rstd, ws, accumulate_dx=False):
+    """dx and the affine partials into the caller's workspace ``ws`` (``colreduce_workspace``); ``layernorm_bwd_final`` finishes."""
+    L = _l.load()
+    M, C, ldx = _mat(x)
+    _, _, lddy = _mat(dy)
+    _, _, lddx = _mat(dx)
+    _l.check(L.mis_layernorm_bwd_parts(_l.ptr(x), ldx, _l.ptr(dy), lddy, _l.ptr(dx), lddx, _l.ptr(gamma), _l.ptr(mean),
+                                       _l.ptr(rstd), M, C, int(accumulate_dx), _l.ptr(ws), ws.numel(), _l.stream_ptr()),
+             "mis_layernorm_bwd_parts")
+
+
+def layernorm_bwd_final(ws, M, C, dgamma, dbeta, accumulate_affine=False):
+    L = _l.load()
+    _l.check(L.mis_layernorm_bwd_final(_l.ptr(ws), ws.numel(), M, C, _l.ptr(dgamma), _l.ptr(dbeta), int(accumulate_affine),
+                                       _l.stream_ptr()), "mis_layernorm_bwd_final")
+
+
+def colreduce_workspace(M, C):
+    """A workspace of the caller's own for layernorm_bwd_parts / _final (the shared scratch is reused by the next call)."""
+    return torch.empty(_l.load().mis_colreduce_workspace_bytes(M, C), dtype=torch.uint8, device="cuda")
+
+
 def colsum(x, out, accumulate=False):
     L = _l.load()
     M, C, ldx = _mat(x)
@@ -375,6 +397,30 @@ def window_attention_bwd(qkv, dout, dqkv, table, dtable, B, H, W, nH, shift, sca
     _l.check(L.mis_window_attention_bwd_ws(_l.ptr(qkv), ldq, _l.ptr(dout), ldo, _l.ptr(dqkv), lddq, _l.ptr(table),
                                            _l.ptr(dtable), int(accumulate_table), B, H, W, nH, shift, scale, window,
                                            _l.ptr(ws), ws.numel(), _l.stream_ptr()), "mis_window_attention_bwd_ws")
+
+
+def window_attention_workspace(B, H, W, nH, window=7):
+    L = _l.load()
+    nb = L.mis_window_attention_workspace_bytes_ws(B, H, W, nH, window)
+    if nb < 0:
+        _l.check(nb, "mis_window_attention_workspace_bytes_ws")
+    return torch.empty(nb, dtype=torch.uint8, device="cuda")
+
+
+def window_attention_bwd_parts(qkv, dout, dqkv, table, ws, B, H, W, nH, shift, scale, window=7):
+    L = _l.load()
+    _, _, ldq = _mat(qkv)
+    _, _, ldo = _mat(dout)
+    _, _, lddq = _mat(dqkv)
+    _l.check(L.mis_window_attention_bwd_parts_ws(_l.ptr(qkv), ldq, _l.ptr(dout), ldo, _l.ptr(dqkv), lddq, _l.ptr(table), B, H,
+                                                 W, nH, shift, scale, window, _l.ptr(ws), ws.numel(), _l.stream_ptr()),
+             "mis_window_attention_bwd_parts_ws")
+
+
+def window_attention_dtable(ws, dtable, B, H, W, nH, accumulate_table=False, window=7):
+    L = _l.load()
+    _l.check(L.mis_window_attention_dtable_ws(_l.ptr(ws), ws.numel(), _l.ptr(dtable), int(accumulate_table), B, H, W, nH,
+                                              window, _l.stream_ptr()), "mis_window_attention_dtable_ws")
 
 
 # ---------------------------------------------------------------- UNETR (full attention, 3-D patch embedding)

@@ -497,6 +497,15 @@ int mis_layernorm_bwd(const float* x, long long ldx, const float* dy, long long 
                       const float* gamma, const float* mean, const float* rstd, float* dgamma, float* dbeta,
                       long long M, int C, int accumulate_dx, int accumulate_affine, void* workspace,
                       long long workspace_bytes, mis_stream_t stream);
+/* mis_layernorm_bwd in two halves (same results bit for bit): _parts = dx and the per-slab partials of the affine gradients in
+ * `workspace` (mis_colreduce_workspace_bytes), _final = dgamma / dbeta from them.  The second half may run on another stream
+ * ordered behind the first -- autograd's LayerNorm backward (:204,211) gives the affine gradients to nobody downstream, so the
+ * token plans keep it off the data-gradient chain (the workspace must then stay untouched until it ran) */
+int mis_layernorm_bwd_parts(const float* x, long long ldx, const float* dy, long long lddy, float* dx, long long lddx,
+                            const float* gamma, const float* mean, const float* rstd, long long M, int C,
+                            int accumulate_dx, void* workspace, long long workspace_bytes, mis_stream_t stream);
+int mis_layernorm_bwd_final(const void* workspace, long long workspace_bytes, long long M, int C, float* dgamma,
+                            float* dbeta, int accumulate_affine, mis_stream_t stream);
 /* out[c] (+)= sum_rows x[row][c]: nn.Linear bias gradient */
 int mis_colsum(const float* x, long long ldx, long long M, int C, float* out, int accumulate, void* workspace,
                long long workspace_bytes, mis_stream_t stream);
@@ -568,6 +577,16 @@ int mis_window_attention_bwd_ws(const float* qkv, long long ldq, const float* do
                                 long long lddq, const float* bias_table, float* dbias_table, int accumulate_table,
                                 int B, int H, int W, int nH, int shift, float scale, int window, void* workspace,
                                 long long workspace_bytes, mis_stream_t stream);
+/* mis_window_attention_bwd_ws in two halves (same results bit for bit): _parts_ws = dqkv and the per-(sample, window, head)
+ * dS partials in `workspace`, _dtable_ws = the gradient of relative_position_bias_table from them (:99-131: autograd's
+ * index_add through relative_position_index).  As with mis_layernorm_bwd_{parts,final}: the table gradient feeds nothing
+ * downstream and may run on another stream behind the first half */
+int mis_window_attention_bwd_parts_ws(const float* qkv, long long ldq, const float* dout, long long ldo, float* dqkv,
+                                      long long lddq, const float* bias_table, int B, int H, int W, int nH, int shift,
+                                      float scale, int window, void* workspace, long long workspace_bytes,
+                                      mis_stream_t stream);
+int mis_window_attention_dtable_ws(void* workspace, long long workspace_bytes, float* dbias_table, int accumulate_table,
+                                   int B, int H, int W, int nH, int window, mis_stream_t stream);
 
 /* ---- UNETR (reference code/networks/unetr.py, built from MONAI blocks that are NOT vendored in the reference:
  * parity of these entry points is pinned to a torch restatement of the published algorithm only) --------------------

@@ -115,3 +115,32 @@ def test_weight_gradient_side_stream_is_bit_identical(monkeypatch):
         torch.cuda.synchronize()
         res.append(model.flat_grad.clone())
     assert torch.equal(res[0], res[1])
+
+
+@pytest.mark.parametrize("kind,shape,C", [("swin", (2, 1, 224, 224), 4), ("swin_w8", (2, 1, 256, 256), 4),
+                                          ("unetr", (1, 1, 96, 96, 96), 2), ("swinunetr", (1, 1, 64, 64, 64), 2)])
+def test_finishing_launches_on_the_side_stream_are_bit_identical(monkeypatch, kind, shape, C):
+    """MIS_DEFER_FINALS: LayerNorm's affine gradients and the relative-position-bias-table gradient finished on the
+    weight-gradient side stream (mis_layernorm_bwd_{parts,final}, mis_window_attention_{bwd_parts,dtable}_ws) give the same
+    flat gradient buffer as the one-call forms on the data-gradient chain -- twice in a row (the second backward reuses the
+    ops' own workspaces)."""
+    from mis_hip import plan
+    res = []
+    for on in (False, True):
+        monkeypatch.setattr(plan, "DEFER", on)
+        torch.manual_seed(11)
+        model = _make(kind, C)
+        model.train()
+        model.dropout_enabled = False
+        x = torch.rand(shape, device="cuda")
+        grads = []
+        for it in range(2):
+            model.forward_raw(x + 0.1 * it)
+            dl = model.logits_grad_buffer()
+            dl.copy_(torch.randn(dl.shape, device="cuda") * 0.1)
+            model.backward_raw()
+            torch.cuda.synchronize()
+            grads.append(model.flat_grad.clone())
+        res.append(grads)
+    for a, b in zip(*res):
+        assert torch.equal(a, b)

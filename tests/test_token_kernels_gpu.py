@@ -220,6 +220,18 @@ def test_layernorm(M, C):
     tops.layernorm_bwd(xd, dy.cuda(), dx, gd, mean, rstd, dg, db, accumulate_dx=True, accumulate_affine=True)
     _close(dx, 2 * x.grad, rtol=3e-4)
     _close(dg, 2 * g.grad, rtol=3e-4, atol=2e-4)
+    # two halves (mis_layernorm_bwd_parts / _final), the second on another stream: bit-identical to the one-call form
+    dx1, dg1, db1 = torch.empty(M, C, device="cuda"), torch.empty(C, device="cuda"), torch.empty(C, device="cuda")
+    tops.layernorm_bwd(xd, dy.cuda(), dx1, gd, mean, rstd, dg1, db1)
+    ws_own = tops.colreduce_workspace(M, C)
+    dx2, dg2, db2 = torch.full_like(dx1, float("nan")), torch.full_like(dg1, float("nan")), torch.full_like(db1, float("nan"))
+    tops.layernorm_bwd_parts(xd, dy.cuda(), dx2, gd, mean, rstd, ws_own)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        tops.layernorm_bwd_final(ws_own, M, C, dg2, db2)
+    torch.cuda.current_stream().wait_stream(side)
+    assert torch.equal(dx1, dx2) and torch.equal(dg1, dg2) and torch.equal(db1, db2)
     bsum = torch.empty(C, device="cuda")
     tops.colsum(dy.cuda(), bsum)
     _close(bsum, dy.double().sum(0), rtol=1e-5, atol=1e-4)
@@ -375,6 +387,17 @@ def test_window_attention(B, H, W, nH, shift, ws, prec):
     tops.window_attention_bwd(qd, dout.float().cuda(), dqkv, td, dt, B, H, W, nH, shift, scale, window=ws)
     _close(dqkv, qkv.grad, rtol=2e-4, atol=1e-5)
     _close(dt, table.grad, rtol=2e-4, atol=1e-4)
+    # the same backward in two halves (mis_window_attention_bwd_parts_ws / _dtable_ws), the second on another stream with a
+    # workspace of the caller's own: bit-identical
+    ws_own = tops.window_attention_workspace(B, H, W, nH, window=ws)
+    dqkv2, dt2 = torch.full_like(dqkv, float("nan")), torch.full_like(dt, float("nan"))
+    tops.window_attention_bwd_parts(qd, dout.float().cuda(), dqkv2, td, ws_own, B, H, W, nH, shift, scale, window=ws)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        tops.window_attention_dtable(ws_own, dt2, B, H, W, nH, window=ws)
+    torch.cuda.current_stream().wait_stream(side)
+    assert torch.equal(dqkv2, dqkv) and torch.equal(dt2, dt)
 
 
 @pytest.mark.parametrize("B,H,K,P,c", [(2, 56, 96, 4, 96), (24, 28, 192, 2, 96), (3, 14, 384, 2, 192), (2, 7, 768, 2, 384)])
