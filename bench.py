@@ -345,9 +345,12 @@ def run_workload(name, args, rank, world, kernel_events=True):
                     2.25 if k.startswith(("wino2d_fwd_kernel", "wino2d_wgrad_kernel")) else 1.0)
 
         def bf3(k):
-            """The Linear GEMMs in their bf16x3 form (gemm.hip: last template argument 1): every algorithmic multiply-add is
-            six v_mfma_f32_16x16x32_bf16 piece products, priced against the dense bf16 matrix peak."""
-            return k.startswith("gemm_nt_kernel<") and k.rstrip(" >").endswith(", 1") or k.startswith("gemm_tn_reg_kernel<1")
+            """The Linear GEMMs in their bf16x3 form (gemm.hip: last template argument 1, or 2 = B pre-split by
+            mis_gemm_split_batch): every algorithmic multiply-add is six bf16 piece products (v_mfma_f32_16x16x32_bf16;
+            16x16x16 in the short-contraction kernel), priced against the dense bf16 matrix peak."""
+            t = k.rstrip(" >")
+            return (k.startswith(("gemm_nt_kernel<", "gemm_nt_short_kernel<")) and t.endswith((", 1", ", 2"))) or \
+                k.startswith("gemm_tn_reg_kernel<1")
 
         def pipe_seconds(k, flops):
             """Time the matrix pipe needs for this launch's EXECUTED flops at its peak."""

@@ -28,6 +28,7 @@
 // 9.5 ms/step vs 13.1 ms/step on config 4), partial tiles in a caller workspace and a fixed-order reduction
 // (deterministic).  Workgroups are ordered XCD-aware over one linear (k-slice, tile) index.
 #include <atomic>
+#include <cstring>
 #include "common.h"
 
 namespace {
@@ -59,6 +60,10 @@ struct GemmArgs {
     // TN only, optional (mis_gemm_dw): dbias[m] (+)= sum_k A[k][m] -- the bias gradient of nn.Linear rides on the weight
     // gradient's read of dy.  Split-K: per-slice sums in wsb [KS][M] (behind the M x N partials), summed by the reduction
     float* dbias; float* wsb; int dbias_acc;
+    // NT only, optional (mis_gemm_nt_split): B as the three bf16 piece planes mis_gemm_split_b wrote (PREC = 2 kernels; the
+    // fp32 B is not read).  b3_plane = bytes of one plane (N x K3 x 2), K3 = K rounded up to the k-step
+    const void* B3; unsigned b3_plane; int K3;
+    int bm_force;          // host only: rows per tile chosen by the caller (0: nt_tile_m)
 };
 
 enum { EP_NONE = 0, EP_GELU_FWD = 1, EP_GELU_BWD = 2, EP_RESIDUAL = 3 };
@@ -90,6 +95,59 @@ __device__ __forceinline__ void bf3_split_pair(float x0, float x1, unsigned& h, 
 }
 __device__ __forceinline__ f32x4 bf3_mfma(const u32x4& a, const u32x4& b, f32x4 c) { return mis_bf3_mfma1(a, b, c); }
 
+// B operand of the NT form, split ahead of the GEMM (weights: once per step instead of once per tile and k-step).  Three planes
+// (h, m, l) of bf16 [N][K3], K3 = K rounded up to 32 (zeros beyond K); inside each block of 32 contraction elements the order is
+// the one the kernels' lanes consume: position lk * 8 + 2 s + e holds element 8 s + 2 lk + e (lane group lk = lane >> 4 takes the
+// float2 at 8 s + 2 lk of the fp32 A rows, s = 0 .. 3), so a lane's 8 elements of a plane are one 16-byte group.  The pieces are
+// mis_bf3_from8's: the PREC = 2 kernels give the same bits as PREC = 1.
+struct SplitJob {
+    const float* B; long long ldb; void* B3;
+    int N, K, K3, first;       // first: prefix sum of the jobs' units (one unit = 256 (row, block, lane group) triples)
+};
+
+__device__ __forceinline__ void split_unit(const SplitJob& j, int unit) {
+    const int kb_n = j.K3 / 32;
+    const long long t = (long long)unit * 256 + threadIdx.x;          // (n, kb, lk)
+    const long long total = (long long)j.N * kb_n * 4;
+    if (t >= total) return;
+    const int lk = (int)(t & 3);
+    const long long r = t >> 2;
+    const int kb = (int)(r % kb_n);
+    const long long n = r / kb_n;
+    float e[8];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const int k = kb * 32 + 8 * s + 2 * lk;
+        float2 v = make_float2(0.f, 0.f);
+        if (k < j.K) v = *reinterpret_cast<const float2*>(j.B + n * j.ldb + k);      // K % 4 == 0, ldb % 4 == 0: pairs are whole
+        e[2 * s] = v.x; e[2 * s + 1] = v.y;
+    }
+    const MisBf3 o = mis_bf3_from8(e[0], e[1], e[2], e[3], e[4], e[5], e[6], e[7]);
+    const long long plane = (long long)j.N * j.K3 * 2;
+    char* const base = reinterpret_cast<char*>(j.B3) + (n * j.K3 + kb * 32 + lk * 8) * 2;
+    *reinterpret_cast<u32x4*>(base) = o.h;
+    *reinterpret_cast<u32x4*>(base + plane) = o.m;
+    *reinterpret_cast<u32x4*>(base + 2 * plane) = o.l;
+}
+
+__global__ __launch_bounds__(256) void gemm_split_kernel(const SplitJob j) { split_unit(j, (int)blockIdx.x); }
+
+// every Linear weight of a network in one launch: a device table of jobs ordered by `first`, binary search per workgroup
+__global__ __launch_bounds__(256) void gemm_split_batch_kernel(const SplitJob* __restrict__ jobs, int n) {
+    __shared__ SplitJob job;
+    if (threadIdx.x == 0) {
+        int lo = 0, hi = n - 1;
+        const int t = (int)blockIdx.x;
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (jobs[mid].first <= t) lo = mid; else hi = mid - 1;
+        }
+        job = jobs[lo];
+    }
+    __syncthreads();
+    split_unit(job, (int)blockIdx.x - job.first);
+}
+
 // Split-precision mask: bit 0 the NT GEMMs (forward, dX), bit 1 the register-only TN GEMM (dW), bit 2 the window-attention
 // products (attention_impl.inc) as bf16x3 products; 0 = fp32 MFMA everywhere.  Default 7 (MIS_GEMM_BF3 overrides at load;
 // mis_gemm_set_split_precision at run time: bench.py times both).
@@ -101,11 +159,13 @@ bool gemm_bf3() { return gemm_bf3_state().load(std::memory_order_relaxed) & 1; }
 bool gemm_bf3_tn() { return gemm_bf3_state().load(std::memory_order_relaxed) & 2; }
 
 // ------------------------------------------------------------------------------------------------ NT
-template <int BMT, int BN>
+template <int BMT, int BN, int PREC = 0>
 struct NtCfg {
     static constexpr int MI = BMT / 32;                   // 16-row MFMA tiles per wave (wave = BMT/2 x BN/2)
     static constexpr int NJ = BN / 32;                    // 16-column MFMA tiles per wave
-    static constexpr int A_FLOATS = BMT * BK, B_FLOATS = BN * BK;
+    // PREC = 2: the B stage holds three bf16 planes [BN][32] (64-byte rows) instead of fp32 [BN][32]
+    static constexpr int A_FLOATS = BMT * BK, B_FLOATS = PREC == 2 ? BN * BK * 3 / 2 : BN * BK;
+    static constexpr int RB3 = BN / 16, PB3 = 3 * RB3;    // PREC = 2: 16-row x 64-byte DMA pieces per plane / per stage
     static constexpr int STAGE = A_FLOATS + B_FLOATS;
     // epilogue: the accumulator tile goes through LDS (row stride BN + 4: the four 4-row lane groups land 16 banks
     // apart) so that C -- and the operands of the fused epilogues -- move as float4 rows instead of 64-byte dword pieces
@@ -122,7 +182,7 @@ struct NtCfg {
 // (measured: every Linear of the step slowed down, 38.5 -> 41.7 ms).
 template <int BMT, int BN, int EP, int PREC = 0>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs a) {
-    using G = NtCfg<BMT, BN>;
+    using G = NtCfg<BMT, BN, PREC>;
     float* const lds = mis_gemm_lds;
 
     const unsigned L = mis_xcd_remap(blockIdx.x, a.n_blocks_padded);
@@ -153,10 +213,27 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs a) {
         const int row = (wave + 4 * i) * 8 + (lane >> 3);
         voA[i] = m0 + row < a.M ? (unsigned)((long long)(m0 + row) * a.lda + ksrc) * 4u : OOB;
     }
+    if constexpr (PREC != 2) {
 #pragma unroll
-    for (int i = 0; i < G::PB / 4; ++i) {
-        const int row = (wave + 4 * i) * 8 + (lane >> 3);
-        voB[i] = n0 + row < a.N ? (unsigned)((long long)(n0 + row) * a.ldb + ksrc) * 4u : OOB;
+        for (int i = 0; i < G::PB / 4; ++i) {
+            const int row = (wave + 4 * i) * 8 + (lane >> 3);
+            voB[i] = n0 + row < a.N ? (unsigned)((long long)(n0 + row) * a.ldb + ksrc) * 4u : OOB;
+        }
+    }
+    // PREC = 2: piece q = (plane q / RB3, rows (q % RB3) * 16 ..+16) x 64 bytes of the k-step: lane -> row lane >> 2, 16-byte
+    // group lane & 3 (= the 8 contraction elements of lane group lk, in the order mis_gemm_split_b stored them); the 1 KiB a
+    // DMA instruction writes is 16 whole rows of the plane, and a wave's operand read is one contiguous KiB again: no swizzle
+    constexpr int NB3 = (G::PB3 + 3) / 4;
+    unsigned voB3[NB3];
+    const i32x4 rB3 = PREC == 2 ? make_rsrc(a.B3, 3u * a.b3_plane) : rB;
+    if constexpr (PREC == 2) {
+#pragma unroll
+        for (int i = 0; i < NB3; ++i) {
+            const int q = wave + 4 * i, plane = q / G::RB3, row = (q % G::RB3) * 16 + (lane >> 2);
+            voB3[i] = (q < G::PB3 && n0 + row < a.N)
+                          ? (unsigned)plane * a.b3_plane + (unsigned)(((long long)(n0 + row) * a.K3 + (lane & 3) * 8) * 2)
+                          : OOB;
+        }
     }
 
     auto stage = [&](int buf, int k0) {
@@ -165,9 +242,16 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs a) {
         const unsigned kb = (unsigned)k0 * 4u;
 #pragma unroll
         for (int i = 0; i < G::PA / 4; ++i) dma_dwordx4(st + (unsigned)((wave + 4 * i) * 256) * 4u, kout ? OOB : voA[i] + kb, rA);
+        if constexpr (PREC == 2) {
 #pragma unroll
-        for (int i = 0; i < G::PB / 4; ++i)
-            dma_dwordx4(st + (unsigned)(G::A_FLOATS + (wave + 4 * i) * 256) * 4u, kout ? OOB : voB[i] + kb, rB);
+            for (int i = 0; i < NB3; ++i)
+                if (wave + 4 * i < G::PB3)      // uniform; the planes are zero beyond K: no k test
+                    dma_dwordx4(st + (unsigned)(G::A_FLOATS * 4 + (wave + 4 * i) * 1024), voB3[i] + (unsigned)k0 * 2u, rB3);
+        } else {
+#pragma unroll
+            for (int i = 0; i < G::PB / 4; ++i)
+                dma_dwordx4(st + (unsigned)(G::A_FLOATS + (wave + 4 * i) * 256) * 4u, kout ? OOB : voB[i] + kb, rB);
+        }
     };
 
     f32x4 acc[G::MI][G::NJ];
@@ -215,7 +299,8 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs a) {
             for (int s = 0; s < BK / 8; ++s) {
                 const float2 v = sA2[((wm + i * 16 + lj) * BK + ((s * 8 + 2 * lk) ^ swz)) >> 1];
                 unsigned h, m, l;
-                bf3_split_pair(v.x, v.y, h, m, l);
+                if constexpr (GDBG & 32) { h = __float_as_uint(v.x); m = __float_as_uint(v.y); l = h; }   // timing only: no A split
+                else bf3_split_pair(v.x, v.y, h, m, l);
                 ah[i][s] = h; am[i][s] = m; al[i][s] = l;
             }
 #pragma unroll
@@ -225,9 +310,44 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs a) {
             for (int s = 0; s < BK / 8; ++s) {
                 const float2 v = sB2[((wn + j * 16 + lj) * BK + ((s * 8 + 2 * lk) ^ swz)) >> 1];
                 unsigned h, m, l;
-                bf3_split_pair(v.x, v.y, h, m, l);
+                if constexpr (GDBG & 16) { h = __float_as_uint(v.x); m = __float_as_uint(v.y); l = h; }   // timing only: no B split
+                else bf3_split_pair(v.x, v.y, h, m, l);
                 bh[s] = h; bm[s] = m; bl[s] = l;
             }
+#pragma unroll
+            for (int i = 0; i < G::MI; ++i) {
+                f32x4 c = acc[i][j];
+                c = bf3_mfma(al[i], bh, c);
+                c = bf3_mfma(ah[i], bl, c);
+                c = bf3_mfma(am[i], bm, c);
+                c = bf3_mfma(am[i], bh, c);
+                c = bf3_mfma(ah[i], bm, c);
+                c = bf3_mfma(ah[i], bh, c);
+                acc[i][j] = c;
+            }
+        }
+    };
+
+    // PREC = 2: B arrives split (mis_gemm_split_b): three 16-byte LDS reads per 16-column tile and no VALU work for B -- the
+    // split of the B fragments was two thirds of the k-loop's vector instructions (264 per k-step of a 64 x 128 tile against
+    // 48 MFMAs of 16 cycles; ablation without it: the 20 SwinUnet shapes 1461 -> 1231 us)
+    auto compute_b3 = [&](const float* st) {
+        const float2* __restrict__ sA2 = reinterpret_cast<const float2*>(st);
+        const u32x4* __restrict__ sB3 = reinterpret_cast<const u32x4*>(st + G::A_FLOATS);
+        u32x4 ah[G::MI], am[G::MI], al[G::MI];
+#pragma unroll
+        for (int i = 0; i < G::MI; ++i)
+#pragma unroll
+            for (int s = 0; s < BK / 8; ++s) {
+                const float2 v = sA2[((wm + i * 16 + lj) * BK + ((s * 8 + 2 * lk) ^ swz)) >> 1];
+                unsigned h, m, l;
+                bf3_split_pair(v.x, v.y, h, m, l);
+                ah[i][s] = h; am[i][s] = m; al[i][s] = l;
+            }
+#pragma unroll
+        for (int j = 0; j < G::NJ; ++j) {
+            const int r = (wn + j * 16 + lj) * 4 + lk;
+            const u32x4 bh = sB3[r], bm = sB3[BN * 4 + r], bl = sB3[2 * BN * 4 + r];
 #pragma unroll
             for (int i = 0; i < G::MI; ++i) {
                 f32x4 c = acc[i][j];
@@ -249,7 +369,8 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs a) {
     int s = 0;
     for (int k0 = kbeg; k0 < kend; k0 += BK, ++s) {
         if (k0 + BK < kend && !(GDBG & 2)) stage((s + 1) & 1, k0 + BK);
-        if constexpr (PREC == 1) compute_bf3(lds + (s & 1) * G::STAGE);
+        if constexpr (PREC == 2) compute_b3(lds + (s & 1) * G::STAGE);
+        else if constexpr (PREC == 1) compute_bf3(lds + (s & 1) * G::STAGE);
         else if constexpr (!(GDBG & 4)) compute(lds + (s & 1) * G::STAGE);
         dma_wait();
         __syncthreads();   // k-step s+1 landed in the other buffer; everyone is done reading this one
@@ -503,7 +624,8 @@ __global__ __launch_bounds__(256) void gemm_nt_short_kernel(const GemmArgs a) {
             for (int s = 0; s < BKS / 8; ++s) {
                 const float2 v = sA2[((wm + i * 16 + lj) * BKS + (((2 * s + (lk >> 1)) ^ swz) * 4 + (lk & 1) * 2)) >> 1];
                 unsigned h, m, l;
-                bf3_split_pair(v.x, v.y, h, m, l);
+                if constexpr (GDBG & 32) { h = __float_as_uint(v.x); m = __float_as_uint(v.y); l = h; }
+                else bf3_split_pair(v.x, v.y, h, m, l);
                 ah[i][s] = h; am[i][s] = m; al[i][s] = l;
             }
 #pragma unroll
@@ -513,7 +635,8 @@ __global__ __launch_bounds__(256) void gemm_nt_short_kernel(const GemmArgs a) {
             for (int s = 0; s < BKS / 8; ++s) {
                 const float2 v = sB2[((wn + j * 16 + lj) * BKS + (((2 * s + (lk >> 1)) ^ swz) * 4 + (lk & 1) * 2)) >> 1];
                 unsigned h, m, l;
-                bf3_split_pair(v.x, v.y, h, m, l);
+                if constexpr (GDBG & 16) { h = __float_as_uint(v.x); m = __float_as_uint(v.y); l = h; }
+                else bf3_split_pair(v.x, v.y, h, m, l);
                 bh[s] = h; bm[s] = m; bl[s] = l;
             }
 #pragma unroll
@@ -590,6 +713,14 @@ __global__ __launch_bounds__(256) void gemm_nt_short_kernel(const GemmArgs a) {
         if (h == 0) __syncthreads();
     }
 }
+
+// (Round 5 also built a PERSISTENT form for K <= 96: a workgroup keeps one 96-column panel of the pre-split B in LDS (55 KB) for
+// its whole life and walks down the row tiles, A tile t + 1 landing by DMA while tile t is multiplied, whole 384-byte output
+// rows through an LDS stage.  Correct on the first run and SLOWER: 150528 x 384 x 96 159 us against the short-contraction
+// kernel's 118, x 288: 134 against 89, x 96: 54 against 35.  The panel, the two A buffers and the stage are 127 KB: one
+// workgroup per CU, one wave per SIMD, and a lone wave pays the LDS latency, the split of its A fragments and the six-deep
+// MFMA chains one after the other -- 4.3 us per tile where the arithmetic is 0.8.  The short-contraction kernel's six resident
+// workgroups hide exactly that.  Removed.)
 
 // ------------------------------------------------------------------------------------------------ TN
 template <int BT>
@@ -1075,6 +1206,12 @@ __global__ __launch_bounds__(256) void gemm_reduce_kernel(const GemmArgs a) {
 // tile edge of the TN form / tile width of the NT form: 96 when it removes padding
 int tn_tile(int M, int N) { return (M % 96 == 0 && N % 96 == 0 && (M % 128 != 0 || N % 128 != 0)) ? 96 : 128; }
 int nt_tile_n(int N) { return (N % 96 == 0 && N % 128 != 0) ? 96 : 128; }
+// pre-split B: a 64 x 96 tile keeps three workgroups per CU (52 KB of LDS; 64 x 128 needs 64 KB: two)
+int nt_tile_n_b3(int N) {       // (MIS_GEMM_B3_RULE=0 sweeps only)
+    static const int pref = getenv("MIS_GEMM_B3_BN") ? atoi(getenv("MIS_GEMM_B3_BN")) : 96;
+    if (pref == 96 && N % 96 == 0) return 96;
+    return nt_tile_n(N);
+}
 
 // NT form: rows per tile (128 / 64) and K slices.  Split-K only when the tiles cannot fill the chip (deep SwinUnet stages,
 // the ViT of UNETR: 60 .. 114 tiles of 128 rows) and K is long: every slice costs a write + read of the M x N partial
@@ -1083,9 +1220,10 @@ int nt_tile_n(int N) { return (N % 96 == 0 && N % 128 != 0) ? 96 : 128; }
 // 114 tiles 158 us).  64-row tiles double the tile count instead: UNETR's M = 1728, N = K = 768 Linears are 84 tiles x 3
 // slices + reduction (49 + 20 us) or 162 tiles unsplit -- the cost model below (workgroup time ~ rows x K / slices, +
 // a fixed share per round, + the reduction) picks between them.
-void nt_choice(int M, int N, int K, int& bm, int& ks) {
-    static const int force = getenv("MIS_GEMM_BM") ? atoi(getenv("MIS_GEMM_BM")) : 0;
-    const long long tn = mis_cdiv(N, nt_tile_n(N));
+void nt_choice(int M, int N, int K, int& bm, int& ks, int rows_arg = 0, int bn_arg = 0) {
+    static const int force_env = getenv("MIS_GEMM_BM") ? atoi(getenv("MIS_GEMM_BM")) : 0;
+    const int force = rows_arg ? rows_arg : force_env;
+    const long long tn = mis_cdiv(N, bn_arg ? bn_arg : nt_tile_n(N));
     if (force != 128 && mis_cdiv(M, 128) * tn >= 512) {      // plenty of tiles: 64 rows = three resident workgroups per CU
         bm = 64; ks = 1;                                      // instead of two (SwinUnet 36.2 -> 35.6 ms per step)
         return;
@@ -1148,7 +1286,7 @@ bool a16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 template <int BMT, int BN, int EP, int PREC>
 int launch_nt_prec(const GemmArgs& a, hipStream_t stream) {
     static std::atomic<unsigned long long> attr_done{0};   // per instantiation, one bit per device
-    using G = NtCfg<BMT, BN>;
+    using G = NtCfg<BMT, BN, PREC>;
     if (mis_set_lds_attr(reinterpret_cast<const void*>(&gemm_nt_kernel<BMT, BN, EP, PREC>), G::LDS_BYTES, attr_done) != MIS_OK)
         return MIS_ERR_LAUNCH;
     hipLaunchKernelGGL((gemm_nt_kernel<BMT, BN, EP, PREC>), dim3(a.n_blocks_padded), dim3(256), G::LDS_BYTES, stream, a);
@@ -1157,6 +1295,7 @@ int launch_nt_prec(const GemmArgs& a, hipStream_t stream) {
 
 template <int BMT, int BN, int EP>
 int launch_nt_ep(const GemmArgs& a, hipStream_t stream) {
+    if (a.B3) return launch_nt_prec<BMT, BN, EP, 2>(a, stream);
     return gemm_bf3() ? launch_nt_prec<BMT, BN, EP, 1>(a, stream) : launch_nt_prec<BMT, BN, EP, 0>(a, stream);
 }
 
@@ -1178,10 +1317,34 @@ int nt_tile_m(int M, int N, int K) {
     return bm;
 }
 
+// Tile shape and k slices of the pre-split form, from per-shape sweeps of the SwinUnet Linears at 16, 24, 32 (256 x 256) and 48
+// images (scripts/gemm_nt_bench.py --split --batch B with MIS_GEMM_B3_RULE=0 MIS_GEMM_BM / MIS_GEMM_B3_BN; 20 shapes each).
+// K <= 96 stays with the short-contraction kernel: a 64-row tile re-fetches its B panel for three k-steps of work and the
+// planes are 1.5x the bytes (118 -> 133 us at 150528 x 384 x 96).  Otherwise 64 x 96 tiles (52 KB of LDS: three workgroups
+// per CU; best or within noise of the best for 60 of the 68 shapes), except wide N with many tiles (N >= 1536 a multiple of
+// 128, >= 1000 tiles of 64 x 96): 128 x 128, which halves the B-panel traffic per output and the re-reads of A (2352 x 3072
+// x 768: 79 -> 63 us; 9408 x 1536 x 384: 74 -> 69).  Sums of the 20 shapes, fp32-B kernels -> this rule: 48 images 1432 ->
+// 1307 us, 32: 1352 -> 1184, 24: 897 -> 832, 16: 708 -> 653.  MIS_GEMM_B3_RULE=0: the tile choice of the fp32-B path.
+bool b3_choice(int M, int N, int K, int& bm, int& bn, int& ks) {
+    static const bool rule = !(getenv("MIS_GEMM_B3_RULE") && getenv("MIS_GEMM_B3_RULE")[0] == '0');
+    static const int kmin = getenv("MIS_GEMM_B3_KMIN") ? atoi(getenv("MIS_GEMM_B3_KMIN")) : 97;
+    if (K < kmin) return false;
+    if (!rule) {
+        bn = nt_tile_n_b3(N);
+        bm = nt_tile_m(M, N, K);
+        ks = pick_ks(M, N, K, 0);
+        return true;
+    }
+    const bool wide = N % 128 == 0 && N >= 1536 && mis_cdiv(M, 64) * mis_cdiv(N, 96) >= 1000;
+    bn = wide ? 128 : (N % 96 == 0 ? 96 : nt_tile_n(N));
+    nt_choice(M, N, K, bm, ks, wide ? 128 : 64, bn);
+    return true;
+}
+
 // the short-contraction kernel serves: float4 epilogue, no split-K, no pixel-shuffle store, K <= 192, many tiles
 bool nt_short(const GemmArgs& a) {
     static const int force = getenv("MIS_GEMM_SHORT") ? atoi(getenv("MIS_GEMM_SHORT")) : -1;
-    if (force == 0 || a.KS > 1 || !a.vec4 || a.ex_P || a.K % 4) return false;
+    if (force == 0 || a.KS > 1 || !a.vec4 || a.ex_P || a.K % 4 || a.B3) return false;
     // bf16x3: the K = 32 products of the general kernel win from K = 192 on (72 vs 75 us at 37632 x 576 x 192); at K = 96 the
     // short kernel's residency still pays (150528 x 384 x 96: 120 vs 132 us, x 288: 93 vs 92, scripts/gemm_nt_bench.py)
     if (gemm_bf3() && force != 1 && a.K > 96) return false;
@@ -1225,7 +1388,7 @@ int launch_nt(GemmArgs& a, hipStream_t stream) {
         a.n_blocks_padded = (unsigned)(mis_cdiv(nbs, MIS_NUM_XCD) * MIS_NUM_XCD);
         return launch_nt_short<BN>(a, stream);
     }
-    const int bm = nt_tile_m(a.M, a.N, a.K);
+    const int bm = a.bm_force ? a.bm_force : nt_tile_m(a.M, a.N, a.K);
     a.tiles_m = (int)mis_cdiv(a.M, bm);
     const long long nb = (long long)a.tiles_n * a.tiles_m * a.KS;
     if (nb > 0x7fffffffLL) return MIS_ERR_UNSUPPORTED;
@@ -1257,6 +1420,15 @@ extern "C" int mis_gemm_nt_kernel_name(int M, int N, int K, int epilogue, char* 
     const int bn = nt_tile_n(N);
     if (nt_short(a)) snprintf(name, name_len, "gemm_nt_short_kernel<%d, %d, %d>", bn, epilogue, gemm_bf3() ? 1 : 0);
     else snprintf(name, name_len, "gemm_nt_kernel<%d, %d, %d, %d>", nt_tile_m(M, N, K), bn, a.KS > 1 ? 0 : epilogue, gemm_bf3() ? 1 : 0);
+    return MIS_OK;
+}
+
+// ... and the instantiation mis_gemm_nt_split runs it with
+extern "C" int mis_gemm_nt_split_kernel_name(int M, int N, int K, int epilogue, char* name, int name_len) {
+    if (M <= 0 || N <= 0 || K <= 0 || !name || name_len <= 0) return MIS_ERR_ARG;
+    int bm, bn, ks;
+    if (!b3_choice(M, N, K, bm, bn, ks)) return MIS_ERR_UNSUPPORTED;
+    snprintf(name, name_len, "gemm_nt_kernel<%d, %d, %d, 2>", bm, bn, ks > 1 ? 0 : epilogue);
     return MIS_OK;
 }
 
@@ -1437,6 +1609,116 @@ extern "C" int mis_gemm_dw(const float* dy, long long lddy, const float* x, long
     if (a.KS > 1)
         hipLaunchKernelGGL(gemm_reduce_kernel, dim3((unsigned)(mis_cdiv((long long)M * N, 32) + mis_cdiv(M, 32))), dim3(256),
                            0, stream, a);
+    return mis_launch_status();
+}
+
+// ---- the NT form with a pre-split B operand ----------------------------------------------------------------------------
+// mis_gemm_split_b cuts B [N][K] (an nn.Linear weight, or its transpose for the data gradient) into the bf16 piece planes once;
+// mis_gemm_nt_split is mis_gemm (trans = 0) / mis_gemm_ex / mis_gemm_expand on them: same products, same sums, same results
+// bit for bit as the bf16x3 kernels that split B per tile -- minus two thirds of their vector instructions.
+static int split_k3(int K) { return (int)(mis_cdiv(K, BK) * BK); }
+
+extern "C" long long mis_gemm_split_bytes(int N, int K) {
+    if (N <= 0 || K <= 0) return MIS_ERR_ARG;
+    return 3LL * N * split_k3(K) * 2;
+}
+
+static long long split_fill(SplitJob& j, const float* B, long long ldb, int N, int K, void* B3, long long first) {
+    if (!B || !B3 || N <= 0 || K <= 0 || first < 0) return MIS_ERR_ARG;
+    if (K % 4 || ldb % 4 || ldb < K || !a16(B) || !a16(B3)) return MIS_ERR_UNSUPPORTED;
+    if (mis_gemm_split_bytes(N, K) >= (1LL << 31)) return MIS_ERR_UNSUPPORTED;      // the GEMM addresses the planes with 32 bits
+    j.B = B; j.ldb = ldb; j.B3 = B3; j.N = N; j.K = K; j.K3 = split_k3(K); j.first = (int)first;
+    const long long units = mis_cdiv((long long)N * (j.K3 / 32) * 4, 256);
+    if (first + units > 0x7fffffffLL) return MIS_ERR_ARG;
+    return units;
+}
+
+extern "C" int mis_gemm_split_b(const float* B, long long ldb, int N, int K, void* B3, hipStream_t stream) {
+    SplitJob j;
+    const long long units = split_fill(j, B, ldb, N, K, B3, 0);
+    if (units < 0) return (int)units;
+    hipLaunchKernelGGL(gemm_split_kernel, dim3((unsigned)units), dim3(256), 0, stream, j);
+    return mis_launch_status();
+}
+
+// batched form, as mis_transpose_job / mis_transpose_batch: records filled on the host, one launch for all of them
+extern "C" long long mis_gemm_split_job_bytes(void) { return (long long)sizeof(SplitJob); }
+
+extern "C" long long mis_gemm_split_job(void* job, const float* B, long long ldb, int N, int K, void* B3, long long first) {
+    if (!job) return MIS_ERR_ARG;
+    SplitJob j;
+    const long long units = split_fill(j, B, ldb, N, K, B3, first);
+    if (units < 0) return units;
+    memcpy(job, &j, sizeof(j));
+    return units;
+}
+
+extern "C" int mis_gemm_split_batch(const void* jobs, int n, long long units, hipStream_t stream) {
+    if (!jobs || n <= 0 || units <= 0 || units > 0x7fffffffLL) return MIS_ERR_ARG;
+    hipLaunchKernelGGL(gemm_split_batch_kernel, dim3((unsigned)units), dim3(256), 0, stream,
+                       reinterpret_cast<const SplitJob*>(jobs), n);
+    return mis_launch_status();
+}
+
+extern "C" long long mis_gemm_nt_split_workspace_bytes(int M, int N, int K) {
+    if (M <= 0 || N <= 0 || K <= 0) return MIS_ERR_ARG;
+    int bm, bn, ks;
+    if (!b3_choice(M, N, K, bm, bn, ks)) return 0;
+    return ks > 1 ? (long long)ks * M * N * 4 : 0;
+}
+
+// C [M][N] (+)= A [M][K] . B^T + bias with B given as mis_gemm_split_b's planes.  epilogue 0: plain (accumulate allowed);
+// 1 .. 3: the fused epilogues of mis_gemm_ex (E1 / C2 / rowscale as there); ex_P > 0: the pixel-shuffle store of
+// mis_gemm_expand (C dense [B H P W P][ex_c], M = B ex_H ex_W, N = P P ex_c, no bias, no epilogue, no split-K).
+// workspace >= mis_gemm_nt_split_workspace_bytes(M, N, K).  MIS_ERR_UNSUPPORTED (also: contractions the rule leaves to the
+// short-contraction kernel): the caller uses the fp32-B entry points.
+extern "C" int mis_gemm_nt_split(const float* A, long long lda, const void* B3, float* C, long long ldc, const float* bias,
+                                 int M, int N, int K, int accumulate, int epilogue, const float* E1, long long lde1,
+                                 float* C2, long long ldc2, const float* rowscale, long long rows_per_scale, int ex_H,
+                                 int ex_W, int ex_P, int ex_c, float* workspace, long long workspace_bytes,
+                                 hipStream_t stream) {
+    if (!A || !B3 || !C || M <= 0 || N <= 0 || K <= 0) return MIS_ERR_ARG;
+    if (epilogue < EP_NONE || epilogue > EP_RESIDUAL) return MIS_ERR_ARG;
+    if (!a16(A) || !a16(B3) || lda % 4 || K % 4) return MIS_ERR_UNSUPPORTED;
+    if ((long long)M * lda * 4 >= (1LL << 31) || mis_gemm_split_bytes(N, K) >= (1LL << 31)) return MIS_ERR_UNSUPPORTED;
+    GemmArgs a{A, lda, nullptr, 0, C, ldc, bias, workspace, M, N, K, 1, K, accumulate};
+    a.B3 = B3; a.K3 = split_k3(K); a.b3_plane = (unsigned)((long long)N * a.K3 * 2);
+    a.ex_P = 0;
+    a.ep = epilogue;
+    a.vec4 = (N % 4 == 0 && ldc % 4 == 0 && a16(C) && (!bias || a16(bias))) ? 1 : 0;
+    if (ex_P > 0) {
+        if (epilogue != EP_NONE || bias || accumulate) return MIS_ERR_ARG;
+        if (ex_H <= 0 || ex_W <= 0 || ex_c <= 0 || ex_c % 16 || M % (ex_H * ex_W) || N != ex_P * ex_P * ex_c) return MIS_ERR_UNSUPPORTED;
+        if ((long long)M * N * 4 >= (1LL << 31)) return MIS_ERR_UNSUPPORTED;
+        a.ex_P = ex_P; a.ex_H = ex_H; a.ex_W = ex_W; a.ex_c = ex_c; a.ldc = N;
+    } else if (epilogue != EP_NONE) {
+        if (accumulate) return MIS_ERR_ARG;
+        if (epilogue == EP_GELU_FWD ? (!C2 || ldc2 < N) : (!E1 || lde1 < N)) return MIS_ERR_ARG;
+        if (epilogue == EP_RESIDUAL && rowscale && rows_per_scale <= 0) return MIS_ERR_ARG;
+        if (!a.vec4) return MIS_ERR_UNSUPPORTED;
+        if (epilogue == EP_GELU_FWD ? (ldc2 % 4 || !a16(C2)) : (lde1 % 4 || !a16(E1))) return MIS_ERR_UNSUPPORTED;
+        a.E1 = E1; a.lde1 = lde1; a.C2 = C2; a.ldc2 = ldc2; a.rowscale = rowscale; a.rps = rows_per_scale;
+    }
+    int bm, bn, ks;
+    if (!b3_choice(M, N, K, bm, bn, ks)) return MIS_ERR_UNSUPPORTED;
+    if (a.ex_P && ks != 1) return MIS_ERR_UNSUPPORTED;
+    a.KS = ks;
+    a.bm_force = bm;
+    if (a.KS > 1) {
+        if (!workspace || workspace_bytes < (long long)a.KS * M * N * 4) return MIS_ERR_WORKSPACE;
+        a.kchunk = (int)(mis_cdiv(mis_cdiv(K, a.KS), BK) * BK);
+        a.KS = (int)mis_cdiv(K, a.kchunk);
+    }
+    a.tiles_n = (int)mis_cdiv(N, bn);
+    a.tiles_m = (int)mis_cdiv(M, BM);
+    const long long nb = (long long)a.tiles_n * a.tiles_m * a.KS;
+    if (nb > 0x7fffffffLL) return MIS_ERR_UNSUPPORTED;
+    a.n_blocks = (unsigned)nb;
+    a.n_blocks_padded = (unsigned)(mis_cdiv(nb, MIS_NUM_XCD) * MIS_NUM_XCD);
+    const int st = bn == 96 ? launch_nt<96>(a, stream) : launch_nt<128>(a, stream);
+    if (st) return st;
+    if (a.KS > 1)
+        hipLaunchKernelGGL(gemm_reduce_kernel, dim3((unsigned)mis_cdiv((long long)M * N, 32)), dim3(256), 0, stream, a);
     return mis_launch_status();
 }
 

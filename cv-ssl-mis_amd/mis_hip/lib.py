@@ -154,6 +154,15 @@ PROTOTYPES = {
     "mis_gemm_set_split_precision": (c_i, [c_i]),
     "mis_gemm_nt_kernel_name": (c_i, [c_i, c_i, c_i, c_i, ctypes.c_char_p, c_i]),
     "mis_gemm_tn_kernel_name": (c_i, [c_p, c_ll, c_p, c_ll, c_p, c_ll, c_i, c_i, c_i, ctypes.c_char_p, c_i]),
+    "mis_gemm_split_bytes": (c_ll, [c_i, c_i]),
+    "mis_gemm_split_b": (c_i, [c_p, c_ll, c_i, c_i, c_p, c_p]),
+    "mis_gemm_split_job_bytes": (c_ll, []),
+    "mis_gemm_split_job": (c_ll, [c_p, c_p, c_ll, c_i, c_i, c_p, c_ll]),
+    "mis_gemm_split_batch": (c_i, [c_p, c_i, c_ll, c_p]),
+    "mis_gemm_nt_split_workspace_bytes": (c_ll, [c_i, c_i, c_i]),
+    "mis_gemm_nt_split": (c_i, [c_p, c_ll, c_p, c_p, c_ll, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_ll, c_p, c_ll, c_p, c_ll,
+                                c_i, c_i, c_i, c_i, c_p, c_ll, c_p]),
+    "mis_gemm_nt_split_kernel_name": (c_i, [c_i, c_i, c_i, c_i, ctypes.c_char_p, c_i]),
     "mis_gemm_expand": (c_i, [c_p, c_ll, c_p, c_ll, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
     "mis_gemm": (c_i, [c_p, c_ll, c_p, c_ll, c_p, c_ll, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_ll, c_p]),
     "mis_gemm_ex": (c_i, [c_p, c_ll, c_p, c_ll, c_p, c_ll, c_p, c_i, c_i, c_i, c_i, c_p, c_ll, c_p, c_ll, c_p, c_ll, c_p,

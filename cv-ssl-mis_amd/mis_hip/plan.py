@@ -710,6 +710,13 @@ class Plan:
         if self._tbatch:
             self._tbatch.run()
 
+    def _split_linear_weights(self, transposed):
+        """Mixed plans: the token-major Linears' weights as pre-split GEMM operands (swin_plan.split_linear_weights)."""
+        if self._tbatch is False:       # no Linear in this plan
+            return False
+        from .swin_plan import split_linear_weights
+        return split_linear_weights(self, self.ops, transposed)
+
     def _fuse_dgrad_norm(self):
         """conv_a -> InstanceNorm -> ReLU -> conv_b (reference UnetConv3, utils.py:99-123): when the activation between
         the two convolutions has no other reader, conv_b's Winograd data gradient also forms the partial sums of the
@@ -775,6 +782,7 @@ class Plan:
         self.generation += 1
         self.inp.t = x5
         self._pack(0)
+        ctx.b3_fwd = self._split_linear_weights(False)
         for op in self.ops:
             op.fwd(ctx)
         return self.out.t
@@ -788,6 +796,7 @@ class Plan:
             self.out.g = dlogits5
         self._pack(1)
         self._transpose_linear_weights()
+        ctx.b3_bwd = self._split_linear_weights(True)
         main = torch.cuda.current_stream()
         side = None
         if WGRAD_STREAM:

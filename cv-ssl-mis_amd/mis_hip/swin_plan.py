@@ -86,21 +86,28 @@ class LinearOp:
         self.wT = None
         self.wT_batched = False      # True: the plan transposes every Linear weight in one launch (SwinPlan.backward)
         self.gelu = self.res = self.dx_gelu = None
+        self.b3 = self.bT3 = None    # W / W^T cut into bf16 pieces once per pass (split_linear_weights)
+
+    def _b3(self, ctx):
+        return self.b3 if getattr(ctx, "b3_fwd", False) else None
+
+    def _bT3(self, ctx):
+        return self.bT3 if getattr(ctx, "b3_bwd", False) else None
 
     def fwd(self, ctx):
         bias = None if self.b is None else self.b.data
         if (FUSE & 1) and self.gelu is not None:
-            if tops.gemm_ex(self.x.t, self.w2, self.y.t, tops.EP_GELU_FWD, bias=bias, C2=self.gelu.y.t):
+            if tops.gemm_ex(self.x.t, self.w2, self.y.t, tops.EP_GELU_FWD, bias=bias, C2=self.gelu.y.t, b3=self._b3(ctx)):
                 self.gelu.skip_fwd = True
                 return
         if (FUSE & 4) and self.res is not None:
             r = self.res
             scales = r.prepare(ctx)
             if tops.gemm_ex(self.x.t, self.w2, r.out.t, tops.EP_RESIDUAL, bias=bias, E1=r.a.t, rowscale=scales,
-                            rows_per_scale=r.rps):
+                            rows_per_scale=r.rps, b3=self._b3(ctx)):
                 r.skip_fwd = True
                 return
-        tops.gemm(self.x.t, self.w2, self.y.t, bias=bias)
+        tops.gemm(self.x.t, self.w2, self.y.t, bias=bias, b3=self._b3(ctx))
 
     def _wgrad(self, dy):
         if self.b is not None:
@@ -127,12 +134,42 @@ class LinearOp:
                 tops.transpose(self.w2, self.wT)
             g = self.dx_gelu
             if (FUSE & 2) and g is not None and not g.x.written and \
-                    tops.gemm_ex(dy, self.wT, g.x.grad(), tops.EP_GELU_BWD, E1=g.x.t):
+                    tops.gemm_ex(dy, self.wT, g.x.grad(), tops.EP_GELU_BWD, E1=g.x.t, b3=self._bT3(ctx)):
                 g.skip_bwd = True        # d(pre-activation) is written; d(gelu output) never exists
                 g.x.mark_written()
                 return
-            tops.gemm(dy, self.wT, self.x.grad(), accumulate=self.x.written)
+            tops.gemm(dy, self.wT, self.x.grad(), accumulate=self.x.written, b3=self._bT3(ctx))
             self.x.mark_written()
+
+
+def split_linear_weights(holder, ops_list, transposed):
+    """Every Linear weight of the op list (``transposed``: its W^T, which the plan's transpose batch just wrote) cut into the
+    bf16 piece planes the NT GEMMs consume, in one launch; the weights changed with the last SGD / EMA update, so once per
+    forward and once per backward.  Returns True when the ops' ``b3`` / ``bT3`` are current (False: bf16x3 products are off)."""
+    if not tops.split_active():
+        return False
+    key = "_split_bwd" if transposed else "_split_fwd"
+    batch = getattr(holder, key, None)
+    if batch is None:
+        splits = []
+        for op in ops_list:
+            if not isinstance(op, LinearOp) or not op.w2.is_contiguous():
+                continue
+            n_out, k_in = op.w2.shape
+            if k_in % 4 or n_out % 4 or 6 * n_out * (k_in + 31) >= 1 << 31:
+                continue
+            if transposed:
+                if op.need_dx and op.wT_batched:
+                    op.bT3 = tops.SplitB(op.wT)
+                    splits.append(op.bT3)
+            else:
+                op.b3 = tops.SplitB(op.w2)
+                splits.append(op.b3)
+        batch = tops.SplitBatch(splits) if splits else False
+        setattr(holder, key, batch)
+    if batch:
+        batch.run()
+    return bool(batch)
 
 
 class LayerNormOp:
@@ -258,7 +295,7 @@ class ExpandLinearOp(LinearOp):
 
     def fwd(self, ctx):
         B, H, W, c, P = self.geo
-        if not tops.gemm_expand(self.x.t, self.w2, self.sh.t, B, H, W, P, c):
+        if not tops.gemm_expand(self.x.t, self.w2, self.sh.t, B, H, W, P, c, b3=self._b3(ctx)):
             super().fwd(ctx)
             tops.token_rearrange(self.y.t, self.sh.t, B, H, W, c, P, 1)
 
@@ -571,6 +608,7 @@ class SwinPlan:
         assert tuple(x5.shape) == self.in_shape, (tuple(x5.shape), self.in_shape)
         self.generation += 1
         self.inp_t = x5[:, :, 0]             # [N, 1 | 3, H, W]
+        ctx.b3_fwd = split_linear_weights(self, self.ops, False)
         for op in self.ops:
             op.fwd(ctx)
         return self.out.t
@@ -582,6 +620,7 @@ class SwinPlan:
         if dlogits5 is not None:
             self.out.g = dlogits5
         self.transpose_weights()
+        ctx.b3_bwd = split_linear_weights(self, self.ops, True)
         from . import plan as _plan
         main, side = torch.cuda.current_stream(), None
         if _plan.WGRAD_STREAM:

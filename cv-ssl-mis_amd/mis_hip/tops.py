@@ -5,12 +5,16 @@ Token tensors are 2-D ``[rows, C]`` fp32 views with a dense last dim and a free 
 so column slices of a wider buffer (the decoder's concat) are valid operands.
 """
 import ctypes
+import os
 
 import torch
 
 from . import lib as _l
 from . import ops as _ops
 from .ops import scratch
+
+# B operands (weights) of the NT GEMMs pre-split into their bf16 pieces once per step (mis_gemm_nt_split); 0: split per tile
+PRESPLIT = os.environ.get("MIS_GEMM_PRESPLIT", "1") != "0"
 
 
 def _mat(t):
@@ -36,8 +40,90 @@ def _tn_name(L, A, lda, B, ldb, C, ldc, M, N, K):
     return buf.value.decode()
 
 
-def gemm(A, B, C, bias=None, trans=False, accumulate=False):
-    """trans=False: C[M,N] (+)= A[M,K] @ B[N,K]^T (+ bias);  trans=True: C[M,N] (+)= A[K,M]^T @ B[K,N]."""
+class SplitB:
+    """The B operand of an NT GEMM cut into its three bf16 piece planes (``mis_gemm_split_b``): ``src`` [N, K] dense fp32 (an
+    nn.Linear weight or its transpose); ``t`` the planes.  ``refresh()`` after the weights changed; a ``SplitBatch`` refreshes
+    every SplitB of a network in one launch."""
+
+    def __init__(self, src):
+        N, K, ldb = _mat(src)
+        nb = _l.load().mis_gemm_split_bytes(N, K)
+        if nb < 0:
+            _l.check(nb, "mis_gemm_split_bytes")
+        self.src, self.N, self.K, self.ldb = src, N, K, ldb
+        self.t = torch.empty(nb, dtype=torch.uint8, device="cuda")
+
+    def refresh(self):
+        _l.check(_l.load().mis_gemm_split_b(_l.ptr(self.src), self.ldb, self.N, self.K, _l.ptr(self.t), _l.stream_ptr()),
+                 "mis_gemm_split_b")
+        return self
+
+
+class SplitBatch:
+    """``refresh()`` of many SplitB in one launch (``mis_gemm_split_batch``); the device job table is built once."""
+
+    def __init__(self, splits):
+        L = _l.load()
+        nb = L.mis_gemm_split_job_bytes()
+        host = (ctypes.c_char * (nb * len(splits)))()
+        first = 0
+        for i, sb in enumerate(splits):
+            n = L.mis_gemm_split_job(ctypes.byref(host, i * nb), _l.ptr(sb.src), sb.ldb, sb.N, sb.K, _l.ptr(sb.t), first)
+            if n < 0:
+                _l.check(n, "mis_gemm_split_job")
+            first += n
+        self.n, self.units, self.keep = len(splits), first, splits
+        self.table = torch.frombuffer(bytearray(bytes(host)), dtype=torch.uint8).cuda()
+
+    def run(self):
+        _l.check(_l.load().mis_gemm_split_batch(_l.ptr(self.table), self.n, self.units, _l.stream_ptr()), "mis_gemm_split_batch")
+
+
+def split_active():
+    """Pre-split B operands are used when the NT GEMMs run as bf16x3 products (``MIS_GEMM_PRESPLIT=0``: never)."""
+    return PRESPLIT and bool(set_split_precision(-1) & 1)
+
+
+def _nt_split(A, b3, C, bias=None, accumulate=False, epilogue=0, E1=None, C2=None, rowscale=None, rows_per_scale=1, ex=None):
+    """mis_gemm_nt_split; False: outside what it covers (the caller runs the fp32-B entry point)."""
+    L = _l.load()
+    M, K, lda = _mat(A)
+    N = b3.N
+    assert K == b3.K, (A.shape, b3.N, b3.K)
+    if ex is None:
+        Mc, Nc, ldc = _mat(C)
+        assert (Mc, Nc) == (M, N), (C.shape, M, N)
+        eH = eW = eP = ec = 0
+    else:
+        eH, eW, eP, ec = ex
+        ldc = N
+    lde1 = _mat(E1)[2] if E1 is not None else 0
+    ldc2 = _mat(C2)[2] if C2 is not None else 0
+    nb = L.mis_gemm_nt_split_workspace_bytes(M, N, K)
+    ws = scratch(nb, "gemm") if nb > 0 else None
+    prof = _ops.PROFILE
+    if prof is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    st = L.mis_gemm_nt_split(_l.ptr(A), lda, _l.ptr(b3.t), _l.ptr(C), ldc, _l.ptr(bias), M, N, K, int(accumulate), int(epilogue),
+                             _l.ptr(E1), lde1, _l.ptr(C2), ldc2, _l.ptr(rowscale), int(rows_per_scale), eH, eW, eP, ec,
+                             _l.ptr(ws), ws.numel() if ws is not None else 0, _l.stream_ptr())
+    if st == -2:
+        return False
+    _l.check(st, "mis_gemm_nt_split")
+    if prof is not None:
+        e1.record()
+        buf = ctypes.create_string_buffer(96)
+        _l.check(L.mis_gemm_nt_split_kernel_name(M, N, K, int(epilogue), buf, 96), "mis_gemm_nt_split_kernel_name")
+        prof.append((buf.value.decode(), 2.0 * M * N * K, e0, e1, 4.0 * (M * K + M * N) + 6.0 * N * K))
+    return True
+
+
+def gemm(A, B, C, bias=None, trans=False, accumulate=False, b3=None):
+    """trans=False: C[M,N] (+)= A[M,K] @ B[N,K]^T (+ bias);  trans=True: C[M,N] (+)= A[K,M]^T @ B[K,N].
+    ``b3``: B pre-split (SplitB, current): used when the NT GEMMs run as bf16x3 products."""
+    if b3 is not None and not trans and split_active() and _nt_split(A, b3, C, bias=bias, accumulate=accumulate):
+        return
     L = _l.load()
     if not trans:
         M, K, lda = _mat(A)
@@ -95,10 +181,13 @@ def gemm_dw(dy, x, dW, db, accumulate=False):
 EP_GELU_FWD, EP_GELU_BWD, EP_RESIDUAL = 1, 2, 3
 
 
-def gemm_ex(A, B, C, epilogue, bias=None, E1=None, C2=None, rowscale=None, rows_per_scale=1):
+def gemm_ex(A, B, C, epilogue, bias=None, E1=None, C2=None, rowscale=None, rows_per_scale=1, b3=None):
     """C = epilogue(A[M,K] @ B[N,K]^T + bias) (mis_gemm_ex): EP_GELU_FWD also writes C2 = gelu(.), EP_GELU_BWD multiplies
     by gelu'(E1), EP_RESIDUAL gives E1 + rowscale[row // rows_per_scale] * (.).  Returns False when the shape is
     outside the fused form (the caller then runs the un-fused ops)."""
+    if b3 is not None and split_active() and _nt_split(A, b3, C, bias=bias, epilogue=epilogue, E1=E1, C2=C2, rowscale=rowscale,
+                                                     rows_per_scale=rows_per_scale):
+        return True
     L = _l.load()
     M, K, lda = _mat(A)
     N, K2, ldb = _mat(B)
@@ -131,9 +220,13 @@ def droppath_table(table, p_dev, salt_dev, nsites, B, state):
                                   _l.stream_ptr()), "mis_droppath_table")
 
 
-def gemm_expand(x, w, out, B, H, W, P, c):
+def gemm_expand(x, w, out, B, H, W, P, c, b3=None):
     """out[(b, h*P+p1, w*P+p2)][c] = (x @ w^T) pixel-shuffled; returns False when the fused form does not cover the
     shape (the caller then runs gemm + token_rearrange)."""
+    if b3 is not None and split_active():
+        assert out.is_contiguous() and out.numel() == B * H * W * P * P * c
+        if _nt_split(x, b3, out, ex=(H, W, P, c)):
+            return True
     L = _l.load()
     M, K, lda = _mat(x)
     N, K2, ldb = _mat(w)

@@ -457,6 +457,30 @@ int mis_gemm_set_split_precision(int mask);
 /* the TN kernel mis_gemm(trans = 1) / mis_gemm_dw run this shape and these operands with, as a profiler names it */
 int mis_gemm_tn_kernel_name(const float* A, long long lda, const float* B, long long ldb, const float* C, long long ldc,
                             int M, int N, int K, char* name, int name_len);
+/* The NT form with a pre-split B operand.  The bf16x3 kernels cut every fp32 operand into three bf16 pieces; for B = an
+ * nn.Linear weight (forward: F.linear(x, W), swin_transformer_unet_skip_expand_decoder_sys.py:14,16,107,109; data gradient:
+ * dy . W, i.e. B = W^T) that cut is the same for every tile of the launch and every launch of the step, so it is done once:
+ * mis_gemm_split_b writes the three piece planes (bf16 [N][K rounded up to 32], in the lane order the kernels consume) into
+ * B3 (mis_gemm_split_bytes(N, K) bytes, 16-byte aligned); mis_gemm_split_job / _batch do it for every weight of a network in one
+ * launch (records filled on the host, as mis_transpose_job / mis_transpose_batch).  mis_gemm_nt_split is then
+ *   epilogue 0, ex_P 0   mis_gemm(trans = 0)            C (+)= A . B^T + bias
+ *   epilogue 1 .. 3      mis_gemm_ex                    the fused GELU / residual epilogues, E1 / C2 / rowscale as there
+ *   ex_P > 0             mis_gemm_expand                C = the pixel-shuffled product, M = B ex_H ex_W rows, N = P P ex_c
+ * with the same results bit for bit as those entry points under mis_gemm_set_split_precision bit 0 (same pieces, same products,
+ * same order) and a third of their vector instructions.  workspace >= mis_gemm_nt_split_workspace_bytes(M, N, K).
+ * MIS_ERR_UNSUPPORTED (alignment, or a contraction the tile rule leaves to the short-contraction kernel: K <= 96): use the
+ * fp32-B entry points. */
+long long mis_gemm_split_bytes(int N, int K);
+int mis_gemm_split_b(const float* B, long long ldb, int N, int K, void* B3, mis_stream_t stream);
+long long mis_gemm_split_job_bytes(void);
+long long mis_gemm_split_job(void* job, const float* B, long long ldb, int N, int K, void* B3, long long first);
+int mis_gemm_split_batch(const void* jobs, int n, long long units, mis_stream_t stream);
+long long mis_gemm_nt_split_workspace_bytes(int M, int N, int K);
+int mis_gemm_nt_split(const float* A, long long lda, const void* B3, float* C, long long ldc, const float* bias, int M, int N,
+                      int K, int accumulate, int epilogue, const float* E1, long long lde1, float* C2, long long ldc2,
+                      const float* rowscale, long long rows_per_scale, int ex_H, int ex_W, int ex_P, int ex_c,
+                      float* workspace, long long workspace_bytes, mis_stream_t stream);
+int mis_gemm_nt_split_kernel_name(int M, int N, int K, int epilogue, char* name, int name_len);
 /* nn.Linear of PatchExpand / FinalPatchExpand_X4 fused with their pixel shuffle
  * 'b h w (p1 p2 c) -> b (h p1) (w p2) c' (swin_transformer_unet_skip_expand_decoder_sys.py:373-380, :401-408):
  * x [B*H*W][K] (row stride lda), W [P*P*c][K] (row stride ldb), out [B*H*P*W*P][c] dense.  No bias.

@@ -21,10 +21,14 @@ def timeit(fn, n=20):
     return e0.elapsed_time(e1) / n * 1e3
 
 
-B = 48
+def _opt(name, default):
+    return int(sys.argv[sys.argv.index(name) + 1]) if name in sys.argv else default
+
+
+B, IMG = _opt("--batch", 48), _opt("--img", 224)
 shapes = []
 for stage, C in enumerate((96, 192, 384, 768)):
-    T = B * (56 >> stage) ** 2
+    T = B * ((IMG // 4) >> stage) ** 2
     for cout, cin in ((3 * C, C), (C, C), (4 * C, C), (C, 4 * C)):
         shapes += [(T, cout, cin), (T, cin, cout)]          # forward, dX
 tot = 0.0
@@ -35,7 +39,8 @@ for M, N, K in shapes:
     seen.add((M, N, K))
     a, w, bias = torch.randn(M, K, device="cuda"), torch.randn(N, K, device="cuda") * K ** -0.5, torch.randn(N, device="cuda")
     c = torch.empty(M, N, device="cuda")
-    t = timeit(lambda: tops.gemm(a, w, c, bias=bias))
+    b3 = tops.SplitB(w).refresh() if "--split" in sys.argv else None
+    t = timeit(lambda: tops.gemm(a, w, c, bias=bias, b3=b3))
     ref = a[:512].double() @ w.double().t() + bias.double()
     err = (c[:512].double() - ref).abs().max().item() / ref.abs().max().item()
     fl = 2.0 * M * N * K

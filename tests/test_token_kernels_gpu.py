@@ -486,3 +486,128 @@ def test_swin_step_fused_equals_unfused():
     gs = float(g1.abs().max())
     assert (g0 - g1).abs().max().item() <= 1e-5 * gs
     assert (p0 - p1).abs().max().item() <= 1e-6 and (t0 - t1).abs().max().item() <= 1e-6
+
+
+@pytest.mark.parametrize("M,N,K", [(6272, 384, 96), (6272, 96, 384), (200, 96, 48), (98, 3072, 768), (98, 768, 3072),
+                                   (33000, 384, 96), (65570, 96, 96), (20000, 768, 192), (16400, 192, 768), (777, 200, 104),
+                                   (1176, 1536, 768), (9408, 1536, 384), (2352, 3072, 768)])
+def test_gemm_with_presplit_weights_is_bit_identical(M, N, K):
+    """mis_gemm_split_b + mis_gemm_nt_split: the B operand (an nn.Linear weight) cut into its bf16 pieces once instead of per
+    tile and k-step.  Same pieces, same products, same order: bit-identical to the bf16x3 kernels that split B themselves, for the
+    plain form (with bias, with accumulation), the three fused epilogues, ragged K (zero-padded planes), N off the tile
+    widths (64 x 96 and 128 x 128 tiles) and the split-K shapes; the batched split writes the same planes as the single one."""
+    import ctypes
+    tops = _t()
+    prev = tops.set_split_precision(7)
+    try:
+        A, W, bias = _rand(M, K, seed=41).cuda(), (_rand(N, K, seed=42) * K ** -0.5).cuda(), _rand(N, seed=43).cuda()
+        b3 = tops.SplitB(W).refresh()
+        b3b = tops.SplitB(W)
+        other = tops.SplitB(_rand(40, 64, seed=44).cuda())
+        tops.SplitBatch([other, b3b]).run()
+        assert torch.equal(b3.t, b3b.t)
+        ref, got = torch.empty(M, N, device="cuda"), torch.full((M, N), float("nan"), device="cuda")
+        from mis_hip import lib as _l
+        # the short-contraction kernel sums K in steps of 16 (v_mfma_f32_16x16x16_bf16), the pre-split form always in steps of
+        # 32: same pieces and products, another association of the fp32 sums -- equal to rounding there, bit for bit elsewhere
+        short = "short" in tops._nt_name(_l.load(), M, N, K, 0)
+        # ... and the two forms choose their k slices separately (gemm.hip nt_choice / b3_choice)
+        short = short or _l.load().mis_gemm_workspace_bytes(M, N, K, 0) != _l.load().mis_gemm_nt_split_workspace_bytes(M, N, K)
+
+        def same(a, b):
+            return torch.allclose(a, b, rtol=2e-6, atol=2e-6) if short else torch.equal(a, b)
+        tops.gemm(A, W, ref, bias=bias)
+        name = ctypes.create_string_buffer(96)
+        covered = _l.load().mis_gemm_nt_split_kernel_name(M, N, K, 0, name, 96) == 0
+        assert covered == (K > 96), name.value
+        if not covered:  # short contraction: left to the short-contraction kernel, the fp32-B entry points serve it
+            assert not tops._nt_split(A, b3, got, bias=bias)
+            tops.gemm(A, W, got, bias=bias, b3=b3)
+            assert torch.equal(ref, got)
+            return
+        assert tops._nt_split(A, b3, got, bias=bias)
+        assert same(ref, got)
+        want = A.double() @ W.double().t() + bias.double()
+        _close(got, want)
+        tops.gemm(A, W, ref, accumulate=True)
+        assert tops._nt_split(A, b3, got, accumulate=True)
+        assert same(ref, got)
+        if N % 4 == 0:
+            E1 = _rand(M, N, seed=45).cuda()
+            sc = (1 + _rand(4, seed=46).abs()).cuda()
+            rps = (M + 3) // 4
+            for ep, kw in ((tops.EP_GELU_FWD, {}), (tops.EP_GELU_BWD, {"E1": E1}),
+                           (tops.EP_RESIDUAL, {"E1": E1, "rowscale": sc, "rows_per_scale": rps})):
+                r2, g2 = torch.empty(M, N, device="cuda"), torch.empty(M, N, device="cuda")
+                if ep == tops.EP_GELU_FWD:
+                    kw = {"C2": r2}
+                    kwg = {"C2": g2}
+                else:
+                    kwg = kw
+                ok = tops.gemm_ex(A, W, ref, ep, bias=bias, **kw)
+                okg = tops._nt_split(A, b3, got, bias=bias, epilogue=ep, **kwg)
+                assert ok == okg
+                if ok:
+                    assert same(ref, got)
+                    if ep == tops.EP_GELU_FWD:
+                        assert same(r2, g2)
+    finally:
+        tops.set_split_precision(prev)
+
+
+@pytest.mark.parametrize("B,H,K,P,c", [(2, 56, 96, 4, 96), (24, 28, 192, 2, 96), (3, 14, 384, 2, 192)])
+def test_gemm_expand_with_presplit_weights_is_bit_identical(B, H, K, P, c):
+    tops = _t()
+    prev = tops.set_split_precision(7)
+    try:
+        M, N = B * H * H, P * P * c
+        x, w = _rand(M, K, seed=31).cuda(), _rand(N, K, seed=32).cuda()
+        ref = torch.empty(M * P * P, c, device="cuda")
+        got = torch.full((M * P * P, c), float("nan"), device="cuda")
+        assert tops.gemm_expand(x, w, ref, B, H, H, P, c)
+        assert tops.gemm_expand(x, w, got, B, H, H, P, c, b3=tops.SplitB(w).refresh())
+        assert torch.equal(ref, got)
+        if K > 96:
+            got.fill_(float("nan"))
+            assert tops._nt_split(x, tops.SplitB(w).refresh(), got, ex=(H, H, P, c))
+            assert torch.equal(ref, got)
+    finally:
+        tops.set_split_precision(prev)
+
+
+def test_swin_step_with_presplit_weights_equals_split_per_tile():
+    """A Mean-Teacher step of SwinUnet with the Linear weights pre-split once per pass (mis_gemm_split_batch +
+    mis_gemm_nt_split) against the kernels that split B per tile: the same products; tile shapes and k slices may differ, so
+    equal to the rounding of the fp32 sums."""
+    from config import lite_config
+    from mis_hip import tops
+    from mis_hip.step import MeanTeacherTrainer
+    from networks.vision_transformer import SwinUnet
+    from oracle import filler
+    from oracle.swin import OracleSwinUnet
+    sd0 = filler.fill_state_dict(OracleSwinUnet(4).new_state())
+    vol = filler.image((4, 1, 224, 224), "volume").cuda()
+    lab = filler.labels((4, 224, 224), 4, torch.uint8).cuda()
+    res = []
+    prev = tops.set_split_precision(7)
+    try:
+        for on in (True, False):
+            tops.PRESPLIT = on
+            m, e = SwinUnet(lite_config(), num_classes=4), SwinUnet(lite_config(), num_classes=4)
+            m.load_state_dict(sd0); e.load_state_dict(sd0)
+            tr = MeanTeacherTrainer(m, e, labeled_bs=2, num_classes=4, cons_start_iter=0, seed=11, iter_num=1500)
+            for _ in range(2):
+                tr.step(vol, lab)
+            torch.cuda.synchronize()
+            used = any(getattr(op, "b3", None) is not None for op in m._last[0].ops)
+            assert used == on
+            res.append((tr.losses(), m.flat_grad.clone(), m.flat_param.clone(), e.flat_param.clone()))
+    finally:
+        tops.PRESPLIT = True
+        tops.set_split_precision(prev)
+    (l0, g0, p0, t0), (l1, g1, p1, t1) = res
+    for k in l0:
+        assert abs(l0[k] - l1[k]) <= 2e-6 * max(1.0, abs(l1[k])), (k, l0[k], l1[k])
+    gs = float(g1.abs().max())
+    assert (g0 - g1).abs().max().item() <= 2e-5 * gs
+    assert (p0 - p1).abs().max().item() <= 1e-6 and (t0 - t1).abs().max().item() <= 1e-6
