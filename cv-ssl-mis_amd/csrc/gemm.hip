@@ -341,7 +341,8 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs a) {
             for (int s = 0; s < BK / 8; ++s) {
                 const float2 v = sA2[((wm + i * 16 + lj) * BK + ((s * 8 + 2 * lk) ^ swz)) >> 1];
                 unsigned h, m, l;
-                bf3_split_pair(v.x, v.y, h, m, l);
+                if constexpr (GDBG & 32) { h = __float_as_uint(v.x); m = __float_as_uint(v.y); l = h; }   // timing only: no A split
+                else bf3_split_pair(v.x, v.y, h, m, l);
                 ah[i][s] = h; am[i][s] = m; al[i][s] = l;
             }
 #pragma unroll
