@@ -136,6 +136,17 @@ __global__ __launch_bounds__(256) void ln_fwd_reg_kernel(const float* __restrict
     }
 }
 
+// Backward of the residual add that produced the LayerNorm's input, in the same pass (x = a + s_b * y, reference
+// ...sys.py:276, :281: `x = shortcut + self.drop_path(x)` followed by `self.norm2(x)` / the next block's norm1): with
+// total = gin + LayerNorm'(dy) -- gin = what the input's other readers already left in its gradient -- the kernel writes
+// dx (+)= total (the shortcut's gradient) and d2 = s_b * total (the branch's), and the input's own gradient buffer is not
+// touched again.  d2 == nullptr: plain LayerNorm backward.
+struct LnRes {
+    const float* gin; long long ldgin;
+    float* d2; long long ldd2;
+    const float* rowscale; long long rps;
+};
+
 template <int LPR, int NV>
 __global__ __launch_bounds__(256) void ln_bwd_dx_reg_kernel(const float* __restrict__ x, long long ldx,
                                                             const float* __restrict__ dy, long long lddy,
@@ -144,7 +155,7 @@ __global__ __launch_bounds__(256) void ln_bwd_dx_reg_kernel(const float* __restr
                                                             const float* __restrict__ mean,
                                                             const float* __restrict__ rstd, long long M, int C,
                                                             int accumulate, long long rows_per_slab,
-                                                            float2* __restrict__ part) {
+                                                            float2* __restrict__ part, const LnRes rz) {
     // One block per slab of rows; a lane owns the same columns in every row, so the affine-gradient column
     // sums (sum dy*xhat, sum dy) ride along in registers and are written as one partial row per slab
     // (part == nullptr: dx only).  rows_per_slab % (256/LPR) == 0.
@@ -202,12 +213,20 @@ __global__ __launch_bounds__(256) void ln_bwd_dx_reg_kernel(const float* __restr
             s1 = group_sum<LPR>(s1) / (float)C;
             s2 = group_sum<LPR>(s2) * rs / (float)C;
             float* __restrict__ or_ = dx + row * lddx;
+            const float sb = (rz.d2 && rz.rowscale) ? rz.rowscale[row / rz.rps] : 1.f;
 #pragma unroll
             for (int i = 0; i < NV; ++i) {
                 const int c = (lane + i * LPR) * 4;
                 if (c < C) {
                     float4 o = make_float4(rs * (a[i].x - s1 - xc[i].x * rs * s2), rs * (a[i].y - s1 - xc[i].y * rs * s2),
                                            rs * (a[i].z - s1 - xc[i].z * rs * s2), rs * (a[i].w - s1 - xc[i].w * rs * s2));
+                    if (rz.d2) {
+                        if (rz.gin) {
+                            const float4 q = *reinterpret_cast<const float4*>(rz.gin + row * rz.ldgin + c);
+                            o.x += q.x; o.y += q.y; o.z += q.z; o.w += q.w;
+                        }
+                        *reinterpret_cast<float4*>(rz.d2 + row * rz.ldd2 + c) = make_float4(sb * o.x, sb * o.y, sb * o.z, sb * o.w);
+                    }
                     if (accumulate) {
                         const float4 p = *reinterpret_cast<const float4*>(or_ + c);
                         o.x += p.x; o.y += p.y; o.z += p.z; o.w += p.w;
@@ -995,7 +1014,7 @@ extern "C" long long mis_colreduce_workspace_bytes(long long M, int C) {
 static int layernorm_bwd_parts(const float* x, long long ldx, const float* dy, long long lddy, float* dx, long long lddx,
                                const float* gamma, const float* mean, const float* rstd, long long M, int C,
                                int accumulate_dx, bool affine, void* workspace, long long workspace_bytes,
-                               hipStream_t stream) {
+                               hipStream_t stream, const LnRes rz = LnRes{nullptr, 0, nullptr, 0, nullptr, 1}) {
     if (!x || !dy || !dx || !gamma || !mean || !rstd || !workspace || M <= 0 || C <= 0) return MIS_ERR_ARG;
     if (C % 4 || ldx % 4 || lddy % 4 || lddx % 4 || !a16(x) || !a16(dy) || !a16(dx) || !a16(gamma))
         return MIS_ERR_UNSUPPORTED;
@@ -1006,7 +1025,7 @@ static int layernorm_bwd_parts(const float* x, long long ldx, const float* dy, l
 #define MIS_LN_BWD(LPR, NV)                                                                                     \
     hipLaunchKernelGGL((ln_bwd_dx_reg_kernel<LPR, NV>), dim3(slabs), dim3(256), 0, stream, x, ldx, dy, lddy, dx, \
                        lddx, gamma, mean, rstd, M, C, accumulate_dx, (long long)COL_SLAB_ROWS,                  \
-                       affine ? part : (float2*)nullptr)
+                       affine ? part : (float2*)nullptr, rz)
     if (C <= 128) MIS_LN_BWD(32, 1);
     else if (C <= 256) MIS_LN_BWD(64, 1);
     else if (C <= 512) MIS_LN_BWD(64, 2);
@@ -1014,6 +1033,7 @@ static int layernorm_bwd_parts(const float* x, long long ldx, const float* dy, l
     else if (C <= 1024) MIS_LN_BWD(64, 4);
     else if (C <= 1536) MIS_LN_BWD(64, 6);
     else {
+        if (rz.d2) return MIS_ERR_UNSUPPORTED;
         if (affine)
             hipLaunchKernelGGL(col_partial_kernel, dim3((C + 127) / 128, slabs), dim3(256), 0, stream, x, ldx, dy, lddy,
                                mean, rstd, M, C, (long long)COL_SLAB_ROWS, 0, part);
@@ -1030,6 +1050,22 @@ extern "C" int mis_layernorm_bwd_parts(const float* x, long long ldx, const floa
                                        hipStream_t stream) {
     return layernorm_bwd_parts(x, ldx, dy, lddy, dx, lddx, gamma, mean, rstd, M, C, accumulate_dx, true, workspace,
                                workspace_bytes, stream);
+}
+
+// mis_layernorm_bwd_parts + the backward of the residual add x = shortcut + s_b * branch that produced the LayerNorm's input
+// (struct LnRes above): d_shortcut (+)= total, d_branch = rowscale[row / rows_per_scale] * total with total = gin + LayerNorm'(dy);
+// gin (may be NULL) = the gradient the input's other readers left, rowscale NULL = 1 (no DropPath).  C <= 1536.
+extern "C" int mis_layernorm_bwd_residual_parts(const float* x, long long ldx, const float* dy, long long lddy, const float* gin,
+                                                long long ldgin, float* d_shortcut, long long ldds, int accumulate_shortcut,
+                                                float* d_branch, long long lddb, const float* rowscale,
+                                                long long rows_per_scale, const float* gamma, const float* mean,
+                                                const float* rstd, long long M, int C, void* workspace,
+                                                long long workspace_bytes, hipStream_t stream) {
+    if (!d_branch || !d_shortcut || (rowscale && rows_per_scale <= 0)) return MIS_ERR_ARG;
+    if (lddb % 4 || !a16(d_branch) || (gin && (ldgin % 4 || !a16(gin)))) return MIS_ERR_UNSUPPORTED;
+    const LnRes rz{gin, ldgin, d_branch, lddb, rowscale, rowscale ? rows_per_scale : 1};
+    return layernorm_bwd_parts(x, ldx, dy, lddy, d_shortcut, ldds, gamma, mean, rstd, M, C, accumulate_shortcut, true, workspace,
+                               workspace_bytes, stream, rz);
 }
 
 extern "C" int mis_layernorm_bwd_final(const void* workspace, long long workspace_bytes, long long M, int C, float* dgamma,

@@ -185,6 +185,8 @@ PROTOTYPES = {
                                 c_ll, c_p]),
     "mis_layernorm_bwd_parts": (c_i, [c_p, c_ll, c_p, c_ll, c_p, c_ll, c_p, c_p, c_p, c_ll, c_i, c_i, c_p, c_ll, c_p]),
     "mis_layernorm_bwd_final": (c_i, [c_p, c_ll, c_ll, c_i, c_p, c_p, c_i, c_p]),
+    "mis_layernorm_bwd_residual_parts": (c_i, [c_p, c_ll, c_p, c_ll, c_p, c_ll, c_p, c_ll, c_i, c_p, c_ll, c_p, c_ll, c_p, c_p,
+                                               c_p, c_ll, c_i, c_p, c_ll, c_p]),
     "mis_colsum": (c_i, [c_p, c_ll, c_ll, c_i, c_p, c_i, c_p, c_ll, c_p]),
     "mis_gelu": (c_i, [c_p, c_p, c_p, c_ll, c_i, c_p]),
     "mis_residual_droppath": (c_i, [c_p, c_ll, c_p, c_ll, c_p, c_ll, c_p, c_ll, c_ll, c_i, c_ll, c_f, c_u, c_p, c_p,

@@ -795,6 +795,9 @@ class Plan:
         if dlogits5 is not None:
             self.out.g = dlogits5
         self._pack(1)
+        if self._tbatch is None:        # first backward of a mixed plan (UNETR, SwinUNETR): pair its token ops
+            from .swin_plan import pair_ln_residual
+            pair_ln_residual(self.ops)
         self._transpose_linear_weights()
         ctx.b3_bwd = self._split_linear_weights(True)
         main = torch.cuda.current_stream()

@@ -142,6 +142,20 @@ class LinearOp:
             self.x.mark_written()
 
 
+# LayerNorm backward + the backward of the residual add in front of it in one pass (MIS_SWIN_LNRES=0: two passes)
+LNRES = os.environ.get("MIS_SWIN_LNRES", "1") != "0"
+
+
+def pair_ln_residual(ops_list):
+    """``x = shortcut + drop_path(branch)`` directly followed by ``norm(x)``: every other reader of x comes later in the forward,
+    i.e. has left its gradient in x.grad by the time the LayerNorm's backward runs, and nothing runs between that backward and
+    the residual's -- the LayerNorm's pass can finish the residual's backward."""
+    for i in range(len(ops_list) - 1):
+        r, ln = ops_list[i], ops_list[i + 1]
+        if isinstance(r, ResidualOp) and isinstance(ln, LayerNormOp) and ln.x is r.out:
+            ln.res_bwd = r
+
+
 def split_linear_weights(holder, ops_list, transposed):
     """Every Linear weight of the op list (``transposed``: its W^T, which the plan's transpose batch just wrote) cut into the
     bf16 piece planes the NT GEMMs consume, in one launch; the weights changed with the last SGD / EMA update, so once per
@@ -178,11 +192,29 @@ class LayerNormOp:
         self.mean = torch.empty(x.rows, dtype=torch.float32, device="cuda")
         self.rstd = torch.empty(x.rows, dtype=torch.float32, device="cuda")
         self._ws = None
+        self.res_bwd = None      # the ResidualOp right in front of this op whose output is x (pair_ln_residual)
 
     def fwd(self, ctx):
         tops.layernorm_fwd(self.x.t, self.y.t, self.g.data, self.b.data, self.mean, self.rstd)
 
     def bwd(self, ctx):
+        r = self.res_bwd if LNRES else None
+        if r is not None and not r.y.written and self.g.grad is not None and self.b.grad is not None:
+            # the residual add that produced x: its backward rides on this pass (mis_layernorm_bwd_residual_parts); x's own
+            # gradient buffer is read (what x's other readers left there) but not written again
+            ok, scales = r.bwd_scales(ctx)
+            if ok:
+                if self._ws is None:
+                    self._ws = tops.colreduce_workspace(self.x.rows, self.x.t.shape[1])
+                if tops.layernorm_bwd_residual_parts(self.x.t, self.y.grad(), self.x.grad() if self.x.written else None,
+                                                     r.a.grad(), r.y.grad(), self.g.data, self.mean, self.rstd, self._ws,
+                                                     rowscale=scales, rows_per_scale=r.rps, accumulate_shortcut=r.a.written):
+                    r.a.mark_written()
+                    r.y.mark_written()
+                    r.skip_bwd = True
+                    if not defer(ctx, self._final):
+                        self._final()
+                    return
         if (self.g.grad is not None or self.b.grad is not None) and defer(ctx, self._final):
             if self._ws is None:
                 self._ws = tops.colreduce_workspace(self.x.rows, self.x.t.shape[1])
@@ -252,7 +284,7 @@ class ResidualOp:
         self.rps, self.drop_p, self.site = rows_per_sample, drop_p, site
         self._p, self._salt, self._state, self._scale = 0.0, 0, None, None
         self.plan = None            # set by SwinPlan.add: the per-forward DropPath scale table lives there
-        self.skip_fwd = False
+        self.skip_fwd = self.skip_bwd = False
 
     def prepare(self, ctx):
         """Fix this pass's DropPath parameters (also used by backward); returns the per-sample scale vector a fused
@@ -274,7 +306,21 @@ class ResidualOp:
         self.prepare(ctx)
         tops.residual_fwd(self.a.t, self.y.t, self.out.t, self.rps, self._p, self._salt, self._state, self._scale)
 
+    def bwd_scales(self, ctx):
+        """(usable, per-sample DropPath scales of this pass as a device vector or None = all ones) for a kernel that fuses this
+        op's backward."""
+        if self._p <= 0:
+            return True, None
+        if self._scale is not None:
+            return True, self._scale
+        if self.plan is None:
+            return False, None
+        return True, self.plan.droppath_scales(ctx)[self.site]
+
     def bwd(self, ctx):
+        if self.skip_bwd:           # the LayerNormOp that reads ``out`` wrote a.grad and y.grad in its own backward pass
+            self.skip_bwd = False
+            return
         assert not self.y.written
         tops.residual_bwd(self.out.grad(), self.a.grad(), self.y.grad(), self.rps, self._p, self._salt, self._state,
                           self._scale, accumulate_shortcut=self.a.written)
@@ -548,6 +594,7 @@ class SwinPlan:
         self._wgrad_stream = None
         self._tbatch = None
         self._dp_gen, self._dp_const = -1, None
+        self._paired = False
 
     def new(self, rows, C):
         a = TAct(rows, C)
@@ -619,6 +666,9 @@ class SwinPlan:
         self.out.reset()
         if dlogits5 is not None:
             self.out.g = dlogits5
+        if not self._paired:
+            pair_ln_residual(self.ops)
+            self._paired = True
         self.transpose_weights()
         ctx.b3_bwd = split_linear_weights(self, self.ops, True)
         from . import plan as _plan

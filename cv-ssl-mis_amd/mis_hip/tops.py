@@ -346,6 +346,26 @@ def layernorm_bwd_parts(x, dy, dx, gamma, mean, rstd, ws, accumulate_dx=False):
              "mis_layernorm_bwd_parts")
 
 
+def layernorm_bwd_residual_parts(x, dy, gin, d_shortcut, d_branch, gamma, mean, rstd, ws, rowscale=None, rows_per_scale=1,
+                                 accumulate_shortcut=False):
+    """LayerNorm backward + the backward of the residual add that produced its input (mis_layernorm_bwd_residual_parts);
+    False: outside the fused form (C > 1536)."""
+    L = _l.load()
+    M, C, ldx = _mat(x)
+    _, _, lddy = _mat(dy)
+    ldg = _mat(gin)[2] if gin is not None else 0
+    _, _, ldds = _mat(d_shortcut)
+    _, _, lddb = _mat(d_branch)
+    st = L.mis_layernorm_bwd_residual_parts(_l.ptr(x), ldx, _l.ptr(dy), lddy, _l.ptr(gin), ldg, _l.ptr(d_shortcut), ldds,
+                                            int(accumulate_shortcut), _l.ptr(d_branch), lddb, _l.ptr(rowscale),
+                                            int(rows_per_scale), _l.ptr(gamma), _l.ptr(mean), _l.ptr(rstd), M, C, _l.ptr(ws),
+                                            ws.numel(), _l.stream_ptr())
+    if st == -2:
+        return False
+    _l.check(st, "mis_layernorm_bwd_residual_parts")
+    return True
+
+
 def layernorm_bwd_final(ws, M, C, dgamma, dbeta, accumulate_affine=False):
     L = _l.load()
     _l.check(L.mis_layernorm_bwd_final(_l.ptr(ws), ws.numel(), M, C, _l.ptr(dgamma), _l.ptr(dbeta), int(accumulate_affine),

@@ -530,6 +530,17 @@ int mis_layernorm_bwd_parts(const float* x, long long ldx, const float* dy, long
                             int accumulate_dx, void* workspace, long long workspace_bytes, mis_stream_t stream);
 int mis_layernorm_bwd_final(const void* workspace, long long workspace_bytes, long long M, int C, float* dgamma,
                             float* dbeta, int accumulate_affine, mis_stream_t stream);
+/* mis_layernorm_bwd_parts and, in the same pass, the backward of the residual add that produced the LayerNorm's input
+ * (`x = shortcut + self.drop_path(x)` followed by `self.norm2(x)` / the next block's `norm1`, :276-281): with
+ * total = gin + LayerNorm'(dy) (gin, may be NULL: what the input's other readers already left in its gradient),
+ * d_shortcut (+)= total and d_branch = rowscale[row / rows_per_scale] * total (rowscale NULL: 1, no DropPath).  The input's
+ * own gradient is not written: one write and one read of a token tensor less than mis_layernorm_bwd +
+ * mis_residual_droppath(backward).  C <= 1536; affine partials as mis_layernorm_bwd_parts (finish with _final) */
+int mis_layernorm_bwd_residual_parts(const float* x, long long ldx, const float* dy, long long lddy, const float* gin,
+                                     long long ldgin, float* d_shortcut, long long ldds, int accumulate_shortcut,
+                                     float* d_branch, long long lddb, const float* rowscale, long long rows_per_scale,
+                                     const float* gamma, const float* mean, const float* rstd, long long M, int C,
+                                     void* workspace, long long workspace_bytes, mis_stream_t stream);
 /* out[c] (+)= sum_rows x[row][c]: nn.Linear bias gradient */
 int mis_colsum(const float* x, long long ldx, long long M, int C, float* out, int accumulate, void* workspace,
                long long workspace_bytes, mis_stream_t stream);

@@ -144,3 +144,32 @@ def test_finishing_launches_on_the_side_stream_are_bit_identical(monkeypatch, ki
         res.append(grads)
     for a, b in zip(*res):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("kind,shape,C", [("swin", (2, 1, 224, 224), 4), ("unetr", (1, 1, 96, 96, 96), 2),
+                                          ("swinunetr", (1, 1, 64, 64, 64), 2)])
+def test_residual_backward_inside_the_layernorm_backward_is_bit_identical(monkeypatch, kind, shape, C):
+    """MIS_SWIN_LNRES: `x = shortcut + drop_path(branch); norm(x)` -- the LayerNorm's backward pass also writes the shortcut's
+    and the branch's gradients (mis_layernorm_bwd_residual_parts); same flat gradient buffer as the two passes (DropPath off
+    here; tests/test_token_kernels_gpu.py runs a Mean-Teacher step with it on)."""
+    from mis_hip import swin_plan
+    res = []
+    for on in (False, True):
+        monkeypatch.setattr(swin_plan, "LNRES", on)
+        torch.manual_seed(11)
+        model = _make(kind, C)
+        model.train()
+        model.dropout_enabled = False
+        x = torch.rand(shape, device="cuda")
+        grads = []
+        for it in range(2):
+            model.forward_raw(x + 0.1 * it)
+            dl = model.logits_grad_buffer()
+            dl.copy_(torch.randn(dl.shape, device="cuda") * 0.1)
+            model.backward_raw()
+            torch.cuda.synchronize()
+            grads.append(model.flat_grad.clone())
+        assert sum(1 for op in model._last[0].ops if getattr(op, "res_bwd", None) is not None) > 0
+        res.append(grads)
+    for a, b in zip(*res):
+        assert torch.equal(a, b)

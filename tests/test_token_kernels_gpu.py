@@ -457,7 +457,8 @@ def test_gemm_fused_epilogues(M, N, K, prec):
 
 def test_swin_step_fused_equals_unfused():
     """The epilogue fusions change where the element-wise work runs, not its arithmetic: a Mean-Teacher step of SwinUnet
-    with DropPath active (device RNG) gives the same losses, gradients and weights with MIS_SWIN_FUSE on and off."""
+    with DropPath active (device RNG) gives the same losses, gradients and weights with MIS_SWIN_FUSE (and the residual
+    backward inside the LayerNorm backward, MIS_SWIN_LNRES) on and off."""
     from config import lite_config
     from mis_hip import swin_plan
     from mis_hip.step import MeanTeacherTrainer
@@ -470,6 +471,7 @@ def test_swin_step_fused_equals_unfused():
     res = []
     for fuse in (7, 0):
         swin_plan.FUSE = fuse
+        swin_plan.LNRES = bool(fuse)
         try:
             m, e = SwinUnet(lite_config(), num_classes=4), SwinUnet(lite_config(), num_classes=4)
             m.load_state_dict(sd0); e.load_state_dict(sd0)
@@ -480,6 +482,7 @@ def test_swin_step_fused_equals_unfused():
             res.append((tr.losses(), m.flat_grad.clone(), m.flat_param.clone(), e.flat_param.clone()))
         finally:
             swin_plan.FUSE = 7
+            swin_plan.LNRES = True
     (l0, g0, p0, t0), (l1, g1, p1, t1) = res
     for k in l0:
         assert abs(l0[k] - l1[k]) <= 1e-6, (k, l0[k], l1[k])
@@ -611,3 +614,39 @@ def test_swin_step_with_presplit_weights_equals_split_per_tile():
     gs = float(g1.abs().max())
     assert (g0 - g1).abs().max().item() <= 2e-5 * gs
     assert (p0 - p1).abs().max().item() <= 1e-6 and (t0 - t1).abs().max().item() <= 1e-6
+
+
+@pytest.mark.parametrize("M,C,B", [(784, 96, 4), (3137, 384, 1), (50, 1536, 2), (6272, 192, 8)])
+def test_layernorm_backward_with_the_residual_backward_in_one_pass(M, C, B):
+    """mis_layernorm_bwd_residual_parts against mis_layernorm_bwd (accumulating into the input's gradient) followed by
+    mis_residual_droppath's backward: bit-identical, with and without a gradient already in the input, with and without
+    DropPath scales, accumulating into the shortcut's gradient or not."""
+    tops = _t()
+    x = (_rand(M, C, seed=51, scale=2.0) + 0.5).cuda()
+    g, b = (1 + 0.2 * _rand(C, seed=52)).cuda(), (0.1 * _rand(C, seed=53)).cuda()
+    dy = _rand(M, C, seed=54).cuda()
+    y = torch.empty(M, C, device="cuda")
+    mean, rstd = torch.empty(M, device="cuda"), torch.empty(M, device="cuda")
+    tops.layernorm_fwd(x, y, g, b, mean, rstd)
+    rps = (M + B - 1) // B
+    for has_gin in (False, True):
+        for scales in (None, (torch.tensor([0.0, 1.25, 1.0, 2.5, 0.0, 1.0, 1.25, 1.25][:B])).cuda()):
+            for acc in (False, True):
+                gin = _rand(M, C, seed=55).cuda() if has_gin else None
+                base = _rand(M, C, seed=56).cuda()
+                # two passes
+                dxin = gin.clone() if has_gin else torch.empty(M, C, device="cuda")
+                dg1, db1 = torch.empty(C, device="cuda"), torch.empty(C, device="cuda")
+                tops.layernorm_bwd(x, dy, dxin, g, mean, rstd, dg1, db1, accumulate_dx=has_gin)
+                ds1, dbr1 = base.clone(), torch.empty(M, C, device="cuda")
+                tops.residual_bwd(dxin, ds1, dbr1, rps, drop_p=0.5 if scales is not None else 0.0, scale_override=scales,
+                                  accumulate_shortcut=acc)
+                # one pass
+                ws = tops.colreduce_workspace(M, C)
+                ds2, dbr2 = base.clone(), torch.full((M, C), float("nan"), device="cuda")
+                assert tops.layernorm_bwd_residual_parts(x, dy, gin, ds2, dbr2, g, mean, rstd, ws, rowscale=scales,
+                                                         rows_per_scale=rps, accumulate_shortcut=acc)
+                dg2, db2 = torch.empty(C, device="cuda"), torch.empty(C, device="cuda")
+                tops.layernorm_bwd_final(ws, M, C, dg2, db2)
+                assert torch.equal(ds1, ds2) and torch.equal(dbr1, dbr2), (has_gin, scales is not None, acc)
+                assert torch.equal(dg1, dg2) and torch.equal(db1, db2)
