@@ -64,9 +64,14 @@ struct GemmArgs {
     // fp32 B is not read).  b3_plane = bytes of one plane (N x K3 x 2), K3 = K rounded up to the k-step
     const void* B3; unsigned b3_plane; int K3;
     int bm_force;          // host only: rows per tile chosen by the caller (0: nt_tile_m)
+    // EP_LNHEAD (mis_gemm_expand_ln_head): LayerNorm over the c = 96 columns of a tile row (= one token of the pixel-shuffled
+    // tensor) + the bias-free output head, in the epilogue; C may be NULL (the expanded tokens are not kept)
+    const float* ln_g; const float* ln_b; const float* head_w;
+    float* ln_mean; float* ln_rstd; float* logits; long long logits_bs;
+    int head_nc; float ln_eps;
 };
 
-enum { EP_NONE = 0, EP_GELU_FWD = 1, EP_GELU_BWD = 2, EP_RESIDUAL = 3 };
+enum { EP_NONE = 0, EP_GELU_FWD = 1, EP_GELU_BWD = 2, EP_RESIDUAL = 3, EP_LNHEAD = 4 };
 
 // same functions as token_ops.hip::gelu_kernel (common.h)
 __device__ __forceinline__ float gelu_f(float x) { return mis_gelu(x); }
@@ -401,6 +406,56 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs a) {
             }
         return;
     }
+    if constexpr (EP == EP_LNHEAD) {
+        // FinalPatchExpand_X4 + its LayerNorm + the output head (reference ...sys.py:401-409, :671, :749-752) on the tile: BN = c =
+        // 96, so the tile's columns are one (p1, p2) and a tile row is one token of the pixel-shuffled tensor.  Rows through LDS;
+        // 32 lanes per row (24 hold a float4), the arithmetic of ln_head_fwd_kernel (token_ops.hip) term for term: same bits.
+        static_assert(BN == 96, "a tile row is one expanded token");
+        float* const ct = lds;
+#pragma unroll
+        for (int i = 0; i < G::MI; ++i)
+#pragma unroll
+            for (int j = 0; j < G::NJ; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    ct[(wm + i * 16 + lk * 4 + r) * G::LDC_T + wn + j * 16 + lj] = acc[i][j][r];
+        __syncthreads();
+        const int l32 = tid & 31, rg = tid >> 5, c4 = l32 * 4;
+        const bool act = c4 < BN;
+        constexpr int NCM = 4;
+        float4 g = make_float4(0.f, 0.f, 0.f, 0.f), bt = g, wv[NCM];
+        if (act) { g = *reinterpret_cast<const float4*>(a.ln_g + c4); bt = *reinterpret_cast<const float4*>(a.ln_b + c4); }
+#pragma unroll
+        for (int n = 0; n < NCM; ++n)
+            wv[n] = (act && n < a.head_nc) ? *reinterpret_cast<const float4*>(a.head_w + n * BN + c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        const int P = a.ex_P, pp = n0 / BN, p1 = pp / P, p2 = pp - p1 * P;
+        const long long S = (long long)a.ex_H * P * a.ex_W * P;
+        for (int it = 0; it < BMT / 8; ++it) {
+            const int row = it * 8 + rg, m = m0 + row;
+            if (m >= a.M) continue;        // uniform within the row group
+            const float4 v = act ? *reinterpret_cast<const float4*>(&ct[row * G::LDC_T + c4]) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const float mu = mis_group_sum<32>((v.x + v.y) + (v.z + v.w)) / (float)BN;
+            const float a0 = v.x - mu, a1 = v.y - mu, a2 = v.z - mu, a3 = v.w - mu;
+            const float ss = act ? (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3) : 0.f;
+            const float rs = 1.f / sqrtf(mis_group_sum<32>(ss) / (float)BN + a.ln_eps);
+            const float y0 = a0 * rs * g.x + bt.x, y1 = a1 * rs * g.y + bt.y, y2 = a2 * rs * g.z + bt.z, y3 = a3 * rs * g.w + bt.w;
+            float pl[NCM];
+#pragma unroll
+            for (int n = 0; n < NCM; ++n)
+                pl[n] = mis_group_sum<32>((y0 * wv[n].x + y1 * wv[n].y) + (y2 * wv[n].z + y3 * wv[n].w));
+            const int w_ = m % a.ex_W, tt = m / a.ex_W, h_ = tt % a.ex_H, b_ = tt / a.ex_H;
+            const long long pix = ((long long)h_ * P + p1) * ((long long)a.ex_W * P) + (long long)w_ * P + p2;
+            const long long tok = (long long)b_ * S + pix;
+            if (a.C && act) *reinterpret_cast<float4*>(a.C + tok * BN + c4) = v;
+            if (l32 == 0) {
+                a.ln_mean[tok] = mu; a.ln_rstd[tok] = rs;
+#pragma unroll
+                for (int n = 0; n < NCM; ++n)
+                    if (n < a.head_nc) a.logits[(long long)b_ * a.logits_bs + (long long)n * S + pix] = pl[n];
+            }
+        }
+        return;
+    }
     if (a.ex_P) {
         // expand epilogue: a 16-column group stays inside one (p1, p2) (c % 16 == 0), so per (row, group) one
         // destination row is computed and 16 lanes store 64 contiguous bytes of it
@@ -471,6 +526,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs a) {
             if constexpr (EP == EP_GELU_FWD) {
                 *reinterpret_cast<float4*>(a.C2 + (long long)m * a.ldc2 + n) =
                     make_float4(gelu_f(v.x), gelu_f(v.y), gelu_f(v.z), gelu_f(v.w));
+                if (!a.C) continue;      // the pre-activation is only the backward's: a forward nobody differentiates drops it
             } else if constexpr (EP == EP_GELU_BWD) {
                 const float4 h = *reinterpret_cast<const float4*>(a.E1 + (long long)m * a.lde1 + n);
                 v.x *= gelu_grad_f(h.x); v.y *= gelu_grad_f(h.y); v.z *= gelu_grad_f(h.z); v.w *= gelu_grad_f(h.w);
@@ -696,6 +752,7 @@ __global__ __launch_bounds__(256) void gemm_nt_short_kernel(const GemmArgs a) {
             if constexpr (EP == EP_GELU_FWD) {
                 *reinterpret_cast<float4*>(a.C2 + (long long)m * a.ldc2 + n) =
                     make_float4(gelu_f(v.x), gelu_f(v.y), gelu_f(v.z), gelu_f(v.w));
+                if (!a.C) continue;      // the pre-activation is only the backward's: a forward nobody differentiates drops it
             } else if constexpr (EP == EP_GELU_BWD) {
                 const float4 g = *reinterpret_cast<const float4*>(a.E1 + (long long)m * a.lde1 + n);
                 v.x *= gelu_grad_f(g.x); v.y *= gelu_grad_f(g.y); v.z *= gelu_grad_f(g.z); v.w *= gelu_grad_f(g.w);
@@ -1195,6 +1252,7 @@ __global__ __launch_bounds__(256) void gemm_reduce_kernel(const GemmArgs a) {
         float* p = a.C + (long long)m * a.ldc + n;
         if (a.ep == EP_GELU_FWD) {
             a.C2[(long long)m * a.ldc2 + n] = gelu_f(s);
+            if (!a.C) return;
         } else if (a.ep == EP_GELU_BWD) {
             s *= gelu_grad_f(a.E1[(long long)m * a.lde1 + n]);
         } else if (a.ep == EP_RESIDUAL) {
@@ -1453,7 +1511,8 @@ extern "C" long long mis_gemm_workspace_bytes(int M, int N, int K, int trans) {
 
 // mis_gemm (NT form only) with a fused epilogue, v = A.B^T + bias:
 //   epilogue 1  C = v, C2 = gelu(v)                      Mlp.fc1 + GELU (reference ...sys.py:14-15,20-21): the
-//                                                        pre-activation stays for the backward, the GELU pass is gone
+//                                                        pre-activation stays for the backward, the GELU pass is gone;
+//                                                        C NULL: only C2 (a forward nobody differentiates)
 //   epilogue 2  C = v * gelu'(E1)                        dX of Mlp.fc2 straight into the gradient of fc1's output
 //   epilogue 3  C = E1 + rowscale[m / rows_per_scale] * v  proj / fc2 + DropPath + residual add (:276, :281);
 //                                                        rowscale NULL = 1
@@ -1462,7 +1521,7 @@ extern "C" int mis_gemm_ex(const float* A, long long lda, const float* B, long l
                            const float* bias, int M, int N, int K, int epilogue, const float* E1, long long lde1,
                            float* C2, long long ldc2, const float* rowscale, long long rows_per_scale,
                            float* workspace, long long workspace_bytes, hipStream_t stream) {
-    if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0) return MIS_ERR_ARG;
+    if (!A || !B || (!C && epilogue != EP_GELU_FWD) || M <= 0 || N <= 0 || K <= 0) return MIS_ERR_ARG;      // epilogue 1: C may be NULL
     if (epilogue < EP_GELU_FWD || epilogue > EP_RESIDUAL) return MIS_ERR_ARG;
     if (epilogue == EP_GELU_FWD ? (!C2 || ldc2 < N) : (!E1 || lde1 < N)) return MIS_ERR_ARG;
     if (epilogue == EP_RESIDUAL && rowscale && rows_per_scale <= 0) return MIS_ERR_ARG;
@@ -1678,7 +1737,7 @@ extern "C" int mis_gemm_nt_split(const float* A, long long lda, const void* B3, 
                                  float* C2, long long ldc2, const float* rowscale, long long rows_per_scale, int ex_H,
                                  int ex_W, int ex_P, int ex_c, float* workspace, long long workspace_bytes,
                                  hipStream_t stream) {
-    if (!A || !B3 || !C || M <= 0 || N <= 0 || K <= 0) return MIS_ERR_ARG;
+    if (!A || !B3 || (!C && epilogue != EP_GELU_FWD) || M <= 0 || N <= 0 || K <= 0) return MIS_ERR_ARG;
     if (epilogue < EP_NONE || epilogue > EP_RESIDUAL) return MIS_ERR_ARG;
     if (!a16(A) || !a16(B3) || lda % 4 || K % 4) return MIS_ERR_UNSUPPORTED;
     if ((long long)M * lda * 4 >= (1LL << 31) || mis_gemm_split_bytes(N, K) >= (1LL << 31)) return MIS_ERR_UNSUPPORTED;
@@ -1747,4 +1806,37 @@ extern "C" int mis_gemm_expand(const float* x, long long lda, const float* W, lo
     a.n_blocks = (unsigned)nb;
     a.n_blocks_padded = (unsigned)(mis_cdiv(nb, MIS_NUM_XCD) * MIS_NUM_XCD);
     return bn == 96 ? launch_nt<96>(a, stream) : launch_nt<128>(a, stream);
+}
+
+// mis_gemm_expand (P x P pixel shuffle, c = 96) with FinalPatchExpand_X4's LayerNorm and the bias-free 1 x 1 output convolution in
+// the GEMM's epilogue (reference swin_transformer_unet_skip_expand_decoder_sys.py:401-409 `x = self.expand(x); rearrange;
+// x = self.norm(x)`, :749-752 `self.output(x)`): per token of the shuffled tensor mean / rstd (saved for the backward, index =
+// token of the shuffled tensor) and logits [B][NC][H P][W P] (batch stride logits_bs floats).  `out` (the shuffled tokens, dense
+// [B H P W P][96]) is what the backward reads; NULL = not kept (a forward nobody differentiates: the EMA teacher).  Same bits as
+// mis_gemm_expand + mis_ln_head_fwd.  MIS_ERR_UNSUPPORTED: c != 96, NC outside 2 .. 4, or a shape mis_gemm_expand refuses.
+extern "C" int mis_gemm_expand_ln_head(const float* x, long long lda, const float* W, long long ldb, float* out, int B, int H,
+                                       int Wd, int K, int P, int c, const float* gamma, const float* beta, const float* head_w,
+                                       int NC, float eps, float* mean, float* rstd, float* logits, long long logits_bs,
+                                       hipStream_t stream) {
+    if (!x || !W || !gamma || !beta || !head_w || !mean || !rstd || !logits || B <= 0 || H <= 0 || Wd <= 0 || K <= 0 || P <= 0)
+        return MIS_ERR_ARG;
+    if (c != 96 || NC < 2 || NC > 4) return MIS_ERR_UNSUPPORTED;
+    const long long M = (long long)B * H * Wd, N = (long long)P * P * c;
+    if (!a16(x) || !a16(W) || lda % 4 || ldb % 4 || K % 4 || (out && !a16(out)) || !a16(gamma) || !a16(beta) || !a16(head_w))
+        return MIS_ERR_UNSUPPORTED;
+    if (M * lda * 4 >= (1LL << 31) || N * ldb * 4 >= (1LL << 31) || M * N * 4 >= (1LL << 31)) return MIS_ERR_UNSUPPORTED;
+    if (logits_bs < (long long)NC * H * P * Wd * P) return MIS_ERR_ARG;
+    if (pick_ks((int)M, (int)N, K, 0) != 1) return MIS_ERR_UNSUPPORTED;
+    GemmArgs a{x, lda, W, ldb, out, N, nullptr, nullptr, (int)M, (int)N, K, 1, K, 0};
+    a.ex_P = P; a.ex_H = H; a.ex_W = Wd; a.ex_c = c;
+    a.ep = EP_LNHEAD;
+    a.ln_g = gamma; a.ln_b = beta; a.head_w = head_w; a.ln_mean = mean; a.ln_rstd = rstd; a.logits = logits;
+    a.logits_bs = logits_bs; a.head_nc = NC; a.ln_eps = eps;
+    a.tiles_n = (int)(N / 96);
+    a.tiles_m = (int)mis_cdiv(M, 64);
+    const long long nb = (long long)a.tiles_n * a.tiles_m;
+    if (nb > 0x7fffffffLL) return MIS_ERR_UNSUPPORTED;
+    a.n_blocks = (unsigned)nb;
+    a.n_blocks_padded = (unsigned)(mis_cdiv(nb, MIS_NUM_XCD) * MIS_NUM_XCD);
+    return gemm_bf3() ? launch_nt_prec<64, 96, EP_LNHEAD, 1>(a, stream) : launch_nt_prec<64, 96, EP_LNHEAD, 0>(a, stream);
 }

@@ -54,29 +54,8 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
     }
 }
 
-// Sum over the LPR (32 or 64) lanes of a row group, result in every lane.  The first four steps are DPP modifiers of the
-// add (quad_perm 1032 / 2301, row_half_mirror, row_mirror: vector-ALU rate), the step across the two 16-lane rows is one
-// ds_swizzle (xor 16), the one across the wave's halves one ds_bpermute -- __shfl_xor is a ds_bpermute per step on gfx9
-// (5 per sum: the fused LayerNorm + head forward issues 6 sums per row and ran at 2.1 TB/s on them).
-__device__ __forceinline__ float dpp_f(float v, int ctrl) {
-    switch (ctrl) {      // the control word is an immediate
-        case 0: return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, false));
-        case 1: return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, false));
-        case 2: return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, false));
-        default: return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, false));
-    }
-}
 template <int LPR>
-__device__ __forceinline__ float group_sum(float v) {
-    static_assert(LPR == 32 || LPR == 64, "row groups of 32 or 64 lanes");
-    v += dpp_f(v, 0);
-    v += dpp_f(v, 1);
-    v += dpp_f(v, 2);
-    v += dpp_f(v, 3);
-    v += __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), (0x10 << 10) | 0x1F));
-    if (LPR == 64) v += __shfl_xor(v, 32, 64);
-    return v;
-}
+__device__ __forceinline__ float group_sum(float v) { return mis_group_sum<LPR>(v); }      // common.h
 
 // Register-resident rows: LPR lanes per row (32 -> two rows per wave for C <= 128), NV float4 per lane,
 // so x is read from HBM/L2 once and the three passes run on registers.  C <= LPR*4*NV.

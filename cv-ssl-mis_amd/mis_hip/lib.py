@@ -154,6 +154,8 @@ PROTOTYPES = {
     "mis_gemm_set_split_precision": (c_i, [c_i]),
     "mis_gemm_nt_kernel_name": (c_i, [c_i, c_i, c_i, c_i, ctypes.c_char_p, c_i]),
     "mis_gemm_tn_kernel_name": (c_i, [c_p, c_ll, c_p, c_ll, c_p, c_ll, c_i, c_i, c_i, ctypes.c_char_p, c_i]),
+    "mis_gemm_expand_ln_head": (c_i, [c_p, c_ll, c_p, c_ll, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_i, c_f, c_p, c_p,
+                                      c_p, c_ll, c_p]),
     "mis_gemm_split_bytes": (c_ll, [c_i, c_i]),
     "mis_gemm_split_b": (c_i, [c_p, c_ll, c_i, c_i, c_p, c_p]),
     "mis_gemm_split_job_bytes": (c_ll, []),

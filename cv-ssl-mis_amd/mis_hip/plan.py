@@ -1016,16 +1016,21 @@ class HipNet(nn.Module):
             yield name, flat[off:off + n].view(shape)
 
     # raw (autograd-free) interface used by the fused training step
-    def forward_raw(self, x):
+    def forward_raw(self, x, no_backward=False):
+        """``no_backward``: nobody will differentiate this pass (the EMA teacher, validation): ops may skip what only a
+        backward reads -- backward_raw() after such a pass fails loudly."""
         x5 = self._as5(x.contiguous())
         plan = self.plan_for(x5.shape)
         ctx = self._ctx()
+        ctx.no_backward = bool(no_backward)
         out = plan.forward(x5, ctx)
         self._last = (plan, ctx)
         return out
 
     def backward_raw(self, dlogits5=None, on_progress=None):
         plan, ctx = self._last
+        if getattr(ctx, "no_backward", False):
+            raise RuntimeError("backward_raw() after forward_raw(no_backward=True): that pass did not keep its activations")
         if on_progress is None:
             plan.backward(dlogits5, ctx)
         else:

@@ -96,12 +96,12 @@ class MeanTeacherTrainer:
                 self._side = torch.cuda.Stream()
             self._side.wait_stream(main)
             with torch.cuda.stream(self._side):
-                t_logits = self.ema_model.forward_raw(self._ema_in)
+                t_logits = self.ema_model.forward_raw(self._ema_in, no_backward=True)
             s_logits = self.model.forward_raw(volume)
             main.wait_stream(self._side)
         else:
             s_logits = self.model.forward_raw(volume)
-            t_logits = self.ema_model.forward_raw(self._ema_in)
+            t_logits = self.ema_model.forward_raw(self._ema_in, no_backward=True)
         ops.loss_tail(s_logits, t_logits, label[:L].contiguous(), L, self.out,
                       dlogits=self.model.logits_grad_buffer(), state=self.state)
         grad_scale = backward_and_sync(self.model, self.pg, self._bucketer)   # the step's only exchange
@@ -180,7 +180,7 @@ class UAMTTrainer(MeanTeacherTrainer):
 
         def teacher_passes():
             self.ema_model.rng_stream = 2
-            t_logits = self.ema_model.forward_raw(self._ema_in)
+            t_logits = self.ema_model.forward_raw(self._ema_in, no_backward=True)
             if self._mean_probs is None or self._mean_probs.shape != t_logits.shape:
                 self._mean_probs = torch.empty_like(t_logits)
             for i in range(self.T // 2):
@@ -191,7 +191,7 @@ class UAMTTrainer(MeanTeacherTrainer):
                     else:
                         torch.add(unl, mc_noise[i][r * U:(r + 1) * U], out=half)
                 self.ema_model.rng_stream = 3 + i          # a fresh dropout stream per MC pass
-                mc_logits = self.ema_model.forward_raw(self._rep_in)
+                mc_logits = self.ema_model.forward_raw(self._rep_in, no_backward=True)
                 ops.softmax_mean_accumulate(mc_logits, self._mean_probs, 2, 1.0 / self.T, first=(i == 0))
             self.ema_model.rng_stream = 2
             return t_logits
@@ -415,13 +415,13 @@ class CnnMeetVitTrainer:
             self._side.wait_stream(main)
             with torch.cuda.stream(self._side):
                 o1 = self.model1.forward_raw(volume_batch)
-                t = self.ema_model.forward_raw(self._ema_in)
+                t = self.ema_model.forward_raw(self._ema_in, no_backward=True)
             o2 = self.model2.forward_raw(volume_batch)
             main.wait_stream(self._side)
         else:
             o1 = self.model1.forward_raw(volume_batch)
             o2 = self.model2.forward_raw(volume_batch)
-            t = self.ema_model.forward_raw(self._ema_in)
+            t = self.ema_model.forward_raw(self._ema_in, no_backward=True)
         lab = label_batch[:L].contiguous()
         w_cps, w_mt = self.weights()
         ops.cross_teaching_tail(o1, o2, lab, L, self.out1, dlogits=self.model1.logits_grad_buffer(),

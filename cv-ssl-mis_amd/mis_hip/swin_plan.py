@@ -18,6 +18,7 @@ from .plan import Act, defer, run_deferred, flush_deferred
 # separate element-wise passes (A/B timing, and the reference point of the fusion tests)
 LN_HEAD = os.environ.get("MIS_LN_HEAD", "1") != "0"        # last LayerNorm + output head in one pass (LnHeadOp)
 UNSHUFFLE = os.environ.get("MIS_LN_HEAD_UNSHUFFLE", "1") != "0"   # ... whose backward stores dx through FinalPatchExpand_X4's inverse shuffle
+EXPAND_HEAD = os.environ.get("MIS_EXPAND_HEAD", "1") != "0"       # ... and its forward inside the expand GEMM's epilogue
 FUSE = int(os.environ.get("MIS_SWIN_FUSE", "7"))      # bit 0: GELU forward, bit 1: GELU backward, bit 2: residual
 
 
@@ -97,7 +98,8 @@ class LinearOp:
     def fwd(self, ctx):
         bias = None if self.b is None else self.b.data
         if (FUSE & 1) and self.gelu is not None:
-            if tops.gemm_ex(self.x.t, self.w2, self.y.t, tops.EP_GELU_FWD, bias=bias, C2=self.gelu.y.t, b3=self._b3(ctx)):
+            pre = None if getattr(ctx, "no_backward", False) else self.y.t      # only the backward reads the pre-activation
+            if tops.gemm_ex(self.x.t, self.w2, pre, tops.EP_GELU_FWD, bias=bias, C2=self.gelu.y.t, b3=self._b3(ctx)):
                 self.gelu.skip_fwd = True
                 return
         if (FUSE & 4) and self.res is not None:
@@ -338,9 +340,16 @@ class ExpandLinearOp(LinearOp):
         super().__init__(x, y, w, None)
         self.sh, self.geo = sh, geo            # geo = (B, H, W, c, P)
         self.unshuffled_by_consumer = False    # set for one backward by the LnHeadOp that consumes ``sh``
+        self.ln_head = None                    # the LnHeadOp that consumes ``sh`` (set by the network): fused forward
 
     def fwd(self, ctx):
         B, H, W, c, P = self.geo
+        h = self.ln_head if EXPAND_HEAD else None
+        keep = None if getattr(ctx, "no_backward", False) else self.sh.t     # the shuffled tokens: only the backward reads them
+        if h is not None and tops.gemm_expand_ln_head(self.x.t, self.w2, keep, B, H, W, P, c, h.g.data, h.b.data, h.w2,
+                                                      h.mean, h.rstd, h.logits.t):
+            h.skip_fwd = True        # LayerNorm + output head ran in this GEMM's epilogue
+            return
         if not tops.gemm_expand(self.x.t, self.w2, self.sh.t, B, H, W, P, c, b3=self._b3(ctx)):
             super().fwd(ctx)
             tops.token_rearrange(self.y.t, self.sh.t, B, H, W, c, P, 1)
@@ -407,12 +416,16 @@ class LnHeadOp:
         self.mean = torch.empty(x.rows, dtype=torch.float32, device="cuda")
         self.rstd = torch.empty(x.rows, dtype=torch.float32, device="cuda")
         self.expand = None
+        self.skip_fwd = False
 
     @staticmethod
     def eligible(C, num_classes):
         return LN_HEAD and C % 4 == 0 and C <= 128 and 2 <= num_classes <= 4
 
     def fwd(self, ctx):
+        if self.skip_fwd:         # the expand GEMM's epilogue did this op's forward (mis_gemm_expand_ln_head)
+            self.skip_fwd = False
+            return
         ok = tops.ln_head_fwd(self.x.t, self.g.data, self.b.data, self.w2, self.mean, self.rstd, self.logits.t)
         assert ok
 

@@ -90,7 +90,10 @@ def _nt_split(A, b3, C, bias=None, accumulate=False, epilogue=0, E1=None, C2=Non
     M, K, lda = _mat(A)
     N = b3.N
     assert K == b3.K, (A.shape, b3.N, b3.K)
-    if ex is None:
+    if ex is None and C is None:       # EP_GELU_FWD without the pre-activation (a forward nobody differentiates)
+        assert epilogue == EP_GELU_FWD and C2 is not None
+        ldc, eH, eW, eP, ec = N, 0, 0, 0, 0
+    elif ex is None:
         Mc, Nc, ldc = _mat(C)
         assert (Mc, Nc) == (M, N), (C.shape, M, N)
         eH = eW = eP = ec = 0
@@ -191,7 +194,11 @@ def gemm_ex(A, B, C, epilogue, bias=None, E1=None, C2=None, rowscale=None, rows_
     L = _l.load()
     M, K, lda = _mat(A)
     N, K2, ldb = _mat(B)
-    Mc, Nc, ldc = _mat(C)
+    if C is None:          # EP_GELU_FWD only: the pre-activation is not kept (a forward nobody differentiates)
+        assert epilogue == EP_GELU_FWD
+        Mc, Nc, ldc = M, N, N
+    else:
+        Mc, Nc, ldc = _mat(C)
     assert K == K2 and (Mc, Nc) == (M, N)
     lde1 = _mat(E1)[2] if E1 is not None else 0
     ldc2 = _mat(C2)[2] if C2 is not None else 0
@@ -242,6 +249,33 @@ def gemm_expand(x, w, out, B, H, W, P, c, b3=None):
     if prof is not None:
         e1.record()
         prof.append((_nt_name(L, M, N, K, 0), 2.0 * M * N * K, e0, e1, 4.0 * (M * K + N * K + M * N)))
+    return True
+
+
+def gemm_expand_ln_head(x, w, out, B, H, W, P, c, gamma, beta, head_w, mean, rstd, logits5, eps=1e-5):
+    """FinalPatchExpand_X4's Linear + pixel shuffle + LayerNorm + output head in one launch (mis_gemm_expand_ln_head):
+    ``out`` [B H P W P, c] (None: the expanded tokens are not kept), mean / rstd per expanded token, logits5 [B, NC, 1, H P, W P].
+    False: outside the fused form."""
+    L = _l.load()
+    M, K, lda = _mat(x)
+    N, K2, ldb = _mat(w)
+    NC = logits5.shape[1]
+    assert K == K2 and M == B * H * W and N == P * P * c and (out is None or (out.is_contiguous() and out.numel() == M * N))
+    assert mean.numel() == M * P * P and rstd.numel() == M * P * P and tuple(head_w.shape) == (NC, c) and head_w.is_contiguous()
+    prof = _ops.PROFILE
+    if prof is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    st = L.mis_gemm_expand_ln_head(_l.ptr(x), lda, _l.ptr(w), ldb, _l.ptr(out), B, H, W, K, P, c, _l.ptr(gamma), _l.ptr(beta),
+                                   _l.ptr(head_w), NC, eps, _l.ptr(mean), _l.ptr(rstd), _l.ptr(logits5), logits5.stride(0),
+                                   _l.stream_ptr())
+    if st == -2:
+        return False
+    _l.check(st, "mis_gemm_expand_ln_head")
+    if prof is not None:
+        e1.record()
+        prec = 1 if (set_split_precision(-1) & 1) else 0
+        prof.append((f"gemm_nt_kernel<64, 96, 4, {prec}>", 2.0 * M * N * K, e0, e1, 4.0 * (M * K + N * K + (M * N if out is not None else 0))))
     return True
 
 

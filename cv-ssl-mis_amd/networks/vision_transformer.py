@@ -299,6 +299,8 @@ class SwinUnet(HipNet):
             head = sp.LnHeadOp(sh, Pn("swin_unet.up.norm.weight"), Pn("swin_unet.up.norm.bias"),
                                Pn("swin_unet.output.weight"), plan.out)
             head.expand = expand if isinstance(expand, sp.ExpandLinearOp) else None
+            if head.expand is not None:
+                head.expand.ln_head = head
             plan.add(head)
         else:
             xf = self._expand(plan, "swin_unet.up", xu, None, B, pr, E, 4)

@@ -38,7 +38,7 @@ def predict_slices(image, net, patch_size, slices_per_launch=16):
             inp = zoom_slices(vol, patch_size)                                   # [Z, 1, ph, pw]
             pred = torch.empty((Z, patch_size[0], patch_size[1]), dtype=torch.uint8, device="cuda")
             for z0 in range(0, Z, slices_per_launch):
-                logits = net.forward_raw(inp[z0:z0 + slices_per_launch].contiguous())   # [n, C, 1, ph, pw]
+                logits = net.forward_raw(inp[z0:z0 + slices_per_launch].contiguous(), no_backward=True)   # [n, C, 1, ph, pw]
                 ops.argmax_channels(logits, pred[z0:z0 + logits.shape[0]].view(-1))
             back = zoom_slices(pred.float(), (x, y))                             # labels are small integers: exact
             prediction = back[:, 0].to(torch.uint8).cpu().numpy()

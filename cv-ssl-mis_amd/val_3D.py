@@ -59,7 +59,7 @@ def test_single_case(net, image, stride_xy, stride_z, patch_size, num_classes=1,
             for first in range(0, len(windows), windows_per_launch):
                 group = windows[first:first + windows_per_launch]
                 batch = torch.stack([vol[win] for win in group]).unsqueeze(1)            # [n, 1, *patch]
-                logits = net.forward_raw(batch.contiguous())
+                logits = net.forward_raw(batch.contiguous(), no_backward=True)
                 probs = torch.empty_like(logits)
                 ops.softmax_mean_accumulate(logits, probs, 1, 1.0, first=True)           # softmax over the classes
                 probs = probs.reshape((len(group), num_classes) + tuple(patch_size))

@@ -457,6 +457,15 @@ int mis_gemm_set_split_precision(int mask);
 /* the TN kernel mis_gemm(trans = 1) / mis_gemm_dw run this shape and these operands with, as a profiler names it */
 int mis_gemm_tn_kernel_name(const float* A, long long lda, const float* B, long long ldb, const float* C, long long ldc,
                             int M, int N, int K, char* name, int name_len);
+/* mis_gemm_expand for FinalPatchExpand_X4 (c = 96) with its LayerNorm and the bias-free 1 x 1 output convolution in the GEMM's
+ * epilogue (:401-409 `x = self.expand(x)`, `rearrange`, `x = self.norm(x)`; :749-752 `self.output(x)`): a 96-wide tile is one
+ * (p1, p2), its rows are whole tokens of the shuffled tensor.  Writes mean / rstd per shuffled token (for mis_ln_head_bwd*),
+ * logits [B][NC][H P][W P] (batch stride logits_bs floats) and, when `out` is not NULL, the shuffled tokens (dense
+ * [B H P W P][96]: what the backward reads; NULL for a forward nobody differentiates).  Same bits as mis_gemm_expand +
+ * mis_ln_head_fwd.  MIS_ERR_UNSUPPORTED: c != 96, NC outside 2..4, or a shape mis_gemm_expand refuses */
+int mis_gemm_expand_ln_head(const float* x, long long lda, const float* W, long long ldb, float* out, int B, int H, int Wd,
+                            int K, int P, int c, const float* gamma, const float* beta, const float* head_w, int NC,
+                            float eps, float* mean, float* rstd, float* logits, long long logits_bs, mis_stream_t stream);
 /* The NT form with a pre-split B operand.  The bf16x3 kernels cut every fp32 operand into three bf16 pieces; for B = an
  * nn.Linear weight (forward: F.linear(x, W), swin_transformer_unet_skip_expand_decoder_sys.py:14,16,107,109; data gradient:
  * dy . W, i.e. B = W^T) that cut is the same for every tile of the launch and every launch of the step, so it is done once:

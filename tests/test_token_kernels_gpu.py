@@ -650,3 +650,34 @@ def test_layernorm_backward_with_the_residual_backward_in_one_pass(M, C, B):
                 tops.layernorm_bwd_final(ws, M, C, dg2, db2)
                 assert torch.equal(ds1, ds2) and torch.equal(dbr1, dbr2), (has_gin, scales is not None, acc)
                 assert torch.equal(dg1, dg2) and torch.equal(db1, db2)
+
+
+@pytest.mark.parametrize("B,H,W,NC,keep", [(2, 56, 56, 4, True), (1, 20, 12, 2, True), (3, 14, 14, 3, False)])
+@pytest.mark.parametrize("prec2", [0, 7], ids=["fp32mfma", "bf16x3"])
+def test_final_expand_layernorm_and_head_in_the_gemm_epilogue(B, H, W, NC, keep, prec2):
+    """mis_gemm_expand_ln_head against mis_gemm_expand + mis_ln_head_fwd: shuffled tokens, mean / rstd and logits bit for bit
+    (same arithmetic term for term); ``out`` NULL keeps only what the loss needs."""
+    tops = _t()
+    prev = tops.set_split_precision(prec2)
+    try:
+        P, c, K = 4, 96, 96
+        M = B * H * W
+        x, w = _rand(M, K, seed=61).cuda(), (_rand(P * P * c, K, seed=62) * 0.1).cuda()
+        g, b = (1 + 0.2 * _rand(c, seed=63)).cuda(), (0.1 * _rand(c, seed=64)).cuda()
+        hw = _rand(NC, c, seed=65, scale=0.3).cuda()
+        T = M * P * P
+        sh0 = torch.empty(T, c, device="cuda")
+        assert tops.gemm_expand(x, w, sh0, B, H, W, P, c)
+        m0, r0 = torch.empty(T, device="cuda"), torch.empty(T, device="cuda")
+        lg0 = torch.empty(B, NC, 1, H * P, W * P, device="cuda")
+        assert tops.ln_head_fwd(sh0, g, b, hw, m0, r0, lg0)
+        sh1 = torch.full((T, c), float("nan"), device="cuda") if keep else None
+        m1, r1 = torch.full((T,), float("nan"), device="cuda"), torch.full((T,), float("nan"), device="cuda")
+        lg1 = torch.full((B, NC, 1, H * P, W * P), float("nan"), device="cuda")
+        assert tops.gemm_expand_ln_head(x, w, sh1, B, H, W, P, c, g, b, hw, m1, r1, lg1)
+        if keep:
+            assert torch.equal(sh0, sh1)
+        assert torch.equal(m0, m1) and torch.equal(r0, r1)
+        assert torch.equal(lg0, lg1)
+    finally:
+        tops.set_split_precision(prev)
