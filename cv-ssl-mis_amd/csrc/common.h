@@ -164,6 +164,48 @@ __device__ __forceinline__ float mis_group_sum(float v) {
     return v;
 }
 
+// Sum over the 8 lanes of a row group (the first three steps of mis_group_sum), result in every lane.
+__device__ __forceinline__ float mis_sum8(float v) {
+    v += mis_dpp_f(v, 0);
+    v += mis_dpp_f(v, 1);
+    v += mis_dpp_f(v, 2);
+    return v;
+}
+
+// LayerNorm over C = 96 channels + NC <= 4 head dot products for ONE token row held by 8 lanes: lane l8 owns the float4 groups
+// l8, l8 + 8, l8 + 16 of the row (12 channels; no idle lane, 3-step reductions -- the 32-lane form of ln_head_fwd_kernel spends
+// 6 x 6 cross-lane steps per row on 24 active lanes and was the bound of that kernel, not its bytes).  Shared by
+// ln96_head_fwd_kernel (token_ops.hip) and the EP_LNHEAD epilogue of gemm_nt_kernel (gemm.hip): same expression, same bits.
+template <int NCM>
+__device__ __forceinline__ void mis_ln96_head_row(const float4 (&v)[3], const float4 (&g)[3], const float4 (&bt)[3],
+                                                  const float4 (&wv)[NCM][3], float eps, float& mu, float& rs,
+                                                  float (&pl)[NCM]) {
+    float s = 0.f;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) s += (v[q].x + v[q].y) + (v[q].z + v[q].w);
+    mu = mis_sum8(s) / 96.f;
+    float4 a[3];
+    float ss = 0.f;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        a[q] = make_float4(v[q].x - mu, v[q].y - mu, v[q].z - mu, v[q].w - mu);
+        ss += (a[q].x * a[q].x + a[q].y * a[q].y) + (a[q].z * a[q].z + a[q].w * a[q].w);
+    }
+    rs = 1.f / sqrtf(mis_sum8(ss) / 96.f + eps);
+    float4 y[3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+        y[q] = make_float4(a[q].x * rs * g[q].x + bt[q].x, a[q].y * rs * g[q].y + bt[q].y, a[q].z * rs * g[q].z + bt[q].z,
+                           a[q].w * rs * g[q].w + bt[q].w);
+#pragma unroll
+    for (int n = 0; n < NCM; ++n) {
+        float p = 0.f;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) p += (y[q].x * wv[n][q].x + y[q].y * wv[n][q].y) + (y[q].z * wv[n][q].z + y[q].w * wv[n][q].w);
+        pl[n] = mis_sum8(p);
+    }
+}
+
 __device__ __forceinline__ float mis_wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

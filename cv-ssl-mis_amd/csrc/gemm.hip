@@ -409,7 +409,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs a) {
     if constexpr (EP == EP_LNHEAD) {
         // FinalPatchExpand_X4 + its LayerNorm + the output head (reference ...sys.py:401-409, :671, :749-752) on the tile: BN = c =
         // 96, so the tile's columns are one (p1, p2) and a tile row is one token of the pixel-shuffled tensor.  Rows through LDS;
-        // 32 lanes per row (24 hold a float4), the arithmetic of ln_head_fwd_kernel (token_ops.hip) term for term: same bits.
+        // the row arithmetic is ln96_head_fwd_kernel's (token_ops.hip): same bits.
         static_assert(BN == 96, "a tile row is one expanded token");
         float* const ct = lds;
 #pragma unroll
@@ -420,34 +420,38 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs a) {
                 for (int r = 0; r < 4; ++r)
                     ct[(wm + i * 16 + lk * 4 + r) * G::LDC_T + wn + j * 16 + lj] = acc[i][j][r];
         __syncthreads();
-        const int l32 = tid & 31, rg = tid >> 5, c4 = l32 * 4;
-        const bool act = c4 < BN;
+        // 8 lanes per token row (mis_ln96_head_row, common.h): 32 rows per pass
+        const int l8 = tid & 7, rg = tid >> 3;
         constexpr int NCM = 4;
-        float4 g = make_float4(0.f, 0.f, 0.f, 0.f), bt = g, wv[NCM];
-        if (act) { g = *reinterpret_cast<const float4*>(a.ln_g + c4); bt = *reinterpret_cast<const float4*>(a.ln_b + c4); }
+        float4 g[3], bt[3], wv[NCM][3];
 #pragma unroll
-        for (int n = 0; n < NCM; ++n)
-            wv[n] = (act && n < a.head_nc) ? *reinterpret_cast<const float4*>(a.head_w + n * BN + c4) : make_float4(0.f, 0.f, 0.f, 0.f);
-        const int P = a.ex_P, pp = n0 / BN, p1 = pp / P, p2 = pp - p1 * P;
-        const long long S = (long long)a.ex_H * P * a.ex_W * P;
-        for (int it = 0; it < BMT / 8; ++it) {
-            const int row = it * 8 + rg, m = m0 + row;
-            if (m >= a.M) continue;        // uniform within the row group
-            const float4 v = act ? *reinterpret_cast<const float4*>(&ct[row * G::LDC_T + c4]) : make_float4(0.f, 0.f, 0.f, 0.f);
-            const float mu = mis_group_sum<32>((v.x + v.y) + (v.z + v.w)) / (float)BN;
-            const float a0 = v.x - mu, a1 = v.y - mu, a2 = v.z - mu, a3 = v.w - mu;
-            const float ss = act ? (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3) : 0.f;
-            const float rs = 1.f / sqrtf(mis_group_sum<32>(ss) / (float)BN + a.ln_eps);
-            const float y0 = a0 * rs * g.x + bt.x, y1 = a1 * rs * g.y + bt.y, y2 = a2 * rs * g.z + bt.z, y3 = a3 * rs * g.w + bt.w;
-            float pl[NCM];
+        for (int q = 0; q < 3; ++q) {
+            const int c4 = (l8 + 8 * q) * 4;
+            g[q] = *reinterpret_cast<const float4*>(a.ln_g + c4);
+            bt[q] = *reinterpret_cast<const float4*>(a.ln_b + c4);
 #pragma unroll
             for (int n = 0; n < NCM; ++n)
-                pl[n] = mis_group_sum<32>((y0 * wv[n].x + y1 * wv[n].y) + (y2 * wv[n].z + y3 * wv[n].w));
+                wv[n][q] = n < a.head_nc ? *reinterpret_cast<const float4*>(a.head_w + n * BN + c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        const int P = a.ex_P, pp = n0 / BN, p1 = pp / P, p2 = pp - p1 * P;
+        const long long S = (long long)a.ex_H * P * a.ex_W * P;
+#pragma unroll
+        for (int it = 0; it < BMT / 32; ++it) {
+            const int row = it * 32 + rg, m = m0 + row;
+            if (m >= a.M) continue;        // uniform within the row group
+            float4 v[3];
+#pragma unroll
+            for (int q = 0; q < 3; ++q) v[q] = *reinterpret_cast<const float4*>(&ct[row * G::LDC_T + (l8 + 8 * q) * 4]);
+            float mu, rs, pl[NCM];
+            mis_ln96_head_row<NCM>(v, g, bt, wv, a.ln_eps, mu, rs, pl);
             const int w_ = m % a.ex_W, tt = m / a.ex_W, h_ = tt % a.ex_H, b_ = tt / a.ex_H;
             const long long pix = ((long long)h_ * P + p1) * ((long long)a.ex_W * P) + (long long)w_ * P + p2;
             const long long tok = (long long)b_ * S + pix;
-            if (a.C && act) *reinterpret_cast<float4*>(a.C + tok * BN + c4) = v;
-            if (l32 == 0) {
+            if (a.C) {
+#pragma unroll
+                for (int q = 0; q < 3; ++q) *reinterpret_cast<float4*>(a.C + tok * BN + (l8 + 8 * q) * 4) = v[q];
+            }
+            if (l8 == 0) {
                 a.ln_mean[tok] = mu; a.ln_rstd[tok] = rs;
 #pragma unroll
                 for (int n = 0; n < NCM; ++n)

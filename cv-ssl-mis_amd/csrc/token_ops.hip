@@ -747,6 +747,59 @@ __global__ __launch_bounds__(256) void ln_head_fwd_kernel(const float* __restric
     }
 }
 
+// C = 96 (SwinUnet's tail): 8 lanes per token row, three float4 per lane (mis_ln96_head_row, common.h) -- no idle lanes, 3-step
+// reductions; 32 rows per pass, RU passes in flight.  The logits of a pass are 32 consecutive pixels per class: staged through LDS
+// and stored as 128-byte pieces.
+template <int NC>
+__global__ __launch_bounds__(256) void ln96_head_fwd_kernel(const float* __restrict__ x, long long ldx,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                            const float* __restrict__ w, float* __restrict__ mean,
+                                                            float* __restrict__ rstd, float* __restrict__ y, long long y_bs,
+                                                            long long M, long long S, float eps) {
+    constexpr int RU = 2, NCM = 4;
+    const int l8 = threadIdx.x & 7, rg = threadIdx.x >> 3;
+    float4 g[3], bt[3], wv[NCM][3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        const int c4 = (l8 + 8 * q) * 4;
+        g[q] = *reinterpret_cast<const float4*>(gamma + c4);
+        bt[q] = *reinterpret_cast<const float4*>(beta + c4);
+#pragma unroll
+        for (int n = 0; n < NCM; ++n) wv[n][q] = n < NC ? *reinterpret_cast<const float4*>(w + n * 96 + c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    __shared__ float sl[NC][32 * RU];
+    for (long long base = blockIdx.x * (32LL * RU); base < M; base += (long long)gridDim.x * 32 * RU) {
+        float4 vv[RU][3];
+#pragma unroll
+        for (int u = 0; u < RU; ++u) {
+            const long long row = base + 32 * u + rg < M ? base + 32 * u + rg : M - 1;
+#pragma unroll
+            for (int q = 0; q < 3; ++q) vv[u][q] = *reinterpret_cast<const float4*>(x + row * ldx + (l8 + 8 * q) * 4);
+        }
+#pragma unroll
+        for (int u = 0; u < RU; ++u) {
+            const long long row = base + 32 * u + rg;
+            float mu, rs, pl[NCM];
+            mis_ln96_head_row<NCM>(vv[u], g, bt, wv, eps, mu, rs, pl);
+            if (l8 == 0) {
+                if (row < M) { mean[row] = mu; rstd[row] = rs; }
+#pragma unroll
+                for (int n = 0; n < NC; ++n) sl[n][u * 32 + rg] = pl[n];
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x < NC * 32 * RU) {
+            const int n = threadIdx.x / (32 * RU), j = threadIdx.x % (32 * RU);
+            const long long row = base + j;
+            if (row < M) {
+                const long long b = row / S, pix = row - b * S;
+                y[b * y_bs + (long long)n * S + pix] = sl[n][j];
+            }
+        }
+        __syncthreads();
+    }
+}
+
 // one block per slab of rows; partial column sums per slab: pln[slab][c] = (sum dy xhat, sum dy), pw[slab][n][c] = sum dl_n y_c
 template <int NC>
 __global__ __launch_bounds__(256) void ln_head_bwd_kernel(const float* __restrict__ x, long long ldx,
@@ -850,6 +903,114 @@ __global__ __launch_bounds__(256) void ln_head_bwd_kernel(const float* __restric
     for (int n = 0; n < NC; ++n) {
         const float4 sw_ = combine(aw[n]);
         if (rg == 0 && act) *reinterpret_cast<float4*>(pw + ((long long)blockIdx.x * NC + n) * C + c) = sw_;
+    }
+}
+
+// ln_head_bwd_kernel for C = 96 with 8 lanes per token row and three float4 per lane (as ln96_head_fwd_kernel): two 3-step
+// reductions per row instead of two 6-step ones on 24 of 32 lanes, 32 rows per pass.  Same partial layout (one row per slab).
+template <int NC>
+__global__ __launch_bounds__(256) void ln96_head_bwd_kernel(const float* __restrict__ x, long long ldx,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                            const float* __restrict__ w, const float* __restrict__ mean,
+                                                            const float* __restrict__ rstd, const float* __restrict__ dl,
+                                                            long long dl_bs, float* __restrict__ dx, long long lddx,
+                                                            int accumulate, long long M, long long S, long long rows_per_slab,
+                                                            float2* __restrict__ pln, float* __restrict__ pw, int ex_P, int ex_H,
+                                                            int ex_W) {
+    constexpr int C = 96;
+    __shared__ float4 red[256];
+    const int l8 = threadIdx.x & 7, rg = threadIdx.x >> 3;
+    float4 g[3], bt[3], wv[NC][3], aw[NC][3], dg[3], db[3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        const int c4 = (l8 + 8 * q) * 4;
+        g[q] = *reinterpret_cast<const float4*>(gamma + c4);
+        bt[q] = *reinterpret_cast<const float4*>(beta + c4);
+        dg[q] = make_float4(0.f, 0.f, 0.f, 0.f); db[q] = dg[q];
+#pragma unroll
+        for (int n = 0; n < NC; ++n) {
+            wv[n][q] = *reinterpret_cast<const float4*>(w + n * C + c4);
+            aw[n][q] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    const long long r0 = blockIdx.x * rows_per_slab;
+    long long r1 = r0 + rows_per_slab;
+    if (r1 > M) r1 = M;
+    for (long long row = r0 + rg; row < r1; row += 32) {
+        const long long b = row / S, pix = row - b * S;
+        float d[NC];
+#pragma unroll
+        for (int n = 0; n < NC; ++n) d[n] = dl[b * dl_bs + (long long)n * S + pix];
+        const float m = mean[row], rs = rstd[row];
+        float4 v[3];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) v[q] = *reinterpret_cast<const float4*>(x + row * ldx + (l8 + 8 * q) * 4);
+        float4 h[3], qv[3];
+        float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            h[q] = make_float4((v[q].x - m) * rs, (v[q].y - m) * rs, (v[q].z - m) * rs, (v[q].w - m) * rs);          // xhat
+            const float4 y = make_float4(h[q].x * g[q].x + bt[q].x, h[q].y * g[q].y + bt[q].y, h[q].z * g[q].z + bt[q].z,
+                                         h[q].w * g[q].w + bt[q].w);
+            float4 e = make_float4(0.f, 0.f, 0.f, 0.f);                                                             // dy
+#pragma unroll
+            for (int n = 0; n < NC; ++n) {
+                const float dn = d[n];
+                e.x += dn * wv[n][q].x; e.y += dn * wv[n][q].y; e.z += dn * wv[n][q].z; e.w += dn * wv[n][q].w;
+                aw[n][q].x += dn * y.x; aw[n][q].y += dn * y.y; aw[n][q].z += dn * y.z; aw[n][q].w += dn * y.w;
+            }
+            dg[q].x += e.x * h[q].x; dg[q].y += e.y * h[q].y; dg[q].z += e.z * h[q].z; dg[q].w += e.w * h[q].w;
+            db[q].x += e.x; db[q].y += e.y; db[q].z += e.z; db[q].w += e.w;
+            qv[q] = make_float4(e.x * g[q].x, e.y * g[q].y, e.z * g[q].z, e.w * g[q].w);
+            t1 += (qv[q].x + qv[q].y) + (qv[q].z + qv[q].w);
+            t2 += (qv[q].x * h[q].x + qv[q].y * h[q].y) + (qv[q].z * h[q].z + qv[q].w * h[q].w);
+        }
+        const float s1 = mis_sum8(t1) / (float)C, s2 = mis_sum8(t2) / (float)C;
+        float* orow = dx + row * lddx;
+        if (ex_P) {
+            const int WP = ex_W * ex_P, pixi = (int)pix, yy = pixi / WP, xx = pixi - yy * WP;
+            const int hh = yy / ex_P, w_ = xx / ex_P;
+            const int p1 = yy - hh * ex_P, p2 = xx - w_ * ex_P;
+            orow = dx + ((b * ex_H + hh) * ex_W + w_) * lddx + (p1 * ex_P + p2) * C;
+        }
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            float4 o = make_float4(rs * (qv[q].x - s1 - h[q].x * s2), rs * (qv[q].y - s1 - h[q].y * s2),
+                                   rs * (qv[q].z - s1 - h[q].z * s2), rs * (qv[q].w - s1 - h[q].w * s2));
+            float* op = orow + (l8 + 8 * q) * 4;
+            if (accumulate) {
+                const float4 pv = *reinterpret_cast<const float4*>(op);
+                o.x += pv.x; o.y += pv.y; o.z += pv.z; o.w += pv.w;
+            }
+            *reinterpret_cast<float4*>(op) = o;
+        }
+    }
+    // the 32 row groups of the block, fixed order, one float4 quantity at a time through LDS
+    auto combine = [&](float4 val) -> float4 {
+        __syncthreads();
+        red[threadIdx.x] = val;
+        __syncthreads();
+        float4 sres = red[l8];
+#pragma unroll 8
+        for (int k = 1; k < 32; ++k) {
+            const float4 pv = red[k * 8 + l8];
+            sres.x += pv.x; sres.y += pv.y; sres.z += pv.z; sres.w += pv.w;
+        }
+        return sres;
+    };
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        const float4 sg = combine(dg[q]), sb = combine(db[q]);
+        if (rg == 0) {
+            float2* o = pln + (long long)blockIdx.x * C + (l8 + 8 * q) * 4;
+            o[0] = make_float2(sg.x, sb.x); o[1] = make_float2(sg.y, sb.y);
+            o[2] = make_float2(sg.z, sb.z); o[3] = make_float2(sg.w, sb.w);
+        }
+#pragma unroll
+        for (int n = 0; n < NC; ++n) {
+            const float4 sw_ = combine(aw[n][q]);
+            if (rg == 0) *reinterpret_cast<float4*>(pw + ((long long)blockIdx.x * NC + n) * C + (l8 + 8 * q) * 4) = sw_;
+        }
     }
 }
 
@@ -1225,6 +1386,16 @@ extern "C" int mis_ln_head_fwd(const float* x, long long ldx, const float* gamma
     if (!x || !gamma || !beta || !w || !mean || !rstd || !logits || B <= 0 || S <= 0 || C <= 0) return MIS_ERR_ARG;
     if (C % 4 || C > 128 || ldx % 4 || !a16(x) || !a16(gamma) || !a16(beta) || !a16(w)) return MIS_ERR_UNSUPPORTED;
     const long long M = (long long)B * S;
+    static const bool l8 = !(getenv("MIS_LN96_LANES8") && getenv("MIS_LN96_LANES8")[0] == '0');
+    if (C == 96 && l8 && NC >= 2 && NC <= 4) {
+        long long blocks8 = mis_cdiv(M, 64);
+        if (blocks8 > 8192) blocks8 = 8192;
+#define MIS_LNH_F8(N_) hipLaunchKernelGGL(ln96_head_fwd_kernel<N_>, dim3((unsigned)blocks8), dim3(256), 0, stream, x, ldx, gamma, \
+                                          beta, w, mean, rstd, logits, y_bs, M, S, eps)
+        if (NC == 2) MIS_LNH_F8(2); else if (NC == 3) MIS_LNH_F8(3); else MIS_LNH_F8(4);
+#undef MIS_LNH_F8
+        return mis_launch_status();
+    }
     long long blocks = mis_cdiv(M, 32);
     if (blocks > 8192) blocks = 8192;
 #define MIS_LNH_F(N_) hipLaunchKernelGGL(ln_head_fwd_kernel<N_>, dim3((unsigned)blocks), dim3(256), 0, stream, x, ldx, gamma, \
@@ -1288,8 +1459,19 @@ static int ln_head_bwd_impl(const float* x, long long ldx, const float* gamma, c
     const int slabs = (int)mis_cdiv(M, COL_SLAB_ROWS);
     float2* pln = reinterpret_cast<float2*>(workspace);
     float* pw = reinterpret_cast<float*>(pln + (long long)slabs * C);
+    static const bool l8 = !(getenv("MIS_LN96_LANES8") && getenv("MIS_LN96_LANES8")[0] == '0');
+#define MIS_LNH_B8(N_) hipLaunchKernelGGL(ln96_head_bwd_kernel<N_>, dim3(slabs), dim3(256), 0, stream, x, ldx, gamma, beta, w, mean, \
+                                          rstd, dlogits, dl_bs, dx, lddx, accumulate_dx, M, S, (long long)COL_SLAB_ROWS, pln, pw, ex_P, ex_H, ex_W)
 #define MIS_LNH_B(N_) hipLaunchKernelGGL(ln_head_bwd_kernel<N_>, dim3(slabs), dim3(256), 0, stream, x, ldx, gamma, beta, w, mean, \
                                          rstd, dlogits, dl_bs, dx, lddx, accumulate_dx, M, S, C, (long long)COL_SLAB_ROWS, pln, pw, ex_P, ex_H, ex_W)
+    if (C == 96 && l8) {
+        switch (NC) {
+            case 2: MIS_LNH_B8(2); break;
+            case 3: MIS_LNH_B8(3); break;
+            case 4: MIS_LNH_B8(4); break;
+            default: return MIS_ERR_UNSUPPORTED;
+        }
+    } else
     switch (NC) {
         case 2: MIS_LNH_B(2); break;
         case 3: MIS_LNH_B(3); break;
