@@ -173,3 +173,26 @@ def test_residual_backward_inside_the_layernorm_backward_is_bit_identical(monkey
         res.append(grads)
     for a, b in zip(*res):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("kind,shape,C", [("swin", (2, 1, 224, 224), 4), ("unet3d", (2, 1, 32, 32, 32), 2), ("unetr", (1, 1, 96, 96, 96), 2)])
+def test_forward_nobody_differentiates_gives_the_same_logits_and_refuses_backward(kind, shape, C):
+    """forward_raw(no_backward=True) -- the EMA teacher, validation -- drops what only a backward reads (SwinUnet: the MLPs'
+    pre-activations, the 16x expanded tokens of the tail); the logits are the same bits, and backward_raw() after it raises
+    instead of differentiating through buffers that were not written."""
+    torch.manual_seed(3)
+    model = _make(kind, C)
+    model.train()
+    model.dropout_enabled = False
+    x = torch.rand(shape, device="cuda")
+    a = model.forward_raw(x).clone()
+    b = model.forward_raw(x, no_backward=True).clone()
+    assert torch.equal(a, b)
+    with pytest.raises(RuntimeError, match="no_backward"):
+        model.backward_raw()
+    model.forward_raw(x)
+    dl = model.logits_grad_buffer()
+    dl.copy_(torch.randn(dl.shape, device="cuda") * 0.1)
+    model.backward_raw()
+    torch.cuda.synchronize()
+    assert torch.isfinite(model.flat_grad).all()
