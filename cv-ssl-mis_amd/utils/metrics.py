@@ -43,6 +43,14 @@ def hd95(result, reference, voxelspacing=None, connectivity=1):
     return float(np.percentile(np.hstack((hd1, hd2)), 95))
 
 
+def hd(result, reference, voxelspacing=None, connectivity=1):
+    """Hausdorff distance: the larger of the two directed maximum surface distances (medpy.metric.binary.hd) --
+    code/test_CNNVIT.py:37 (which names it ``hd95``)."""
+    hd1 = _surface_distances(result, reference, voxelspacing, connectivity).max()
+    hd2 = _surface_distances(reference, result, voxelspacing, connectivity).max()
+    return float(max(hd1, hd2))
+
+
 def asd(result, reference, voxelspacing=None, connectivity=1):
     """Average surface distance: mean distance of the surface voxels of ``result`` to the surface of ``reference``
     (medpy.metric.binary.asd; not symmetric) -- code/test_3D_util.py:147-152."""

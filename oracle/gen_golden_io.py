@@ -15,6 +15,7 @@ What is run, on closed-form / seeded inputs, and stored as data (arrays, index s
 
   val2d.npz    val_2D.test_single_volume        (code/val_2D.py:18-39)   around the real networks.unet.UNet
   val3d.npz    val_3D.test_single_case          (code/val_3D.py:14-79)   around the real networks.unet_3D.unet_3D
+  cnnvit_infer.npz  test_CNNVIT.test_single_volume (code/test_CNNVIT.py:43-79) around the real SwinUnet and the real UNet
   aug2d.npz    dataloaders.dataset.RandomGenerator.__call__   (code/dataloaders/dataset.py:406-425)
   aug3d.npz    dataloaders.brats2019.RandomRotFlip -> RandomCrop -> ToTensor (code/dataloaders/brats2019.py:80-147,196-208)
   sampler.npz  dataloaders.dataset.TwoStreamBatchSampler (+ the brats2019 twin)  (dataset.py:247-294)
@@ -52,7 +53,7 @@ def install_stubs():
         RECORDED.append((np.array(pred, copy=True), np.array(gt, copy=True)))
         return 0.0
 
-    binary = mod("medpy.metric.binary", dc=dc, hd95=lambda pred, gt: 0.0, asd=lambda pred, gt: 0.0)
+    binary = mod("medpy.metric.binary", dc=dc, hd95=lambda pred, gt: 0.0, asd=lambda pred, gt: 0.0, hd=lambda pred, gt: 0.0)
     metric = mod("medpy.metric", binary=binary)
     mod("medpy", metric=metric)
     for name in ("h5py", "nibabel", "SimpleITK", "cv2"):
@@ -183,6 +184,90 @@ def gen_val3d():
     np.savez_compressed(os.path.join(GOLD, "val3d.npz"), **out)
 
 
+# --------------------------------------------------------------------------------------------------- test_CNNVIT.py
+CNNVIT = dict(shape=(3, 50, 44), classes=4, image="cnnvitimg", case="patient101_frame01")
+
+
+def gen_cnnvit_infer():
+    """The label maps the REAL ``test_CNNVIT.test_single_volume`` (code/test_CNNVIT.py:43-79: slice-wise nearest zoom to 224 x
+    224, forward, arg-max of the softmax, nearest zoom back) builds around the REAL SwinUnet and the REAL UNet.  Importing the
+    script runs its top-level imports: ``h5py`` / ``SimpleITK`` / ``nibabel`` / ``medpy`` are stand-ins (h5py.File serves the
+    filler volume, SimpleITK swallows the three NIfTI writes, medpy records the masks), ``config`` (yacs, absent) and
+    ``networks.net_factory`` (module-level argparse + ten other backbones) are empty stand-ins that ``test_single_volume``
+    never touches."""
+    from types import SimpleNamespace as NS
+    from scipy.ndimage import zoom
+    from oracle.gen_golden import build_reference
+    Z, X, Y = CNNVIT["shape"]
+    C = CNNVIT["classes"]
+    image = filler.image((1,) + CNNVIT["shape"], CNNVIT["image"])[0].numpy()
+    label = filler.labels(CNNVIT["shape"], C, torch.uint8).numpy()
+
+    class H5:
+        def __init__(self, path, mode):
+            assert path.endswith("/data/{}.h5".format(CNNVIT["case"])) and mode == "r", path
+            self.d = {"image": image, "label": label}
+
+        def __getitem__(self, k):
+            return self.d[k]
+
+    sys.modules["h5py"].File = H5
+    itk = sys.modules["SimpleITK"]
+    itk.GetImageFromArray = lambda a: NS(SetSpacing=lambda s: None)
+    itk.WriteImage = lambda img, path: None
+    for name, attrs in (("config", dict(get_config=lambda a: None)),
+                        ("networks.net_factory", dict(net_factory=None, config=None, args=None))):
+        m = types.ModuleType(name)
+        m.__dict__.update(attrs)
+        sys.modules[name] = m
+    swin = build_reference("swin", 1, C)          # installs the timm shim, puts REF on sys.path
+    import test_CNNVIT as ref
+    unet = build_reference("unet2d", 1, C)
+    out = dict(shape=np.array(CNNVIT["shape"]), classes=C, image_sum=float(image.astype(np.float64).sum()),
+               label_sum=int(label.astype(np.int64).sum()))
+    for tag, net, head, scale in (("swin", swin, "swin_unet.output.weight", 60.0), ("unet", unet, "decoder.out_conv.weight", 400.0)):
+        sd = filler.fill_state_dict(net.state_dict())
+        sd[head] = sd[head] * scale                   # confident predictions
+        net.load_state_dict(sd)
+        if tag == "unet":
+            # classifier bias (3 decimals, stored in the fixture) balanced so that every class wins a share of the pixels
+            sd["decoder.out_conv.bias"] = torch.zeros(C)
+            net.load_state_dict(sd)
+            net.eval()
+            with torch.no_grad():
+                lg = torch.cat([net(torch.from_numpy(zoom(sl, (224 / X, 224 / Y), order=0))[None, None].float()) for sl in image])
+            bias = -lg.mean((0, 2, 3))
+            spread = float(lg.std())
+            for _ in range(200):
+                share = torch.bincount((lg + bias.view(1, C, 1, 1)).argmax(1).flatten(), minlength=C).float() / lg[:, 0].numel()
+                bias = bias + 0.5 * spread * (1.0 / C - share)
+            out["out_bias_unet"] = (torch.round(bias * 1000) / 1000).numpy()
+            sd["decoder.out_conv.bias"] = torch.from_numpy(out["out_bias_unet"]).clone()
+            net.load_state_dict(sd)
+        rec = Recording(net)
+        rec.train()                                   # test_single_volume switches to eval itself (:54)
+        del RECORDED[:]
+        metrics = ref.test_single_volume(CNNVIT["case"], rec, "/nonexistent/", NS(root_path="/nonexistent", model="unet"))
+        assert len(metrics) == 3 and len(RECORDED) == 3 and len(rec.logits) == Z and not rec.training
+        pred = np.zeros((Z, X, Y), np.uint8)
+        for i, (p, g) in enumerate(RECORDED, start=1):
+            # calculate_metric_percase binarises its arguments in place before dc() sees them: still the class-i masks
+            assert np.array_equal(g.astype(bool), label == i)
+            pred[p.astype(bool)] = i
+        ties = np.zeros((Z, X, Y), bool)
+        for z, lg in enumerate(rec.logits):
+            assert tuple(lg.shape) == (1, C, 224, 224)
+            pr = torch.softmax(lg, dim=1)[0]
+            top2 = torch.topk(pr, 2, dim=0).values
+            ties[z] = zoom(((top2[0] - top2[1]) < 1e-3).numpy().astype(np.uint8), (X / 224, Y / 224), order=0) > 0
+            want = zoom(pr.argmax(0).numpy(), (X / 224, Y / 224), order=0)
+            assert np.array_equal(want.astype(np.uint8), pred[z]), "recorded masks do not rebuild the reference prediction"
+        out[f"prediction_{tag}"], out[f"ties_{tag}"], out[f"weight_scale_{tag}"] = pred, ties, scale
+        out[f"logit_samples_{tag}"] = torch.stack(rec.logits)[:, 0].flatten()[::997].numpy()
+        print(f"cnnvit_infer {tag}: prediction classes", np.bincount(pred.ravel(), minlength=C), "ties", int(ties.sum()))
+    np.savez_compressed(os.path.join(GOLD, "cnnvit_infer.npz"), **out)
+
+
 # --------------------------------------------------------------------------------------------------- augmentations
 AUG2D = dict(seed=11, n=20, out=((48, 40), (64, 64)), lo=20, hi=70)
 AUG3D = dict(seed=12, patch=(16, 20, 12), shapes=((30, 26, 22), (23, 37, 15), (14, 40, 30), (16, 29, 16), (12, 11, 8)), n=12)
@@ -296,6 +381,7 @@ def main():
     gen_aug3d()
     gen_val2d()
     gen_val3d()
+    gen_cnnvit_infer()
 
 
 if __name__ == "__main__":

@@ -15,6 +15,19 @@ import torch
 import torch.nn.functional as F
 
 
+# Pre-activation hook (tests/test_parity_gpu.py, float64 gate): ``PRE_ACT(x) -> x`` is called on the input of every ReLU /
+# LeakyReLU of a forward that records gradients (the student's; the teacher runs under no_grad) in call order.  The gate uses
+# it to find the pre-activations that lie within fp32 rounding of zero and to re-evaluate the float64 step with their signs
+# reversed -- the same measurement oracle/gen_golden.py::reference_grads64 makes on the reference modules with forward hooks.
+PRE_ACT = None
+
+
+def _pre_act(x):
+    if PRE_ACT is None or not torch.is_grad_enabled():
+        return x
+    return PRE_ACT(x)
+
+
 def _dropout(x, p, training, drop, site):
     if not training or p == 0.0 or drop == "off":
         return x
@@ -83,7 +96,7 @@ class OracleUNet2D:
                 sd[f"{prefix}.{bn}.num_batches_tracked"] += 1
             x = F.batch_norm(x, sd[f"{prefix}.{bn}.running_mean"], sd[f"{prefix}.{bn}.running_var"],
                              sd[f"{prefix}.{bn}.weight"], sd[f"{prefix}.{bn}.bias"], training, 0.1, 1e-5)
-            x = F.leaky_relu(x, 0.01)
+            x = F.leaky_relu(_pre_act(x), 0.01)
             if pp is not None:
                 x = _dropout(x, pp, training, drop, site)
         return x
@@ -150,7 +163,7 @@ class OracleUNet3D:
     def _unetconv(self, sd, prefix, x):
         for sub in ("conv1", "conv2"):
             x = F.conv3d(x, sd[f"{prefix}.{sub}.0.weight"], sd[f"{prefix}.{sub}.0.bias"], padding=1)
-            x = F.relu(F.instance_norm(x, eps=1e-5))
+            x = F.relu(_pre_act(F.instance_norm(x, eps=1e-5)))
         return x
 
     def forward(self, sd, x, training=True, drop=None):
@@ -230,7 +243,7 @@ class OracleVNet:
             x = F.group_norm(x, 16, sd[bn + ".weight"], sd[bn + ".bias"], 1e-5)
         elif self.normalization == 'instancenorm':                                    # vnet.py:21-22
             x = F.instance_norm(x, eps=1e-5)
-        return F.relu(x)
+        return F.relu(_pre_act(x))
 
     def _block(self, sd, name, kind, stages, x, training):
         for s in range(stages):

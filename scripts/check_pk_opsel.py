@@ -8,7 +8,10 @@ round 5: cv-ssl-mis_amd/csrc/wino.h had one such instruction and every Winograd 
 waves returned wrong rows).  op_sel:[1,...] on src0 and same-register sources are fine.  Works on the built library (extracts the
 offload bundles, disassembles them): no recompilation.  tests/test_oracle_cpu.py runs it.
 
-    python scripts/check_pk_opsel.py [path/to/libmis_hip.so]        exit status 1 and the offending instructions when found"""
+    python scripts/check_pk_opsel.py [--patterns] [path/to/lib.so]        exit status 1 and the offending instructions when found
+
+Foreign libraries too (round 6: torch/lib/librccl.so, whose reduction kernels run beside this library's bf16 MFMA waves when the
+gradient buckets are all-reduced during the backward): ``--patterns`` lists every packed-fp32 operand pattern with its count."""
 import os
 import re
 import shutil
@@ -49,31 +52,129 @@ def scan_text(lines):
     return bad
 
 
-def scan_library(path):
+BUNDLER = "/opt/rocm/lib/llvm/bin/clang-offload-bundler"
+TARGET = "hipv4-amdgcn-amd-amdhsa--gfx950"
+
+
+def _fatbin_bundles(path):
+    """Byte ranges (offset, size) of the offload bundles inside the ``.hip_fatbin`` section of an ELF shared library: plain
+    ``__CLANG_OFFLOAD_BUNDLE__`` bundles (one per translation unit, 4 KiB aligned) or compressed ``CCOB`` ones (torch's
+    librccl.so ships ONE zstd bundle of 333 MB / 3.3 GB uncompressed for 13 architectures, on which
+    ``llvm-objdump --offloading`` dies with SIGSEGV)."""
+    import mmap
+    import struct
+    with open(path, "rb") as f:
+        m = mmap.mmap(f.fileno(), 0, access=mmap.ACCESS_READ)
+        shoff = struct.unpack_from("<Q", m, 0x28)[0]
+        entsize, shnum, shstrndx = struct.unpack_from("<HHH", m, 0x3A)
+        secs = [struct.unpack_from("<IIQQQQ", m, shoff + i * entsize) for i in range(shnum)]
+        stro = secs[shstrndx][4]
+        fat = None
+        for name, _, _, _, off, size in secs:
+            end = m.find(b"\0", stro + name)
+            if m[stro + name:end] == b".hip_fatbin":
+                fat = (off, size)
+        if fat is None:
+            raise RuntimeError(f"{path}: no .hip_fatbin section")
+        out, o, stop = [], fat[0], fat[0] + fat[1]
+        while o < stop:
+            if m[o:o + 4] == b"CCOB":
+                version = struct.unpack_from("<H", m, o + 4)[0]
+                size = struct.unpack_from("<Q" if version >= 3 else "<I", m, o + 8)[0]
+            elif m[o:o + 24] == b"__CLANG_OFFLOAD_BUNDLE__":
+                n = struct.unpack_from("<Q", m, o + 24)[0]
+                q, size = o + 32, 0
+                for _ in range(n):
+                    eo, es, tl = struct.unpack_from("<QQQ", m, q)
+                    size = max(size, eo + es)
+                    q += 24 + tl
+                size = max(size, q - o)
+            else:                                   # padding between bundles
+                o += 8
+                continue
+            out.append((o, size))
+            o += (size + 7) // 8 * 8
+        m.close()
+    return out
+
+
+def extract_gfx950(path, td):
+    """gfx950 code objects of ``path`` as files under ``td``: llvm-objdump --offloading when it survives, else the bundles of
+    .hip_fatbin one by one through clang-offload-bundler (which also decompresses)."""
+    lib = os.path.join(td, "lib.so")
+    if os.path.getsize(path) < (64 << 20):
+        shutil.copy(path, lib)
+        r = subprocess.run([OBJDUMP, "--offloading", lib], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        objs = [os.path.join(td, f) for f in sorted(os.listdir(td)) if "amdgcn" in f and "gfx950" in f]
+        if r.returncode == 0 and objs:
+            return objs
+    objs = []
+    with open(path, "rb") as f:
+        for i, (off, size) in enumerate(_fatbin_bundles(path)):
+            raw = os.path.join(td, f"bundle{i}.bin")
+            f.seek(off)
+            with open(raw, "wb") as g:
+                left = size
+                while left:
+                    chunk = f.read(min(left, 64 << 20))
+                    if not chunk:
+                        break
+                    g.write(chunk)
+                    left -= len(chunk)
+            listing = subprocess.run([BUNDLER, "--list", "--type=o", f"--input={raw}"], capture_output=True, text=True)
+            if listing.returncode != 0:
+                raise RuntimeError(f"clang-offload-bundler --list failed on bundle {i} of {path}: {listing.stderr[-300:]}")
+            if TARGET in listing.stdout.split():
+                co = os.path.join(td, f"gfx950_{i}.co")
+                subprocess.run([BUNDLER, "--unbundle", "--type=o", f"--input={raw}", f"--targets={TARGET}", f"--output={co}"],
+                               check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+                objs.append(co)
+            os.remove(raw)
+    return objs
+
+
+def scan_library(path, summary=None):
+    """(offending instructions, packed fp32 instruction count, code object count); ``summary``: dict filled with the operand-
+    modifier patterns seen (registers anonymised) -> count, for reports on foreign libraries."""
     td = tempfile.mkdtemp(prefix="mis_pk_")
     try:
-        lib = os.path.join(td, "lib.so")
-        shutil.copy(path, lib)
-        subprocess.run([OBJDUMP, "--offloading", lib], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
-        objs = [os.path.join(td, f) for f in sorted(os.listdir(td)) if "amdgcn" in f]
+        objs = extract_gfx950(path, td)
         if not objs:
             raise RuntimeError(f"no gfx950 code objects found in {path}")
         found, n_pk = [], 0
         for o in objs:
-            out = subprocess.run([OBJDUMP, "-d", o], check=True, capture_output=True, text=True).stdout.splitlines()
-            n_pk += sum(1 for ln in out if PK.match(ln.split("//")[0]))
-            found += scan_text(out)
+            # streamed: the disassembly of RCCL's 50 MB of gfx950 text is ~10^7 lines
+            p = subprocess.Popen([OBJDUMP, "-d", o], stdout=subprocess.PIPE, text=True, errors="replace")
+            for ln in p.stdout:
+                if "v_pk_" not in ln:
+                    continue
+                code = ln.split("//")[0]
+                if not PK.match(code):
+                    continue
+                n_pk += 1
+                found += scan_text([ln])
+                if summary is not None:
+                    key = re.sub(r"\b[vs]\[?[0-9:]+\]?", "R", " ".join(code.split()))
+                    summary[key] = summary.get(key, 0) + 1
+            if p.wait() != 0:
+                raise RuntimeError(f"llvm-objdump -d failed on {o}")
         return found, n_pk, len(objs)
     finally:
         shutil.rmtree(td, ignore_errors=True)
 
 
 def main(argv):
+    verbose = "--patterns" in argv
+    argv = [a for a in argv if a != "--patterns"]
     path = argv[0] if argv else os.path.join(ROOT, "cv-ssl-mis_amd", "mis_hip", "libmis_hip.so")
-    found, n_pk, n_obj = scan_library(path)
-    print(f"{os.path.basename(path)}: {n_obj} code objects, {n_pk} packed fp32 instructions, {len(found)} with the broken operand pattern")
+    summary = {} if verbose else None
+    found, n_pk, n_obj = scan_library(path, summary)
+    print(f"{os.path.basename(path)}: {n_obj} gfx950 code objects, {n_pk} packed fp32 instructions, {len(found)} with the broken operand pattern")
     for f in sorted(set(found))[:20]:
         print("   ", f)
+    if summary:
+        for k, v in sorted(summary.items(), key=lambda kv: -kv[1]):
+            print(f"    {v:6d}  {k}")
     return 1 if found else 0
 
 

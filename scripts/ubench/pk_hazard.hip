@@ -1,6 +1,8 @@
 // Do packed fp32 adds with per-half modifiers compute the right thing beside a foreign wave's bf16 MFMAs on the same SIMD?
 // Victim kernel: every form below on lane-dependent inputs, results checked against unpacked VALU arithmetic, mismatches counted.
 // Neighbour: v_mfma_f32_16x16x32_bf16 back to back on a second stream (or nothing).
+// Forms 28-30 (round 6): the op_sel_hi-only patterns that librccl.so's gfx950 kernels (168 x v_pk_fma_f32 op_sel_hi:[0,1,1]) and this
+// library's own compiler-packed code contain: the LOW lane reads low halves only.
 // hipcc --offload-arch=gfx950 -O3 -w pk_hazard.hip -o pk_hazard.bin && ./pk_hazard.bin
 #include <hip/hip_runtime.h>
 #include <stdio.h>
@@ -50,7 +52,10 @@ __global__ __launch_bounds__(256) void spin(int iters, float* sink, int kind) {
     X(24, "v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1]") \
     X(25, "v_pk_add_f32 %0, %1, %1 op_sel:[0,1] op_sel_hi:[0,1] neg_hi:[0,1]") \
     X(26, "v_pk_add_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1] neg_lo:[1,0] neg_hi:[0,1]") \
-    X(27, "v_pk_add_f32 %0, %1, %2 op_sel_hi:[1,0] neg_lo:[0,1]")
+    X(27, "v_pk_add_f32 %0, %1, %2 op_sel_hi:[1,0] neg_lo:[0,1]") \
+    X(28, "v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,1,1]") \
+    X(29, "v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,1,0]") \
+    X(30, "v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]")
 
 template <int FORM>
 __device__ __forceinline__ f32x2 form(f32x2 a, f32x2 b) {

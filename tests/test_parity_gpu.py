@@ -358,12 +358,57 @@ F64_MEDIAN_RATIO = 2.0
 # rounding error of any fp32 convolution.  Which side an implementation lands on is a coin toss, and one flipped element of
 # `vnet_gn_64_masks` (margin 4e-7) moves block_five.conv.3.weight by 32 % of its maximum and every tensor above it by 3-8 %:
 # exactly the "22x the reference's own error, same to three digits whatever is changed at the 8^3 level" of round 4.  The
-# golden now carries the FLIP ENVELOPE (the float64 step with the sign of each of the 4 smallest such pre-activations
-# reversed, largest change per tensor); a tensor may deviate by F64_FLIP x that, and the median ratio is taken against
-# max(e32, flip).  The gate no longer depends on which kernel serves the 8^3 level, and the split-contraction launch is
-# chosen on performance alone (conv_wino.hip::wino_splits).
-F64_FLIP = 1.5
+# golden carries the FLIP ENVELOPE (the float64 step with the sign of each of the 4 smallest such pre-activations reversed,
+# largest change per tensor) and round 5 let a tensor deviate by 1.5 x that -- up to 9.3 x a tensor's own maximum on
+# `vnet_gn_64_masks`, i.e. no gate at all for a quarter of the tensors (round-5 advisor).  Round 6: the gate re-evaluates the
+# float64 oracle step on the test machine with each of those pre-activations flipped (oracle/nets.py::PRE_ACT; the margins it
+# finds must be the golden's, which come from hooks on the reference modules), forms the 2^4 candidate solutions
+# G_S = G_0 + sum_{k in S} (G_k - G_0) -- single flips are exact, combinations superpose to first order -- and holds EVERY
+# tensor to the NORMAL tolerance against ONE solution: the subset S that fits the HIP gradients best.  A wrong halo row or
+# weight gradient in the deep layers is no longer inside any envelope; which side of a rounding-level discontinuity the
+# kernels land on still does not decide the test, nor which kernel serves the 8^3 level (conv_wino.hip::wino_splits).
+F64_FLIPS = 4
 F64_GN = dict(K=F64_K, median=F64_MEDIAN_RATIO)
+
+
+def _flipped_solutions(run, flips):
+    """[G_0, G_1 .. G_flips] (gradient dicts of ``run()``) and the margins: G_0 the plain float64 step, G_k the step with the
+    sign of the k-th smallest deep-level (<= 64 positions per channel) student pre-activation reversed -- the measurement of
+    oracle/gen_golden.py::reference_grads64, on the oracle instead of the reference modules."""
+    from oracle import nets
+    cands, state = [], dict(i=0)
+
+    def probe(x):
+        i = state["i"]
+        state["i"] += 1
+        v = x.detach()
+        if v.dim() >= 4 and int(np.prod(v.shape[2:])) <= 64:
+            a = v.abs().flatten()
+            k = torch.topk(a, min(flips, a.numel()), largest=False)
+            cands.extend((float(val / a.max()), i, int(j)) for val, j in zip(k.values, k.indices))
+        return x
+
+    nets.PRE_ACT = probe
+    try:
+        sols = [run()]
+        cands.sort()
+        for _, site, j in cands[:flips]:
+            state["i"] = 0
+
+            def flip(x, site=site, j=j):
+                i = state["i"]
+                state["i"] += 1
+                if i != site:
+                    return x
+                sign = torch.ones_like(x).view(-1)
+                sign[j] = -1.0
+                return x * sign.view_as(x)
+
+            nets.PRE_ACT = flip
+            sols.append(run())
+    finally:
+        nets.PRE_ACT = None
+    return sols, [c[0] for c in cands[:flips]]
 
 
 @pytest.mark.parametrize("name,it", F64_CASES)
@@ -425,18 +470,45 @@ def test_step_gradients_match_float64_oracle(name, it):
     # oracle/gen_golden.py::reference_grads64: these fixtures are ill-conditioned through the normalisation layers
     # (no-norm V-Net: 1e-7; BatchNorm / GroupNorm / InstanceNorm nets: 1e-2 .. 1e-1 for ANY fp32 implementation)
     ref32 = z[f"it{it}_grad_relerr32"]
-    fkey = f"it{it}_grad_flip_relerr"
-    flip = z[fkey] if fkey in z.files else np.zeros_like(ref32)       # what ONE legitimate ReLU flip costs (see above)
-    rows, ratios = [], []
-    for i, (n, g) in enumerate(model.named_flat(model.flat_grad)):
-        ref = orc["grads"][n]
-        gmax = float(ref.abs().max())
-        err = (g.cpu().double() - ref).abs().max().item()
-        K = F64_GN["K"] if "groupnorm" in kind else F64_K
-        tol = max(K * float(ref32[i]), F64_FLIP * float(flip[i]), F64_REL) * gmax + F64_ABS * gscale
-        rows.append((err / tol, n, err, gmax))
-        if gmax > 1e-4 * gscale:
-            ratios.append((err / gmax) / max(float(ref32[i]), float(flip[i]), 1e-3))
+    names = [n for n, _ in model.named_flat(model.flat_grad)]
+    hip = {n: g.cpu().double() for n, g in model.named_flat(model.flat_grad)}
+    K = F64_GN["K"] if "groupnorm" in kind else F64_K
+
+    def score(sol):
+        """(err / tolerance, name, err, |g|max) per tensor and the error ratios against the reference's own fp32 noise."""
+        rows, ratios = [], []
+        for i, n in enumerate(names):
+            ref = sol[n]
+            gmax = float(ref.abs().max())
+            err = (hip[n] - ref).abs().max().item()
+            tol = max(K * float(ref32[i]), F64_REL) * gmax + F64_ABS * gscale
+            rows.append((err / tol, n, err, gmax))
+            if gmax > 1e-4 * gscale:
+                ratios.append((err / gmax) / max(float(ref32[i]), 1e-3))
+        return rows, ratios
+
+    rows, ratios = score(orc["grads"])
+    flipped = ()
+    if f"it{it}_flip_margins" in z.files and max(rows)[0] > 1.0:
+        # pre-activations within fp32 rounding of zero: candidate solutions with their signs reversed (see F64_FLIPS)
+        sols, margins = _flipped_solutions(lambda: mean_teacher_step(
+            onet, {k: d(v) for k, v in sd0.items()}, {k: d(v) for k, v in tsd0.items()}, {}, volume.double(), label,
+            noise.double(), it, labeled_bs=L, num_classes=C, base_lr=cfg["base_lr"], max_iterations=cfg["max_iterations"],
+            ema_decay=cfg["ema_decay"], consistency=cfg["consistency"], rampup=cfg["rampup"],
+            cons_start_iter=cfg["cons_start_iter"], drop_student=dd(drop_s), drop_teacher=dd(drop_t), apply_update=False)["grads"],
+            F64_FLIPS)
+        want = np.sort(z[f"it{it}_flip_margins"])
+        assert np.allclose(np.sort(margins), want, rtol=0.05, atol=1e-9), (margins, want)     # the reference's own near-zeros
+        base = sols[0]
+        best = None
+        for mask in range(1, 1 << (len(sols) - 1)):
+            pick = [k for k in range(1, len(sols)) if mask >> (k - 1) & 1]
+            sol = {n: base[n] + sum(sols[k][n] - base[n] for k in pick) for n in names}
+            r = score(sol)
+            if best is None or max(r[0])[0] < max(best[0][0])[0]:
+                best = (r, tuple(pick))
+        if max(best[0][0])[0] < max(rows)[0]:
+            (rows, ratios), flipped = best
     worst = max(rows)
     if os.environ.get("MIS_PRINT_GRAD_ROWS"):
         for r in sorted(rows, reverse=True)[:12]:
@@ -444,7 +516,8 @@ def test_step_gradients_match_float64_oracle(name, it):
     ratios = np.sort(np.array(ratios))
     print(f"\n{name}: logits max err {logit_err:.2e}, losses max err {loss_err:.2e}; worst gradient error / tolerance = "
           f"{worst[0]:.3f} at {worst[1]} (err {worst[2]:.2e}, |g|max {worst[3]:.2e}); HIP error / reference-fp32 error "
-          f"per tensor: median {np.median(ratios):.2f}, p90 {ratios[int(0.9 * (len(ratios) - 1))]:.2f}, max {ratios[-1]:.2f}")
+          f"per tensor: median {np.median(ratios):.2f}, p90 {ratios[int(0.9 * (len(ratios) - 1))]:.2f}, max {ratios[-1]:.2f}"
+          + (f"; against the float64 solution with near-zero pre-activation(s) {flipped} flipped" if flipped else ""))
     assert logit_err <= F64_LOGIT, logit_err                      # logits vs exact arithmetic (north-star bar: 1e-3)
     assert loss_err <= 5e-5, loss_err
     assert worst[0] <= 1.0, worst

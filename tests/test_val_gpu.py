@@ -117,3 +117,65 @@ def test_single_case_3d_matches_the_reference_function():
         assert got.shape == want.shape == shape
         diff = got != want
         assert np.all(ties[diff]) and diff.mean() < 2e-3, (n, int(diff.sum()), int((diff & ~ties).sum()))
+
+
+@pytest.mark.parametrize("choice", ["1", "2"], ids=["swin", "unet"])
+def test_cnnvit_inference_matches_the_reference_function(choice, tmp_path, monkeypatch):
+    """cnnvit_infer.npz: the label maps the REAL test_CNNVIT.test_single_volume (code/test_CNNVIT.py:43-79: slice-wise nearest
+    zoom to 224 x 224, forward, arg-max, zoom back) built around the REAL SwinUnet / UNet on the filler volume; the drop-in's
+    ``Inference`` runs from a checkpoint file on an .npz case, through both branches of the reference's model question (:93-101),
+    and its (dice, asd, hd) per class must be the metrics of the reference's label map."""
+    import sys
+    pkg = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "cv-ssl-mis_amd")
+    sys.path.insert(0, pkg)
+    import test_CNNVIT as cli
+    from networks.net_factory import net_factory
+    from oracle import filler
+    g = np.load(os.path.join(GOLD, "cnnvit_infer.npz"))
+    C, shape = int(g["classes"]), tuple(int(v) for v in g["shape"])
+    tag = "swin" if choice == "1" else "unet"
+    net = net_factory("ViT_Seg" if tag == "swin" else "unet", 1, C)
+    sd = filler.fill_state_dict(net.state_dict())
+    head = "swin_unet.output.weight" if tag == "swin" else "decoder.out_conv.weight"
+    sd[head] = sd[head] * float(g[f"weight_scale_{tag}"])
+    if tag == "unet":
+        sd["decoder.out_conv.bias"] = torch.from_numpy(g["out_bias_unet"]).to(sd["decoder.out_conv.bias"])
+    image = filler.image((1,) + shape, "cnnvitimg")[0].numpy()
+    label = filler.labels(shape, C, torch.uint8).numpy()
+    assert abs(float(image.astype(np.float64).sum()) - float(g["image_sum"])) < 1e-6
+    data = tmp_path / "ACDC"
+    (data / "data").mkdir(parents=True)
+    np.savez(data / "data" / "patient101_frame01.npz", image=image, label=label)
+    (data / "test.list").write_text("patient101_frame01.h5\n")
+    ckpt = tmp_path / "weights.pth"
+    torch.save(sd, ckpt)
+    work = tmp_path / "code"
+    work.mkdir()
+    monkeypatch.chdir(work)
+    FLAGS = cli.parser.parse_args(["--root_path", str(data), "--exp", "ACDC/X", "--labeled_num", "7", "--choice", choice,
+                                   "--checkpoint", str(ckpt)])
+    avg = cli.Inference(FLAGS)
+    pred = np.load(tmp_path / "model" / "ACDC" / "X_7" / "unet_predictions" / "patient101_frame01_pred.npz")["prediction"]
+    want, ties = g[f"prediction_{tag}"], g[f"ties_{tag}"]
+    assert pred.shape == want.shape == shape and len(np.unique(want[want > 0])) == 3
+    diff = pred != want
+    assert np.all(ties[diff]) and diff.mean() < 5e-3, (int(diff.sum()), int((diff & ~ties).sum()))
+    for i in (1, 2, 3):
+        ref = cli.calculate_metric_percase(want == i, label == i)
+        assert abs(avg[i - 1][0] - ref[0]) < 5e-3 and abs(avg[i - 1][1] - ref[1]) <= 0.5 and abs(avg[i - 1][2] - ref[2]) <= 1.5
+
+
+def test_cnnvit_metrics_follow_medpy_definitions():
+    """hd = the larger directed maximum surface distance, asd = mean directed surface distance (medpy.metric.binary.hd / asd)."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "cv-ssl-mis_amd"))
+    from utils import metrics
+    a = np.zeros((1, 20, 20), bool)
+    b = np.zeros((1, 20, 20), bool)
+    a[0, 2:6, 2:6] = True
+    b[0, 2:6, 2:11] = True            # b extends a by 5 columns
+    assert metrics.hd(a, b) == 5.0 and metrics.hd(b, a) == 5.0
+    assert metrics.asd(a, a) == 0.0 and 0.0 < metrics.asd(b, a) < 5.0
+    assert metrics.hd95(a, b) <= metrics.hd(a, b)
+    with pytest.raises(RuntimeError):
+        metrics.hd(a, np.zeros_like(a))
