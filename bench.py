@@ -296,6 +296,10 @@ def run_workload(name, args, rank, world, kernel_events=True):
         _lib.check(_lib.load().mis_debug_poison_lds(None, _lib.stream_ptr()), "mis_debug_poison_lds")
     for _ in range(args.warmup):
         tr.step(vol, lab)
+    # the product step is a launch tape (mis_hip/step.py::_TapedStep: two eager steps, one recorded, then replays): the timed
+    # region must be replays whatever --warmup says (more untimed steps than asked for, never fewer)
+    while getattr(tr, "use_tape", False) and getattr(tr, "_tape", None) is None:
+        tr.step(vol, lab)
     dt_local = timed(args.steps)
     host_enqueue_ms = enqueue[-1][0] / enqueue[-1][1] * 1e3
     dt, per_rank = dt_local, [dt_local]
@@ -309,7 +313,7 @@ def run_workload(name, args, rank, world, kernel_events=True):
     # ---- data parallel: prove the exchange happened and price it (before any diagnostic region changes the weights)
     dist_info = None
     if _dist_on(world):
-        dist_info = _distributed_checks(tr, timed, args, rank, world, dev, stub, dt_local)
+        dist_info = _distributed_checks(tr, timed, args, rank, world, dev, stub, dt_local, retape=lambda: _retape(tr, vol, lab))
 
     # ---- roofline region: the same step with the side streams off, every MFMA launch bracketed by HIP events on its
     # launch stream.  A launch's duration measures the kernel only when it has the chip to itself: in the timed region
@@ -317,8 +321,10 @@ def run_workload(name, args, rank, world, kernel_events=True):
     prof, serial_dt, serial_steps = None, None, 0
     if not stub and kernel_events:
         from mis_hip import ops, plan as _plan, step as _stepmod
-        keep = (_stepmod.TWO_STREAM, _plan.WGRAD_STREAM)
+        keep = (_stepmod.TWO_STREAM, _plan.WGRAD_STREAM, getattr(tr, "use_tape", False))
         _stepmod.TWO_STREAM, _plan.WGRAD_STREAM = False, False
+        if keep[2]:
+            tr.use_tape = False          # the events are recorded by the eager op graph (a replayed tape has no Python around its launches)
         try:
             tr.step(vol, lab)
             ops.PROFILE = prof = []
@@ -326,7 +332,9 @@ def run_workload(name, args, rank, world, kernel_events=True):
             serial_dt = timed(serial_steps)
         finally:
             ops.PROFILE = None
-            _stepmod.TWO_STREAM, _plan.WGRAD_STREAM = keep
+            _stepmod.TWO_STREAM, _plan.WGRAD_STREAM = keep[:2]
+            if keep[2]:
+                tr.use_tape = True
     losses = tr.losses()
     assert all(map(lambda v: v == v and abs(v) < 1e6, losses.values())), f"non-finite losses {losses}"
 
@@ -427,6 +435,9 @@ def run_workload(name, args, rank, world, kernel_events=True):
     res = dict(value=round(shape[0] * world * args.steps / dt, 3), unit=UNIT.get(name, "images/s"), grad_bytes=grad_bytes,
                ms_per_step=round(step_s * 1e3, 3), step_flop_frac=round(step_frac, 4),
                host_enqueue_ms_per_step=round(host_enqueue_ms, 3),
+               step_enqueue=("launch tape: the recorded C-ABI launch sequence of one eager step, replayed (%d entries; "
+                             "MIS_STEP_TAPE=0: the eager op graph)" % len(tr._tape)) if getattr(tr, "_tape", None) is not None
+               else "eager op graph",
                executed_step_frac=None if exec_frac is None else round(exec_frac, 4), roofline=roofline,
                losses={k: round(v, 6) for k, v in losses.items()},
                per_rank_ms_per_step=[round(t / args.steps * 1e3, 3) for t in per_rank], distributed=dist_info)
@@ -436,7 +447,15 @@ def run_workload(name, args, rank, world, kernel_events=True):
     return res
 
 
-def _distributed_checks(tr, timed, args, rank, world, dev, stub, dt_overlap):
+def _retape(tr, vol, lab):
+    """After a configuration change (bucketers swapped out, exchange stubbed): drop the recorded step and record it again, untimed."""
+    if getattr(tr, "use_tape", False):
+        tr._tape, tr._tape_warm = None, 0
+        while tr._tape is None:
+            tr.step(vol, lab)
+
+
+def _distributed_checks(tr, timed, args, rank, world, dev, stub, dt_overlap, retape=lambda: None):
     """N > 1: (1) every rank must hold bit-identical student (and teacher) weights after the timed steps -- the
     gradients were exchanged and the same update applied everywhere; the run FAILS otherwise.  (2) The price of the
     exchange: the same steps with one blocking all-reduce after the backward instead of the bucketed one overlapped with
@@ -462,6 +481,7 @@ def _distributed_checks(tr, timed, args, rank, world, dev, stub, dt_overlap):
     n = max(3, min(args.steps, 10))
 
     def region():
+        retape()
         t = torch.tensor([timed(n)], device=dev, dtype=torch.float64)
         tdist.all_reduce(t, op=tdist.ReduceOp.MAX)
         return float(t.item()) / n * 1e3
@@ -486,6 +506,7 @@ def _distributed_checks(tr, timed, args, rank, world, dev, stub, dt_overlap):
         mdist.sync_gradients = real_sync
         for a, v in keep.items():
             setattr(tr, a, v)
+    retape()          # back to the product configuration
     out["exposed_allreduce_ms_per_step"] = round(out["overlapped_ms_per_step"] - out["no_exchange_ms_per_step"], 3)
     return out
 
@@ -749,7 +770,8 @@ def main():
                        "global_batch": wl["shape"][0] * world, "parallelism": f"dp{world}",
                        "dropout": "on (Philox)", "teacher_noise": "on", "iter_num_start": 1000,
                        "teacher_forward": "side stream (beside the student forward)" if two_stream else "same stream",
-                       "weight_gradients": "side stream (beside the data-gradient chain)" if wgrad_stream else "same stream"},
+                       "weight_gradients": "side stream (beside the data-gradient chain)" if wgrad_stream else "same stream",
+                       "step_enqueue": res.get("step_enqueue", "eager op graph")},
             "distributed": dict(res["distributed"] or {"world_size_seen": 1}, backend=backend,
                                 per_rank_ms_per_step=res["per_rank_ms_per_step"], max_ms_per_step=res["ms_per_step"],
                                 affinity_rank0=affinity, predicted=_predicted_exchange(res, world)),

@@ -95,6 +95,15 @@ extern "C" int mis_window_attention_dtable_ws(void* workspace, long long workspa
     return MIS_ERR_UNSUPPORTED;
 }
 
+// Shape of the bias-table partials mis_window_attention_bwd_parts_ws leaves at the start of its workspace: float [rows][cols],
+// cols = (2 window - 1)^2 * nH in the layout of relative_position_bias_table -- dtable = their column sum, which
+// mis_window_attention_dtable_ws forms, or a mis_colsum_batch job together with the other finishing sums of a backward pass.
+extern "C" int mis_window_attention_table_partials(int B, int H, int W, int nH, int window, long long* rows, int* cols) {
+    if (window == 7) return ws7::window_attention_table_partials(B, H, W, nH, rows, cols);
+    if (window == 8) return ws8::window_attention_table_partials(B, H, W, nH, rows, cols);
+    return MIS_ERR_UNSUPPORTED;
+}
+
 // the window-7 entry points of ABI version 1
 extern "C" int mis_window_attention_fwd(const float* qkv, long long ldq, float* out, long long ldo,
                                         const float* bias_table, int B, int H, int W, int nH, int shift, float scale,

@@ -108,6 +108,7 @@ __device__ __forceinline__ f32x4 bf3_mfma(const u32x4& a, const u32x4& b, f32x4 
 struct SplitJob {
     const float* B; long long ldb; void* B3;
     int N, K, K3, first;       // first: prefix sum of the jobs' units (one unit = 256 (row, block, lane group) triples)
+    int natural, pad;          // natural: lane group lk's 16-byte group holds elements 8 lk .. 8 lk + 7 (gemm_nt_rega_kernel)
 };
 
 __device__ __forceinline__ void split_unit(const SplitJob& j, int unit) {
@@ -122,7 +123,7 @@ __device__ __forceinline__ void split_unit(const SplitJob& j, int unit) {
     float e[8];
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-        const int k = kb * 32 + 8 * s + 2 * lk;
+        const int k = j.natural ? kb * 32 + 8 * lk + 2 * s : kb * 32 + 8 * s + 2 * lk;
         float2 v = make_float2(0.f, 0.f);
         if (k < j.K) v = *reinterpret_cast<const float2*>(j.B + n * j.ldb + k);      // K % 4 == 0, ldb % 4 == 0: pairs are whole
         e[2 * s] = v.x; e[2 * s + 1] = v.y;
@@ -783,6 +784,166 @@ __global__ __launch_bounds__(256) void gemm_nt_short_kernel(const GemmArgs a) {
 // workgroup per CU, one wave per SIMD, and a lone wave pays the LDS latency, the split of its A fragments and the six-deep
 // MFMA chains one after the other -- 4.3 us per tile where the arithmetic is 0.8.  The short-contraction kernel's six resident
 // workgroups hide exactly that.  Removed.)
+
+// ------------------------------------------------------------------------------------------------ NT, A operand in registers
+// Round 6.  Ablations of gemm_nt_kernel<64, 96, ., 2> on the 20 Linear shapes of a SwinUnet step (scripts/gemm_variants.sh,
+// profiles/r06_gemm_nt_ablation.txt): without its MFMAs the kernel takes the SAME time (1366 vs 1368 us), without the DMAs of its
+// k-loop -13 %, without the A split -7 %, without the epilogue -30 %: the matrix pipe is idle two thirds of the time and what a
+// tile pays for is moving its operands through LDS.  With v_mfma_f32_16x16x32_bf16 the A operand of lane (lj, g) is row lj, 8
+// CONSECUTIVE contraction elements 8 g .. 8 g + 7 -- 32 contiguous bytes of a row-major activation row, and the four lane groups
+// of a row read one 128-byte line: unlike the fp32 MFMA's 4-element operands (round 4's register-only attempt: 16-byte pieces
+// on 16 rows per load) the row-major A can be loaded straight into the operand registers.  So here:
+//   * A never touches LDS: two buffer_load_dwordx4 per 16-row tile and k-step, one k-step ahead in registers (no DMA issue, no
+//     ds_read, and the barrier of a k-step does not wait for it);
+//   * a wave owns 32 rows x the tile's full 96 (128) columns: B -- the pre-split planes, NATURAL element order (SplitJob::
+//     natural) -- is staged through LDS once per 128 rows instead of once per 64 and read once per wave (18 ds_read_b128 per
+//     72 MFMAs);
+//   * 48 accumulator registers, ~150 in all: three waves per SIMD, three workgroups per CU (the epilogue tile, 51 KB, aliases
+//     the two B stages) -- the residency that hides the phases of a short contraction (see the persistent form's obituary above).
+// Same split products and the same k-block order as the other bf16x3 kernels; the element order inside a K = 32 block differs,
+// so results agree with them to fp32 rounding, not bit for bit.  Float4 epilogue only (plain / GELU / residual), no split-K.
+template <int BN, int EP>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void gemm_nt_rega_kernel(const GemmArgs a) {
+    constexpr int MI = 2, NJ = BN / 16, BMT = 128;
+    constexpr int RB3 = BN / 16, PB3 = 3 * RB3, NB3 = (PB3 + 3) / 4;
+    constexpr int B_FLOATS = BN * BK * 3 / 2;                   // one stage: three planes [BN][32] bf16
+    constexpr int LDC_T = BN + 4;
+    float* const lds = mis_gemm_lds;
+    const unsigned L = mis_xcd_remap(blockIdx.x, a.n_blocks_padded);
+    if (L >= a.n_blocks) return;
+    const int tn = L % a.tiles_n, tm = L / a.tiles_n;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, lj = lane & 15;
+    const int m0 = tm * BMT, n0 = tn * BN, wm = wave * 32;
+    const unsigned lds0 = lds_addr(lds);
+    const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.A), 0,
+                                                                        (int)(((long long)(a.M - 1) * a.lda + a.K) * 4), 0x00020000);
+    const i32x4 rB3 = make_rsrc(a.B3, 3u * a.b3_plane);
+    // A: lane (lj, g) of tile i reads row m0 + wm + 16 i + lj, floats k0 + 8 g .. + 7 (two 16-byte loads)
+    int voA[MI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+        const int row = m0 + wm + 16 * i + lj;
+        voA[i] = row < a.M ? (int)(((long long)row * a.lda + 8 * g) * 4) : (int)OOB;
+    }
+    // B planes: piece q = (plane q / RB3, rows (q % RB3) * 16 ..+16) x the 64 bytes of the k-step (as gemm_nt_kernel, PREC = 2)
+    unsigned voB3[NB3];
+#pragma unroll
+    for (int i = 0; i < NB3; ++i) {
+        const int q = wave + 4 * i, plane = q / RB3, row = (q % RB3) * 16 + (lane >> 2);
+        voB3[i] = (q < PB3 && n0 + row < a.N)
+                      ? (unsigned)plane * a.b3_plane + (unsigned)(((long long)(n0 + row) * a.K3 + (lane & 3) * 8) * 2)
+                      : OOB;
+    }
+    auto stage_b = [&](int buf, int k0) {
+        const unsigned st = lds0 + (unsigned)buf * (B_FLOATS * 4);
+#pragma unroll
+        for (int i = 0; i < NB3; ++i)
+            if (wave + 4 * i < PB3) dma_dwordx4(st + (unsigned)((wave + 4 * i) * 1024), voB3[i] + (unsigned)k0 * 2u, rB3);
+    };
+    auto load_a = [&](f32x4 (&r)[MI][2], int k0) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                // K % 4 == 0: a 16-byte group is all in or all out; beyond K the planes are zero but A must not read the next row
+                const bool in = k0 + 8 * g + 4 * h < a.K;
+                r[i][h] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rA, in ? voA[i] + 16 * h : (int)OOB, k0 * 4, 0));
+            }
+    };
+
+    f32x4 acc[MI][NJ];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 cur[MI][2], nxt[MI][2];
+
+    stage_b(0, 0);
+    load_a(cur, 0);
+    dma_wait();
+    __syncthreads();
+    int s = 0;
+    for (int k0 = 0; k0 < a.K; k0 += BK, ++s) {
+        const bool more = k0 + BK < a.K;
+        if (more) { stage_b((s + 1) & 1, k0 + BK); load_a(nxt, k0 + BK); }
+        MisBf3 a3[MI];
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+            a3[i] = mis_bf3_from8(cur[i][0][0], cur[i][0][1], cur[i][0][2], cur[i][0][3], cur[i][1][0], cur[i][1][1], cur[i][1][2], cur[i][1][3]);
+        const u32x4* __restrict__ sB3 = reinterpret_cast<const u32x4*>(lds + (s & 1) * B_FLOATS);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int r = (j * 16 + lj) * 4 + g;
+            const u32x4 bh = sB3[r], bm = sB3[BN * 4 + r], bl = sB3[2 * BN * 4 + r];
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                f32x4 c = acc[i][j];
+                c = bf3_mfma(a3[i].l, bh, c);
+                c = bf3_mfma(a3[i].h, bl, c);
+                c = bf3_mfma(a3[i].m, bm, c);
+                c = bf3_mfma(a3[i].m, bh, c);
+                c = bf3_mfma(a3[i].h, bm, c);
+                c = bf3_mfma(a3[i].h, bh, c);
+                acc[i][j] = c;
+            }
+        }
+        if (more) {
+#pragma unroll
+            for (int i = 0; i < MI; ++i) { cur[i][0] = nxt[i][0]; cur[i][1] = nxt[i][1]; }
+        }
+        dma_wait();
+        __syncthreads();
+    }
+
+    // ---- epilogue: accumulators -> LDS tile [128][BN + 4] (over the B stages: the loop ended with a barrier) -> float4 rows ----
+    float* const ct = lds;
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ct[(wm + i * 16 + g * 4 + r) * LDC_T + j * 16 + lj] = acc[i][j][r];
+    __syncthreads();
+    constexpr int Q = BN / 4;
+#pragma unroll 4
+    for (int it = 0; it < BMT * Q / 256; ++it) {
+        const int e = tid + it * 256;
+        const int row = e / Q, q = e - row * Q;
+        const int m = m0 + row, n = n0 + q * 4;
+        if (m >= a.M || n >= a.N) continue;
+        float4 v = *reinterpret_cast<const float4*>(&ct[row * LDC_T + q * 4]);
+        if (a.bias) {
+            const float4 b = *reinterpret_cast<const float4*>(a.bias + n);
+            v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+        }
+        float* const cp = a.C + (long long)m * a.ldc + n;
+        if constexpr (EP == EP_GELU_FWD) {
+            *reinterpret_cast<float4*>(a.C2 + (long long)m * a.ldc2 + n) =
+                make_float4(gelu_f(v.x), gelu_f(v.y), gelu_f(v.z), gelu_f(v.w));
+            if (!a.C) continue;
+        } else if constexpr (EP == EP_GELU_BWD) {
+            const float4 h = *reinterpret_cast<const float4*>(a.E1 + (long long)m * a.lde1 + n);
+            v.x *= gelu_grad_f(h.x); v.y *= gelu_grad_f(h.y); v.z *= gelu_grad_f(h.z); v.w *= gelu_grad_f(h.w);
+        } else if constexpr (EP == EP_RESIDUAL) {
+            const float4 sc = *reinterpret_cast<const float4*>(a.E1 + (long long)m * a.lde1 + n);
+            const float rs = a.rowscale ? a.rowscale[m / a.rps] : 1.f;
+            v.x = sc.x + rs * v.x; v.y = sc.y + rs * v.y; v.z = sc.z + rs * v.z; v.w = sc.w + rs * v.w;
+        } else {
+            if (a.accumulate) {
+                const float4 o = *reinterpret_cast<const float4*>(cp);
+                v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+            }
+        }
+        *reinterpret_cast<float4*>(cp) = v;
+    }
+}
+
+template <int BN>
+constexpr int rega_lds_bytes() {
+    return (2 * (BN * BK * 3 / 2) > 128 * (BN + 4) ? 2 * (BN * BK * 3 / 2) : 128 * (BN + 4)) * 4;
+}
 
 // ------------------------------------------------------------------------------------------------ TN
 template <int BT>
@@ -1460,6 +1621,40 @@ int launch_nt(GemmArgs& a, hipStream_t stream) {
     return bm == 64 ? launch_nt_bm<64, BN>(a, stream) : launch_nt_bm<BM, BN>(a, stream);
 }
 
+// the register-A kernel serves: bf16x3 products, pre-split B in the natural element order, N a multiple of 96, the float4
+// epilogue, no split-K, no pixel-shuffle store, enough 128-row tiles for three workgroups per CU (MIS_GEMM_REGA=0: never)
+bool nt_rega_shape(int M, int N, int K) {
+    static const int on = getenv("MIS_GEMM_REGA") ? atoi(getenv("MIS_GEMM_REGA")) : 1;
+    static const int kmin = getenv("MIS_GEMM_REGA_KMIN") ? atoi(getenv("MIS_GEMM_REGA_KMIN")) : 96;
+    static const int tmin = getenv("MIS_GEMM_REGA_TILES") ? atoi(getenv("MIS_GEMM_REGA_TILES")) : 512;
+    if (!on || !gemm_bf3() || N % 96 || N % 4 || K % 4 || K < kmin) return false;
+    if ((long long)M * 4 >= (1LL << 31)) return false;
+    return mis_cdiv(M, 128) * (N / 96) >= tmin;
+}
+
+template <int BN, int EP>
+int launch_nt_rega_ep(const GemmArgs& a, hipStream_t stream) {
+    static std::atomic<unsigned long long> attr_done{0};
+    constexpr int LDSB = rega_lds_bytes<BN>();
+    if (mis_set_lds_attr(reinterpret_cast<const void*>(&gemm_nt_rega_kernel<BN, EP>), LDSB, attr_done) != MIS_OK) return MIS_ERR_LAUNCH;
+    hipLaunchKernelGGL((gemm_nt_rega_kernel<BN, EP>), dim3(a.n_blocks_padded), dim3(256), LDSB, stream, a);
+    return mis_launch_status();
+}
+
+int launch_nt_rega(GemmArgs& a, hipStream_t stream) {
+    a.tiles_n = a.N / 96;
+    a.tiles_m = (int)mis_cdiv(a.M, 128);
+    const long long nb = (long long)a.tiles_n * a.tiles_m;
+    if (nb > 0x7fffffffLL) return MIS_ERR_UNSUPPORTED;
+    a.n_blocks = (unsigned)nb;
+    a.n_blocks_padded = (unsigned)(mis_cdiv(nb, MIS_NUM_XCD) * MIS_NUM_XCD);
+    a.KS = 1;
+    if (a.ep == EP_NONE) return launch_nt_rega_ep<96, EP_NONE>(a, stream);
+    if (a.ep == EP_GELU_FWD) return launch_nt_rega_ep<96, EP_GELU_FWD>(a, stream);
+    if (a.ep == EP_GELU_BWD) return launch_nt_rega_ep<96, EP_GELU_BWD>(a, stream);
+    return launch_nt_rega_ep<96, EP_RESIDUAL>(a, stream);
+}
+
 }  // namespace
 
 int mis_split_precision_mask() { return gemm_bf3_state().load(std::memory_order_relaxed); }
@@ -1492,6 +1687,14 @@ extern "C" int mis_gemm_nt_split_kernel_name(int M, int N, int K, int epilogue, 
     int bm, bn, ks;
     if (!b3_choice(M, N, K, bm, bn, ks)) return MIS_ERR_UNSUPPORTED;
     snprintf(name, name_len, "gemm_nt_kernel<%d, %d, %d, 2>", bm, bn, ks > 1 ? 0 : epilogue);
+    return MIS_OK;
+}
+// ... on natural-order planes (layout 1): the register-A kernel
+extern "C" int mis_gemm_nt_split_layout_kernel_name(int M, int N, int K, int epilogue, int layout, char* name, int name_len) {
+    if (!layout) return mis_gemm_nt_split_kernel_name(M, N, K, epilogue, name, name_len);
+    if (M <= 0 || N <= 0 || K <= 0 || !name || name_len <= 0) return MIS_ERR_ARG;
+    if (!nt_rega_shape(M, N, K)) return MIS_ERR_UNSUPPORTED;
+    snprintf(name, name_len, "gemm_nt_rega_kernel<96, %d>", epilogue);
     return MIS_OK;
 }
 
@@ -1626,10 +1829,13 @@ extern "C" long long mis_gemm_dw_workspace_bytes(int M, int N, int K) {
     return ks > 1 ? (long long)ks * M * (N + 1) * 4 : 0;
 }
 
-extern "C" int mis_gemm_dw(const float* dy, long long lddy, const float* x, long long ldx, float* dW, long long lddw,
-                           float* db, int M, int N, int K, int accumulate, float* workspace, long long workspace_bytes,
-                           hipStream_t stream) {
-    if (!dy || !x || !dW || !db || M <= 0 || N <= 0 || K <= 0) return MIS_ERR_ARG;
+// reduce != 0: dW / db are finished here (gemm_reduce_kernel).  reduce == 0 (mis_gemm_dw_parts): a split contraction leaves its
+// partials in `workspace` -- [KS][M][N] floats, then [KS][M] column sums of dy -- and *slices = KS (0: the contraction was not
+// split and dW / db are complete); the caller sums the slices later (mis_colsum_batch), off the launch sequence of the backward.
+static int gemm_dw_impl(const float* dy, long long lddy, const float* x, long long ldx, float* dW, long long lddw,
+                        float* db, int M, int N, int K, int accumulate, float* workspace, long long workspace_bytes,
+                        hipStream_t stream, int reduce, int* slices) {
+    if (!dy || !x || !dW || (!db && reduce) || M <= 0 || N <= 0 || K <= 0) return MIS_ERR_ARG;
     if (!a16(dy) || !a16(x) || lddy % 4 || ldx % 4 || M % 4 || N % 4) return MIS_ERR_UNSUPPORTED;
     GemmArgs a{dy, lddy, x, ldx, dW, lddw, nullptr, workspace, M, N, K, 1, K, accumulate};
     a.ex_P = 0;
@@ -1637,6 +1843,8 @@ extern "C" int mis_gemm_dw(const float* dy, long long lddy, const float* x, long
     a.vec4 = 0;
     a.dbias = db;
     a.dbias_acc = accumulate;
+    if (slices) *slices = 0;
+    const unsigned red_blocks = (unsigned)(mis_cdiv((long long)M * N, 32) + (db ? mis_cdiv(M, 32) : 0));
     if (tn_reg_ok(dy, lddy, x, ldx, dW, lddw, M, N, K) && (long long)K * lddy * 4 < (1LL << 31) && (long long)K * ldx * 4 < (1LL << 31)) {
         tn_reg_plan(a);
         if (a.KS > 1) {
@@ -1645,9 +1853,10 @@ extern "C" int mis_gemm_dw(const float* dy, long long lddy, const float* x, long
         }
         const int st = launch_tn_reg(a, stream);
         if (st) return st;
-        if (a.KS > 1)
-            hipLaunchKernelGGL(gemm_reduce_kernel, dim3((unsigned)(mis_cdiv((long long)M * N, 32) + mis_cdiv(M, 32))), dim3(256),
-                               0, stream, a);
+        if (a.KS > 1) {
+            if (!reduce) { *slices = a.KS; return MIS_OK; }
+            hipLaunchKernelGGL(gemm_reduce_kernel, dim3(red_blocks), dim3(256), 0, stream, a);
+        }
         return mis_launch_status();
     }
     a.KS = pick_ks(M, N, K, 1);
@@ -1670,10 +1879,27 @@ extern "C" int mis_gemm_dw(const float* dy, long long lddy, const float* x, long
         hipLaunchKernelGGL(gemm_tn_kernel<128>, dim3(a.n_blocks_padded), dim3(256), 0, stream, a);
     const int st = mis_launch_status();
     if (st) return st;
-    if (a.KS > 1)
-        hipLaunchKernelGGL(gemm_reduce_kernel, dim3((unsigned)(mis_cdiv((long long)M * N, 32) + mis_cdiv(M, 32))), dim3(256),
-                           0, stream, a);
+    if (a.KS > 1) {
+        if (!reduce) { *slices = a.KS; return MIS_OK; }
+        hipLaunchKernelGGL(gemm_reduce_kernel, dim3(red_blocks), dim3(256), 0, stream, a);
+    }
     return mis_launch_status();
+}
+
+extern "C" int mis_gemm_dw(const float* dy, long long lddy, const float* x, long long ldx, float* dW, long long lddw,
+                           float* db, int M, int N, int K, int accumulate, float* workspace, long long workspace_bytes,
+                           hipStream_t stream) {
+    return gemm_dw_impl(dy, lddy, x, ldx, dW, lddw, db, M, N, K, accumulate, workspace, workspace_bytes, stream, 1, nullptr);
+}
+
+// mis_gemm_dw without its finishing launch (db may be NULL: weight gradient only).  *slices > 0: `workspace` (the caller's own
+// until the sums have run) holds `*slices` partial matrices [M][N] followed by `*slices` partial rows [M] of the bias gradient;
+// dW / db are untouched (`accumulate` is the final sum's business).  *slices == 0: dW / db are complete.
+extern "C" int mis_gemm_dw_parts(const float* dy, long long lddy, const float* x, long long ldx, float* dW, long long lddw,
+                                 float* db, int M, int N, int K, int accumulate, float* workspace, long long workspace_bytes,
+                                 int* slices, hipStream_t stream) {
+    if (!slices) return MIS_ERR_ARG;
+    return gemm_dw_impl(dy, lddy, x, ldx, dW, lddw, db, M, N, K, accumulate, workspace, workspace_bytes, stream, 0, slices);
 }
 
 // ---- the NT form with a pre-split B operand ----------------------------------------------------------------------------
@@ -1687,34 +1913,51 @@ extern "C" long long mis_gemm_split_bytes(int N, int K) {
     return 3LL * N * split_k3(K) * 2;
 }
 
-static long long split_fill(SplitJob& j, const float* B, long long ldb, int N, int K, void* B3, long long first) {
+static long long split_fill(SplitJob& j, const float* B, long long ldb, int N, int K, void* B3, long long first, int natural = 0) {
     if (!B || !B3 || N <= 0 || K <= 0 || first < 0) return MIS_ERR_ARG;
     if (K % 4 || ldb % 4 || ldb < K || !a16(B) || !a16(B3)) return MIS_ERR_UNSUPPORTED;
     if (mis_gemm_split_bytes(N, K) >= (1LL << 31)) return MIS_ERR_UNSUPPORTED;      // the GEMM addresses the planes with 32 bits
-    j.B = B; j.ldb = ldb; j.B3 = B3; j.N = N; j.K = K; j.K3 = split_k3(K); j.first = (int)first;
+    j.B = B; j.ldb = ldb; j.B3 = B3; j.N = N; j.K = K; j.K3 = split_k3(K); j.first = (int)first; j.natural = natural ? 1 : 0;
     const long long units = mis_cdiv((long long)N * (j.K3 / 32) * 4, 256);
     if (first + units > 0x7fffffffLL) return MIS_ERR_ARG;
     return units;
 }
 
-extern "C" int mis_gemm_split_b(const float* B, long long ldb, int N, int K, void* B3, hipStream_t stream) {
+extern "C" int mis_gemm_split_b_layout(const float* B, long long ldb, int N, int K, void* B3, int natural, hipStream_t stream) {
     SplitJob j;
-    const long long units = split_fill(j, B, ldb, N, K, B3, 0);
+    memset(&j, 0, sizeof(j));
+    const long long units = split_fill(j, B, ldb, N, K, B3, 0, natural);
     if (units < 0) return (int)units;
     hipLaunchKernelGGL(gemm_split_kernel, dim3((unsigned)units), dim3(256), 0, stream, j);
     return mis_launch_status();
 }
 
+extern "C" int mis_gemm_split_b(const float* B, long long ldb, int N, int K, void* B3, hipStream_t stream) {
+    return mis_gemm_split_b_layout(B, ldb, N, K, B3, 0, stream);
+}
+
 // batched form, as mis_transpose_job / mis_transpose_batch: records filled on the host, one launch for all of them
 extern "C" long long mis_gemm_split_job_bytes(void) { return (long long)sizeof(SplitJob); }
 
-extern "C" long long mis_gemm_split_job(void* job, const float* B, long long ldb, int N, int K, void* B3, long long first) {
+extern "C" long long mis_gemm_split_job_layout(void* job, const float* B, long long ldb, int N, int K, void* B3, long long first,
+                                               int natural) {
     if (!job) return MIS_ERR_ARG;
     SplitJob j;
-    const long long units = split_fill(j, B, ldb, N, K, B3, first);
+    memset(&j, 0, sizeof(j));
+    const long long units = split_fill(j, B, ldb, N, K, B3, first, natural);
     if (units < 0) return units;
     memcpy(job, &j, sizeof(j));
     return units;
+}
+
+extern "C" long long mis_gemm_split_job(void* job, const float* B, long long ldb, int N, int K, void* B3, long long first) {
+    return mis_gemm_split_job_layout(job, B, ldb, N, K, B3, first, 0);
+}
+
+// 1: mis_gemm_nt_split runs this shape on the register-A kernel, which reads the planes in the NATURAL element order
+// (mis_gemm_split_*_layout with natural = 1, mis_gemm_nt_split_layout with layout = 1); 0: the staged kernels' order
+extern "C" int mis_gemm_nt_split_natural(int M, int N, int K) {
+    return (M > 0 && N > 0 && K > 0 && nt_rega_shape(M, N, K)) ? 1 : 0;
 }
 
 extern "C" int mis_gemm_split_batch(const void* jobs, int n, long long units, hipStream_t stream) {
@@ -1736,11 +1979,11 @@ extern "C" long long mis_gemm_nt_split_workspace_bytes(int M, int N, int K) {
 // mis_gemm_expand (C dense [B H P W P][ex_c], M = B ex_H ex_W, N = P P ex_c, no bias, no epilogue, no split-K).
 // workspace >= mis_gemm_nt_split_workspace_bytes(M, N, K).  MIS_ERR_UNSUPPORTED (also: contractions the rule leaves to the
 // short-contraction kernel): the caller uses the fp32-B entry points.
-extern "C" int mis_gemm_nt_split(const float* A, long long lda, const void* B3, float* C, long long ldc, const float* bias,
-                                 int M, int N, int K, int accumulate, int epilogue, const float* E1, long long lde1,
-                                 float* C2, long long ldc2, const float* rowscale, long long rows_per_scale, int ex_H,
-                                 int ex_W, int ex_P, int ex_c, float* workspace, long long workspace_bytes,
-                                 hipStream_t stream) {
+static int gemm_nt_split_impl(const float* A, long long lda, const void* B3, float* C, long long ldc, const float* bias,
+                              int M, int N, int K, int accumulate, int epilogue, const float* E1, long long lde1,
+                              float* C2, long long ldc2, const float* rowscale, long long rows_per_scale, int ex_H,
+                              int ex_W, int ex_P, int ex_c, float* workspace, long long workspace_bytes,
+                              hipStream_t stream, int layout) {
     if (!A || !B3 || (!C && epilogue != EP_GELU_FWD) || M <= 0 || N <= 0 || K <= 0) return MIS_ERR_ARG;
     if (epilogue < EP_NONE || epilogue > EP_RESIDUAL) return MIS_ERR_ARG;
     if (!a16(A) || !a16(B3) || lda % 4 || K % 4) return MIS_ERR_UNSUPPORTED;
@@ -1763,6 +2006,11 @@ extern "C" int mis_gemm_nt_split(const float* A, long long lda, const void* B3, 
         if (epilogue == EP_GELU_FWD ? (ldc2 % 4 || !a16(C2)) : (lde1 % 4 || !a16(E1))) return MIS_ERR_UNSUPPORTED;
         a.E1 = E1; a.lde1 = lde1; a.C2 = C2; a.ldc2 = ldc2; a.rowscale = rowscale; a.rps = rows_per_scale;
     }
+    if (layout) {
+        // natural-order planes: only the register-A kernel reads them (the caller asked mis_gemm_nt_split_natural)
+        if (!nt_rega_shape(M, N, K) || a.ex_P || !a.vec4) return MIS_ERR_UNSUPPORTED;
+        return launch_nt_rega(a, stream);
+    }
     int bm, bn, ks;
     if (!b3_choice(M, N, K, bm, bn, ks)) return MIS_ERR_UNSUPPORTED;
     if (a.ex_P && ks != 1) return MIS_ERR_UNSUPPORTED;
@@ -1784,6 +2032,26 @@ extern "C" int mis_gemm_nt_split(const float* A, long long lda, const void* B3, 
     if (a.KS > 1)
         hipLaunchKernelGGL(gemm_reduce_kernel, dim3((unsigned)mis_cdiv((long long)M * N, 32)), dim3(256), 0, stream, a);
     return mis_launch_status();
+}
+
+extern "C" int mis_gemm_nt_split(const float* A, long long lda, const void* B3, float* C, long long ldc, const float* bias,
+                                 int M, int N, int K, int accumulate, int epilogue, const float* E1, long long lde1,
+                                 float* C2, long long ldc2, const float* rowscale, long long rows_per_scale, int ex_H,
+                                 int ex_W, int ex_P, int ex_c, float* workspace, long long workspace_bytes,
+                                 hipStream_t stream) {
+    return gemm_nt_split_impl(A, lda, B3, C, ldc, bias, M, N, K, accumulate, epilogue, E1, lde1, C2, ldc2, rowscale, rows_per_scale,
+                              ex_H, ex_W, ex_P, ex_c, workspace, workspace_bytes, stream, 0);
+}
+
+// mis_gemm_nt_split on planes in the layout `layout` (0: as mis_gemm_nt_split; 1: natural order, shapes for which
+// mis_gemm_nt_split_natural says 1 -- the register-A kernel: A straight from HBM into the MFMA operand registers, round 6)
+extern "C" int mis_gemm_nt_split_layout(const float* A, long long lda, const void* B3, float* C, long long ldc, const float* bias,
+                                        int M, int N, int K, int accumulate, int epilogue, const float* E1, long long lde1,
+                                        float* C2, long long ldc2, const float* rowscale, long long rows_per_scale, int ex_H,
+                                        int ex_W, int ex_P, int ex_c, float* workspace, long long workspace_bytes, int layout,
+                                        hipStream_t stream) {
+    return gemm_nt_split_impl(A, lda, B3, C, ldc, bias, M, N, K, accumulate, epilogue, E1, lde1, C2, ldc2, rowscale, rows_per_scale,
+                              ex_H, ex_W, ex_P, ex_c, workspace, workspace_bytes, stream, layout);
 }
 
 // nn.Linear of PatchExpand / FinalPatchExpand_X4 fused with their pixel shuffle (reference

@@ -386,6 +386,119 @@ __global__ __launch_bounds__(1024) void col_final_kernel(const float2* __restric
     }
 }
 
+// Every finishing column sum of a backward pass in ONE launch (round 6): the affine gradients of the LayerNorms (float2 partial
+// rows per slab of tokens), the weight / bias gradients of the split-K dW GEMMs (one partial matrix per k-slice) and the
+// relative-position-bias gradients of the window attentions (one partial table per (image, window)) are all "out[c] (+)= sum over
+// slabs of part[slab][c]" -- ~130 launches of 5 .. 9 us per SwinUnet step that nothing downstream of the backward reads.  The
+// token plans queue a job per reduction and run the queue as one launch per flush (mis_hip/plan.py::flush_deferred).  A job owns
+// ceil(C / 32) consecutive workgroups (`first` = prefix sum); the workgroup is col_final_kernel's: 32 columns x 32 slab lanes,
+// double accumulators, fixed order -- a job's result does not depend on what else is in the batch.
+struct ColsumJob {
+    const void* part;          // float [slabs][stride] (pairs == 0) or float2 [slabs][stride] (pairs == 1)
+    float* out_a; float* out_b;
+    long long stride;          // elements between two slabs
+    int slabs, C, pairs, accumulate;
+    int first, blocks;
+    int wide, pad;             // wide: few slabs x many columns (the k-slices of a weight gradient), see below
+};
+
+// Two workgroup shapes (1024 threads): "tall" jobs (LayerNorm / bias-table partials: 10^2 .. 10^3 slabs of 10^2 .. 10^3 columns)
+// take 32 columns x 32 slab lanes like col_final_kernel; "wide" jobs (split-K partials of a weight gradient: 2 .. 85 slices of
+// 10^4 .. 10^6 columns) take 256 float4 column groups x 4 slab lanes -- a tall workgroup would keep KS of its 32 slab lanes busy
+// and read 128-byte pieces (first version: one batch of a SwinUnet step took 3 ms).  Double accumulators, fixed order.
+constexpr int COLSUM_WIDE_COLS = 1024;
+
+__global__ __launch_bounds__(1024) void colsum_batch_kernel(const ColsumJob* __restrict__ jobs, int n) {
+    __shared__ ColsumJob job;
+    __shared__ double ra[1024], rb[1024];
+    if (threadIdx.x == 0) {
+        int lo = 0, hi = n - 1;
+        const int t = (int)blockIdx.x;
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (jobs[mid].first <= t) lo = mid; else hi = mid - 1;
+        }
+        job = jobs[lo];
+    }
+    __syncthreads();
+    const int slabs = job.slabs;
+    const long long ld = job.stride;
+    if (job.wide) {
+        // thread = (column group cg of 4 floats, slab lane sl of 4); slabs sl, sl + 4, ... four loads in flight
+        const int cg = threadIdx.x & 255, sl = threadIdx.x >> 8;
+        const int col = ((int)blockIdx.x - job.first) * COLSUM_WIDE_COLS + cg * 4;
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+        if (col < job.C) {
+            const float* __restrict__ part = reinterpret_cast<const float*>(job.part) + col;
+            int s = sl;
+            for (; s + 12 < slabs; s += 16) {
+                float4 p[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) p[j] = *reinterpret_cast<const float4*>(part + (long long)(s + 4 * j) * ld);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { a0 += p[j].x; a1 += p[j].y; a2 += p[j].z; a3 += p[j].w; }
+            }
+            for (; s < slabs; s += 4) {
+                const float4 p = *reinterpret_cast<const float4*>(part + (long long)s * ld);
+                a0 += p.x; a1 += p.y; a2 += p.z; a3 += p.w;
+            }
+        }
+        // fixed-order sum over the 4 slab lanes through LDS: lanes 1..3 publish, lane 0 adds them in order
+        __shared__ double wred[3][256][4];
+        if (sl) { wred[sl - 1][cg][0] = a0; wred[sl - 1][cg][1] = a1; wred[sl - 1][cg][2] = a2; wred[sl - 1][cg][3] = a3; }
+        __syncthreads();
+        if (sl == 0 && col < job.C) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { a0 += wred[k][cg][0]; a1 += wred[k][cg][1]; a2 += wred[k][cg][2]; a3 += wred[k][cg][3]; }
+            float4* o = reinterpret_cast<float4*>(job.out_a + col);
+            float4 v = make_float4((float)a0, (float)a1, (float)a2, (float)a3);
+            if (job.accumulate) { const float4 q = *o; v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w; }
+            *o = v;
+        }
+        return;
+    }
+    const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
+    const int col = ((int)blockIdx.x - job.first) * 32 + cl;
+    double a = 0.0, b = 0.0;
+    if (col < job.C) {
+        if (job.pairs) {
+            const float2* __restrict__ part = reinterpret_cast<const float2*>(job.part);
+            int s = sl;
+            for (; s + 224 < slabs; s += 256) {
+                float2 p[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) p[j] = part[(long long)(s + 32 * j) * ld + col];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { a += p[j].x; b += p[j].y; }
+            }
+            for (; s < slabs; s += 32) {
+                const float2 p = part[(long long)s * ld + col];
+                a += p.x; b += p.y;
+            }
+        } else {
+            const float* __restrict__ part = reinterpret_cast<const float*>(job.part);
+            int s = sl;
+            for (; s + 224 < slabs; s += 256) {
+                float p[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) p[j] = part[(long long)(s + 32 * j) * ld + col];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) a += p[j];
+            }
+            for (; s < slabs; s += 32) a += part[(long long)s * ld + col];
+        }
+    }
+    ra[threadIdx.x] = a;
+    rb[threadIdx.x] = b;
+    __syncthreads();
+    if (sl == 0 && col < job.C) {
+#pragma unroll
+        for (int k = 1; k < 32; ++k) { a += ra[k * 32 + cl]; b += rb[k * 32 + cl]; }
+        if (job.out_a) job.out_a[col] = job.accumulate ? job.out_a[col] + (float)a : (float)a;
+        if (job.out_b) job.out_b[col] = job.accumulate ? job.out_b[col] + (float)b : (float)b;
+    }
+}
+
 // ------------------------------------------------------------------ GELU (erf form; mis_gelu in common.h)
 __global__ __launch_bounds__(256) void gelu_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                    float* __restrict__ out, long long n4, int backward) {
@@ -1227,6 +1340,39 @@ extern "C" int mis_layernorm_bwd(const float* x, long long ldx, const float* dy,
                                        workspace_bytes, stream);
     if (st != MIS_OK || !affine) return st;
     return mis_layernorm_bwd_final(workspace, workspace_bytes, M, C, dgamma, dbeta, accumulate_affine, stream);
+}
+
+// ---- batched finishing sums (colsum_batch_kernel) ----
+extern "C" long long mis_colsum_job_bytes(void) { return (long long)sizeof(ColsumJob); }
+
+// number of partial rows mis_layernorm_bwd_parts / _residual_parts leave in their workspace (float2 [slabs][C])
+extern "C" long long mis_colreduce_slabs(long long M) { return M > 0 ? mis_cdiv(M, COL_SLAB_ROWS) : MIS_ERR_ARG; }
+
+// fills one job of a batch: out_a[c] (+)= sum_s part[s][c] (pairs: .x -> out_a, .y -> out_b; either may be NULL);
+// returns the number of workgroups the job owns (the caller's running prefix sum is the next job's `first`)
+extern "C" long long mis_colsum_job(void* job, const void* part, long long stride, long long slabs, int C, int pairs,
+                                    float* out_a, float* out_b, int accumulate, long long first) {
+    if (!job || !part || slabs <= 0 || C <= 0 || stride < C || (!out_a && !out_b) || (!pairs && out_b)) return MIS_ERR_ARG;
+    // wide form: float4 columns (16-byte aligned rows) and few slabs
+    const bool wide = !pairs && slabs <= 128 && C >= 256 && C % 4 == 0 && stride % 4 == 0 &&
+                      !((uintptr_t)part & 15) && !((uintptr_t)out_a & 15);
+    const long long blocks = wide ? mis_cdiv(C, COLSUM_WIDE_COLS) : mis_cdiv(C, 32);
+    if (slabs > 0x7fffffffLL || first + blocks > 0x7fffffffLL) return MIS_ERR_UNSUPPORTED;
+    ColsumJob j;
+    memset(&j, 0, sizeof(j));
+    j.part = part; j.out_a = out_a; j.out_b = out_b; j.stride = stride;
+    j.slabs = (int)slabs; j.C = C; j.pairs = pairs ? 1 : 0; j.accumulate = accumulate ? 1 : 0;
+    j.first = (int)first; j.blocks = (int)blocks; j.wide = wide ? 1 : 0;
+    memcpy(job, &j, sizeof(j));
+    return blocks;
+}
+
+// jobs: device array of n jobs ordered by `first`; blocks = the sum of their workgroup counts
+extern "C" int mis_colsum_batch(const void* jobs, int n, long long blocks, hipStream_t stream) {
+    if (!jobs || n <= 0 || blocks <= 0 || blocks > 0x7fffffffLL) return MIS_ERR_ARG;
+    hipLaunchKernelGGL(colsum_batch_kernel, dim3((unsigned)blocks), dim3(1024), 0, stream,
+                       reinterpret_cast<const ColsumJob*>(jobs), n);
+    return mis_launch_status();
 }
 
 // out[c] (+)= sum_rows x[row][c]   (nn.Linear bias gradient)

@@ -151,6 +151,7 @@ PROTOTYPES = {
     "mis_gemm_workspace_bytes": (c_ll, [c_i, c_i, c_i, c_i]),
     "mis_gemm_dw_workspace_bytes": (c_ll, [c_i, c_i, c_i]),
     "mis_gemm_dw": (c_i, [c_p, c_ll, c_p, c_ll, c_p, c_ll, c_p, c_i, c_i, c_i, c_i, c_p, c_ll, c_p]),
+    "mis_gemm_dw_parts": (c_i, [c_p, c_ll, c_p, c_ll, c_p, c_ll, c_p, c_i, c_i, c_i, c_i, c_p, c_ll, c_p, c_p]),
     "mis_gemm_set_split_precision": (c_i, [c_i]),
     "mis_gemm_nt_kernel_name": (c_i, [c_i, c_i, c_i, c_i, ctypes.c_char_p, c_i]),
     "mis_gemm_tn_kernel_name": (c_i, [c_p, c_ll, c_p, c_ll, c_p, c_ll, c_i, c_i, c_i, ctypes.c_char_p, c_i]),
@@ -158,6 +159,12 @@ PROTOTYPES = {
                                       c_p, c_ll, c_p]),
     "mis_gemm_split_bytes": (c_ll, [c_i, c_i]),
     "mis_gemm_split_b": (c_i, [c_p, c_ll, c_i, c_i, c_p, c_p]),
+    "mis_gemm_split_b_layout": (c_i, [c_p, c_ll, c_i, c_i, c_p, c_i, c_p]),
+    "mis_gemm_split_job_layout": (c_ll, [c_p, c_p, c_ll, c_i, c_i, c_p, c_ll, c_i]),
+    "mis_gemm_nt_split_natural": (c_i, [c_i, c_i, c_i]),
+    "mis_gemm_nt_split_layout": (c_i, [c_p, c_ll, c_p, c_p, c_ll, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_ll, c_p, c_ll, c_p, c_ll,
+                                       c_i, c_i, c_i, c_i, c_p, c_ll, c_i, c_p]),
+    "mis_gemm_nt_split_layout_kernel_name": (c_i, [c_i, c_i, c_i, c_i, c_i, ctypes.c_char_p, c_i]),
     "mis_gemm_split_job_bytes": (c_ll, []),
     "mis_gemm_split_job": (c_ll, [c_p, c_p, c_ll, c_i, c_i, c_p, c_ll]),
     "mis_gemm_split_batch": (c_i, [c_p, c_i, c_ll, c_p]),
@@ -187,6 +194,10 @@ PROTOTYPES = {
                                 c_ll, c_p]),
     "mis_layernorm_bwd_parts": (c_i, [c_p, c_ll, c_p, c_ll, c_p, c_ll, c_p, c_p, c_p, c_ll, c_i, c_i, c_p, c_ll, c_p]),
     "mis_layernorm_bwd_final": (c_i, [c_p, c_ll, c_ll, c_i, c_p, c_p, c_i, c_p]),
+    "mis_colsum_job_bytes": (c_ll, []),
+    "mis_colreduce_slabs": (c_ll, [c_ll]),
+    "mis_colsum_job": (c_ll, [c_p, c_p, c_ll, c_ll, c_i, c_i, c_p, c_p, c_i, c_ll]),
+    "mis_colsum_batch": (c_i, [c_p, c_i, c_ll, c_p]),
     "mis_layernorm_bwd_residual_parts": (c_i, [c_p, c_ll, c_p, c_ll, c_p, c_ll, c_p, c_ll, c_i, c_p, c_ll, c_p, c_ll, c_p, c_p,
                                                c_p, c_ll, c_i, c_p, c_ll, c_p]),
     "mis_colsum": (c_i, [c_p, c_ll, c_ll, c_i, c_p, c_i, c_p, c_ll, c_p]),
@@ -216,6 +227,7 @@ PROTOTYPES = {
     "mis_window_attention_bwd_parts_ws": (c_i, [c_p, c_ll, c_p, c_ll, c_p, c_ll, c_p, c_i, c_i, c_i, c_i, c_i, c_f, c_i, c_p,
                                                 c_ll, c_p]),
     "mis_window_attention_dtable_ws": (c_i, [c_p, c_ll, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
+    "mis_window_attention_table_partials": (c_i, [c_i, c_i, c_i, c_i, c_i, c_p, c_p]),
     "mis_full_attention_fwd": (c_i, [c_p, c_ll, c_p, c_ll, c_p, c_i, c_i, c_i, c_f, c_p]),
     "mis_full_attention_workspace_bytes": (c_ll, [c_i, c_i, c_i]),
     "mis_full_attention_bwd": (c_i, [c_p, c_ll, c_p, c_ll, c_p, c_ll, c_p, c_i, c_i, c_i, c_f, c_p, c_ll, c_p]),
@@ -231,10 +243,92 @@ AUG2D_BYTES = 88       # sizeof(MisAug2D)
 CROP3D_BYTES = 48      # sizeof(MisCrop3D)
 
 
+class StreamPtr(ctypes.c_void_p):
+    """The hipStream_t argument of a launching entry point (``stream_ptr()``): what marks a call as a launch for a LaunchTape."""
+
+
+class LaunchTape:
+    """One training step as a flat list of ``(callable, args)``: every C-ABI launch the eager step issued (the ctypes function and
+    its already converted arguments: raw pointers into the plans' static buffers), the stream dependencies between them (HIP
+    event record / wait pairs) and the Python callbacks of the gradient exchange (bucket all-reduces, on their streams).
+
+    Why: the step is static -- same buffers, same launch sequence, the per-step scalars (RNG offset, learning rate, EMA alpha,
+    consistency weight) live in a device-resident MisStepState -- but enqueueing it through the op graph costs the host 8 .. 10 ms
+    of a 20 ms SwinUnet step (623 launches x ~14 us of Python per launch), and a captured hipGraph is no way out on this stack:
+    replaying the SwinUnet step's graph costs the host 10.9 ms (measured, profiles/r06_*: ROCm enqueues the nodes one by one).
+    Replaying the tape is one ctypes call per launch (~2.5 us).  ``recording()`` is the context the trainers run ONE eager step
+    in; afterwards ``replay()`` is the step.  Everything the recorded step touched must stay where it is: inputs are copied
+    into the static tensors the recording saw, grow-only scratch buffers are never freed (ops.scratch)."""
+
+    def __init__(self):
+        self.items = []
+        self.keep = []          # objects the recorded arguments point into (events, tensors)
+
+    def recording(self):
+        return _Recording(self)
+
+    def replay(self):
+        for fn, args in self.items:
+            st = fn(*args)
+            if st:
+                raise RuntimeError(f"launch tape: {getattr(fn, '__name__', fn)} failed with status {st}")
+
+    def __len__(self):
+        return len(self.items)
+
+
+class _Recording:
+    def __init__(self, tape):
+        self.tape = tape
+
+    def __enter__(self):
+        global TAPE
+        if TAPE is not None:
+            raise RuntimeError("a launch tape is already being recorded")
+        TAPE = self.tape
+        return self.tape
+
+    def __exit__(self, *exc):
+        global TAPE
+        TAPE = None
+        return False
+
+
+TAPE = None        # the LaunchTape being recorded (None: eager)
+
+
+class _RecordingLib:
+    """Stands in for the ctypes library while a tape is recorded: calls go through, launches (last argument a StreamPtr) are
+    appended to the tape with their argument tuples."""
+
+    def __init__(self, lib):
+        self._lib = lib
+
+    def __getattr__(self, name):
+        fn = getattr(self._lib, name)
+
+        def call(*args):
+            st = fn(*args)
+            # a refused call (MIS_ERR_UNSUPPORTED: the caller goes on to another entry point) launched nothing
+            if st == 0 and TAPE is not None and args and isinstance(args[-1], StreamPtr):
+                TAPE.items.append((fn, args))
+            return st
+        call.__name__ = name
+        setattr(self, name, call)
+        return call
+
+
+_rec_lib = None
+
+
 def load():
     """Load libmis_hip.so (once) and attach prototypes.  Raises if it is not built."""
-    global _lib
+    global _lib, _rec_lib
     if _lib is not None:
+        if TAPE is not None:
+            if _rec_lib is None:
+                _rec_lib = _RecordingLib(_lib)
+            return _rec_lib
         return _lib
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(
@@ -256,7 +350,67 @@ def check(status, what):
 
 def stream_ptr():
     """hipStream_t of torch's current stream, as a void*."""
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return StreamPtr(torch.cuda.current_stream().cuda_stream)
+
+
+_hip = None
+
+
+def _hip_runtime():
+    """The libamdhip64 torch has loaded (for event record / wait pairs on a tape)."""
+    global _hip
+    if _hip is None:
+        path = None
+        with open("/proc/self/maps") as f:
+            for line in f:
+                if "libamdhip64.so" in line:
+                    path = line.split()[-1]
+                    break
+        if path is None:
+            raise RuntimeError("libamdhip64.so is not loaded in this process")
+        h = ctypes.CDLL(path)
+        h.hipEventCreateWithFlags.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_uint]
+        h.hipEventRecord.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        h.hipStreamWaitEvent.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint]
+        for fn in (h.hipEventCreateWithFlags, h.hipEventRecord, h.hipStreamWaitEvent):
+            fn.restype = ctypes.c_int
+        _hip = h
+    return _hip
+
+
+def wait_stream(waiter, waited):
+    """``waiter.wait_stream(waited)``; while a tape is recorded the dependency is an event record / wait pair of the tape's own
+    (replayed as two HIP runtime calls)."""
+    if TAPE is None:
+        waiter.wait_stream(waited)
+        return
+    h = _hip_runtime()
+    ev = ctypes.c_void_p()
+    if h.hipEventCreateWithFlags(ctypes.byref(ev), 0x2) != 0:          # hipEventDisableTiming
+        raise RuntimeError("hipEventCreateWithFlags failed")
+    rec = (h.hipEventRecord, (ev, ctypes.c_void_p(waited.cuda_stream)))
+    wai = (h.hipStreamWaitEvent, (ctypes.c_void_p(waiter.cuda_stream), ev, 0))
+    for fn, args in (rec, wai):
+        if fn(*args) != 0:
+            raise RuntimeError("HIP event record / wait failed")
+        TAPE.items.append((fn, args))
+    TAPE.keep.append(ev)
+
+
+def tape_call(fn, *args):
+    """``fn(*args)`` now, and again -- with the stream that is current now -- at this point of every replay when a tape is being
+    recorded (the Python side of the gradient exchange: torch.distributed collectives order themselves behind the current
+    stream).  Returns fn's result."""
+    r = fn(*args)
+    if TAPE is not None:
+        stream = torch.cuda.current_stream()
+
+        def again():
+            with torch.cuda.stream(stream):
+                fn(*args)
+        again.__name__ = getattr(fn, "__name__", "callback")
+        TAPE.items.append((again, ()))
+    return r
 
 
 def ptr(t):

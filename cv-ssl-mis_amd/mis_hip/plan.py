@@ -20,6 +20,7 @@ import os
 import torch
 import torch.nn as nn
 
+from . import lib as _lib
 from . import ops
 
 _net_ids = itertools.count(1)
@@ -145,7 +146,7 @@ class ConvOp:
         dy = self.y.grad()
         side = getattr(ctx, "wgrad_stream", None) if self.need_dx else None
         if side is not None:
-            side.wait_stream(torch.cuda.current_stream())     # dy is final
+            _lib.wait_stream(side, torch.cuda.current_stream())     # dy is final
             with torch.cuda.stream(side):
                 run_deferred(ctx)
                 ops.conv_wgrad(self.x.t, dy, self.w.grad, self.ksize)
@@ -808,27 +809,28 @@ class Plan:
             side = self._wgrad_stream
         ctx.wgrad_stream = side
         ctx.deferred = [] if side is not None else None      # see defer(): finishing launches queued for the side stream
+        begin_finals(ctx, self)
         if on_progress is None:
             for op in reversed(self.ops):
                 op.bwd(ctx)
             flush_deferred(ctx)
-            ctx.deferred = None
+            ctx.deferred = ctx.finals = None
             if side is not None:
-                main.wait_stream(side)      # every weight gradient is in the flat buffer before the optimizer reads it
+                _lib.wait_stream(main, side)      # every weight gradient is in the flat buffer before the optimizer reads it
             return
         if self._progress is None:
             from .dist import param_progress
             self._progress = param_progress(self.ops, self.net.flat_grad)
-        report = progress_reporter(on_progress, main, side)
+        # a reported gradient range is complete on (main, side): what was queued is finished before the callback issues anything
+        report = progress_reporter(on_progress, main, side, before=lambda: flush_deferred(ctx))
         for i in range(len(self.ops) - 1, -1, -1):
             self.ops[i].bwd(ctx)
             if i == 0 or self._progress[i] != self._progress[i - 1] or i == len(self.ops) - 1:
-                flush_deferred(ctx)         # a reported gradient range is complete on (main, side): finish what was queued
                 report(self._progress[i])
         flush_deferred(ctx)
-        ctx.deferred = None
+        ctx.deferred = ctx.finals = None
         if side is not None:
-            main.wait_stream(side)          # every weight gradient is in the flat buffer before the optimizer reads it
+            _lib.wait_stream(main, side)          # every weight gradient is in the flat buffer before the optimizer reads it
 
     def drop_sites(self):
         """Site ids (keys of ``net.drop_masks``) of the active dropout layers, in forward order."""
@@ -853,6 +855,49 @@ def defer(ctx, fn):
     return True
 
 
+# Finishing column sums of a backward pass (LayerNorm affine gradients, split-K partials of the Linear weight / bias gradients,
+# relative-position-bias tables: ~130 launches of 5 .. 9 us per SwinUnet step) as ColsumJob records run in ONE launch per flush
+# (tops.ColsumBatch / mis_colsum_batch) instead of one or two launches each.  MIS_BATCH_FINALS=0: the per-op launches.  A batch
+# is also run when the queued partials exceed FINALS_FLUSH_BYTES, so that the sums overlap the rest of the backward instead of
+# all landing behind its last kernel.
+BATCH_FINALS = os.environ.get("MIS_BATCH_FINALS", "1") != "0"
+FINALS_FLUSH_BYTES = int(os.environ.get("MIS_FINALS_FLUSH_MB", "32")) << 20
+
+
+def begin_finals(ctx, holder):
+    """Start a backward pass: ``ctx.finals`` collects ColsumJob records (None: batching is off -- no side stream, or switched
+    off); the device job tables are cached on ``holder`` (the plan) by the identity of the jobs of a flush."""
+    on = BATCH_FINALS and DEFER and getattr(ctx, "wgrad_stream", None) is not None
+    ctx.finals = [] if on else None
+    ctx.finals_bytes = 0
+    if on and not hasattr(holder, "_final_batches"):
+        holder._final_batches = {}
+    ctx.final_batches = getattr(holder, "_final_batches", None)
+
+
+def defer_final(ctx, *jobs):
+    """Queue finishing sums for the next batch (False: batching is off and the caller launches its own finishing kernel)."""
+    if getattr(ctx, "finals", None) is None:
+        return False
+    ctx.finals.extend(jobs)
+    ctx.finals_bytes += sum(j.bytes for j in jobs)
+    return True
+
+
+def run_finals(ctx):
+    """Called with the side stream current and ordered behind the producers of every queued partial."""
+    pend = getattr(ctx, "finals", None)
+    if pend:
+        from . import tops
+        key = tuple(id(j) for j in pend)
+        batch = ctx.final_batches.get(key)
+        if batch is None:
+            batch = ctx.final_batches[key] = tops.ColsumBatch(pend)
+        batch.run()
+        del pend[:]
+        ctx.finals_bytes = 0
+
+
 def run_deferred(ctx):
     """Called with the side stream current and ordered behind everything enqueued on the compute stream so far."""
     pend = getattr(ctx, "deferred", None)
@@ -860,17 +905,20 @@ def run_deferred(ctx):
         for fn in pend:
             fn()
         del pend[:]
+    if getattr(ctx, "finals_bytes", 0) >= FINALS_FLUSH_BYTES:
+        run_finals(ctx)
 
 
 def flush_deferred(ctx):
     side = getattr(ctx, "wgrad_stream", None)
-    if side is not None and getattr(ctx, "deferred", None):
-        side.wait_stream(torch.cuda.current_stream())
+    if side is not None and (getattr(ctx, "deferred", None) or getattr(ctx, "finals", None)):
+        _lib.wait_stream(side, torch.cuda.current_stream())
         with torch.cuda.stream(side):
             run_deferred(ctx)
+            run_finals(ctx)
 
 
-def progress_reporter(on_progress, main, side):
+def progress_reporter(on_progress, main, side, before=None):
     """How a backward pass reports ``on_progress(lo)`` when weight gradients run on a side stream.
 
     The finished suffix includes gradients still in flight on ``side``.  The compute stream must NOT wait for them (that
@@ -878,24 +926,30 @@ def progress_reporter(on_progress, main, side):
     waits for ``main`` (free: its later work is issued behind main's anyway) and the callback runs with ``side`` as the
     current stream, so whatever it enqueues -- the bucket all-reduce of mis_hip.dist.GradBucketer, which orders itself
     behind the current stream -- sees both streams' work.  A callback that is a bound method of an object with
-    ``would_issue(lo)`` (the bucketer) is only called when it would do something: no stream dependency otherwise."""
+    ``would_issue(lo)`` (the bucketer) is only called when it would do something: no stream dependency otherwise.
+    ``before()`` runs ahead of every callback that IS made (the plans finish their queued parameter-gradient sums there: a
+    range that is not reported yet may keep its finishing launches queued, so they batch up between two buckets)."""
     probe = getattr(getattr(on_progress, "__self__", None), "would_issue", None)
     if PROGRESS_SYNC_MAIN:          # A/B switch (scripts/ddp_overhead.py): the compute stream waits at every report
         probe = None
 
     def report(lo):
         if PROGRESS_SYNC_MAIN and side is not None:
-            main.wait_stream(side)
-            on_progress(lo)
+            if before is not None:
+                before()
+            _lib.wait_stream(main, side)
+            _lib.tape_call(on_progress, lo)
             return
         if probe is not None and not probe(lo):
             return
+        if before is not None:
+            before()
         if side is None:
-            on_progress(lo)
+            _lib.tape_call(on_progress, lo)        # (tape_call: the callback is part of a recorded step, lib.LaunchTape)
             return
-        side.wait_stream(main)
+        _lib.wait_stream(side, main)
         with torch.cuda.stream(side):
-            on_progress(lo)
+            _lib.tape_call(on_progress, lo)
     return report
 
 

@@ -19,10 +19,15 @@ import os
 import torch
 
 from . import dist, ops
+from . import lib as _lib
 
 # teacher forward (cross teaching: the second student) on a side stream, see _run: bit-identical training, the second
 # network's launches fill the CUs the first one's launch tails and small deep layers leave idle (MIS_TWO_STREAM=0: off)
 TWO_STREAM = os.environ.get("MIS_TWO_STREAM", "1") != "0"
+# the step as a launch tape (lib.LaunchTape): after two eager steps the trainer records one step's launches and replays them --
+# one ctypes call per launch instead of the Python op graph (host enqueue 8.6 -> ~2 ms of a 20 ms SwinUnet step; a captured
+# hipGraph costs the host MORE than the eager step on this stack).  MIS_STEP_TAPE=0: eager.  Bit-identical training.
+STEP_TAPE = os.environ.get("MIS_STEP_TAPE", "1") != "0"
 # data parallel: issue the all-reduce of finished gradient buckets while the backward is still running
 # (dist.GradBucketer); MIS_GRAD_OVERLAP=0 falls back to one blocking all-reduce after the backward
 GRAD_OVERLAP = os.environ.get("MIS_GRAD_OVERLAP", "1") != "0"
@@ -33,10 +38,10 @@ def backward_and_sync(model, pg, bucketer=None):
     1/world scale the optimizer kernel folds in.  With a bucketer the finished buckets travel during the backward."""
     if bucketer is None:
         model.backward_raw()
-        return dist.sync_gradients(model.flat_grad, pg)
-    bucketer.begin()
+        return _lib.tape_call(dist.sync_gradients, model.flat_grad, pg)
+    _lib.tape_call(bucketer.begin)
     model.backward_raw(on_progress=bucketer.advance)
-    return bucketer.finish()
+    return _lib.tape_call(bucketer.finish)
 
 
 def make_bucketer(model, pg, defer_tail=False):
@@ -46,10 +51,41 @@ def make_bucketer(model, pg, defer_tail=False):
     return dist.GradBucketer(model.flat_grad, pg, defer_tail=defer_tail) if (GRAD_OVERLAP and on) else None
 
 
-class MeanTeacherTrainer:
+class _TapedStep:
+    """Mixin: ``_tape_step(run, tensors)`` runs ``run(*static)`` eagerly twice (plans, scratch buffers and lazily built job
+    tables settle), records the third run as a lib.LaunchTape and replays it from then on.  ``tensors`` are the step's inputs:
+    the recording sees static copies (or the caller's own tensors when they are the same storage every step, as in bench.py)."""
+
+    _tape = None
+    _tape_warm = 0
+    _tape_static = None
+    TAPE_WARMUP = 2
+
+    def _tape_step(self, run, tensors):
+        if self._tape is None:
+            if self._tape_warm < self.TAPE_WARMUP:
+                self._tape_warm += 1
+                run(*tensors)
+                return
+            self._tape_static = tuple(t.clone() for t in tensors)
+            self._tape_src = tuple((t.data_ptr(), tuple(t.shape)) for t in tensors)
+            tape = _lib.LaunchTape()
+            with tape.recording():
+                run(*self._tape_static)
+            self._tape = tape
+            return
+        for t, st in zip(tensors, self._tape_static):
+            if t.shape != st.shape or t.dtype != st.dtype:
+                raise RuntimeError("the taped step was recorded for inputs of another shape; construct the trainer with "
+                                   "use_tape=False (MIS_STEP_TAPE=0) for varying batch geometry")
+            st.copy_(t)
+        self._tape.replay()
+
+
+class MeanTeacherTrainer(_TapedStep):
     def __init__(self, model, ema_model, *, labeled_bs, num_classes, base_lr=0.01, max_iterations=30000,
                  ema_decay=0.99, consistency=0.1, consistency_rampup=200.0, cons_start_iter=0, seed=1337,
-                 iter_num=0, momentum=0.9, weight_decay=1e-4, process_group=None, use_graph=False):
+                 iter_num=0, momentum=0.9, weight_decay=1e-4, process_group=None, use_graph=False, use_tape=None):
         if model.flat_param.numel() != ema_model.flat_param.numel():
             raise RuntimeError("student and teacher must be the same architecture")
         self.model, self.ema_model = model, ema_model
@@ -72,6 +108,7 @@ class MeanTeacherTrainer:
         self.iter_num = iter_num
         # a captured replay of a step that contains an RCCL collective is not verified on hardware: single-GPU only
         self.use_graph = bool(use_graph) and self.world == 1
+        self.use_tape = (STEP_TAPE if use_tape is None else bool(use_tape)) and not self.use_graph
         self._graph = None
         self._static = None
         self._ema_in = None
@@ -94,11 +131,11 @@ class MeanTeacherTrainer:
             main = torch.cuda.current_stream()
             if self._side is None:
                 self._side = torch.cuda.Stream()
-            self._side.wait_stream(main)
+            _lib.wait_stream(self._side, main)
             with torch.cuda.stream(self._side):
                 t_logits = self.ema_model.forward_raw(self._ema_in, no_backward=True)
             s_logits = self.model.forward_raw(volume)
-            main.wait_stream(self._side)
+            _lib.wait_stream(main, self._side)
         else:
             s_logits = self.model.forward_raw(volume)
             t_logits = self.ema_model.forward_raw(self._ema_in, no_backward=True)
@@ -119,6 +156,8 @@ class MeanTeacherTrainer:
             raise RuntimeError("Mean-Teacher step runs both networks in train mode (reference never calls .eval())")
         if self.use_graph and noise is None:
             self._step_graph(volume_batch, label_batch)
+        elif self.use_tape and noise is None and type(self) is MeanTeacherTrainer:
+            self._tape_step(lambda v, l: self._run(v, l, None), (volume_batch, label_batch))
         else:
             self._run(volume_batch, label_batch, noise)
         self.iter_num += 1
@@ -202,11 +241,11 @@ class UAMTTrainer(MeanTeacherTrainer):
             main = torch.cuda.current_stream()
             if self._side is None:
                 self._side = torch.cuda.Stream()
-            self._side.wait_stream(main)
+            _lib.wait_stream(self._side, main)
             with torch.cuda.stream(self._side):
                 t_logits = teacher_passes()
             s_logits = self.model.forward_raw(volume)
-            main.wait_stream(self._side)
+            _lib.wait_stream(main, self._side)
         else:
             s_logits = self.model.forward_raw(volume)
             t_logits = teacher_passes()
@@ -235,7 +274,7 @@ class UAMTTrainer(MeanTeacherTrainer):
         return d
 
 
-class CrossTeachingTrainer:
+class CrossTeachingTrainer(_TapedStep):
     """Cross teaching between a CNN and a Transformer (reference
     code/train_cross_teaching_between_cnn_transformer_2D.py:216-263): two students see the whole batch, each is
     supervised on the labeled half and by the OTHER network's arg-max pseudo labels (Dice) on the unlabeled
@@ -244,7 +283,8 @@ class CrossTeachingTrainer:
 
     def __init__(self, model1, model2, *, labeled_bs, num_classes, base_lr=0.01, max_iterations=30000,
                  consistency=0.1, consistency_rampup=200.0, seed=1337, iter_num=0, momentum=0.9, weight_decay=1e-4,
-                 process_group=None, pseudo_ce=False):
+                 process_group=None, pseudo_ce=False, use_tape=None):
+        self.use_tape = STEP_TAPE if use_tape is None else bool(use_tape)
         # pseudo_ce=True: cross pseudo supervision (code/train_cross_pseudo_supervision_{2D,3D}.py): the same step
         # with a cross-entropy pseudo-supervision term instead of Dice
         self.pseudo_ce = bool(pseudo_ce)
@@ -276,6 +316,14 @@ class CrossTeachingTrainer:
     def step(self, volume_batch, label_batch):
         if not (self.model1.training and self.model2.training):
             raise RuntimeError("cross teaching trains both networks (train mode)")
+        if self.use_tape:
+            self._tape_step(self._run, (volume_batch, label_batch))
+        else:
+            self._run(volume_batch, label_batch)
+        self.iter_num += 1
+        return self.out1, self.out2
+
+    def _run(self, volume_batch, label_batch):
         L = self.labeled_bs
         lab = label_batch[:L].contiguous()
         if TWO_STREAM:
@@ -283,11 +331,11 @@ class CrossTeachingTrainer:
             main = torch.cuda.current_stream()
             if self._side is None:
                 self._side = torch.cuda.Stream()
-            self._side.wait_stream(main)
+            _lib.wait_stream(self._side, main)
             with torch.cuda.stream(self._side):
                 o2 = self.model2.forward_raw(volume_batch)
             o1 = self.model1.forward_raw(volume_batch)
-            main.wait_stream(self._side)
+            _lib.wait_stream(main, self._side)
         else:
             o1 = self.model1.forward_raw(volume_batch)
             o2 = self.model2.forward_raw(volume_batch)
@@ -296,43 +344,41 @@ class CrossTeachingTrainer:
         ops.cross_teaching_tail(o2, o1, lab, L, self.out2, dlogits=self.model2.logits_grad_buffer(), state=self.state,
                                 pseudo_ce=self.pseudo_ce)
         if TWO_STREAM and self._bucketers[0] is None:
-            self._side.wait_stream(main)
+            _lib.wait_stream(self._side, main)
             with torch.cuda.stream(self._side):
                 self.model2.backward_raw()
             self.model1.backward_raw()
-            main.wait_stream(self._side)
-            scales = [dist.sync_gradients(m.flat_grad, self.pg) for m in (self.model1, self.model2)]
+            _lib.wait_stream(main, self._side)
+            scales = [_lib.tape_call(dist.sync_gradients, m.flat_grad, self.pg) for m in (self.model1, self.model2)]
         elif self._bucketers[0] is not None:
             # both students' buckets are in flight while the other student's backward runs; one wait at the end.  With
             # TWO_STREAM the second student's backward runs on the side stream as on one GPU: its collectives are still
             # ENQUEUED by this thread in program order (model2's buckets, then model1's), the same on every rank.
             b1, b2 = self._bucketers
-            b1.begin()
-            b2.begin()
+            _lib.tape_call(b1.begin)
+            _lib.tape_call(b2.begin)
             if TWO_STREAM:
-                self._side.wait_stream(main)
+                _lib.wait_stream(self._side, main)
                 with torch.cuda.stream(self._side):
                     self.model2.backward_raw(on_progress=b2.advance)
                 self.model1.backward_raw(on_progress=b1.advance)
-                main.wait_stream(self._side)
-                scales = [b1.finish(), b2.finish()]           # b1's tail went out with its backward; b2's goes now
+                _lib.wait_stream(main, self._side)
+                scales = [_lib.tape_call(b1.finish), _lib.tape_call(b2.finish)]      # b1's tail went out with its backward; b2's goes now
             else:
                 self.model1.backward_raw(on_progress=b1.advance)
-                b1.advance(0, final=True)
+                _lib.tape_call(b1.advance, 0, True)
                 self.model2.backward_raw(on_progress=b2.advance)
-                scales = [b1.finish(), b2.finish()]
+                scales = [_lib.tape_call(b1.finish), _lib.tape_call(b2.finish)]
         else:
             self.model1.backward_raw()
             self.model2.backward_raw()
-            scales = [dist.sync_gradients(m.flat_grad, self.pg) for m in (self.model1, self.model2)]
+            scales = [_lib.tape_call(dist.sync_gradients, m.flat_grad, self.pg) for m in (self.model1, self.model2)]
         for m, mom, scale in ((self.model1, self.mom1, scales[0]), (self.model2, self.mom2, scales[1])):
             ops.sgd_ema_step(m.flat_param, m.flat_grad, mom, None, momentum=self.momentum,
                              weight_decay=self.weight_decay, grad_scale=scale, state=self.state)
         h = self.hyper
         ops.step_advance(self.state, h["base_lr"], h["max_iterations"], h["ema_decay"], h["consistency"], h["rampup"],
                          h["ramp_div"], h["cons_start_iter"], h["lr_post_increment"])
-        self.iter_num += 1
-        return self.out1, self.out2
 
     def losses(self):
         a, b = self.out1.cpu(), self.out2.cpu()
@@ -412,12 +458,12 @@ class CnnMeetVitTrainer:
             main = torch.cuda.current_stream()
             if self._side is None:
                 self._side = torch.cuda.Stream()
-            self._side.wait_stream(main)
+            _lib.wait_stream(self._side, main)
             with torch.cuda.stream(self._side):
                 o1 = self.model1.forward_raw(volume_batch)
                 t = self.ema_model.forward_raw(self._ema_in, no_backward=True)
             o2 = self.model2.forward_raw(volume_batch)
-            main.wait_stream(self._side)
+            _lib.wait_stream(main, self._side)
         else:
             o1 = self.model1.forward_raw(volume_batch)
             o2 = self.model2.forward_raw(volume_batch)
@@ -432,14 +478,14 @@ class CnnMeetVitTrainer:
         if two:
             # model1's backward is enqueued first, on the side stream: with bucketers its tail bucket is deferred to
             # finish() (defer_tail), as for the side-stream student of cross teaching
-            self._side.wait_stream(main)
+            _lib.wait_stream(self._side, main)
             if b1 is not None:
                 b1.begin()
                 b2.begin()
             with torch.cuda.stream(self._side):
                 self.model1.backward_raw(on_progress=None if b1 is None else b1.advance)
             self.model2.backward_raw(on_progress=None if b2 is None else b2.advance)
-            main.wait_stream(self._side)
+            _lib.wait_stream(main, self._side)
             if b1 is not None:
                 scales = [b1.finish(), b2.finish()]
             else:

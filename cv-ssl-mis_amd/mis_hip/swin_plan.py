@@ -11,8 +11,9 @@ import os
 
 import torch
 
+from . import lib as _lib
 from . import tops
-from .plan import Act, defer, run_deferred, flush_deferred
+from .plan import Act, begin_finals, defer, defer_final, run_deferred, flush_deferred
 
 # GEMM epilogue fusions (GELU into fc1 / fc2-dX, DropPath + residual add into proj / fc2); MIS_SWIN_FUSE=0 runs the
 # separate element-wise passes (A/B timing, and the reference point of the fusion tests)
@@ -88,6 +89,7 @@ class LinearOp:
         self.wT_batched = False      # True: the plan transposes every Linear weight in one launch (SwinPlan.backward)
         self.gelu = self.res = self.dx_gelu = None
         self.b3 = self.bT3 = None    # W / W^T cut into bf16 pieces once per pass (split_linear_weights)
+        self._dw_ws, self._dw_jobs = None, {}      # own split-K workspace of the weight gradient + its finishing-sum jobs
 
     def _b3(self, ctx):
         return self.b3 if getattr(ctx, "b3_fwd", False) else None
@@ -111,9 +113,29 @@ class LinearOp:
                 return
         tops.gemm(self.x.t, self.w2, self.y.t, bias=bias, b3=self._b3(ctx))
 
-    def _wgrad(self, dy):
-        if self.b is not None:
-            tops.gemm_dw(dy, self.x.t, self.gw2, self.b.grad)      # db rides on the dW GEMM's read of dy
+    def _wgrad(self, dy, ctx=None):
+        db = None if self.b is None else self.b.grad
+        if ctx is not None and getattr(ctx, "finals", None) is not None and self.gw2.is_contiguous() and \
+                self.gw2.shape[0] % 4 == 0 and self.gw2.shape[1] % 4 == 0:
+            # split contraction: the k-slices' partials stay in a workspace of this layer's own and their sums join the pass's
+            # batch of finishing sums (plan.defer_final) -- no gemm_reduce launch per Linear
+            M, N = self.gw2.shape
+            if self._dw_ws is None:
+                ws = tops.gemm_dw_workspace(M, N, dy.shape[0])
+                self._dw_ws = False if ws is None else ws
+            ws = self._dw_ws if self._dw_ws is not False else None
+            slices = tops.gemm_dw_parts(dy, self.x.t, self.gw2, db, ws)
+            if slices:
+                jobs = self._dw_jobs.get(slices)
+                if jobs is None:
+                    jobs = [tops.ColsumJob(ws, 0, M * N, slices, M * N, False, self.gw2.view(-1))]
+                    if db is not None:
+                        jobs.append(tops.ColsumJob(ws, slices * M * N, M, slices, M, False, db))
+                    self._dw_jobs[slices] = jobs
+                defer_final(ctx, *jobs)
+            return
+        if db is not None:
+            tops.gemm_dw(dy, self.x.t, self.gw2, db)      # db rides on the dW GEMM's read of dy
         else:
             tops.gemm(dy, self.x.t, self.gw2, trans=True)
 
@@ -123,10 +145,10 @@ class LinearOp:
         # dX chain (mis_hip.plan.WGRAD_STREAM)
         side = getattr(ctx, "wgrad_stream", None) if self.need_dx else None
         if side is not None:
-            side.wait_stream(torch.cuda.current_stream())
+            _lib.wait_stream(side, torch.cuda.current_stream())
             with torch.cuda.stream(side):
                 run_deferred(ctx)
-                self._wgrad(dy)
+                self._wgrad(dy, ctx)
         else:
             self._wgrad(dy)
         if self.need_dx:
@@ -174,12 +196,15 @@ def split_linear_weights(holder, ops_list, transposed):
             n_out, k_in = op.w2.shape
             if k_in % 4 or n_out % 4 or 6 * n_out * (k_in + 31) >= 1 << 31:
                 continue
+            # planes in the element order of the kernel that will read them: the register-A kernel (many token rows, float4
+            # epilogue) wants the natural order; the pixel-shuffle / LayerNorm-head stores of the expand layers stay staged
+            staged_only = isinstance(op, ExpandLinearOp)
             if transposed:
                 if op.need_dx and op.wT_batched:
-                    op.bT3 = tops.SplitB(op.wT)
+                    op.bT3 = tops.SplitB(op.wT, rows=op.y.rows)
                     splits.append(op.bT3)
             else:
-                op.b3 = tops.SplitB(op.w2)
+                op.b3 = tops.SplitB(op.w2, rows=None if staged_only else op.x.rows)
                 splits.append(op.b3)
         batch = tops.SplitBatch(splits) if splits else False
         setattr(holder, key, batch)
@@ -194,6 +219,7 @@ class LayerNormOp:
         self.mean = torch.empty(x.rows, dtype=torch.float32, device="cuda")
         self.rstd = torch.empty(x.rows, dtype=torch.float32, device="cuda")
         self._ws = None
+        self._job = None
         self.res_bwd = None      # the ResidualOp right in front of this op whose output is x (pair_ln_residual)
 
     def fwd(self, ctx):
@@ -214,14 +240,15 @@ class LayerNormOp:
                     r.a.mark_written()
                     r.y.mark_written()
                     r.skip_bwd = True
-                    if not defer(ctx, self._final):
+                    if not self._defer_final(ctx):
                         self._final()
                     return
-        if (self.g.grad is not None or self.b.grad is not None) and defer(ctx, self._final):
+        if (self.g.grad is not None or self.b.grad is not None) and self._can_defer(ctx):
             if self._ws is None:
                 self._ws = tops.colreduce_workspace(self.x.rows, self.x.t.shape[1])
             tops.layernorm_bwd_parts(self.x.t, self.y.grad(), self.x.grad(), self.g.data, self.mean, self.rstd, self._ws,
                                      accumulate_dx=self.x.written)
+            self._defer_final(ctx)
         else:
             tops.layernorm_bwd(self.x.t, self.y.grad(), self.x.grad(), self.g.data, self.mean, self.rstd, self.g.grad,
                                self.b.grad, accumulate_dx=self.x.written)
@@ -229,6 +256,22 @@ class LayerNormOp:
 
     def _final(self):
         tops.layernorm_bwd_final(self._ws, self.x.rows, self.x.t.shape[1], self.g.grad, self.b.grad)
+
+    @staticmethod
+    def _can_defer(ctx):
+        from .plan import DEFER
+        return DEFER and getattr(ctx, "wgrad_stream", None) is not None and getattr(ctx, "deferred", None) is not None
+
+    def _defer_final(self, ctx):
+        """The affine gradients from the partial rows in ``_ws``: a job of the pass's batch of finishing sums, else the deferred
+        per-op launch; False: neither (the caller finishes on its own stream)."""
+        if getattr(ctx, "finals", None) is not None and self.g.grad is not None and self.b.grad is not None:
+            if self._job is None:
+                C = self.x.t.shape[1]
+                self._job = tops.ColsumJob(self._ws.view(torch.float32), 0, C, tops.colreduce_slabs(self.x.rows), C, True,
+                                           self.g.grad, self.b.grad)
+            return defer_final(ctx, self._job)
+        return defer(ctx, self._final)
 
 
 class GeluOp:
@@ -258,17 +301,28 @@ class AttnOp:
         self.scale = 32 ** -0.5
         self.window = window
         self._ws = None
+        self._job = None
 
     def fwd(self, ctx):
         tops.window_attention_fwd(self.qkv.t, self.out.t, self.table.data, *self.geo, self.scale, window=self.window)
 
     def bwd(self, ctx):
         assert not self.qkv.written
-        if defer(ctx, self._dtable):
+        if LayerNormOp._can_defer(ctx):
             if self._ws is None:
                 self._ws = tops.window_attention_workspace(*self.geo[:4], window=self.window)
             tops.window_attention_bwd_parts(self.qkv.t, self.out.grad(), self.qkv.grad(), self.table.data, self._ws,
                                             *self.geo, self.scale, window=self.window)
+            if getattr(ctx, "finals", None) is not None and self.table.grad.is_contiguous():
+                if self._job is None:
+                    shape = tops.window_attention_table_partials(*self.geo[:4], window=self.window)
+                    self._job = False if shape is None else tops.ColsumJob(self._ws.view(torch.float32), 0, shape[1], shape[0],
+                                                                           shape[1], False, self.table.grad.view(-1))
+                if self._job:
+                    defer_final(ctx, self._job)
+                    self.qkv.mark_written()
+                    return
+            defer(ctx, self._dtable)
         else:
             tops.window_attention_bwd(self.qkv.t, self.out.grad(), self.qkv.grad(), self.table.data, self.table.grad,
                                       *self.geo, self.scale, window=self.window)
@@ -692,27 +746,27 @@ class SwinPlan:
             side = self._wgrad_stream
         ctx.wgrad_stream = side
         ctx.deferred = [] if side is not None else None
+        begin_finals(ctx, self)
         if on_progress is None:
             for op in reversed(self.ops):
                 op.bwd(ctx)
             flush_deferred(ctx)
-            ctx.deferred = None
+            ctx.deferred = ctx.finals = None
             if side is not None:
-                main.wait_stream(side)
+                _lib.wait_stream(main, side)
             return
         if self._progress is None:
             from .dist import param_progress
             self._progress = param_progress(self.ops, self.net.flat_grad)
-        report = _plan.progress_reporter(on_progress, main, side)
+        report = _plan.progress_reporter(on_progress, main, side, before=lambda: flush_deferred(ctx))
         for i in range(len(self.ops) - 1, -1, -1):      # see mis_hip.plan.Plan.backward
             self.ops[i].bwd(ctx)
             if i == 0 or self._progress[i] != self._progress[i - 1] or i == len(self.ops) - 1:
-                flush_deferred(ctx)      # a reported gradient range is complete on (main, side): finish what was queued
                 report(self._progress[i])
         flush_deferred(ctx)
-        ctx.deferred = None
+        ctx.deferred = ctx.finals = None
         if side is not None:
-            main.wait_stream(side)
+            _lib.wait_stream(main, side)
 
     def drop_sites(self):
         return [op.site for op in self.ops if isinstance(op, ResidualOp) and op.drop_p > 0]

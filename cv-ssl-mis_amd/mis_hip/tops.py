@@ -45,17 +45,22 @@ class SplitB:
     nn.Linear weight or its transpose); ``t`` the planes.  ``refresh()`` after the weights changed; a ``SplitBatch`` refreshes
     every SplitB of a network in one launch."""
 
-    def __init__(self, src):
+    def __init__(self, src, rows=None):
+        """``rows``: the token rows M of the GEMM these planes serve -- decides the element order inside a K = 32 block
+        (``natural``: the register-A kernel's, mis_gemm_nt_split_natural; None: the staged kernels' order)."""
         N, K, ldb = _mat(src)
-        nb = _l.load().mis_gemm_split_bytes(N, K)
+        L = _l.load()
+        nb = L.mis_gemm_split_bytes(N, K)
         if nb < 0:
             _l.check(nb, "mis_gemm_split_bytes")
         self.src, self.N, self.K, self.ldb = src, N, K, ldb
+        self.natural = bool(rows) and bool(L.mis_gemm_nt_split_natural(int(rows), N, K))
+        self.rows = rows
         self.t = torch.empty(nb, dtype=torch.uint8, device="cuda")
 
     def refresh(self):
-        _l.check(_l.load().mis_gemm_split_b(_l.ptr(self.src), self.ldb, self.N, self.K, _l.ptr(self.t), _l.stream_ptr()),
-                 "mis_gemm_split_b")
+        _l.check(_l.load().mis_gemm_split_b_layout(_l.ptr(self.src), self.ldb, self.N, self.K, _l.ptr(self.t), int(self.natural),
+                                                   _l.stream_ptr()), "mis_gemm_split_b_layout")
         return self
 
 
@@ -68,9 +73,10 @@ class SplitBatch:
         host = (ctypes.c_char * (nb * len(splits)))()
         first = 0
         for i, sb in enumerate(splits):
-            n = L.mis_gemm_split_job(ctypes.byref(host, i * nb), _l.ptr(sb.src), sb.ldb, sb.N, sb.K, _l.ptr(sb.t), first)
+            n = L.mis_gemm_split_job_layout(ctypes.byref(host, i * nb), _l.ptr(sb.src), sb.ldb, sb.N, sb.K, _l.ptr(sb.t), first,
+                                            int(sb.natural))
             if n < 0:
-                _l.check(n, "mis_gemm_split_job")
+                _l.check(n, "mis_gemm_split_job_layout")
             first += n
         self.n, self.units, self.keep = len(splits), first, splits
         self.table = torch.frombuffer(bytearray(bytes(host)), dtype=torch.uint8).cuda()
@@ -108,16 +114,20 @@ def _nt_split(A, b3, C, bias=None, accumulate=False, epilogue=0, E1=None, C2=Non
     if prof is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    st = L.mis_gemm_nt_split(_l.ptr(A), lda, _l.ptr(b3.t), _l.ptr(C), ldc, _l.ptr(bias), M, N, K, int(accumulate), int(epilogue),
-                             _l.ptr(E1), lde1, _l.ptr(C2), ldc2, _l.ptr(rowscale), int(rows_per_scale), eH, eW, eP, ec,
-                             _l.ptr(ws), ws.numel() if ws is not None else 0, _l.stream_ptr())
+    if b3.natural and b3.rows != M:
+        raise RuntimeError(f"natural-order planes were cut for {b3.rows} token rows, the GEMM has {M}")
+    st = L.mis_gemm_nt_split_layout(_l.ptr(A), lda, _l.ptr(b3.t), _l.ptr(C), ldc, _l.ptr(bias), M, N, K, int(accumulate),
+                                    int(epilogue), _l.ptr(E1), lde1, _l.ptr(C2), ldc2, _l.ptr(rowscale), int(rows_per_scale), eH, eW,
+                                    eP, ec, _l.ptr(ws), ws.numel() if ws is not None else 0, int(b3.natural), _l.stream_ptr())
     if st == -2:
+        if b3.natural:
+            raise RuntimeError("natural-order planes, but the register-A kernel refuses this call (the staged kernels cannot read them)")
         return False
-    _l.check(st, "mis_gemm_nt_split")
+    _l.check(st, "mis_gemm_nt_split_layout")
     if prof is not None:
         e1.record()
         buf = ctypes.create_string_buffer(96)
-        _l.check(L.mis_gemm_nt_split_kernel_name(M, N, K, int(epilogue), buf, 96), "mis_gemm_nt_split_kernel_name")
+        _l.check(L.mis_gemm_nt_split_layout_kernel_name(M, N, K, int(epilogue), int(b3.natural), buf, 96), "mis_gemm_nt_split_layout_kernel_name")
         prof.append((buf.value.decode(), 2.0 * M * N * K, e0, e1, 4.0 * (M * K + M * N) + 6.0 * N * K))
     return True
 
@@ -179,6 +189,88 @@ def gemm_dw(dy, x, dW, db, accumulate=False):
     if prof is not None:
         e1.record()
         prof.append((_tn_name(L, dy, lddy, x, ldx, dW, ldw, M, N, K), 2.0 * M * N * K, e0, e1, 4.0 * (M * K + N * K + M * N)))
+
+
+def gemm_dw_parts(dy, x, dW, db, ws, accumulate=False):
+    """``gemm_dw`` without its finishing launch (mis_gemm_dw_parts): returns the number of k-slices whose partials now sit in the
+    caller's workspace ``ws`` (fp32: ``slices`` matrices [M, N], then ``slices`` rows [M] when ``db`` is given) -- 0: the
+    contraction was not split and dW / db are complete.  ``db`` may be None (bias-free Linear)."""
+    L = _l.load()
+    K, M, lddy = _mat(dy)
+    K2, N, ldx = _mat(x)
+    Mc, Nc, ldw = _mat(dW)
+    assert K == K2 and (Mc, Nc) == (M, N) and (db is None or (db.numel() == M and db.is_contiguous())), (dy.shape, x.shape, dW.shape)
+    prof = _ops.PROFILE
+    if prof is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    slices = ctypes.c_int(0)
+    _l.check(L.mis_gemm_dw_parts(_l.ptr(dy), lddy, _l.ptr(x), ldx, _l.ptr(dW), ldw, _l.ptr(db), M, N, K, int(accumulate),
+                                 _l.ptr(ws), ws.numel() * ws.element_size() if ws is not None else 0, ctypes.byref(slices),
+                                 _l.stream_ptr()), "mis_gemm_dw_parts")
+    if prof is not None:
+        e1.record()
+        prof.append((_tn_name(L, dy, lddy, x, ldx, dW, ldw, M, N, K), 2.0 * M * N * K, e0, e1, 4.0 * (M * K + N * K + M * N)))
+    return slices.value
+
+
+def gemm_dw_workspace(M, N, K):
+    """A workspace of the caller's own for gemm_dw_parts (None: this shape is never split)."""
+    nb = _l.load().mis_gemm_dw_workspace_bytes(M, N, K)
+    if nb < 0:
+        _l.check(nb, "mis_gemm_dw_workspace_bytes")
+    return torch.empty(nb // 4, dtype=torch.float32, device="cuda") if nb > 0 else None
+
+
+class ColsumJob:
+    """One finishing column sum ``out_a[c] (+)= sum_s part[s][c]`` (``pairs``: part is float2, .x -> out_a, .y -> out_b) for a
+    ``ColsumBatch`` (mis_colsum_job).  ``part`` is a tensor whose storage holds the partial rows, ``offset`` floats into it."""
+
+    def __init__(self, part, offset, stride, slabs, C, pairs, out_a, out_b=None, accumulate=False):
+        self.part, self.offset, self.stride, self.slabs, self.C, self.pairs = part, int(offset), int(stride), int(slabs), int(C), bool(pairs)
+        self.out_a, self.out_b, self.accumulate = out_a, out_b, bool(accumulate)
+        for o in (out_a, out_b):
+            assert o is None or (o.is_contiguous() and o.numel() >= C and o.dtype == torch.float32)
+        self.bytes = self.slabs * self.C * (8 if pairs else 4)
+
+    def part_ptr(self):
+        return self.part.data_ptr() + 4 * self.offset
+
+
+class ColsumBatch:
+    """Many ColsumJob in one launch (``mis_colsum_batch``); the device job table is built once and holds raw pointers."""
+
+    def __init__(self, jobs):
+        L = _l.load()
+        nb = L.mis_colsum_job_bytes()
+        host = (ctypes.c_char * (nb * len(jobs)))()
+        first = 0
+        for i, j in enumerate(jobs):
+            n = L.mis_colsum_job(ctypes.byref(host, i * nb), ctypes.c_void_p(j.part_ptr()), j.stride, j.slabs, j.C, int(j.pairs),
+                                 _l.ptr(j.out_a), _l.ptr(j.out_b), int(j.accumulate), first)
+            if n < 0:
+                _l.check(n, "mis_colsum_job")
+            first += n
+        self.n, self.blocks, self.keep = len(jobs), first, list(jobs)
+        self.table = torch.frombuffer(bytearray(bytes(host)), dtype=torch.uint8).cuda()
+
+    def run(self):
+        _l.check(_l.load().mis_colsum_batch(_l.ptr(self.table), self.n, self.blocks, _l.stream_ptr()), "mis_colsum_batch")
+
+
+def colreduce_slabs(M):
+    return int(_l.load().mis_colreduce_slabs(M))
+
+
+def window_attention_table_partials(B, H, W, nH, window=7):
+    """(rows, cols) of the bias-table partials ``window_attention_bwd_parts`` leaves at the start of its workspace, or None when
+    the vector-pipe kernels (dS-block partials) are selected."""
+    rows, cols = ctypes.c_longlong(0), ctypes.c_int(0)
+    st = _l.load().mis_window_attention_table_partials(B, H, W, nH, window, ctypes.byref(rows), ctypes.byref(cols))
+    if st == -2:
+        return None
+    _l.check(st, "mis_window_attention_table_partials")
+    return rows.value, cols.value
 
 
 EP_GELU_FWD, EP_GELU_BWD, EP_RESIDUAL = 1, 2, 3

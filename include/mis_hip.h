@@ -445,6 +445,13 @@ long long mis_gemm_workspace_bytes(int M, int N, int K, int trans);
 long long mis_gemm_dw_workspace_bytes(int M, int N, int K);
 int mis_gemm_dw(const float* dy, long long lddy, const float* x, long long ldx, float* dW, long long lddw, float* db, int M,
                 int N, int K, int accumulate, float* workspace, long long workspace_bytes, hipStream_t stream);
+/* mis_gemm_dw without its finishing launch (db may be NULL: the weight gradient of a bias-free Linear, :361-362, :390).
+ * *slices > 0: the contraction was split and `workspace` -- the caller's own until the sums have run -- holds *slices partial
+ * matrices [M][N] followed by *slices partial rows [M] of the bias gradient; dW / db are untouched and `accumulate` is the sum's
+ * business (two mis_colsum_job records: stride M*N -> dW, stride M -> db).  *slices == 0: dW / db are complete. */
+int mis_gemm_dw_parts(const float* dy, long long lddy, const float* x, long long ldx, float* dW, long long lddw, float* db,
+                      int M, int N, int K, int accumulate, float* workspace, long long workspace_bytes, int* slices,
+                      hipStream_t stream);
 /* the NT kernel instantiation mis_gemm / mis_gemm_ex run this shape with (aligned operands), as a profiler names it */
 int mis_gemm_nt_kernel_name(int M, int N, int K, int epilogue, char* name, int name_len);
 /* Arithmetic of the nn.Linear GEMMs (mis_gemm / mis_gemm_ex / mis_gemm_dw / mis_gemm_expand): bit 0 forward + dX, bit 1 dW as
@@ -489,6 +496,21 @@ int mis_gemm_nt_split(const float* A, long long lda, const void* B3, float* C, l
                       int K, int accumulate, int epilogue, const float* E1, long long lde1, float* C2, long long ldc2,
                       const float* rowscale, long long rows_per_scale, int ex_H, int ex_W, int ex_P, int ex_c,
                       float* workspace, long long workspace_bytes, mis_stream_t stream);
+/* Round 6: the register-A form of mis_gemm_nt_split.  For many token rows the A operand of the forward / data-gradient GEMMs
+ * (nn.Linear at :14,16,107,109 and their autograd) goes from HBM straight into the v_mfma_f32_16x16x32_bf16 operand registers
+ * (lane (row, g) = 8 consecutive contraction elements = 32 contiguous bytes of a row-major activation row); only the pre-split
+ * weight planes pass through LDS.  That kernel reads the planes in the NATURAL element order inside a K = 32 block:
+ * mis_gemm_nt_split_natural(M, N, K) = 1 says mis_gemm_nt_split_layout(.., layout = 1, ..) serves the shape and that its planes
+ * must be cut with mis_gemm_split_b_layout / mis_gemm_split_job_layout (natural = 1); layout / natural = 0 are the entry points
+ * above.  Same split products, same k-block order: results agree with the staged kernels to fp32 rounding. */
+int mis_gemm_nt_split_natural(int M, int N, int K);
+int mis_gemm_split_b_layout(const float* B, long long ldb, int N, int K, void* B3, int natural, hipStream_t stream);
+long long mis_gemm_split_job_layout(void* job, const float* B, long long ldb, int N, int K, void* B3, long long first, int natural);
+int mis_gemm_nt_split_layout(const float* A, long long lda, const void* B3, float* C, long long ldc, const float* bias, int M,
+                             int N, int K, int accumulate, int epilogue, const float* E1, long long lde1, float* C2,
+                             long long ldc2, const float* rowscale, long long rows_per_scale, int ex_H, int ex_W, int ex_P,
+                             int ex_c, float* workspace, long long workspace_bytes, int layout, hipStream_t stream);
+int mis_gemm_nt_split_layout_kernel_name(int M, int N, int K, int epilogue, int layout, char* name, int name_len);
 int mis_gemm_nt_split_kernel_name(int M, int N, int K, int epilogue, char* name, int name_len);
 /* nn.Linear of PatchExpand / FinalPatchExpand_X4 fused with their pixel shuffle
  * 'b h w (p1 p2 c) -> b (h p1) (w p2) c' (swin_transformer_unet_skip_expand_decoder_sys.py:373-380, :401-408):
@@ -539,6 +561,20 @@ int mis_layernorm_bwd_parts(const float* x, long long ldx, const float* dy, long
                             int accumulate_dx, void* workspace, long long workspace_bytes, mis_stream_t stream);
 int mis_layernorm_bwd_final(const void* workspace, long long workspace_bytes, long long M, int C, float* dgamma,
                             float* dbeta, int accumulate_affine, mis_stream_t stream);
+/* Every finishing column sum of a backward pass in one launch.  The parameter gradients that autograd hands to nobody downstream
+ * -- LayerNorm weight / bias (:204,211,323,365,393), the split-K partials of the nn.Linear weight / bias gradients
+ * (:14,16,107,109), relative_position_bias_table (:99-102) -- are all  out[c] (+)= sum_s part[s][c]  over per-slab / per-slice /
+ * per-window partial rows that the producing kernels (mis_layernorm_bwd_parts, mis_gemm_dw_parts,
+ * mis_window_attention_bwd_parts_ws) left in caller-owned workspaces.  mis_colsum_job fills one record of a HOST table
+ * (mis_colsum_job_bytes each): part = float [slabs][stride] (pairs = 0, -> out_a) or float2 [slabs][stride] (pairs = 1: .x ->
+ * out_a, .y -> out_b, either may be NULL), C <= stride columns, `first` = workgroups of the jobs before it; it returns the job's
+ * workgroup count.  mis_colsum_batch runs the table (uploaded by the caller) as one launch: double accumulators, fixed order, a
+ * job's result independent of its batch.  mis_colreduce_slabs = the partial rows mis_layernorm_bwd_parts leaves for M tokens. */
+long long mis_colsum_job_bytes(void);
+long long mis_colreduce_slabs(long long M);
+long long mis_colsum_job(void* job, const void* part, long long stride, long long slabs, int C, int pairs, float* out_a,
+                         float* out_b, int accumulate, long long first);
+int mis_colsum_batch(const void* jobs, int n, long long blocks, mis_stream_t stream);
 /* mis_layernorm_bwd_parts and, in the same pass, the backward of the residual add that produced the LayerNorm's input
  * (`x = shortcut + self.drop_path(x)` followed by `self.norm2(x)` / the next block's `norm1`, :276-281): with
  * total = gin + LayerNorm'(dy) (gin, may be NULL: what the input's other readers already left in its gradient),
@@ -621,16 +657,20 @@ int mis_window_attention_bwd_ws(const float* qkv, long long ldq, const float* do
                                 long long lddq, const float* bias_table, float* dbias_table, int accumulate_table,
                                 int B, int H, int W, int nH, int shift, float scale, int window, void* workspace,
                                 long long workspace_bytes, mis_stream_t stream);
-/* mis_window_attention_bwd_ws in two halves (same results bit for bit): _parts_ws = dqkv and the per-(sample, window, head)
- * dS partials in `workspace`, _dtable_ws = the gradient of relative_position_bias_table from them (:99-131: autograd's
- * index_add through relative_position_index).  As with mis_layernorm_bwd_{parts,final}: the table gradient feeds nothing
- * downstream and may run on another stream behind the first half */
+/* mis_window_attention_bwd_ws in two halves (same results bit for bit): _parts_ws = dqkv and the per-(sample, window) partials
+ * of the table gradient in `workspace` (round 6: each (sample, window, head) wave reduces its dS block to the (2 window - 1)^2
+ * table entries itself), _dtable_ws = the gradient of relative_position_bias_table from them (:99-131: autograd's index_add
+ * through relative_position_index).  As with mis_layernorm_bwd_{parts,final}: the table gradient feeds nothing downstream and
+ * may run on another stream behind the first half -- or as a mis_colsum_batch job: mis_window_attention_table_partials gives
+ * the shape of the partials (float [rows][cols] at the start of the workspace, cols in the table's own [index][head] order;
+ * MIS_ERR_UNSUPPORTED when the vector-pipe kernels, whose partials are dS blocks, are selected) */
 int mis_window_attention_bwd_parts_ws(const float* qkv, long long ldq, const float* dout, long long ldo, float* dqkv,
                                       long long lddq, const float* bias_table, int B, int H, int W, int nH, int shift,
                                       float scale, int window, void* workspace, long long workspace_bytes,
                                       mis_stream_t stream);
 int mis_window_attention_dtable_ws(void* workspace, long long workspace_bytes, float* dbias_table, int accumulate_table,
                                    int B, int H, int W, int nH, int window, mis_stream_t stream);
+int mis_window_attention_table_partials(int B, int H, int W, int nH, int window, long long* rows, int* cols);
 
 /* ---- UNETR (reference code/networks/unetr.py, built from MONAI blocks that are NOT vendored in the reference:
  * parity of these entry points is pinned to a torch restatement of the published algorithm only) --------------------

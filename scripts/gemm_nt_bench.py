@@ -39,7 +39,8 @@ for M, N, K in shapes:
     seen.add((M, N, K))
     a, w, bias = torch.randn(M, K, device="cuda"), torch.randn(N, K, device="cuda") * K ** -0.5, torch.randn(N, device="cuda")
     c = torch.empty(M, N, device="cuda")
-    b3 = tops.SplitB(w).refresh() if "--split" in sys.argv else None
+    # --split: pre-split planes for the staged kernels; --rega: planes in the natural order where the register-A kernel serves
+    b3 = tops.SplitB(w, rows=M if "--rega" in sys.argv else None).refresh() if ("--split" in sys.argv or "--rega" in sys.argv) else None
     t = timeit(lambda: tops.gemm(a, w, c, bias=bias, b3=b3))
     ref = a[:512].double() @ w.double().t() + bias.double()
     err = (c[:512].double() - ref).abs().max().item() / ref.abs().max().item()
@@ -48,6 +49,7 @@ for M, N, K in shapes:
     # the two floors of this shape: the fp32 matrix pipe at 2.4 GHz, and A + C (+ W once) over HBM at 5 TB/s (what the
     # streaming passes of this code reach)
     t_mfma, t_hbm = fl / 157.3e6, (M * K + M * N + N * K) * 4 / 5e6
-    print(f"M={M:7d} N={N:5d} K={K:5d}: {t:8.1f} us  {fl / t / 1e6:6.1f} TF ({fl / t / 1e6 / 157.3:.3f})  floors: pipe {t_mfma:6.1f} us, "
+    tag = "R" if (b3 is not None and b3.natural) else " "
+    print(f"{tag} M={M:7d} N={N:5d} K={K:5d}: {t:8.1f} us  {fl / t / 1e6:6.1f} TF ({fl / t / 1e6 / 157.3:.3f})  floors: pipe {t_mfma:6.1f} us, "
           f"HBM {t_hbm:6.1f} us -> {t / max(t_mfma, t_hbm):.2f}x the larger, {t / (t_mfma + t_hbm):.2f}x their sum  rel err {err:.1e}", flush=True)
 print(f"sum {tot:.1f} us")

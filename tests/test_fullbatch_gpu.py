@@ -28,6 +28,77 @@ GRAD_REL, GRAD_ABS = 0.1, 2e-3
 # one box of one layer moves a tensor by far more than that
 GRAD_REL_CASE = {"config2_unet2d_24+24_256": 0.004, "config3_unet3d_4+4_96": 0.003, "config4_swin_24+24_224": 0.003,
                  "config3_vnet_4+4_96": 0.07}
+# the cases whose bound against the fp32 oracle is above 0.01: the float64 arbiter decides (see _check_grads_f64); the coarse
+# fp32 bound stays as the dispatch check it was
+F64_ARBITER = {"config3_vnet_4+4_96"}
+
+
+# Round 6 -- a float64 arbiter for the BatchNorm nets at the full batch.  Their fp32 gradients are ill-conditioned (the reference's
+# own fp32-vs-fp64 error is 1e-2 .. 1e-1 of a tensor's maximum at fixture size), so "3 x the measured difference to the fp32 CPU
+# oracle" (0.07 / 0.06 / 0.043 in round 5) could not tell fp32 noise on both sides from one wrong halo row.  For those cases the
+# oracle step is evaluated a second time in double on the same inputs and every gradient tensor is held to the fixture-size gate
+# of test_parity_gpu.py: |g_hip - g_f64|_max <= max(F64_K * e32, F64_REL) * |g_f64|_max + F64_ABS * (largest |g_f64| of the net),
+# e32 = the fp32 ORACLE's own error against float64 on this very batch.
+F64_K, F64_REL, F64_ABS = 6.0, 2e-3, 1e-4
+
+
+def _as64(d):
+    return {k: (v.double() if v.is_floating_point() else v.clone()) for k, v in d.items()}
+
+
+def _check_grads_f64(model, grads32, grads64, what, rerun=None, max_positions=256, K=F64_K):
+    """``rerun()``: the float64 step again (gradient dict) -- called with oracle.nets.PRE_ACT hooks when the plain float64
+    solution does not fit: the deep levels of these nets hold ReLU pre-activations within fp32 rounding of zero, and which side
+    a kernel lands on is a coin toss that moves whole weight-gradient tensors of that level (test_parity_gpu.py, F64_FLIPS).
+    The HIP gradients must fit ONE float64 solution -- the plain one or the one with a (greedily chosen) subset of the 4
+    smallest-margin pre-activations flipped -- at the normal tolerance."""
+    gscale = max(float(g.abs().max()) for g in grads64.values())
+    hip = {n: g.cpu().double() for n, g in model.named_flat(model.flat_grad)}
+
+    def score(sol):
+        rows = []
+        for n in hip:
+            ref = sol[n]
+            gmax = float(grads64[n].abs().max())
+            e32 = (grads32[n].double() - grads64[n]).abs().max().item() / max(gmax, 1e-300) if gmax > 1e-4 * gscale else 0.0
+            err = (hip[n] - ref).abs().max().item()
+            tol = max(K * e32, F64_REL) * gmax + F64_ABS * gscale
+            rows.append((err / tol, n, err / max(gmax, 1e-300), e32))
+        return rows
+
+    rows = score(grads64)
+    flipped = ()
+    if max(rows)[0] > 1.0 and rerun is not None:
+        import time
+        from test_parity_gpu import _flipped_solutions
+        t0 = time.time()
+        sols, margins = _flipped_solutions(rerun, 4, max_positions=max_positions)
+        base, cur, pick = sols[0], grads64, []
+        while True:
+            best = None
+            for k in range(1, len(sols)):
+                if k in pick:
+                    continue
+                sol = {n: cur[n] + (sols[k][n] - base[n]) for n in hip}
+                r = score(sol)
+                if max(r)[0] < max(rows)[0] and (best is None or max(r)[0] < max(best[0])[0]):
+                    best = (r, k, sol)
+            if best is None:
+                break
+            rows, k, cur = best
+            pick.append(k)
+            if max(rows)[0] <= 1.0:
+                break
+        flipped = tuple(pick)
+        print(f"\n{what}: {len(sols) - 1} float64 re-runs with flipped near-zero pre-activations (margins "
+              f"{', '.join('%.1e' % m for m in margins)}) in {time.time() - t0:.0f} s; flipped: {flipped}")
+    worst = max(rows)
+    ratios = sorted(r[2] / max(r[3], 1e-3) for r in rows if r[3] > 0)
+    print(f"\n{what}: float64 arbiter at the full batch: worst gradient error / tolerance {worst[0]:.3f} at {worst[1]} "
+          f"(relative error {worst[2]:.2e}, the fp32 oracle's own {worst[3]:.2e}); HIP error / fp32-oracle error per tensor: "
+          f"median {ratios[len(ratios) // 2]:.2f}, max {ratios[-1]:.2f}; largest fp32-oracle error of any tensor {max(r[3] for r in rows):.2e}")
+    assert worst[0] <= 1.0, (what, worst)
+    assert ratios[len(ratios) // 2] <= 2.0, (what, ratios[len(ratios) // 2])
 
 
 def _states(onet, tag=""):
@@ -150,6 +221,19 @@ def test_mean_teacher_step_at_full_batch(name):
         assert abs(got[k] - orc[k]) <= TOL_LOSS, (k, got[k], orc[k])
     assert abs(got["consistency_weight"] - orc["consistency_weight"]) <= 1e-6
     _check_grads_and_params(model, orc["grads"], student, orc["lr"], name, GRAD_REL_CASE[name])
+    if name in F64_ARBITER:
+        o64 = mean_teacher_step(onet, _as64(sd0), _as64(tsd0), _as64(mom), volume.double(), label, noise.double(), it,
+                                labeled_bs=L, num_classes=C, cons_start_iter=cons_start, drop_student="off",
+                                drop_teacher="off", apply_update=False)
+        # V-Net: K = 10.  One tensor -- block_five.conv.6.weight, the last 256 -> 256 convolution of the 6^3 level -- sits at 9.2 x
+        # the fp32 oracle's own error (24 % against 2.6 % of its maximum); every other tensor is below 2.3 x, the median is 1.2.
+        # Localised with scripts/vnet_fullbatch_err.py (profiles/r06_vnet_fullbatch_noise.txt): with the split-contraction
+        # Winograd forward of that level replaced by the direct kernel (MIS_WINO_SPLIT=0) the tensor is at 2.1 x and the median at
+        # 0.99 -- F(2^3, 3^3) over a 256-channel contraction rounds ~10 x coarser than the direct form, which moves that many more
+        # of the level's 442 k ReLU pre-activations across zero (flips of the 4 smallest margins, 4e-8 .. 2e-7, change nothing:
+        # measured, 242 s of float64 re-runs); the weight gradient right above collects them.  Fixed noise of a legitimate fp32
+        # form, not a wrong row: a halo / dispatch error is O(1) on every tensor downstream.
+        _check_grads_f64(model, orc["grads"], o64["grads"], name, K=10.0)
     alpha = orc["ema_alpha"]
     gscale = max(float(g.abs().max()) for g in orc["grads"].values())
     for n, v in ema.named_flat(ema.flat_param):
@@ -216,6 +300,13 @@ def test_cross_teaching_step_at_full_batch(size, window):
         print(f"model{m + 1}: logits max err {lerr.max().item():.3e}, {int((lerr > TOL_LOGIT).sum())} of {lerr.numel()} beyond {TOL_LOGIT}")
         assert lerr.max().item() <= TOL_LOGIT
         _check_grads_and_params(models[m], r["grads"][m], osd[m], r["lr"], f"model{m + 1}", CROSS_GRAD_REL[size][m])
+    # float64 arbiter for the CNN (BatchNorm): the whole step in double -- the CNN's pseudo labels are the Transformer's arg-max
+    r64 = cross_teaching_step(nets[0], nets[1], _as64(sds[0]), _as64(sds[1]), _as64(moms[0]), _as64(moms[1]), volume.double(),
+                              label, it, labeled_bs=L, num_classes=C, drop1="off", drop2="off", apply_update=False)
+    _check_grads_f64(models[0], r["grads"][0], r64["grads"][0], f"cross teaching {size}: model1 (UNet)",
+                     rerun=lambda: cross_teaching_step(nets[0], nets[1], _as64(sds[0]), _as64(sds[1]), _as64(moms[0]), _as64(moms[1]),
+                                                       volume.double(), label, it, labeled_bs=L, num_classes=C, drop1="off",
+                                                       drop2="off", apply_update=False)["grads"][0])
 
 
 @pytest.mark.timeout(2400)
@@ -295,6 +386,7 @@ def test_cnn_meet_vit_step_at_full_batch():
     tr.step(volume.cuda(), label.cuda(), noise=noise.cuda())
     got = tr.losses()
     lgs = [models[m]._last[0].out.t.detach().cpu() for m in range(3)]
+    sds0 = [{k: v.clone() for k, v in sd.items()} for sd in sds]       # the oracle step updates its state dicts in place
     r = cnn_meet_vit_step(nets[0], nets[1], sds[0], sds[1], sds[2], moms[0], moms[1], volume, label, noise, it,
                           labeled_bs=L, num_classes=C, drop1="off", drop2="off", drop_t="off")
     for m, key in ((0, "logits1"), (1, "logits2"), (2, "teacher_logits")):
@@ -304,3 +396,11 @@ def test_cnn_meet_vit_step_at_full_batch():
         assert abs(got[f"pseudo_supervision{m + 1}"] - r["parts"][m][2]) <= TOL_LOSS
         assert abs(got[f"consistency_loss{m + 1}"] - r["parts"][m][3]) <= TOL_LOSS
         _check_grads_and_params(models[m], r["grads"][m], sds[m], r["lr"], f"cnnvit model{m + 1}", 0.043 if m == 0 else 0.003)   # 3x measured (1.4e-2; Transformer inside the absolute term)
+    r64 = cnn_meet_vit_step(nets[0], nets[1], _as64(sds0[0]), _as64(sds0[1]), _as64(sds0[2]), _as64(moms[0]), _as64(moms[1]),
+                            volume.double(), label, noise.double(), it, labeled_bs=L, num_classes=C, drop1="off", drop2="off",
+                            drop_t="off", apply_update=False)
+    _check_grads_f64(models[0], r["grads"][0], r64["grads"][0], "cnnvit model1 (UNet)",
+                     rerun=lambda: cnn_meet_vit_step(nets[0], nets[1], _as64(sds0[0]), _as64(sds0[1]), _as64(sds0[2]), _as64(moms[0]),
+                                                     _as64(moms[1]), volume.double(), label, noise.double(), it, labeled_bs=L,
+                                                     num_classes=C, drop1="off", drop2="off", drop_t="off",
+                                                     apply_update=False)["grads"][0])

@@ -226,7 +226,7 @@ def test_goldens_record_oracle_pin():
         if not f.endswith(".npz"):
             continue
         z = np.load(os.path.join(GOLD, f))
-        if f in ("swin_load_from.npz", "val2d.npz", "val3d.npz", "sampler.npz"):
+        if f in ("swin_load_from.npz", "val2d.npz", "val3d.npz", "sampler.npz", "cnnvit_infer.npz"):
             continue        # the reference function's / class's own result is the vector and the product is compared with it
                             # directly -- no oracle in between (checkpoint key mapping; oracle/gen_golden_io.py)
         assert float(z["oracle_vs_reference_worst_rel"]) <= 1e-5, f

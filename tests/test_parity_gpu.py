@@ -362,18 +362,18 @@ F64_MEDIAN_RATIO = 2.0
 # largest change per tensor) and round 5 let a tensor deviate by 1.5 x that -- up to 9.3 x a tensor's own maximum on
 # `vnet_gn_64_masks`, i.e. no gate at all for a quarter of the tensors (round-5 advisor).  Round 6: the gate re-evaluates the
 # float64 oracle step on the test machine with each of those pre-activations flipped (oracle/nets.py::PRE_ACT; the margins it
-# finds must be the golden's, which come from hooks on the reference modules), forms the 2^4 candidate solutions
+# finds must be the golden's, which come from hooks on the reference modules), forms candidate solutions
 # G_S = G_0 + sum_{k in S} (G_k - G_0) -- single flips are exact, combinations superpose to first order -- and holds EVERY
-# tensor to the NORMAL tolerance against ONE solution: the subset S that fits the HIP gradients best.  A wrong halo row or
+# tensor to the NORMAL tolerance against ONE solution: the subset S (greedy over the 8 smallest margins) that fits the HIP gradients.  A wrong halo row or
 # weight gradient in the deep layers is no longer inside any envelope; which side of a rounding-level discontinuity the
 # kernels land on still does not decide the test, nor which kernel serves the 8^3 level (conv_wino.hip::wino_splits).
-F64_FLIPS = 4
+F64_FLIPS = 8      # candidates re-evaluated here (the golden stores the margins of the 4 smallest)
 F64_GN = dict(K=F64_K, median=F64_MEDIAN_RATIO)
 
 
-def _flipped_solutions(run, flips):
+def _flipped_solutions(run, flips, max_positions=64):
     """[G_0, G_1 .. G_flips] (gradient dicts of ``run()``) and the margins: G_0 the plain float64 step, G_k the step with the
-    sign of the k-th smallest deep-level (<= 64 positions per channel) student pre-activation reversed -- the measurement of
+    sign of the k-th smallest deep-level (<= ``max_positions`` per channel) student pre-activation reversed -- the measurement of
     oracle/gen_golden.py::reference_grads64, on the oracle instead of the reference modules."""
     from oracle import nets
     cands, state = [], dict(i=0)
@@ -382,7 +382,7 @@ def _flipped_solutions(run, flips):
         i = state["i"]
         state["i"] += 1
         v = x.detach()
-        if v.dim() >= 4 and int(np.prod(v.shape[2:])) <= 64:
+        if v.dim() >= 4 and int(np.prod(v.shape[2:])) <= max_positions:
             a = v.abs().flatten()
             k = torch.topk(a, min(flips, a.numel()), largest=False)
             cands.extend((float(val / a.max()), i, int(j)) for val, j in zip(k.values, k.indices))
@@ -498,17 +498,25 @@ def test_step_gradients_match_float64_oracle(name, it):
             cons_start_iter=cfg["cons_start_iter"], drop_student=dd(drop_s), drop_teacher=dd(drop_t), apply_update=False)["grads"],
             F64_FLIPS)
         want = np.sort(z[f"it{it}_flip_margins"])
-        assert np.allclose(np.sort(margins), want, rtol=0.05, atol=1e-9), (margins, want)     # the reference's own near-zeros
-        base = sols[0]
-        best = None
-        for mask in range(1, 1 << (len(sols) - 1)):
-            pick = [k for k in range(1, len(sols)) if mask >> (k - 1) & 1]
-            sol = {n: base[n] + sum(sols[k][n] - base[n] for k in pick) for n in names}
-            r = score(sol)
-            if best is None or max(r[0])[0] < max(best[0][0])[0]:
-                best = (r, tuple(pick))
-        if max(best[0][0])[0] < max(rows)[0]:
-            (rows, ratios), flipped = best
+        assert np.allclose(np.sort(margins)[:len(want)], want, rtol=0.05, atol=1e-9), (margins, want)     # the reference's own near-zeros
+        # greedy: add the flip that lowers the worst (error / tolerance) most, until none does
+        base, pick, cur = sols[0], [], orc["grads"]
+        while True:
+            best = None
+            for k in range(1, len(sols)):
+                if k in pick:
+                    continue
+                sol = {n: cur[n] + (sols[k][n] - base[n]) for n in names}
+                r = score(sol)
+                if max(r[0])[0] < max(rows)[0] and (best is None or max(r[0])[0] < max(best[0][0])[0]):
+                    best = (r, k, sol)
+            if best is None:
+                break
+            (rows, ratios), k, cur = best
+            pick.append(k)
+            if max(rows)[0] <= 1.0:
+                break
+        flipped = tuple(pick)
     worst = max(rows)
     if os.environ.get("MIS_PRINT_GRAD_ROWS"):
         for r in sorted(rows, reverse=True)[:12]:

@@ -681,3 +681,179 @@ def test_final_expand_layernorm_and_head_in_the_gemm_epilogue(B, H, W, NC, keep,
         assert torch.equal(lg0, lg1)
     finally:
         tops.set_split_precision(prev)
+
+
+def test_colsum_batch_jobs_are_independent_column_sums():
+    """mis_colsum_batch: jobs of both partial formats (float / float2), strides wider than C, ragged widths, accumulate, in one
+    launch; every job's result is the fixed-order double sum of its own partial rows whatever else is in the batch."""
+    tops = _t()
+    g = torch.Generator().manual_seed(5)
+    specs = [(7, 96, 96, False, False), (300, 100, 128, True, False), (1, 4, 4, False, True), (1882, 96, 96, True, True),
+             (85, 27648, 27648, False, False), (33, 507, 507, False, False)]
+    jobs, want, outs = [], [], []
+    for slabs, C, stride, pairs, acc in specs:
+        part = (torch.rand(slabs, stride, 2 if pairs else 1, generator=g) - 0.5).cuda()
+        oa = torch.full((C,), 0.25, device="cuda")
+        ob = torch.full((C,), -0.5, device="cuda") if pairs else None
+        jobs.append(tops.ColsumJob(part, 0, stride, slabs, C, pairs, oa, ob, accumulate=acc))
+        s = part.double().sum(0)[:C]
+        want.append((s[:, 0] + (0.25 if acc else 0.0), s[:, 1] + (-0.5 if acc else 0.0) if pairs else None))
+        outs.append((oa, ob))
+    tops.ColsumBatch(jobs).run()
+    for (oa, ob), (wa, wb) in zip(outs, want):
+        assert (oa.double() - wa).abs().max().item() <= 1e-6 * max(1.0, wa.abs().max().item())
+        if ob is not None:
+            assert (ob.double() - wb).abs().max().item() <= 1e-6 * max(1.0, wb.abs().max().item())
+    # the same jobs in another order / another batch: bit-identical results
+    first = [o[0].clone() for o in outs]
+    for (oa, ob), (_, _, _, _, acc) in zip(outs, specs):
+        oa.fill_(0.25)
+        if ob is not None:
+            ob.fill_(-0.5)
+    tops.ColsumBatch(jobs[::-1]).run()
+    tops_again = [o[0] for o in outs]
+    assert all(torch.equal(a, b) for a, b in zip(first, tops_again))
+
+
+@pytest.mark.parametrize("T,Cout,Cin,bias", [(20000, 96, 288, True), (150528, 288, 96, True), (2352, 768, 3072, True),
+                                             (49, 1536, 768, True), (3137, 100, 36, True), (9408, 384, 1536, False)])
+def test_gemm_dw_parts_plus_batched_sums_equal_gemm_dw(T, Cout, Cin, bias, prec):
+    """mis_gemm_dw_parts leaves the k-slices' partials in the caller's workspace; two mis_colsum_batch jobs finish dW / db
+    (the token plans' batched form of nn.Linear's parameter gradients).  Same values as mis_gemm_dw to fp32 rounding."""
+    tops = _t()
+    X, dY = _rand(T, Cin, seed=15).cuda(), (_rand(T, Cout, seed=16) + 0.25).cuda()
+    dW = torch.full((Cout, Cin), float("nan"), device="cuda")
+    db = torch.full((Cout,), float("nan"), device="cuda") if bias else None
+    ws = tops.gemm_dw_workspace(Cout, Cin, T)
+    slices = tops.gemm_dw_parts(dY, X, dW, db, ws)
+    if slices:
+        assert torch.isnan(dW).all()                          # untouched until the sums run
+        jobs = [tops.ColsumJob(ws, 0, Cout * Cin, slices, Cout * Cin, False, dW.view(-1))]
+        if bias:
+            jobs.append(tops.ColsumJob(ws, slices * Cout * Cin, Cout, slices, Cout, False, db))
+        tops.ColsumBatch(jobs).run()
+    else:
+        assert ws is None or T < 4096
+    _close(dW, dY.double().t() @ X.double(), rtol=3e-4)
+    ref = torch.empty_like(dW)
+    if bias:
+        refb = torch.empty_like(db)
+        tops.gemm_dw(dY, X, ref, refb)
+        assert (db - refb).abs().max().item() <= 2e-6 * max(1.0, refb.abs().max().item())
+    else:
+        tops.gemm(dY, X, ref, trans=True)
+    assert (dW - ref).abs().max().item() <= 2e-6 * max(1.0, ref.abs().max().item())
+
+
+def test_window_attention_table_gradient_as_a_batched_sum(prec):
+    """The MFMA backward reduces each (sample, window, head) unit's dS to the (2 ws - 1)^2 table entries in the kernel and
+    leaves [units / nH][entries][nH] partial rows: their column sum -- as a mis_colsum_batch job -- is the table gradient the
+    one-call form returns."""
+    tops = _t()
+    for B, H, W, nH, shift, ws in ((3, 14, 21, 2, 3, 7), (5, 16, 24, 3, 4, 8)):
+        C = nH * 32
+        qkv = (_rand(B * H * W, 3 * C, seed=22, scale=1.5)).cuda()
+        table = (_rand((2 * ws - 1) ** 2, nH, seed=23, scale=0.5)).cuda()
+        dout = _rand(B * H * W, C, seed=24).cuda()
+        scale = 32 ** -0.5
+        dqkv, dt = torch.empty(B * H * W, 3 * C, device="cuda"), torch.empty_like(table)
+        tops.window_attention_bwd(qkv, dout, dqkv, table, dt, B, H, W, nH, shift, scale, window=ws)
+        own = tops.window_attention_workspace(B, H, W, nH, window=ws)
+        dqkv2, dt2 = torch.empty_like(dqkv), torch.full_like(dt, float("nan"))
+        tops.window_attention_bwd_parts(qkv, dout, dqkv2, table, own, B, H, W, nH, shift, scale, window=ws)
+        rows, cols = tops.window_attention_table_partials(B, H, W, nH, window=ws)
+        assert (rows, cols) == (B * (H // ws) * (W // ws), (2 * ws - 1) ** 2 * nH)
+        tops.ColsumBatch([tops.ColsumJob(own.view(torch.float32), 0, cols, rows, cols, False, dt2.view(-1))]).run()
+        assert torch.equal(dqkv, dqkv2) and torch.equal(dt, dt2)
+
+
+def test_swin_step_with_batched_finishing_sums_equals_per_op_launches():
+    """plan.BATCH_FINALS: the LayerNorm affine, Linear weight / bias and bias-table gradients of a SwinUnet Mean-Teacher step
+    finished by a few mis_colsum_batch launches instead of ~130 per-op launches -- same step to fp32 rounding, and the batched
+    form is bit-reproducible."""
+    from config import lite_config
+    from mis_hip import plan
+    from mis_hip.step import MeanTeacherTrainer
+    from networks.vision_transformer import SwinUnet
+    from oracle import filler
+    from oracle.swin import OracleSwinUnet
+    sd0 = filler.fill_state_dict(OracleSwinUnet(4).new_state())
+    vol = filler.image((4, 1, 224, 224), "volume").cuda()
+    lab = filler.labels((4, 224, 224), 4, torch.uint8).cuda()
+    res = []
+    for batch, flush_mb in ((True, 32), (False, 32), (True, 1)):
+        plan.BATCH_FINALS, plan.FINALS_FLUSH_BYTES = batch, flush_mb << 20
+        try:
+            m, e = SwinUnet(lite_config(), num_classes=4), SwinUnet(lite_config(), num_classes=4)
+            m.load_state_dict(sd0); e.load_state_dict(sd0)
+            tr = MeanTeacherTrainer(m, e, labeled_bs=2, num_classes=4, cons_start_iter=0, seed=11, iter_num=1500)
+            for _ in range(2):
+                tr.step(vol, lab)
+            torch.cuda.synchronize()
+            res.append((tr.losses(), m.flat_grad.clone(), m.flat_param.clone(), e.flat_param.clone()))
+        finally:
+            plan.BATCH_FINALS, plan.FINALS_FLUSH_BYTES = True, 32 << 20
+    (l0, g0, p0, t0), (l1, g1, p1, t1), (l2, g2, p2, t2) = res
+    for k in l0:
+        assert abs(l0[k] - l1[k]) <= 1e-6, (k, l0[k], l1[k])
+    gs = float(g1.abs().max())
+    assert (g0 - g1).abs().max().item() <= 1e-5 * gs
+    assert (p0 - p1).abs().max().item() <= 1e-6 and (t0 - t1).abs().max().item() <= 1e-6
+    # how the jobs are grouped into launches does not change a bit
+    assert torch.equal(g0, g2) and torch.equal(p0, p2) and torch.equal(t0, t2)
+
+
+@pytest.mark.parametrize("M,N,K", [(150528, 288, 96), (150528, 96, 384), (37632, 576, 192), (37632, 192, 768), (65570, 96, 96),
+                                   (70001, 192, 100), (9408 * 8, 384, 1152)])
+def test_register_a_nt_gemm(M, N, K):
+    """gemm_nt_rega_kernel (round 6): the A operand goes from HBM straight into the v_mfma_f32_16x16x32_bf16 operand registers,
+    the pre-split weight planes (NATURAL element order, SplitB(rows=M)) through LDS.  Plain / bias / accumulate, the three fused
+    epilogues, a ragged last row tile, K not a multiple of 32, strided C and E1 -- against float64; agreement with the staged
+    kernel to fp32 rounding (other element order inside a K = 32 block: not bit for bit); deterministic."""
+    tops = _t()
+    prev = tops.set_split_precision(7)
+    try:
+        A, W = _rand(M, K, seed=41), _rand(N, K, seed=42, scale=K ** -0.5)
+        bias = _rand(N, seed=43)
+        Ad, Wd, bd = A.cuda(), W.cuda(), bias.cuda()
+        b3 = tops.SplitB(Wd, rows=M).refresh()
+        assert b3.natural, "the register-A kernel serves this shape"
+        idx = torch.cat([torch.arange(0, 300), torch.arange(M - 300, M)])         # first and last (ragged) row tiles
+        ref = A[idx].double() @ W.double().t()
+        C = torch.full((M, N), float("nan"), device="cuda")
+        tops.gemm(Ad, Wd, C, bias=bd, b3=b3)
+        _close(C[idx.cuda()], ref + bias.double())
+        assert torch.isfinite(C).all()
+        C2 = torch.empty_like(C)
+        tops.gemm(Ad, Wd, C2, bias=bd, b3=b3)
+        assert torch.equal(C, C2)
+        staged = torch.empty_like(C)
+        tops.gemm(Ad, Wd, staged, bias=bd, b3=tops.SplitB(Wd).refresh())
+        assert (C - staged).abs().max().item() <= 2e-6 * max(1.0, staged.abs().max().item())
+        tops.gemm(Ad, Wd, C, accumulate=True, b3=b3)
+        _close(C[idx.cuda()], 2 * ref + bias.double())
+        wide = torch.zeros(M, N + 32, device="cuda")
+        tops.gemm(Ad, Wd, wide[:, 32:], b3=b3)
+        _close(wide[idx.cuda(), 32:], ref)
+        assert wide[:, :32].abs().max().item() == 0
+        del wide, staged, C2
+        v = ref + bias.double()
+        Cg = torch.empty(M, N, device="cuda")
+        assert tops.gemm_ex(Ad, Wd, C, tops.EP_GELU_FWD, bias=bd, C2=Cg, b3=b3)
+        _close(C[idx.cuda()], v)
+        _close(Cg[idx.cuda()], F.gelu(v))
+        assert tops.gemm_ex(Ad, Wd, None, tops.EP_GELU_FWD, bias=bd, C2=Cg, b3=b3)          # a forward nobody differentiates
+        _close(Cg[idx.cuda()], F.gelu(v))
+        h = _rand(M, N, seed=44, scale=1.5)
+        hd = h[idx].double().requires_grad_(True)
+        F.gelu(hd).backward(torch.ones(idx.numel(), N, dtype=torch.float64))
+        assert tops.gemm_ex(Ad, Wd, C, tops.EP_GELU_BWD, E1=h.cuda(), b3=b3)
+        _close(C[idx.cuda()], ref * hd.grad)
+        rps = M // 2 if M % 2 == 0 else M
+        wide = _rand(M, N + 32, seed=45)
+        sc = torch.tensor([0.0, 1.25] if rps < M else [1.25])
+        assert tops.gemm_ex(Ad, Wd, C, tops.EP_RESIDUAL, bias=bd, E1=wide.cuda()[:, 16:16 + N], rowscale=sc.cuda(),
+                            rows_per_scale=rps, b3=b3)
+        _close(C[idx.cuda()], wide[idx, 16:16 + N].double() + sc.repeat_interleave(rps)[idx, None].double() * v)
+    finally:
+        tops.set_split_precision(prev)
