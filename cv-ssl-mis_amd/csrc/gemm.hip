@@ -798,16 +798,67 @@ __global__ __launch_bounds__(256) void gemm_nt_short_kernel(const GemmArgs a) {
 //   * a wave owns 32 rows x the tile's full 96 (128) columns: B -- the pre-split planes, NATURAL element order (SplitJob::
 //     natural) -- is staged through LDS once per 128 rows instead of once per 64 and read once per wave (18 ds_read_b128 per
 //     72 MFMAs);
-//   * 48 accumulator registers, ~150 in all: three waves per SIMD, three workgroups per CU (the epilogue tile, 51 KB, aliases
-//     the two B stages) -- the residency that hides the phases of a short contraction (see the persistent form's obituary above).
+//   * the weight tile is the MFMA's ROW operand: a lane's accumulator is four consecutive columns n of one token row -- a float4
+//     of C -- and the epilogue (bias, GELU, residual, accumulate) stores straight from the registers: no LDS tile, no barrier
+//     behind the k-loop (the staged kernel's epilogue is 30 % of its time);
+//   * 48 accumulator registers, ~150 in all, 36 KB of LDS: three waves per SIMD, three workgroups per CU -- the residency that
+//     hides the phases of a short contraction (see the persistent form's obituary above).
 // Same split products and the same k-block order as the other bf16x3 kernels; the element order inside a K = 32 block differs,
 // so results agree with them to fp32 rounding, not bit for bit.  Float4 epilogue only (plain / GELU / residual), no split-K.
+// Epilogue of the register-A kernels, straight from the accumulators: tile (i, j) of lane (lj, g) = C[mrow + 16 i + lj][n0 + 16 j +
+// 4 g .. + 3], a float4 of the row (the four lane groups of a row write 64 contiguous bytes, the tiles j the row's 4 * BN): no LDS
+// PRE: the lane's bias float4s (bv, zeros without a bias) and its E1 / accumulate operands (ev) were loaded by the caller -- the
+// persistent kernel requests them BEFORE the next slab's A loads: vmcnt retires in order, so a load issued in the epilogue would
+// wait for the whole prefetch in front of it.
+template <int NJ, int EP, bool PRE = false>
+__device__ __forceinline__ void rega_store(const GemmArgs& a, const f32x4 (&acc)[2][NJ], int mrow, int n0, int lj, int g,
+                                           const float4* bv = nullptr, const float4 (*ev)[NJ] = nullptr) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int m = mrow + 16 * i + lj;
+        if (m >= a.M) continue;
+        const float rs = (EP == EP_RESIDUAL && a.rowscale) ? a.rowscale[m / a.rps] : 1.f;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int n = n0 + 16 * j + 4 * g;
+            if (n >= a.N) continue;
+            float4 v = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+            if constexpr (PRE) {
+                v.x += bv[j].x; v.y += bv[j].y; v.z += bv[j].z; v.w += bv[j].w;
+            } else if (a.bias) {
+                const float4 b = *reinterpret_cast<const float4*>(a.bias + n);
+                v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+            }
+            float* const cp = a.C + (long long)m * a.ldc + n;
+            if constexpr (EP == EP_GELU_FWD) {
+                *reinterpret_cast<float4*>(a.C2 + (long long)m * a.ldc2 + n) =
+                    make_float4(gelu_f(v.x), gelu_f(v.y), gelu_f(v.z), gelu_f(v.w));
+                if (!a.C) continue;
+            } else if constexpr (EP == EP_GELU_BWD) {
+                float4 h;
+                if constexpr (PRE) h = ev[i][j]; else h = *reinterpret_cast<const float4*>(a.E1 + (long long)m * a.lde1 + n);
+                v.x *= gelu_grad_f(h.x); v.y *= gelu_grad_f(h.y); v.z *= gelu_grad_f(h.z); v.w *= gelu_grad_f(h.w);
+            } else if constexpr (EP == EP_RESIDUAL) {
+                float4 sc;
+                if constexpr (PRE) sc = ev[i][j]; else sc = *reinterpret_cast<const float4*>(a.E1 + (long long)m * a.lde1 + n);
+                v.x = sc.x + rs * v.x; v.y = sc.y + rs * v.y; v.z = sc.z + rs * v.z; v.w = sc.w + rs * v.w;
+            } else {
+                if (a.accumulate) {
+                    float4 o;
+                    if constexpr (PRE) o = ev[i][j]; else o = *reinterpret_cast<const float4*>(cp);
+                    v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+                }
+            }
+            *reinterpret_cast<float4*>(cp) = v;
+        }
+    }
+}
+
 template <int BN, int EP>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void gemm_nt_rega_kernel(const GemmArgs a) {
     constexpr int MI = 2, NJ = BN / 16, BMT = 128;
     constexpr int RB3 = BN / 16, PB3 = 3 * RB3, NB3 = (PB3 + 3) / 4;
     constexpr int B_FLOATS = BN * BK * 3 / 2;                   // one stage: three planes [BN][32] bf16
-    constexpr int LDC_T = BN + 4;
     float* const lds = mis_gemm_lds;
     const unsigned L = mis_xcd_remap(blockIdx.x, a.n_blocks_padded);
     if (L >= a.n_blocks) return;
@@ -879,13 +930,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
             const u32x4 bh = sB3[r], bm = sB3[BN * 4 + r], bl = sB3[2 * BN * 4 + r];
 #pragma unroll
             for (int i = 0; i < MI; ++i) {
+                // the WEIGHT tile is the MFMA's row operand: D[row = column n of C, 4 g + r][col = token lj] -- a lane ends up
+                // with four consecutive n of one token, i.e. a float4 of a C row (see the epilogue)
                 f32x4 c = acc[i][j];
-                c = bf3_mfma(a3[i].l, bh, c);
-                c = bf3_mfma(a3[i].h, bl, c);
-                c = bf3_mfma(a3[i].m, bm, c);
-                c = bf3_mfma(a3[i].m, bh, c);
-                c = bf3_mfma(a3[i].h, bm, c);
-                c = bf3_mfma(a3[i].h, bh, c);
+                c = bf3_mfma(bh, a3[i].l, c);
+                c = bf3_mfma(bl, a3[i].h, c);
+                c = bf3_mfma(bm, a3[i].m, c);
+                c = bf3_mfma(bh, a3[i].m, c);
+                c = bf3_mfma(bm, a3[i].h, c);
+                c = bf3_mfma(bh, a3[i].h, c);
                 acc[i][j] = c;
             }
         }
@@ -897,52 +950,162 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         __syncthreads();
     }
 
-    // ---- epilogue: accumulators -> LDS tile [128][BN + 4] (over the B stages: the loop ended with a barrier) -> float4 rows ----
-    float* const ct = lds;
-#pragma unroll
-    for (int i = 0; i < MI; ++i)
-#pragma unroll
-        for (int j = 0; j < NJ; ++j)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) ct[(wm + i * 16 + g * 4 + r) * LDC_T + j * 16 + lj] = acc[i][j][r];
-    __syncthreads();
-    constexpr int Q = BN / 4;
-#pragma unroll 4
-    for (int it = 0; it < BMT * Q / 256; ++it) {
-        const int e = tid + it * 256;
-        const int row = e / Q, q = e - row * Q;
-        const int m = m0 + row, n = n0 + q * 4;
-        if (m >= a.M || n >= a.N) continue;
-        float4 v = *reinterpret_cast<const float4*>(&ct[row * LDC_T + q * 4]);
-        if (a.bias) {
-            const float4 b = *reinterpret_cast<const float4*>(a.bias + n);
-            v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
-        }
-        float* const cp = a.C + (long long)m * a.ldc + n;
-        if constexpr (EP == EP_GELU_FWD) {
-            *reinterpret_cast<float4*>(a.C2 + (long long)m * a.ldc2 + n) =
-                make_float4(gelu_f(v.x), gelu_f(v.y), gelu_f(v.z), gelu_f(v.w));
-            if (!a.C) continue;
-        } else if constexpr (EP == EP_GELU_BWD) {
-            const float4 h = *reinterpret_cast<const float4*>(a.E1 + (long long)m * a.lde1 + n);
-            v.x *= gelu_grad_f(h.x); v.y *= gelu_grad_f(h.y); v.z *= gelu_grad_f(h.z); v.w *= gelu_grad_f(h.w);
-        } else if constexpr (EP == EP_RESIDUAL) {
-            const float4 sc = *reinterpret_cast<const float4*>(a.E1 + (long long)m * a.lde1 + n);
-            const float rs = a.rowscale ? a.rowscale[m / a.rps] : 1.f;
-            v.x = sc.x + rs * v.x; v.y = sc.y + rs * v.y; v.z = sc.z + rs * v.z; v.w = sc.w + rs * v.w;
-        } else {
-            if (a.accumulate) {
-                const float4 o = *reinterpret_cast<const float4*>(cp);
-                v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
-            }
-        }
-        *reinterpret_cast<float4*>(cp) = v;
-    }
+    rega_store<NJ, EP>(a, acc, m0 + wm, n0, lj, g);
 }
 
 template <int BN>
-constexpr int rega_lds_bytes() {
-    return (2 * (BN * BK * 3 / 2) > 128 * (BN + 4) ? 2 * (BN * BK * 3 / 2) : 128 * (BN + 4)) * 4;
+constexpr int rega_lds_bytes() { return 2 * (BN * BK * 3 / 2) * 4; }      // the two B stages (36 KB for BN = 96)
+
+template <int NJ>
+__device__ __forceinline__ void rega_store_plain(const GemmArgs& a, const f32x4 (&acc)[2][NJ], int mrow, int n0, int lj, int g,
+                                                 const float4* bv) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int m = mrow + 16 * i + lj;
+        if (m >= a.M) continue;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int n = n0 + 16 * j + 4 * g;
+            if (n >= a.N) continue;
+            *reinterpret_cast<float4*>(a.C + (long long)m * a.ldc + n) =
+                make_float4(acc[i][j][0] + bv[j].x, acc[i][j][1] + bv[j].y, acc[i][j][2] + bv[j].z, acc[i][j][3] + bv[j].w);
+        }
+    }
+}
+
+// The same kernel for K <= 96 (the 96-channel stage: qkv / proj / fc1 forward, proj / fc2 data gradient -- ~2 ms of a SwinUnet step
+// at 10^5 token rows), PERSISTENT with the weight panel RESIDENT.  A k-loop of three steps is all prologue: the streamed kernel
+// spends ~19 us on a tile whose MFMAs take 1.6 (one batch of loads per barrier).  Here a workgroup keeps its 96-column panel of
+// the planes in LDS for its whole life (K3 / 32 x 18 KB = 55 KB: two workgroups per CU) and its four waves walk down the
+// 32-row slabs of the matrix independently: a wave requests the WHOLE contraction of its next slab (12 x 16 bytes per lane)
+// before it multiplies the current one (216 MFMAs) and stores it from the accumulators -- no barrier and no LDS write after the
+// prologue, two slabs of loads in flight per wave, two waves per SIMD.  (Round 5's persistent form staged A through LDS and the
+// accumulators back through it: one workgroup per CU.)
+template <int EP>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_nt_rega_res_kernel(const GemmArgs a) {
+    constexpr int BN = 96, MI = 2, NJ = BN / 16, KBM = 3;
+    constexpr int RB3 = BN / 16, PB3 = 3 * RB3;
+    constexpr int B_FLOATS = BN * BK * 3 / 2;                   // one k-block: three planes [96][32] bf16
+    float* const lds = mis_gemm_lds;
+    const unsigned L = mis_xcd_remap(blockIdx.x, a.n_blocks_padded);
+    if (L >= a.n_blocks) return;
+    const int tn = L % a.tiles_n, p = L / a.tiles_n;             // column panel, walker index
+    const int walkers = a.n_blocks / a.tiles_n;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, lj = lane & 15;
+    const int n0 = tn * BN;
+    const int kb_n = a.K3 / BK;                                  // 1 .. 3
+    const unsigned lds0 = lds_addr(lds);
+    const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.A), 0,
+                                                                        (int)(((long long)(a.M - 1) * a.lda + a.K) * 4), 0x00020000);
+    const i32x4 rB3 = make_rsrc(a.B3, 3u * a.b3_plane);
+    // ---- prologue: the panel, all k-blocks ----
+    for (int q = wave; q < kb_n * PB3; q += 4) {
+        const int kb = q / PB3, qq = q - kb * PB3;
+        const int plane = qq / RB3, row = (qq % RB3) * 16 + (lane >> 2);
+        const unsigned vo = n0 + row < a.N
+                                ? (unsigned)plane * a.b3_plane + (unsigned)(((long long)(n0 + row) * a.K3 + kb * 32 + (lane & 3) * 8) * 2)
+                                : OOB;
+        dma_dwordx4(lds0 + (unsigned)(kb * B_FLOATS * 4 + qq * 1024), vo, rB3);
+    }
+    dma_wait();
+    __syncthreads();
+
+    const int slabs = (a.M + 31) / 32;
+    const int stride = walkers * 4;
+    auto load_a = [&](f32x4 (&r)[KBM][MI][2], int slab) {
+        const int mrow = slab * 32;
+#pragma unroll
+        for (int kb = 0; kb < KBM; ++kb)
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                const int row = mrow + 16 * i + lj;
+                const int vo = row < a.M ? (int)(((long long)row * a.lda + 8 * g) * 4) : (int)OOB;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const bool in = kb * 32 + 8 * g + 4 * h < a.K;      // also false for k-blocks past K3
+                    r[kb][i][h] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rA, in ? vo + 16 * h : (int)OOB, kb * 128, 0));
+                }
+            }
+    };
+    f32x4 cur[KBM][MI][2], nxt[KBM][MI][2];
+    int slab = p * 4 + wave;
+    if (slab >= slabs) return;
+    float4 bv[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int n = n0 + 16 * j + 4 * g;
+        bv[j] = (a.bias && n < a.N) ? *reinterpret_cast<const float4*>(a.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    // the epilogue's second operand (pre-activation / shortcut / old C) of THIS slab, requested ahead of the next slab's A
+    constexpr bool HAS_E = EP == EP_GELU_BWD || EP == EP_RESIDUAL || EP == EP_NONE;
+    const bool use_e = EP == EP_NONE ? a.accumulate != 0 : true;
+    const float* const ebase = EP == EP_NONE ? a.C : a.E1;
+    const long long lde = EP == EP_NONE ? a.ldc : a.lde1;
+    float4 ev[MI][NJ];
+    load_a(cur, slab);
+    for (; slab < slabs; slab += stride) {
+        const bool more = slab + stride < slabs;
+        if constexpr (HAS_E) {
+            if (use_e) {
+#pragma unroll
+                for (int i = 0; i < MI; ++i) {
+                    const int m = slab * 32 + 16 * i + lj;
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) {
+                        const int n = n0 + 16 * j + 4 * g;
+                        ev[i][j] = (m < a.M && n < a.N) ? *reinterpret_cast<const float4*>(ebase + (long long)m * lde + n)
+                                                        : make_float4(0.f, 0.f, 0.f, 0.f);
+                    }
+                }
+            }
+        }
+        if (more) load_a(nxt, slab + stride);
+        f32x4 acc[MI][NJ];
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kb = 0; kb < KBM; ++kb) {
+            if (kb >= kb_n) break;
+            MisBf3 a3[MI];
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+                a3[i] = mis_bf3_from8(cur[kb][i][0][0], cur[kb][i][0][1], cur[kb][i][0][2], cur[kb][i][0][3],
+                                      cur[kb][i][1][0], cur[kb][i][1][1], cur[kb][i][1][2], cur[kb][i][1][3]);
+            const u32x4* __restrict__ sB3 = reinterpret_cast<const u32x4*>(lds + kb * B_FLOATS);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int r = (j * 16 + lj) * 4 + g;
+                const u32x4 bh = sB3[r], bm = sB3[BN * 4 + r], bl = sB3[2 * BN * 4 + r];
+#pragma unroll
+                for (int i = 0; i < MI; ++i) {
+                    f32x4 c = acc[i][j];
+                    c = bf3_mfma(bh, a3[i].l, c);
+                    c = bf3_mfma(bl, a3[i].h, c);
+                    c = bf3_mfma(bm, a3[i].m, c);
+                    c = bf3_mfma(bh, a3[i].m, c);
+                    c = bf3_mfma(bm, a3[i].h, c);
+                    c = bf3_mfma(bh, a3[i].h, c);
+                    acc[i][j] = c;
+                }
+            }
+        }
+        if constexpr (EP == EP_NONE) {
+            if (use_e) rega_store<NJ, EP, true>(a, acc, slab * 32, n0, lj, g, bv, ev);
+            else rega_store_plain<NJ>(a, acc, slab * 32, n0, lj, g, bv);
+        } else {
+            rega_store<NJ, EP, true>(a, acc, slab * 32, n0, lj, g, bv, ev);
+        }
+        if (more) {
+#pragma unroll
+            for (int kb = 0; kb < KBM; ++kb)
+#pragma unroll
+                for (int i = 0; i < MI; ++i) { cur[kb][i][0] = nxt[kb][i][0]; cur[kb][i][1] = nxt[kb][i][1]; }
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ TN
@@ -1627,8 +1790,12 @@ bool nt_rega_shape(int M, int N, int K) {
     static const int on = getenv("MIS_GEMM_REGA") ? atoi(getenv("MIS_GEMM_REGA")) : 1;
     static const int kmin = getenv("MIS_GEMM_REGA_KMIN") ? atoi(getenv("MIS_GEMM_REGA_KMIN")) : 96;
     static const int tmin = getenv("MIS_GEMM_REGA_TILES") ? atoi(getenv("MIS_GEMM_REGA_TILES")) : 512;
+    static const int mmin = getenv("MIS_GEMM_REGA_MMIN") ? atoi(getenv("MIS_GEMM_REGA_MMIN")) : 30000;
     if (!on || !gemm_bf3() || N % 96 || N % 4 || K % 4 || K < kmin) return false;
     if ((long long)M * 4 >= (1LL << 31)) return false;
+    // per-shape sweep at 48 images (scripts/gemm_nt_bench.py --rega, profiles/r06_gemm_nt_rega.txt): ahead of the staged kernels
+    // for the 10^5-row stage and, at 4 x 10^4 rows, where the output is wider than the contraction; behind them below that
+    if (M < mmin || (M < 100000 && N <= K)) return false;
     return mis_cdiv(M, 128) * (N / 96) >= tmin;
 }
 
@@ -1641,7 +1808,34 @@ int launch_nt_rega_ep(const GemmArgs& a, hipStream_t stream) {
     return mis_launch_status();
 }
 
+template <int EP>
+int launch_nt_rega_res_ep(const GemmArgs& a, hipStream_t stream) {
+    static std::atomic<unsigned long long> attr_done{0};
+    const int ldsb = (a.K3 / BK) * (96 * BK * 3 / 2) * 4;
+    if (mis_set_lds_attr(reinterpret_cast<const void*>(&gemm_nt_rega_res_kernel<EP>), 3 * (96 * BK * 3 / 2) * 4, attr_done) != MIS_OK)
+        return MIS_ERR_LAUNCH;
+    hipLaunchKernelGGL((gemm_nt_rega_res_kernel<EP>), dim3(a.n_blocks_padded), dim3(256), ldsb, stream, a);
+    return mis_launch_status();
+}
+
 int launch_nt_rega(GemmArgs& a, hipStream_t stream) {
+    static const int res_on = getenv("MIS_GEMM_REGA_RES") ? atoi(getenv("MIS_GEMM_REGA_RES")) : 1;
+    if (res_on && a.K3 <= 96) {
+        // persistent: two workgroups per CU, split evenly over the column panels; a walker's four waves want >= 2 slabs each
+        a.tiles_n = a.N / 96;
+        long long walkers = 512 / a.tiles_n;
+        const long long slabs = mis_cdiv(a.M, 32);
+        if (walkers > mis_cdiv(slabs, 8)) walkers = mis_cdiv(slabs, 8);
+        if (walkers < 1) walkers = 1;
+        a.tiles_m = (int)walkers;
+        a.n_blocks = (unsigned)(walkers * a.tiles_n);
+        a.n_blocks_padded = (unsigned)(mis_cdiv((long long)a.n_blocks, MIS_NUM_XCD) * MIS_NUM_XCD);
+        a.KS = 1;
+        if (a.ep == EP_NONE) return launch_nt_rega_res_ep<EP_NONE>(a, stream);
+        if (a.ep == EP_GELU_FWD) return launch_nt_rega_res_ep<EP_GELU_FWD>(a, stream);
+        if (a.ep == EP_GELU_BWD) return launch_nt_rega_res_ep<EP_GELU_BWD>(a, stream);
+        return launch_nt_rega_res_ep<EP_RESIDUAL>(a, stream);
+    }
     a.tiles_n = a.N / 96;
     a.tiles_m = (int)mis_cdiv(a.M, 128);
     const long long nb = (long long)a.tiles_n * a.tiles_m;
@@ -1689,12 +1883,15 @@ extern "C" int mis_gemm_nt_split_kernel_name(int M, int N, int K, int epilogue, 
     snprintf(name, name_len, "gemm_nt_kernel<%d, %d, %d, 2>", bm, bn, ks > 1 ? 0 : epilogue);
     return MIS_OK;
 }
+static int split_k3(int K);
 // ... on natural-order planes (layout 1): the register-A kernel
 extern "C" int mis_gemm_nt_split_layout_kernel_name(int M, int N, int K, int epilogue, int layout, char* name, int name_len) {
     if (!layout) return mis_gemm_nt_split_kernel_name(M, N, K, epilogue, name, name_len);
     if (M <= 0 || N <= 0 || K <= 0 || !name || name_len <= 0) return MIS_ERR_ARG;
     if (!nt_rega_shape(M, N, K)) return MIS_ERR_UNSUPPORTED;
-    snprintf(name, name_len, "gemm_nt_rega_kernel<96, %d>", epilogue);
+    static const int res_on = getenv("MIS_GEMM_REGA_RES") ? atoi(getenv("MIS_GEMM_REGA_RES")) : 1;
+    if (res_on && split_k3(K) <= 96) snprintf(name, name_len, "gemm_nt_rega_res_kernel<%d>", epilogue);
+    else snprintf(name, name_len, "gemm_nt_rega_kernel<96, %d>", epilogue);
     return MIS_OK;
 }
 

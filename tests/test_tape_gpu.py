@@ -39,7 +39,7 @@ def _mt(kind, tape):
         from oracle.nets import OracleUNet3D
         sd0 = filler.fill_state_dict(OracleUNet3D(2, 1).new_state())
         make = lambda: net_factory_3d("unet_3D", 1, 2)
-        shape, C, L, ldt = (4, 1, 48, 48, 48), 2, 2, torch.int64
+        shape, C, L, ldt = (2, 1, 64, 64, 64), 2, 1, torch.int64
     m, e = make(), make()
     m.load_state_dict(sd0); e.load_state_dict(sd0)
     m.train(); e.train()

@@ -803,8 +803,8 @@ def test_swin_step_with_batched_finishing_sums_equals_per_op_launches():
     assert torch.equal(g0, g2) and torch.equal(p0, p2) and torch.equal(t0, t2)
 
 
-@pytest.mark.parametrize("M,N,K", [(150528, 288, 96), (150528, 96, 384), (37632, 576, 192), (37632, 192, 768), (65570, 96, 96),
-                                   (70001, 192, 100), (9408 * 8, 384, 1152)])
+@pytest.mark.parametrize("M,N,K", [(150528, 288, 96), (150528, 96, 384), (37632, 576, 192), (37632, 768, 192), (165570, 96, 96),
+                                   (70001, 192, 100), (9408 * 12, 384, 1152)])
 def test_register_a_nt_gemm(M, N, K):
     """gemm_nt_rega_kernel (round 6): the A operand goes from HBM straight into the v_mfma_f32_16x16x32_bf16 operand registers,
     the pre-split weight planes (NATURAL element order, SplitB(rows=M)) through LDS.  Plain / bias / accumulate, the three fused
