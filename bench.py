@@ -298,7 +298,9 @@ def run_workload(name, args, rank, world, kernel_events=True):
         tr.step(vol, lab)
     # the product step is a launch tape (mis_hip/step.py::_TapedStep: two eager steps, one recorded, then replays): the timed
     # region must be replays whatever --warmup says (more untimed steps than asked for, never fewer)
-    while getattr(tr, "use_tape", False) and getattr(tr, "_tape", None) is None:
+    for _ in range(4):
+        if not getattr(tr, "use_tape", False) or getattr(tr, "_tape", None) is not None:
+            break
         tr.step(vol, lab)
     dt_local = timed(args.steps)
     host_loop_ms = enqueue[-1][0] / enqueue[-1][1] * 1e3
@@ -464,7 +466,9 @@ def _retape(tr, vol, lab):
     """After a configuration change (bucketers swapped out, exchange stubbed): drop the recorded step and record it again, untimed."""
     if getattr(tr, "use_tape", False):
         tr._tape, tr._tape_warm = None, 0
-        while tr._tape is None:
+        for _ in range(4):
+            if tr._tape is not None:
+                break
             tr.step(vol, lab)
 
 

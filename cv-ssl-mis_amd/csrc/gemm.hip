@@ -71,7 +71,7 @@ struct GemmArgs {
     int head_nc; float ln_eps;
 };
 
-enum { EP_NONE = 0, EP_GELU_FWD = 1, EP_GELU_BWD = 2, EP_RESIDUAL = 3, EP_LNHEAD = 4 };
+enum { EP_NONE = 0, EP_GELU_FWD = 1, EP_GELU_BWD = 2, EP_RESIDUAL = 3, EP_LNHEAD = 4, EP_RESIDUAL_LN = 5 };
 
 // same functions as token_ops.hip::gelu_kernel (common.h)
 __device__ __forceinline__ float gelu_f(float x) { return mis_gelu(x); }
@@ -810,9 +810,62 @@ __global__ __launch_bounds__(256) void gemm_nt_short_kernel(const GemmArgs a) {
 // PRE: the lane's bias float4s (bv, zeros without a bias) and its E1 / accumulate operands (ev) were loaded by the caller -- the
 // persistent kernel requests them BEFORE the next slab's A loads: vmcnt retires in order, so a load issued in the epilogue would
 // wait for the whole prefetch in front of it.
+// EP_RESIDUAL_LN (N = 96: a row is one tile row): x = E1 + rowscale * v goes to C and LayerNorm(x) * gamma + beta to C2, mean /
+// rstd to ln_mean / ln_rstd (`x = shortcut + drop_path(branch)` followed by `self.norm2(x)` / the next block's `norm1`, reference
+// ...sys.py:276-281, :244-250).  The row's 96 values sit in the four lanes (lj, g = 0 .. 3): two in-lane sums of 24 and two
+// cross-group steps each for mean and variance -- no LDS pass, and the LayerNorm launch with its read of x is gone.  gamma / beta
+// come from LDS (`gb`: [gamma 96][beta 96], staged by the kernel): a global load here would wait behind the A prefetch.
 template <int NJ, int EP, bool PRE = false>
 __device__ __forceinline__ void rega_store(const GemmArgs& a, const f32x4 (&acc)[2][NJ], int mrow, int n0, int lj, int g,
-                                           const float4* bv = nullptr, const float4 (*ev)[NJ] = nullptr) {
+                                           const float4* bv = nullptr, const float4 (*ev)[NJ] = nullptr, const float* gb = nullptr) {
+    if constexpr (EP == EP_RESIDUAL_LN) {
+        static_assert(NJ == 6, "a 96-column row");
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int m = mrow + 16 * i + lj;
+            const bool live = m < a.M;                       // (every lane takes part in the cross-group sums)
+            const float rs = (a.rowscale && live) ? a.rowscale[m / a.rps] : 1.f;
+            float4 x[NJ];
+            float s = 0.f;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int n = 16 * j + 4 * g;
+                float4 v = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+                float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
+                if constexpr (PRE) b = bv[j];
+                else if (a.bias) b = *reinterpret_cast<const float4*>(a.bias + n);
+                float4 sc = make_float4(0.f, 0.f, 0.f, 0.f);
+                if constexpr (PRE) sc = ev[i][j];
+                else if (live) sc = *reinterpret_cast<const float4*>(a.E1 + (long long)m * a.lde1 + n);
+                x[j] = make_float4(sc.x + rs * (v.x + b.x), sc.y + rs * (v.y + b.y), sc.z + rs * (v.z + b.z), sc.w + rs * (v.w + b.w));
+                s += (x[j].x + x[j].y) + (x[j].z + x[j].w);
+                if (live) *reinterpret_cast<float4*>(a.C + (long long)m * a.ldc + n) = x[j];
+            }
+            s += __shfl_xor(s, 16, 64);
+            s += __shfl_xor(s, 32, 64);
+            const float mu = s / 96.f;
+            float ss = 0.f;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                x[j] = make_float4(x[j].x - mu, x[j].y - mu, x[j].z - mu, x[j].w - mu);
+                ss += (x[j].x * x[j].x + x[j].y * x[j].y) + (x[j].z * x[j].z + x[j].w * x[j].w);
+            }
+            ss += __shfl_xor(ss, 16, 64);
+            ss += __shfl_xor(ss, 32, 64);
+            const float rstd = 1.f / sqrtf(ss / 96.f + a.ln_eps);
+            if (!live) continue;
+            if (g == 0) { a.ln_mean[m] = mu; a.ln_rstd[m] = rstd; }
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int n = 16 * j + 4 * g;
+                const float4 ga = *reinterpret_cast<const float4*>(gb + n), be = *reinterpret_cast<const float4*>(gb + 96 + n);
+                *reinterpret_cast<float4*>(a.C2 + (long long)m * a.ldc2 + n) =
+                    make_float4(x[j].x * rstd * ga.x + be.x, x[j].y * rstd * ga.y + be.y, x[j].z * rstd * ga.z + be.z,
+                                x[j].w * rstd * ga.w + be.w);
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int m = mrow + 16 * i + lj;
@@ -911,6 +964,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     f32x4 cur[MI][2], nxt[MI][2];
 
+    float* const gb = lds + 2 * B_FLOATS;          // EP_RESIDUAL_LN: [gamma 96][beta 96] behind the two stages
+    if constexpr (EP == EP_RESIDUAL_LN) {
+        if (tid < 96) { gb[tid] = a.ln_g[tid]; gb[96 + tid] = a.ln_b[tid]; }
+    }
     stage_b(0, 0);
     load_a(cur, 0);
     dma_wait();
@@ -950,11 +1007,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         __syncthreads();
     }
 
-    rega_store<NJ, EP>(a, acc, m0 + wm, n0, lj, g);
+    rega_store<NJ, EP>(a, acc, m0 + wm, n0, lj, g, nullptr, nullptr, gb);
 }
 
 template <int BN>
-constexpr int rega_lds_bytes() { return 2 * (BN * BK * 3 / 2) * 4; }      // the two B stages (36 KB for BN = 96)
+constexpr int rega_lds_bytes() { return 2 * (BN * BK * 3 / 2) * 4 + 768; }      // the two B stages (36 KB for BN = 96) + gamma / beta
 
 template <int NJ>
 __device__ __forceinline__ void rega_store_plain(const GemmArgs& a, const f32x4 (&acc)[2][NJ], int mrow, int n0, int lj, int g,
@@ -1009,6 +1066,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                                 : OOB;
         dma_dwordx4(lds0 + (unsigned)(kb * B_FLOATS * 4 + qq * 1024), vo, rB3);
     }
+    float* const gb = lds + KBM * B_FLOATS;        // EP_RESIDUAL_LN: [gamma 96][beta 96] behind the panel
+    if constexpr (EP == EP_RESIDUAL_LN) {
+        if (tid < 96) { gb[tid] = a.ln_g[tid]; gb[96 + tid] = a.ln_b[tid]; }
+    }
     dma_wait();
     __syncthreads();
 
@@ -1039,7 +1100,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         bv[j] = (a.bias && n < a.N) ? *reinterpret_cast<const float4*>(a.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     // the epilogue's second operand (pre-activation / shortcut / old C) of THIS slab, requested ahead of the next slab's A
-    constexpr bool HAS_E = EP == EP_GELU_BWD || EP == EP_RESIDUAL || EP == EP_NONE;
+    constexpr bool HAS_E = EP == EP_GELU_BWD || EP == EP_RESIDUAL || EP == EP_RESIDUAL_LN || EP == EP_NONE;
     const bool use_e = EP == EP_NONE ? a.accumulate != 0 : true;
     const float* const ebase = EP == EP_NONE ? a.C : a.E1;
     const long long lde = EP == EP_NONE ? a.ldc : a.lde1;
@@ -1097,7 +1158,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             if (use_e) rega_store<NJ, EP, true>(a, acc, slab * 32, n0, lj, g, bv, ev);
             else rega_store_plain<NJ>(a, acc, slab * 32, n0, lj, g, bv);
         } else {
-            rega_store<NJ, EP, true>(a, acc, slab * 32, n0, lj, g, bv, ev);
+            rega_store<NJ, EP, true>(a, acc, slab * 32, n0, lj, g, bv, ev, gb);
         }
         if (more) {
 #pragma unroll
@@ -1795,7 +1856,8 @@ bool nt_rega_shape(int M, int N, int K) {
     if ((long long)M * 4 >= (1LL << 31)) return false;
     // per-shape sweep at 48 images (scripts/gemm_nt_bench.py --rega, profiles/r06_gemm_nt_rega.txt): ahead of the staged kernels
     // for the 10^5-row stage and, at 4 x 10^4 rows, where the output is wider than the contraction; behind them below that
-    if (M < mmin || (M < 100000 && N <= K)) return false;
+    static const int msq = getenv("MIS_GEMM_REGA_MSQ") ? atoi(getenv("MIS_GEMM_REGA_MSQ")) : 50000;
+    if (M < mmin || (M < msq && N <= K)) return false;
     return mis_cdiv(M, 128) * (N / 96) >= tmin;
 }
 
@@ -1811,8 +1873,8 @@ int launch_nt_rega_ep(const GemmArgs& a, hipStream_t stream) {
 template <int EP>
 int launch_nt_rega_res_ep(const GemmArgs& a, hipStream_t stream) {
     static std::atomic<unsigned long long> attr_done{0};
-    const int ldsb = (a.K3 / BK) * (96 * BK * 3 / 2) * 4;
-    if (mis_set_lds_attr(reinterpret_cast<const void*>(&gemm_nt_rega_res_kernel<EP>), 3 * (96 * BK * 3 / 2) * 4, attr_done) != MIS_OK)
+    const int ldsb = 3 * (96 * BK * 3 / 2) * 4 + 768;            // the panel (up to three k-blocks) + gamma / beta
+    if (mis_set_lds_attr(reinterpret_cast<const void*>(&gemm_nt_rega_res_kernel<EP>), ldsb, attr_done) != MIS_OK)
         return MIS_ERR_LAUNCH;
     hipLaunchKernelGGL((gemm_nt_rega_res_kernel<EP>), dim3(a.n_blocks_padded), dim3(256), ldsb, stream, a);
     return mis_launch_status();
@@ -1834,6 +1896,7 @@ int launch_nt_rega(GemmArgs& a, hipStream_t stream) {
         if (a.ep == EP_NONE) return launch_nt_rega_res_ep<EP_NONE>(a, stream);
         if (a.ep == EP_GELU_FWD) return launch_nt_rega_res_ep<EP_GELU_FWD>(a, stream);
         if (a.ep == EP_GELU_BWD) return launch_nt_rega_res_ep<EP_GELU_BWD>(a, stream);
+        if (a.ep == EP_RESIDUAL_LN) return launch_nt_rega_res_ep<EP_RESIDUAL_LN>(a, stream);
         return launch_nt_rega_res_ep<EP_RESIDUAL>(a, stream);
     }
     a.tiles_n = a.N / 96;
@@ -1846,6 +1909,7 @@ int launch_nt_rega(GemmArgs& a, hipStream_t stream) {
     if (a.ep == EP_NONE) return launch_nt_rega_ep<96, EP_NONE>(a, stream);
     if (a.ep == EP_GELU_FWD) return launch_nt_rega_ep<96, EP_GELU_FWD>(a, stream);
     if (a.ep == EP_GELU_BWD) return launch_nt_rega_ep<96, EP_GELU_BWD>(a, stream);
+    if (a.ep == EP_RESIDUAL_LN) return launch_nt_rega_ep<96, EP_RESIDUAL_LN>(a, stream);
     return launch_nt_rega_ep<96, EP_RESIDUAL>(a, stream);
 }
 
@@ -2249,6 +2313,30 @@ extern "C" int mis_gemm_nt_split_layout(const float* A, long long lda, const voi
                                         hipStream_t stream) {
     return gemm_nt_split_impl(A, lda, B3, C, ldc, bias, M, N, K, accumulate, epilogue, E1, lde1, C2, ldc2, rowscale, rows_per_scale,
                               ex_H, ex_W, ex_P, ex_c, workspace, workspace_bytes, stream, layout);
+}
+
+// proj / fc2 of a 96-channel Swin block with everything up to the next LayerNorm in the epilogue (register-A kernels, natural-order
+// planes): X = E1 + rowscale[m / rows_per_scale] * (A . B^T + bias) -> X (the block's residual stream, row stride ldx), and
+// Y = LayerNorm(X) * gamma + beta (row stride ldy), mean / rstd [M] for the backward -- `x = shortcut + self.drop_path(x)` then
+// `self.norm2(x)` (reference ...sys.py:276-281) or the next block's `norm1` (:244-250).  N must be 96 (a row = one tile row).
+// MIS_ERR_UNSUPPORTED: mis_gemm_nt_split_natural(M, 96, K) is 0 or an operand is not float4-addressable.
+extern "C" int mis_gemm_nt_residual_ln(const float* A, long long lda, const void* B3, const float* bias, int M, int N, int K,
+                                       const float* E1, long long lde1, const float* rowscale, long long rows_per_scale,
+                                       float* X, long long ldx, const float* gamma, const float* beta, float eps, float* Y,
+                                       long long ldy, float* mean, float* rstd, hipStream_t stream) {
+    if (!A || !B3 || !E1 || !X || !gamma || !beta || !Y || !mean || !rstd || M <= 0 || K <= 0) return MIS_ERR_ARG;
+    if (rowscale && rows_per_scale <= 0) return MIS_ERR_ARG;
+    if (N != 96 || !nt_rega_shape(M, N, K)) return MIS_ERR_UNSUPPORTED;
+    if (!a16(A) || !a16(B3) || !a16(E1) || !a16(X) || !a16(Y) || (bias && !a16(bias)) || lda % 4 || lde1 % 4 || ldx % 4 || ldy % 4 || K % 4)
+        return MIS_ERR_UNSUPPORTED;
+    if ((long long)M * lda * 4 >= (1LL << 31) || mis_gemm_split_bytes(N, K) >= (1LL << 31)) return MIS_ERR_UNSUPPORTED;
+    GemmArgs a{A, lda, nullptr, 0, X, ldx, bias, nullptr, M, N, K, 1, K, 0};
+    a.B3 = B3; a.K3 = split_k3(K); a.b3_plane = (unsigned)((long long)N * a.K3 * 2);
+    a.ex_P = 0; a.vec4 = 1;
+    a.ep = EP_RESIDUAL_LN;
+    a.E1 = E1; a.lde1 = lde1; a.C2 = Y; a.ldc2 = ldy; a.rowscale = rowscale; a.rps = rowscale ? rows_per_scale : 1;
+    a.ln_g = gamma; a.ln_b = beta; a.ln_mean = mean; a.ln_rstd = rstd; a.ln_eps = eps;
+    return launch_nt_rega(a, stream);
 }
 
 // nn.Linear of PatchExpand / FinalPatchExpand_X4 fused with their pixel shuffle (reference

@@ -404,9 +404,10 @@ struct ColsumJob {
 
 // Two workgroup shapes (1024 threads): "tall" jobs (LayerNorm / bias-table partials: 10^2 .. 10^3 slabs of 10^2 .. 10^3 columns)
 // take 32 columns x 32 slab lanes like col_final_kernel; "wide" jobs (split-K partials of a weight gradient: 2 .. 85 slices of
-// 10^4 .. 10^6 columns) take 256 float4 column groups x 4 slab lanes -- a tall workgroup would keep KS of its 32 slab lanes busy
-// and read 128-byte pieces (first version: one batch of a SwinUnet step took 3 ms).  Double accumulators, fixed order.
-constexpr int COLSUM_WIDE_COLS = 1024;
+// 10^4 .. 10^6 columns) take 128 float4 column groups x 8 slice lanes in gemm_reduce_kernel's own summation order (fp32) -- a
+// tall workgroup would keep KS of its 32 slab lanes busy and read 128-byte pieces (first version: one batch of a SwinUnet step
+// took 3 ms).  Fixed order; tall jobs accumulate in double like col_final_kernel.
+constexpr int COLSUM_WIDE_COLS = 512;
 
 __global__ __launch_bounds__(1024) void colsum_batch_kernel(const ColsumJob* __restrict__ jobs, int n) {
     __shared__ ColsumJob job;
@@ -424,36 +425,36 @@ __global__ __launch_bounds__(1024) void colsum_batch_kernel(const ColsumJob* __r
     const int slabs = job.slabs;
     const long long ld = job.stride;
     if (job.wide) {
-        // thread = (column group cg of 4 floats, slab lane sl of 4); slabs sl, sl + 4, ... four loads in flight
-        const int cg = threadIdx.x & 255, sl = threadIdx.x >> 8;
+        // thread = (column group cg of 4 floats, slice lane kl of 8): lane kl sums slices kl, kl + 8, ... in order, then lane 0
+        // adds lanes 1 .. 7 in order -- gemm_reduce_kernel's sums exactly (fp32, same order): the batched weight gradients are
+        // bit-identical to the per-op launches
+        const int cg = threadIdx.x & 127, kl = threadIdx.x >> 7;
         const int col = ((int)blockIdx.x - job.first) * COLSUM_WIDE_COLS + cg * 4;
-        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
         if (col < job.C) {
             const float* __restrict__ part = reinterpret_cast<const float*>(job.part) + col;
-            int s = sl;
-            for (; s + 12 < slabs; s += 16) {
+            int k = kl;
+            for (; k + 24 < slabs; k += 32) {
                 float4 p[4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) p[j] = *reinterpret_cast<const float4*>(part + (long long)(s + 4 * j) * ld);
+                for (int j = 0; j < 4; ++j) p[j] = *reinterpret_cast<const float4*>(part + (long long)(k + 8 * j) * ld);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) { a0 += p[j].x; a1 += p[j].y; a2 += p[j].z; a3 += p[j].w; }
+                for (int j = 0; j < 4; ++j) { acc.x += p[j].x; acc.y += p[j].y; acc.z += p[j].z; acc.w += p[j].w; }
             }
-            for (; s < slabs; s += 4) {
-                const float4 p = *reinterpret_cast<const float4*>(part + (long long)s * ld);
-                a0 += p.x; a1 += p.y; a2 += p.z; a3 += p.w;
+            for (; k < slabs; k += 8) {
+                const float4 p = *reinterpret_cast<const float4*>(part + (long long)k * ld);
+                acc.x += p.x; acc.y += p.y; acc.z += p.z; acc.w += p.w;
             }
         }
-        // fixed-order sum over the 4 slab lanes through LDS: lanes 1..3 publish, lane 0 adds them in order
-        __shared__ double wred[3][256][4];
-        if (sl) { wred[sl - 1][cg][0] = a0; wred[sl - 1][cg][1] = a1; wred[sl - 1][cg][2] = a2; wred[sl - 1][cg][3] = a3; }
+        __shared__ float4 wred[7][128];
+        if (kl) wred[kl - 1][cg] = acc;
         __syncthreads();
-        if (sl == 0 && col < job.C) {
+        if (kl == 0 && col < job.C) {
 #pragma unroll
-            for (int k = 0; k < 3; ++k) { a0 += wred[k][cg][0]; a1 += wred[k][cg][1]; a2 += wred[k][cg][2]; a3 += wred[k][cg][3]; }
+            for (int j = 0; j < 7; ++j) { const float4 q = wred[j][cg]; acc.x += q.x; acc.y += q.y; acc.z += q.z; acc.w += q.w; }
             float4* o = reinterpret_cast<float4*>(job.out_a + col);
-            float4 v = make_float4((float)a0, (float)a1, (float)a2, (float)a3);
-            if (job.accumulate) { const float4 q = *o; v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w; }
-            *o = v;
+            if (job.accumulate) { const float4 q = *o; acc.x = q.x + acc.x; acc.y = q.y + acc.y; acc.z = q.z + acc.z; acc.w = q.w + acc.w; }
+            *o = acc;
         }
         return;
     }
@@ -1352,10 +1353,12 @@ extern "C" long long mis_colreduce_slabs(long long M) { return M > 0 ? mis_cdiv(
 // returns the number of workgroups the job owns (the caller's running prefix sum is the next job's `first`)
 extern "C" long long mis_colsum_job(void* job, const void* part, long long stride, long long slabs, int C, int pairs,
                                     float* out_a, float* out_b, int accumulate, long long first) {
-    if (!job || !part || slabs <= 0 || C <= 0 || stride < C || (!out_a && !out_b) || (!pairs && out_b)) return MIS_ERR_ARG;
-    // wide form: float4 columns (16-byte aligned rows) and few slabs
-    const bool wide = !pairs && slabs <= 128 && C >= 256 && C % 4 == 0 && stride % 4 == 0 &&
-                      !((uintptr_t)part & 15) && !((uintptr_t)out_a & 15);
+    if (!job || !part || slabs <= 0 || C <= 0 || stride < C || (!out_a && !out_b) || (pairs != 1 && out_b) || pairs < 0 || pairs > 2)
+        return MIS_ERR_ARG;
+    // pairs == 2: the split-K partials of a GEMM, summed in gemm_reduce_kernel's order (the wide form: float4 columns)
+    const bool wide = pairs == 2;
+    if (wide && (C % 4 || stride % 4 || ((uintptr_t)part & 15) || ((uintptr_t)out_a & 15) || out_b)) return MIS_ERR_UNSUPPORTED;
+    if (wide) pairs = 0;
     const long long blocks = wide ? mis_cdiv(C, COLSUM_WIDE_COLS) : mis_cdiv(C, 32);
     if (slabs > 0x7fffffffLL || first + blocks > 0x7fffffffLL) return MIS_ERR_UNSUPPORTED;
     ColsumJob j;

@@ -199,6 +199,7 @@ class UAMTTrainer(MeanTeacherTrainer):
 
     def __init__(self, *args, **kw):
         kw.pop("use_graph", None)
+        kw["use_tape"] = False          # (the MC passes cycle the teacher through RNG sub-streams set from Python: eager)
         super().__init__(*args, **kw)
         self._rep_in = None
         self._mean_probs = None

@@ -107,6 +107,12 @@ class LinearOp:
         if (FUSE & 4) and self.res is not None:
             r = self.res
             scales = r.prepare(ctx)
+            ln = r.ln_next if LN_EPILOGUE else None
+            if ln is not None and tops.gemm_residual_ln(self.x.t, self._b3(ctx), r.out.t, r.a.t, ln.g.data, ln.b.data, ln.y.t,
+                                                        ln.mean, ln.rstd, bias=bias, rowscale=scales, rows_per_scale=r.rps):
+                r.skip_fwd = True        # the residual add AND the LayerNorm that reads it ran in this GEMM's epilogue
+                ln.skip_fwd = True
+                return
             if tops.gemm_ex(self.x.t, self.w2, r.out.t, tops.EP_RESIDUAL, bias=bias, E1=r.a.t, rowscale=scales,
                             rows_per_scale=r.rps, b3=self._b3(ctx)):
                 r.skip_fwd = True
@@ -128,9 +134,9 @@ class LinearOp:
             if slices:
                 jobs = self._dw_jobs.get(slices)
                 if jobs is None:
-                    jobs = [tops.ColsumJob(ws, 0, M * N, slices, M * N, False, self.gw2.view(-1))]
+                    jobs = [tops.ColsumJob(ws, 0, M * N, slices, M * N, 2, self.gw2.view(-1))]
                     if db is not None:
-                        jobs.append(tops.ColsumJob(ws, slices * M * N, M, slices, M, False, db))
+                        jobs.append(tops.ColsumJob(ws, slices * M * N, M, slices, M, 2, db))
                     self._dw_jobs[slices] = jobs
                 defer_final(ctx, *jobs)
             return
@@ -168,6 +174,8 @@ class LinearOp:
 
 # LayerNorm backward + the backward of the residual add in front of it in one pass (MIS_SWIN_LNRES=0: two passes)
 LNRES = os.environ.get("MIS_SWIN_LNRES", "1") != "0"
+# 96-channel blocks: the LayerNorm that follows a residual add runs in the producing GEMM's epilogue (register-A kernels, round 6)
+LN_EPILOGUE = os.environ.get("MIS_LN_EPILOGUE", "1") != "0"
 
 
 def pair_ln_residual(ops_list):
@@ -178,6 +186,7 @@ def pair_ln_residual(ops_list):
         r, ln = ops_list[i], ops_list[i + 1]
         if isinstance(r, ResidualOp) and isinstance(ln, LayerNormOp) and ln.x is r.out:
             ln.res_bwd = r
+            r.ln_next = ln           # forward: the producing GEMM's epilogue may run this LayerNorm (LinearOp.fwd)
 
 
 def split_linear_weights(holder, ops_list, transposed):
@@ -220,9 +229,13 @@ class LayerNormOp:
         self.rstd = torch.empty(x.rows, dtype=torch.float32, device="cuda")
         self._ws = None
         self._job = None
+        self.skip_fwd = False
         self.res_bwd = None      # the ResidualOp right in front of this op whose output is x (pair_ln_residual)
 
     def fwd(self, ctx):
+        if self.skip_fwd:           # ran in the epilogue of the GEMM that produced x (LinearOp.fwd, LN_EPILOGUE)
+            self.skip_fwd = False
+            return
         tops.layernorm_fwd(self.x.t, self.y.t, self.g.data, self.b.data, self.mean, self.rstd)
 
     def bwd(self, ctx):
@@ -341,6 +354,7 @@ class ResidualOp:
         self._p, self._salt, self._state, self._scale = 0.0, 0, None, None
         self.plan = None            # set by SwinPlan.add: the per-forward DropPath scale table lives there
         self.skip_fwd = self.skip_bwd = False
+        self.ln_next = None         # the LayerNormOp directly behind this op that reads ``out`` (pair_ln_residual)
 
     def prepare(self, ctx):
         """Fix this pass's DropPath parameters (also used by backward); returns the per-sample scale vector a fused
@@ -720,6 +734,9 @@ class SwinPlan:
 
     def forward(self, x5, ctx):
         assert tuple(x5.shape) == self.in_shape, (tuple(x5.shape), self.in_shape)
+        if not self._paired:
+            pair_ln_residual(self.ops)
+            self._paired = True
         self.generation += 1
         self.inp_t = x5[:, :, 0]             # [N, 1 | 3, H, W]
         ctx.b3_fwd = split_linear_weights(self, self.ops, False)

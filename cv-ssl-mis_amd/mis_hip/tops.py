@@ -227,11 +227,13 @@ class ColsumJob:
     ``ColsumBatch`` (mis_colsum_job).  ``part`` is a tensor whose storage holds the partial rows, ``offset`` floats into it."""
 
     def __init__(self, part, offset, stride, slabs, C, pairs, out_a, out_b=None, accumulate=False):
-        self.part, self.offset, self.stride, self.slabs, self.C, self.pairs = part, int(offset), int(stride), int(slabs), int(C), bool(pairs)
+        """``pairs``: False / 0 float partial rows, True / 1 float2 (``.x -> out_a, .y -> out_b``), 2 the k-slices of a split GEMM
+        (fp32 sums in the order of the GEMM's own reduction kernel: bit-identical to ``gemm_dw``)."""
+        self.part, self.offset, self.stride, self.slabs, self.C, self.pairs = part, int(offset), int(stride), int(slabs), int(C), int(pairs)
         self.out_a, self.out_b, self.accumulate = out_a, out_b, bool(accumulate)
         for o in (out_a, out_b):
             assert o is None or (o.is_contiguous() and o.numel() >= C and o.dtype == torch.float32)
-        self.bytes = self.slabs * self.C * (8 if pairs else 4)
+        self.bytes = self.slabs * self.C * (8 if self.pairs == 1 else 4)
 
     def part_ptr(self):
         return self.part.data_ptr() + 4 * self.offset
@@ -310,6 +312,36 @@ def gemm_ex(A, B, C, epilogue, bias=None, E1=None, C2=None, rowscale=None, rows_
         e1.record()
         # (split-K shapes run the plain instantiation + the reduce kernel; the label keeps the requested epilogue)
         prof.append((_nt_name(L, M, N, K, epilogue), 2.0 * M * N * K, e0, e1, 4.0 * (M * K + N * K + M * N)))
+    return True
+
+
+def gemm_residual_ln(A, b3, X, E1, gamma, beta, Y, mean, rstd, bias=None, rowscale=None, rows_per_scale=1, eps=1e-5):
+    """X = E1 + rowscale[row // rows_per_scale] * (A @ W^T + bias) and Y = LayerNorm(X) * gamma + beta (mean / rstd kept) in one
+    launch (mis_gemm_nt_residual_ln: the register-A kernels, 96 channels).  False: outside what it covers."""
+    if b3 is None or not b3.natural or not split_active():
+        return False
+    L = _l.load()
+    M, K, lda = _mat(A)
+    Mx, N, ldx = _mat(X)
+    _, _, lde1 = _mat(E1)
+    _, _, ldy = _mat(Y)
+    if N != 96 or b3.N != 96 or b3.K != K or Mx != M or b3.rows != M:
+        return False
+    prof = _ops.PROFILE
+    if prof is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    st = L.mis_gemm_nt_residual_ln(_l.ptr(A), lda, _l.ptr(b3.t), _l.ptr(bias), M, N, K, _l.ptr(E1), lde1, _l.ptr(rowscale),
+                                   int(rows_per_scale), _l.ptr(X), ldx, _l.ptr(gamma), _l.ptr(beta), eps, _l.ptr(Y), ldy,
+                                   _l.ptr(mean), _l.ptr(rstd), _l.stream_ptr())
+    if st == -2:
+        return False
+    _l.check(st, "mis_gemm_nt_residual_ln")
+    if prof is not None:
+        e1.record()
+        buf = ctypes.create_string_buffer(96)
+        _l.check(L.mis_gemm_nt_split_layout_kernel_name(M, N, K, 5, 1, buf, 96), "mis_gemm_nt_split_layout_kernel_name")
+        prof.append((buf.value.decode(), 2.0 * M * N * K, e0, e1, 4.0 * (M * K + 3 * M * N) + 6.0 * N * K))
     return True
 
 

@@ -511,6 +511,15 @@ int mis_gemm_nt_split_layout(const float* A, long long lda, const void* B3, floa
                              long long ldc2, const float* rowscale, long long rows_per_scale, int ex_H, int ex_W, int ex_P,
                              int ex_c, float* workspace, long long workspace_bytes, int layout, hipStream_t stream);
 int mis_gemm_nt_split_layout_kernel_name(int M, int N, int K, int epilogue, int layout, char* name, int name_len);
+/* proj / fc2 of a 96-channel Swin block with everything up to the next LayerNorm in the register-A kernels' epilogue (planes in
+ * the natural order): X = E1 + rowscale[m / rows_per_scale] * (A . B^T + bias) (the residual stream, :276 / :281) and
+ * Y = LayerNorm(X) * gamma + beta with mean / rstd [M] kept for the backward (`self.norm2(x)`, :280, or the next block's `norm1`,
+ * :249) -- the LayerNorm launch and its read of X are gone.  N must be 96.  MIS_ERR_UNSUPPORTED: mis_gemm_nt_split_natural(M, 96, K)
+ * is 0, or an operand is not float4-addressable. */
+int mis_gemm_nt_residual_ln(const float* A, long long lda, const void* B3, const float* bias, int M, int N, int K,
+                            const float* E1, long long lde1, const float* rowscale, long long rows_per_scale, float* X,
+                            long long ldx, const float* gamma, const float* beta, float eps, float* Y, long long ldy,
+                            float* mean, float* rstd, hipStream_t stream);
 int mis_gemm_nt_split_kernel_name(int M, int N, int K, int epilogue, char* name, int name_len);
 /* nn.Linear of PatchExpand / FinalPatchExpand_X4 fused with their pixel shuffle
  * 'b h w (p1 p2 c) -> b (h p1) (w p2) c' (swin_transformer_unet_skip_expand_decoder_sys.py:373-380, :401-408):
@@ -566,10 +575,12 @@ int mis_layernorm_bwd_final(const void* workspace, long long workspace_bytes, lo
  * (:14,16,107,109), relative_position_bias_table (:99-102) -- are all  out[c] (+)= sum_s part[s][c]  over per-slab / per-slice /
  * per-window partial rows that the producing kernels (mis_layernorm_bwd_parts, mis_gemm_dw_parts,
  * mis_window_attention_bwd_parts_ws) left in caller-owned workspaces.  mis_colsum_job fills one record of a HOST table
- * (mis_colsum_job_bytes each): part = float [slabs][stride] (pairs = 0, -> out_a) or float2 [slabs][stride] (pairs = 1: .x ->
- * out_a, .y -> out_b, either may be NULL), C <= stride columns, `first` = workgroups of the jobs before it; it returns the job's
- * workgroup count.  mis_colsum_batch runs the table (uploaded by the caller) as one launch: double accumulators, fixed order, a
- * job's result independent of its batch.  mis_colreduce_slabs = the partial rows mis_layernorm_bwd_parts leaves for M tokens. */
+ * (mis_colsum_job_bytes each): part = float [slabs][stride] (pairs = 0, -> out_a), float2 [slabs][stride] (pairs = 1: .x ->
+ * out_a, .y -> out_b, either may be NULL) or the k-slices of a split GEMM (pairs = 2: float, C % 4 == 0, 16-byte aligned,
+ * summed in fp32 in the order of the GEMMs' own reduction -- the bits of mis_gemm_dw), C <= stride columns, `first` = workgroups
+ * of the jobs before it; it returns the job's workgroup count.  mis_colsum_batch runs the table (uploaded by the caller) as one
+ * launch: fixed order (pairs 0 / 1: double accumulators, the bits of mis_layernorm_bwd_final / mis_window_attention_dtable_ws),
+ * a job's result independent of its batch.  mis_colreduce_slabs = the partial rows mis_layernorm_bwd_parts leaves for M tokens. */
 long long mis_colsum_job_bytes(void);
 long long mis_colreduce_slabs(long long M);
 long long mis_colsum_job(void* job, const void* part, long long stride, long long slabs, int C, int pairs, float* out_a,

@@ -688,20 +688,20 @@ def test_colsum_batch_jobs_are_independent_column_sums():
     launch; every job's result is the fixed-order double sum of its own partial rows whatever else is in the batch."""
     tops = _t()
     g = torch.Generator().manual_seed(5)
-    specs = [(7, 96, 96, False, False), (300, 100, 128, True, False), (1, 4, 4, False, True), (1882, 96, 96, True, True),
-             (85, 27648, 27648, False, False), (33, 507, 507, False, False)]
+    specs = [(7, 96, 96, 0, False), (300, 100, 128, 1, False), (1, 4, 4, 0, True), (1882, 96, 96, 1, True),
+             (85, 27648, 27648, 2, False), (33, 507, 507, 0, False), (3, 288, 288, 2, True)]
     jobs, want, outs = [], [], []
     for slabs, C, stride, pairs, acc in specs:
-        part = (torch.rand(slabs, stride, 2 if pairs else 1, generator=g) - 0.5).cuda()
+        part = (torch.rand(slabs, stride, 2 if pairs == 1 else 1, generator=g) - 0.5).cuda()
         oa = torch.full((C,), 0.25, device="cuda")
-        ob = torch.full((C,), -0.5, device="cuda") if pairs else None
+        ob = torch.full((C,), -0.5, device="cuda") if pairs == 1 else None
         jobs.append(tops.ColsumJob(part, 0, stride, slabs, C, pairs, oa, ob, accumulate=acc))
         s = part.double().sum(0)[:C]
-        want.append((s[:, 0] + (0.25 if acc else 0.0), s[:, 1] + (-0.5 if acc else 0.0) if pairs else None))
+        want.append((s[:, 0] + (0.25 if acc else 0.0), s[:, 1] + (-0.5 if acc else 0.0) if pairs == 1 else None))
         outs.append((oa, ob))
     tops.ColsumBatch(jobs).run()
     for (oa, ob), (wa, wb) in zip(outs, want):
-        assert (oa.double() - wa).abs().max().item() <= 1e-6 * max(1.0, wa.abs().max().item())
+        assert (oa.double() - wa).abs().max().item() <= 4e-6 * max(1.0, wa.abs().max().item())
         if ob is not None:
             assert (ob.double() - wb).abs().max().item() <= 1e-6 * max(1.0, wb.abs().max().item())
     # the same jobs in another order / another batch: bit-identical results
@@ -719,7 +719,7 @@ def test_colsum_batch_jobs_are_independent_column_sums():
                                              (49, 1536, 768, True), (3137, 100, 36, True), (9408, 384, 1536, False)])
 def test_gemm_dw_parts_plus_batched_sums_equal_gemm_dw(T, Cout, Cin, bias, prec):
     """mis_gemm_dw_parts leaves the k-slices' partials in the caller's workspace; two mis_colsum_batch jobs finish dW / db
-    (the token plans' batched form of nn.Linear's parameter gradients).  Same values as mis_gemm_dw to fp32 rounding."""
+    (the token plans' batched form of nn.Linear's parameter gradients).  Bit-identical to mis_gemm_dw."""
     tops = _t()
     X, dY = _rand(T, Cin, seed=15).cuda(), (_rand(T, Cout, seed=16) + 0.25).cuda()
     dW = torch.full((Cout, Cin), float("nan"), device="cuda")
@@ -728,9 +728,9 @@ def test_gemm_dw_parts_plus_batched_sums_equal_gemm_dw(T, Cout, Cin, bias, prec)
     slices = tops.gemm_dw_parts(dY, X, dW, db, ws)
     if slices:
         assert torch.isnan(dW).all()                          # untouched until the sums run
-        jobs = [tops.ColsumJob(ws, 0, Cout * Cin, slices, Cout * Cin, False, dW.view(-1))]
+        jobs = [tops.ColsumJob(ws, 0, Cout * Cin, slices, Cout * Cin, 2, dW.view(-1))]
         if bias:
-            jobs.append(tops.ColsumJob(ws, slices * Cout * Cin, Cout, slices, Cout, False, db))
+            jobs.append(tops.ColsumJob(ws, slices * Cout * Cin, Cout, slices, Cout, 2, db))
         tops.ColsumBatch(jobs).run()
     else:
         assert ws is None or T < 4096
@@ -739,10 +739,10 @@ def test_gemm_dw_parts_plus_batched_sums_equal_gemm_dw(T, Cout, Cin, bias, prec)
     if bias:
         refb = torch.empty_like(db)
         tops.gemm_dw(dY, X, ref, refb)
-        assert (db - refb).abs().max().item() <= 2e-6 * max(1.0, refb.abs().max().item())
+        assert torch.equal(db, refb)
     else:
         tops.gemm(dY, X, ref, trans=True)
-    assert (dW - ref).abs().max().item() <= 2e-6 * max(1.0, ref.abs().max().item())
+    assert torch.equal(dW, ref)           # pairs = 2: the GEMM's own summation order
 
 
 def test_window_attention_table_gradient_as_a_batched_sum(prec):
@@ -769,8 +769,7 @@ def test_window_attention_table_gradient_as_a_batched_sum(prec):
 
 def test_swin_step_with_batched_finishing_sums_equals_per_op_launches():
     """plan.BATCH_FINALS: the LayerNorm affine, Linear weight / bias and bias-table gradients of a SwinUnet Mean-Teacher step
-    finished by a few mis_colsum_batch launches instead of ~130 per-op launches -- same step to fp32 rounding, and the batched
-    form is bit-reproducible."""
+    finished by a few mis_colsum_batch launches instead of ~130 per-op launches -- the same step bit for bit."""
     from config import lite_config
     from mis_hip import plan
     from mis_hip.step import MeanTeacherTrainer
@@ -794,12 +793,9 @@ def test_swin_step_with_batched_finishing_sums_equals_per_op_launches():
         finally:
             plan.BATCH_FINALS, plan.FINALS_FLUSH_BYTES = True, 32 << 20
     (l0, g0, p0, t0), (l1, g1, p1, t1), (l2, g2, p2, t2) = res
-    for k in l0:
-        assert abs(l0[k] - l1[k]) <= 1e-6, (k, l0[k], l1[k])
-    gs = float(g1.abs().max())
-    assert (g0 - g1).abs().max().item() <= 1e-5 * gs
-    assert (p0 - p1).abs().max().item() <= 1e-6 and (t0 - t1).abs().max().item() <= 1e-6
-    # how the jobs are grouped into launches does not change a bit
+    assert l0 == l1
+    # the batch kernel sums every job in its per-op launch's own order: not a bit changes, however the jobs are grouped
+    assert torch.equal(g0, g1) and torch.equal(p0, p1) and torch.equal(t0, t1)
     assert torch.equal(g0, g2) and torch.equal(p0, p2) and torch.equal(t0, t2)
 
 
@@ -855,5 +851,44 @@ def test_register_a_nt_gemm(M, N, K):
         assert tops.gemm_ex(Ad, Wd, C, tops.EP_RESIDUAL, bias=bd, E1=wide.cuda()[:, 16:16 + N], rowscale=sc.cuda(),
                             rows_per_scale=rps, b3=b3)
         _close(C[idx.cuda()], wide[idx, 16:16 + N].double() + sc.repeat_interleave(rps)[idx, None].double() * v)
+    finally:
+        tops.set_split_precision(prev)
+
+
+@pytest.mark.parametrize("M,K", [(150528, 96), (150528, 384), (75264, 96), (65570, 288)])
+def test_residual_and_layernorm_in_the_register_a_epilogue(M, K):
+    """mis_gemm_nt_residual_ln: X = E1 + rowscale * (A W^T + b) and Y = LayerNorm(X) g + be, mean / rstd, in one launch (the
+    persistent resident-panel kernel for K = 96, the streamed one above) against float64; ragged last slab; strided E1 / X."""
+    tops = _t()
+    prev = tops.set_split_precision(7)
+    try:
+        N = 96
+        A, W, bias = _rand(M, K, seed=51), _rand(N, K, seed=52, scale=K ** -0.5), _rand(N, seed=53)
+        gam, bet = _rand(N, seed=54) + 1.5, _rand(N, seed=55)
+        wide = _rand(M, N + 32, seed=56)
+        rps = M // 2 if M % 2 == 0 else M
+        sc = torch.tensor([0.5, 1.25] if rps < M else [1.25])
+        b3 = tops.SplitB(W.cuda(), rows=M).refresh()
+        if not b3.natural:
+            pytest.skip("the register-A kernels do not serve this shape")
+        Xw = torch.zeros(M, N + 16, device="cuda")
+        Y = torch.empty(M, N, device="cuda")
+        mean, rstd = torch.empty(M, device="cuda"), torch.empty(M, device="cuda")
+        assert tops.gemm_residual_ln(A.cuda(), b3, Xw[:, 16:], wide.cuda()[:, 16:16 + N], gam.cuda(), bet.cuda(), Y, mean, rstd,
+                                     bias=bias.cuda(), rowscale=sc.cuda(), rows_per_scale=rps)
+        idx = torch.cat([torch.arange(0, 200), torch.arange(M // 2 - 100, M // 2 + 100), torch.arange(M - 200, M)])
+        v = A[idx].double() @ W.double().t() + bias.double()
+        x = wide[idx, 16:16 + N].double() + sc.repeat_interleave(rps)[idx, None].double() * v
+        _close(Xw[idx.cuda(), 16:], x)
+        assert Xw[:, :16].abs().max().item() == 0
+        mu = x.mean(1)
+        rs = 1.0 / torch.sqrt(x.var(1, unbiased=False) + 1e-5)
+        assert (mean[idx.cuda()].cpu().double() - mu).abs().max().item() <= 1e-5 * max(1.0, mu.abs().max().item())
+        assert ((rstd[idx.cuda()].cpu().double() - rs) / rs).abs().max().item() <= 1e-4
+        _close(Y[idx.cuda()], (x - mu[:, None]) * rs[:, None] * gam.double() + bet.double(), rtol=3e-4, atol=2e-5)
+        # the separate LayerNorm on the same X: the same normalisation to fp32 rounding
+        Y2, m2, r2 = torch.empty_like(Y), torch.empty_like(mean), torch.empty_like(rstd)
+        tops.layernorm_fwd(Xw[:, 16:], Y2, gam.cuda(), bet.cuda(), m2, r2)
+        assert (Y - Y2).abs().max().item() <= 2e-5 * max(1.0, Y2.abs().max().item())
     finally:
         tops.set_split_precision(prev)
