@@ -818,6 +818,72 @@ __global__ __launch_bounds__(256) void gemm_nt_short_kernel(const GemmArgs a) {
 template <int NJ, int EP, bool PRE = false>
 __device__ __forceinline__ void rega_store(const GemmArgs& a, const f32x4 (&acc)[2][NJ], int mrow, int n0, int lj, int g,
                                            const float4* bv = nullptr, const float4 (*ev)[NJ] = nullptr, const float* gb = nullptr) {
+    if constexpr (EP == EP_LNHEAD) {
+        // FinalPatchExpand_X4 + its LayerNorm + the output head (reference ...sys.py:401-409, :671, :749-752): the tile's 96
+        // columns are one (p1, p2) of the pixel shuffle, a tile row one token of the shuffled tensor.  gb = [gamma 96][beta 96]
+        // [head_w NC x 96] in LDS.  The row's values sit in the four lanes (lj, g): LayerNorm and the NC head dot products are
+        // in-lane sums over 24 values + two cross-group steps each.
+        static_assert(NJ == 6, "a 96-column row");
+        const int P = a.ex_P, pp = n0 / 96, p1 = pp / P, p2 = pp - p1 * P;
+        const long long S = (long long)a.ex_H * P * a.ex_W * P;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int m = mrow + 16 * i + lj;
+            const bool live = m < a.M;
+            float4 x[NJ];
+            float s = 0.f;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                x[j] = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+                s += (x[j].x + x[j].y) + (x[j].z + x[j].w);
+            }
+            const int mm = live ? m : 0;
+            const int w_ = mm % a.ex_W, tt = mm / a.ex_W, h_ = tt % a.ex_H, b_ = tt / a.ex_H;
+            const long long pix = ((long long)h_ * P + p1) * ((long long)a.ex_W * P) + (long long)w_ * P + p2;
+            const long long tok = (long long)b_ * S + pix;
+            if (live && a.C) {
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) *reinterpret_cast<float4*>(a.C + tok * 96 + 16 * j + 4 * g) = x[j];
+            }
+            s += __shfl_xor(s, 16, 64);
+            s += __shfl_xor(s, 32, 64);
+            const float mu = s / 96.f;
+            float ss = 0.f;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                x[j] = make_float4(x[j].x - mu, x[j].y - mu, x[j].z - mu, x[j].w - mu);
+                ss += (x[j].x * x[j].x + x[j].y * x[j].y) + (x[j].z * x[j].z + x[j].w * x[j].w);
+            }
+            ss += __shfl_xor(ss, 16, 64);
+            ss += __shfl_xor(ss, 32, 64);
+            const float rstd = 1.f / sqrtf(ss / 96.f + a.ln_eps);
+            float pl[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int n = 16 * j + 4 * g;
+                const float4 ga = *reinterpret_cast<const float4*>(gb + n), be = *reinterpret_cast<const float4*>(gb + 96 + n);
+                const float4 y = make_float4(x[j].x * rstd * ga.x + be.x, x[j].y * rstd * ga.y + be.y, x[j].z * rstd * ga.z + be.z,
+                                             x[j].w * rstd * ga.w + be.w);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const float4 w = *reinterpret_cast<const float4*>(gb + 192 + c * 96 + n);      // zero rows beyond head_nc
+                    pl[c] += (y.x * w.x + y.y * w.y) + (y.z * w.z + y.w * w.w);
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                pl[c] += __shfl_xor(pl[c], 16, 64);
+                pl[c] += __shfl_xor(pl[c], 32, 64);
+            }
+            if (live && g == 0) {
+                a.ln_mean[tok] = mu; a.ln_rstd[tok] = rstd;
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    if (c < a.head_nc) a.logits[(long long)b_ * a.logits_bs + (long long)c * S + pix] = pl[c];
+            }
+        }
+        return;
+    }
     if constexpr (EP == EP_RESIDUAL_LN) {
         static_assert(NJ == 6, "a 96-column row");
 #pragma unroll
@@ -1066,9 +1132,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                                 : OOB;
         dma_dwordx4(lds0 + (unsigned)(kb * B_FLOATS * 4 + qq * 1024), vo, rB3);
     }
-    float* const gb = lds + KBM * B_FLOATS;        // EP_RESIDUAL_LN: [gamma 96][beta 96] behind the panel
-    if constexpr (EP == EP_RESIDUAL_LN) {
+    float* const gb = lds + KBM * B_FLOATS;        // EP_RESIDUAL_LN / EP_LNHEAD: [gamma 96][beta 96]([head_w 4 x 96]) behind the panel
+    if constexpr (EP == EP_RESIDUAL_LN || EP == EP_LNHEAD) {
         if (tid < 96) { gb[tid] = a.ln_g[tid]; gb[96 + tid] = a.ln_b[tid]; }
+    }
+    if constexpr (EP == EP_LNHEAD) {
+        for (int t = tid; t < 4 * 96; t += 256) gb[192 + t] = t < a.head_nc * 96 ? a.head_w[t] : 0.f;
     }
     dma_wait();
     __syncthreads();
@@ -1100,11 +1169,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         bv[j] = (a.bias && n < a.N) ? *reinterpret_cast<const float4*>(a.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     // the epilogue's second operand (pre-activation / shortcut / old C) of THIS slab, requested ahead of the next slab's A
-    constexpr bool HAS_E = EP == EP_GELU_BWD || EP == EP_RESIDUAL || EP == EP_RESIDUAL_LN || EP == EP_NONE;
+    constexpr bool HAS_E = EP == EP_GELU_BWD || EP == EP_RESIDUAL || EP == EP_RESIDUAL_LN || EP == EP_NONE;      // (not EP_LNHEAD)
     const bool use_e = EP == EP_NONE ? a.accumulate != 0 : true;
     const float* const ebase = EP == EP_NONE ? a.C : a.E1;
     const long long lde = EP == EP_NONE ? a.ldc : a.lde1;
     float4 ev[MI][NJ];
+    // EP_LNHEAD: no second A buffer (its epilogue -- LayerNorm + head on 24 values per lane -- needs the registers; the launch is
+    // bound by the 925 MB it writes, or short: the teacher's)
+    constexpr bool PREFETCH = EP != EP_LNHEAD;
     load_a(cur, slab);
     for (; slab < slabs; slab += stride) {
         const bool more = slab + stride < slabs;
@@ -1122,7 +1194,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 }
             }
         }
-        if (more) load_a(nxt, slab + stride);
+        if (PREFETCH && more) load_a(nxt, slab + stride);
         f32x4 acc[MI][NJ];
 #pragma unroll
         for (int i = 0; i < MI; ++i)
@@ -1161,10 +1233,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             rega_store<NJ, EP, true>(a, acc, slab * 32, n0, lj, g, bv, ev, gb);
         }
         if (more) {
+            if constexpr (PREFETCH) {
 #pragma unroll
-            for (int kb = 0; kb < KBM; ++kb)
+                for (int kb = 0; kb < KBM; ++kb)
 #pragma unroll
-                for (int i = 0; i < MI; ++i) { cur[kb][i][0] = nxt[kb][i][0]; cur[kb][i][1] = nxt[kb][i][1]; }
+                    for (int i = 0; i < MI; ++i) { cur[kb][i][0] = nxt[kb][i][0]; cur[kb][i][1] = nxt[kb][i][1]; }
+            } else {
+                __builtin_amdgcn_sched_barrier(0);          // (the loads must not move up into the epilogue: registers)
+                load_a(cur, slab + stride);
+            }
         }
     }
 }
@@ -1856,7 +1933,7 @@ bool nt_rega_shape(int M, int N, int K) {
     if ((long long)M * 4 >= (1LL << 31)) return false;
     // per-shape sweep at 48 images (scripts/gemm_nt_bench.py --rega, profiles/r06_gemm_nt_rega.txt): ahead of the staged kernels
     // for the 10^5-row stage and, at 4 x 10^4 rows, where the output is wider than the contraction; behind them below that
-    static const int msq = getenv("MIS_GEMM_REGA_MSQ") ? atoi(getenv("MIS_GEMM_REGA_MSQ")) : 50000;
+    static const int msq = getenv("MIS_GEMM_REGA_MSQ") ? atoi(getenv("MIS_GEMM_REGA_MSQ")) : 100000;
     if (M < mmin || (M < msq && N <= K)) return false;
     return mis_cdiv(M, 128) * (N / 96) >= tmin;
 }
@@ -1873,7 +1950,7 @@ int launch_nt_rega_ep(const GemmArgs& a, hipStream_t stream) {
 template <int EP>
 int launch_nt_rega_res_ep(const GemmArgs& a, hipStream_t stream) {
     static std::atomic<unsigned long long> attr_done{0};
-    const int ldsb = 3 * (96 * BK * 3 / 2) * 4 + 768;            // the panel (up to three k-blocks) + gamma / beta
+    const int ldsb = 3 * (96 * BK * 3 / 2) * 4 + (192 + 384) * 4;      // the panel (up to three k-blocks) + gamma / beta / head weights
     if (mis_set_lds_attr(reinterpret_cast<const void*>(&gemm_nt_rega_res_kernel<EP>), ldsb, attr_done) != MIS_OK)
         return MIS_ERR_LAUNCH;
     hipLaunchKernelGGL((gemm_nt_rega_res_kernel<EP>), dim3(a.n_blocks_padded), dim3(256), ldsb, stream, a);
@@ -1897,8 +1974,10 @@ int launch_nt_rega(GemmArgs& a, hipStream_t stream) {
         if (a.ep == EP_GELU_FWD) return launch_nt_rega_res_ep<EP_GELU_FWD>(a, stream);
         if (a.ep == EP_GELU_BWD) return launch_nt_rega_res_ep<EP_GELU_BWD>(a, stream);
         if (a.ep == EP_RESIDUAL_LN) return launch_nt_rega_res_ep<EP_RESIDUAL_LN>(a, stream);
+        if (a.ep == EP_LNHEAD) return launch_nt_rega_res_ep<EP_LNHEAD>(a, stream);
         return launch_nt_rega_res_ep<EP_RESIDUAL>(a, stream);
     }
+    if (a.ep == EP_LNHEAD) return MIS_ERR_UNSUPPORTED;
     a.tiles_n = a.N / 96;
     a.tiles_m = (int)mis_cdiv(a.M, 128);
     const long long nb = (long long)a.tiles_n * a.tiles_m;
@@ -2313,6 +2392,31 @@ extern "C" int mis_gemm_nt_split_layout(const float* A, long long lda, const voi
                                         hipStream_t stream) {
     return gemm_nt_split_impl(A, lda, B3, C, ldc, bias, M, N, K, accumulate, epilogue, E1, lde1, C2, ldc2, rowscale, rows_per_scale,
                               ex_H, ex_W, ex_P, ex_c, workspace, workspace_bytes, stream, layout);
+}
+
+// mis_gemm_expand_ln_head on natural-order planes of the expand weight (round 6): the persistent resident-panel register-A kernel
+// -- K <= 96, c = 96, the 16 (p1, p2) column panels of FinalPatchExpand_X4 stay in LDS, a wave's accumulators ARE token rows of
+// the shuffled tensor, so LayerNorm and the output head run in registers.  Same arguments otherwise.  MIS_ERR_UNSUPPORTED:
+// mis_gemm_nt_split_natural(M, N, K) is 0, K > 96, c != 96, NC outside 2 .. 4.
+extern "C" int mis_gemm_expand_ln_head_split(const float* x, long long lda, const void* B3, float* out, int B, int H, int Wd, int K,
+                                             int P, int c, const float* gamma, const float* beta, const float* head_w, int NC,
+                                             float eps, float* mean, float* rstd, float* logits, long long logits_bs,
+                                             hipStream_t stream) {
+    if (!x || !B3 || !gamma || !beta || !head_w || !mean || !rstd || !logits || B <= 0 || H <= 0 || Wd <= 0 || K <= 0 || P <= 0)
+        return MIS_ERR_ARG;
+    if (c != 96 || NC < 2 || NC > 4) return MIS_ERR_UNSUPPORTED;
+    const long long M = (long long)B * H * Wd, N = (long long)P * P * c;
+    if (M * 4 >= (1LL << 31) || !nt_rega_shape((int)M, (int)N, K) || split_k3(K) > 96) return MIS_ERR_UNSUPPORTED;
+    if (!a16(x) || !a16(B3) || lda % 4 || K % 4 || (out && !a16(out))) return MIS_ERR_UNSUPPORTED;
+    if (M * lda * 4 >= (1LL << 31) || mis_gemm_split_bytes((int)N, K) >= (1LL << 31)) return MIS_ERR_UNSUPPORTED;
+    if (logits_bs < (long long)NC * H * P * Wd * P) return MIS_ERR_ARG;
+    GemmArgs a{x, lda, nullptr, 0, out, N, nullptr, nullptr, (int)M, (int)N, K, 1, K, 0};
+    a.B3 = B3; a.K3 = split_k3(K); a.b3_plane = (unsigned)(N * a.K3 * 2);
+    a.ex_P = P; a.ex_H = H; a.ex_W = Wd; a.ex_c = c; a.vec4 = 1;
+    a.ep = EP_LNHEAD;
+    a.ln_g = gamma; a.ln_b = beta; a.head_w = head_w; a.ln_mean = mean; a.ln_rstd = rstd; a.logits = logits;
+    a.logits_bs = logits_bs; a.head_nc = NC; a.ln_eps = eps;
+    return launch_nt_rega(a, stream);
 }
 
 // proj / fc2 of a 96-channel Swin block with everything up to the next LayerNorm in the epilogue (register-A kernels, natural-order

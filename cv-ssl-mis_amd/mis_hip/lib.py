@@ -165,6 +165,8 @@ PROTOTYPES = {
     "mis_gemm_nt_split_layout": (c_i, [c_p, c_ll, c_p, c_p, c_ll, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_ll, c_p, c_ll, c_p, c_ll,
                                        c_i, c_i, c_i, c_i, c_p, c_ll, c_i, c_p]),
     "mis_gemm_nt_split_layout_kernel_name": (c_i, [c_i, c_i, c_i, c_i, c_i, ctypes.c_char_p, c_i]),
+    "mis_gemm_expand_ln_head_split": (c_i, [c_p, c_ll, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_i, c_f, c_p, c_p, c_p,
+                                            c_ll, c_p]),
     "mis_gemm_nt_residual_ln": (c_i, [c_p, c_ll, c_p, c_p, c_i, c_i, c_i, c_p, c_ll, c_p, c_ll, c_p, c_ll, c_p, c_p, c_f, c_p, c_ll,
                                       c_p, c_p, c_p]),
     "mis_gemm_split_job_bytes": (c_ll, []),

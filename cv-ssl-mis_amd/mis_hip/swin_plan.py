@@ -207,7 +207,8 @@ def split_linear_weights(holder, ops_list, transposed):
                 continue
             # planes in the element order of the kernel that will read them: the register-A kernel (many token rows, float4
             # epilogue) wants the natural order; the pixel-shuffle / LayerNorm-head stores of the expand layers stay staged
-            staged_only = isinstance(op, ExpandLinearOp)
+            # (the final expand with LayerNorm + head in its epilogue has a register-A form: LnHeadOp.eligible shapes, K <= 96)
+            staged_only = isinstance(op, ExpandLinearOp) and not (EXPAND_HEAD and op.ln_head is not None and op.w2.shape[1] <= 96 and op.geo[3] == 96)
             if transposed:
                 if op.need_dx and op.wT_batched:
                     op.bT3 = tops.SplitB(op.wT, rows=op.y.rows)
@@ -415,7 +416,7 @@ class ExpandLinearOp(LinearOp):
         h = self.ln_head if EXPAND_HEAD else None
         keep = None if getattr(ctx, "no_backward", False) else self.sh.t     # the shuffled tokens: only the backward reads them
         if h is not None and tops.gemm_expand_ln_head(self.x.t, self.w2, keep, B, H, W, P, c, h.g.data, h.b.data, h.w2,
-                                                      h.mean, h.rstd, h.logits.t):
+                                                      h.mean, h.rstd, h.logits.t, b3=self._b3(ctx)):
             h.skip_fwd = True        # LayerNorm + output head ran in this GEMM's epilogue
             return
         if not tops.gemm_expand(self.x.t, self.w2, self.sh.t, B, H, W, P, c, b3=self._b3(ctx)):

@@ -354,7 +354,7 @@ def droppath_table(table, p_dev, salt_dev, nsites, B, state):
 def gemm_expand(x, w, out, B, H, W, P, c, b3=None):
     """out[(b, h*P+p1, w*P+p2)][c] = (x @ w^T) pixel-shuffled; returns False when the fused form does not cover the
     shape (the caller then runs gemm + token_rearrange)."""
-    if b3 is not None and split_active():
+    if b3 is not None and not b3.natural and split_active():      # (natural-order planes: only the register-A kernels read them)
         assert out.is_contiguous() and out.numel() == B * H * W * P * P * c
         if _nt_split(x, b3, out, ex=(H, W, P, c)):
             return True
@@ -376,10 +376,11 @@ def gemm_expand(x, w, out, B, H, W, P, c, b3=None):
     return True
 
 
-def gemm_expand_ln_head(x, w, out, B, H, W, P, c, gamma, beta, head_w, mean, rstd, logits5, eps=1e-5):
+def gemm_expand_ln_head(x, w, out, B, H, W, P, c, gamma, beta, head_w, mean, rstd, logits5, eps=1e-5, b3=None):
     """FinalPatchExpand_X4's Linear + pixel shuffle + LayerNorm + output head in one launch (mis_gemm_expand_ln_head):
     ``out`` [B H P W P, c] (None: the expanded tokens are not kept), mean / rstd per expanded token, logits5 [B, NC, 1, H P, W P].
-    False: outside the fused form."""
+    ``b3``: the expand weight's planes in the natural order (SplitB(rows=M)): the persistent register-A kernel
+    (mis_gemm_expand_ln_head_split).  False: outside the fused form."""
     L = _l.load()
     M, K, lda = _mat(x)
     N, K2, ldb = _mat(w)
@@ -390,6 +391,18 @@ def gemm_expand_ln_head(x, w, out, B, H, W, P, c, gamma, beta, head_w, mean, rst
     if prof is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
+    if b3 is not None and b3.natural and b3.rows == M and split_active():
+        st = L.mis_gemm_expand_ln_head_split(_l.ptr(x), lda, _l.ptr(b3.t), _l.ptr(out), B, H, W, K, P, c, _l.ptr(gamma), _l.ptr(beta),
+                                             _l.ptr(head_w), NC, eps, _l.ptr(mean), _l.ptr(rstd), _l.ptr(logits5),
+                                             logits5.stride(0), _l.stream_ptr())
+        if st == 0:
+            if prof is not None:
+                e1.record()
+                prof.append(("gemm_nt_rega_res_kernel<4>", 2.0 * M * N * K, e0, e1,
+                             4.0 * (M * K + (M * N if out is not None else 0)) + 6.0 * N * K))
+            return True
+        if st != -2:
+            _l.check(st, "mis_gemm_expand_ln_head_split")
     st = L.mis_gemm_expand_ln_head(_l.ptr(x), lda, _l.ptr(w), ldb, _l.ptr(out), B, H, W, K, P, c, _l.ptr(gamma), _l.ptr(beta),
                                    _l.ptr(head_w), NC, eps, _l.ptr(mean), _l.ptr(rstd), _l.ptr(logits5), logits5.stride(0),
                                    _l.stream_ptr())

@@ -473,6 +473,12 @@ int mis_gemm_tn_kernel_name(const float* A, long long lda, const float* B, long 
 int mis_gemm_expand_ln_head(const float* x, long long lda, const float* W, long long ldb, float* out, int B, int H, int Wd,
                             int K, int P, int c, const float* gamma, const float* beta, const float* head_w, int NC,
                             float eps, float* mean, float* rstd, float* logits, long long logits_bs, mis_stream_t stream);
+/* ... on natural-order planes of the expand weight (mis_gemm_split_*_layout, natural = 1; mis_gemm_nt_split_natural(B H W, P P c, K)
+ * must say 1 and K <= 96): the persistent resident-panel register-A kernel -- the (p1, p2) column panels stay in LDS, a wave's
+ * accumulators are token rows of the shuffled tensor, LayerNorm and the head run in registers. */
+int mis_gemm_expand_ln_head_split(const float* x, long long lda, const void* B3, float* out, int B, int H, int W, int K, int P,
+                                  int c, const float* gamma, const float* beta, const float* head_w, int NC, float eps,
+                                  float* mean, float* rstd, float* logits, long long logits_bs, hipStream_t stream);
 /* The NT form with a pre-split B operand.  The bf16x3 kernels cut every fp32 operand into three bf16 pieces; for B = an
  * nn.Linear weight (forward: F.linear(x, W), swin_transformer_unet_skip_expand_decoder_sys.py:14,16,107,109; data gradient:
  * dy . W, i.e. B = W^T) that cut is the same for every tile of the launch and every launch of the step, so it is done once:

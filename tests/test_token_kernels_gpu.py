@@ -892,3 +892,45 @@ def test_residual_and_layernorm_in_the_register_a_epilogue(M, K):
         assert (Y - Y2).abs().max().item() <= 2e-5 * max(1.0, Y2.abs().max().item())
     finally:
         tops.set_split_precision(prev)
+
+
+@pytest.mark.parametrize("B,H,W,NC,keep", [(24, 56, 56, 4, True), (12, 56, 56, 3, False), (9, 60, 52, 2, True)])
+def test_final_expand_layernorm_and_head_on_the_register_a_kernel(B, H, W, NC, keep):
+    """mis_gemm_expand_ln_head_split: the persistent resident-panel register-A kernel with LayerNorm + output head on the
+    accumulators (a lane holds 24 of a shuffled token's 96 values; cross-group sums) against mis_gemm_expand + mis_ln_head_fwd:
+    shuffled tokens, mean / rstd, logits to fp32 rounding (other element order inside a K = 32 block); ragged last slab."""
+    tops = _t()
+    prev = tops.set_split_precision(7)
+    try:
+        P, c, K = 4, 96, 96
+        M = B * H * W
+        x, w = _rand(M, K, seed=61).cuda(), (_rand(P * P * c, K, seed=62) * 0.1).cuda()
+        g, b = (1 + 0.2 * _rand(c, seed=63)).cuda(), (0.1 * _rand(c, seed=64)).cuda()
+        hw = _rand(NC, c, seed=65, scale=0.3).cuda()
+        b3 = tops.SplitB(w, rows=M).refresh()
+        assert b3.natural
+        T = M * P * P
+        sh0 = torch.empty(T, c, device="cuda")
+        assert tops.gemm_expand(x, w, sh0, B, H, W, P, c)
+        m0, r0 = torch.empty(T, device="cuda"), torch.empty(T, device="cuda")
+        lg0 = torch.empty(B, NC, 1, H * P, W * P, device="cuda")
+        assert tops.ln_head_fwd(sh0, g, b, hw, m0, r0, lg0)
+        sh1 = torch.full((T, c), float("nan"), device="cuda") if keep else None
+        m1, r1 = torch.full((T,), float("nan"), device="cuda"), torch.full((T,), float("nan"), device="cuda")
+        lg1 = torch.full((B, NC, 1, H * P, W * P), float("nan"), device="cuda")
+        from mis_hip import ops
+        ops.PROFILE = []
+        try:
+            assert tops.gemm_expand_ln_head(x, w, sh1, B, H, W, P, c, g, b, hw, m1, r1, lg1, b3=b3)
+            assert ops.PROFILE[-1][0] == "gemm_nt_rega_res_kernel<4>"
+        finally:
+            ops.PROFILE = None
+        if keep:
+            assert (sh0 - sh1).abs().max().item() <= 2e-6 * max(1.0, sh0.abs().max().item())
+        assert (m0 - m1).abs().max().item() <= 1e-6 and ((r0 - r1) / r0).abs().max().item() <= 1e-4
+        assert (lg0 - lg1).abs().max().item() <= 1e-4 * max(1.0, lg0.abs().max().item())
+        lg2 = torch.full_like(lg1, float("nan"))
+        assert tops.gemm_expand_ln_head(x, w, sh1, B, H, W, P, c, g, b, hw, m1, r1, lg2, b3=b3)
+        assert torch.equal(lg1, lg2)
+    finally:
+        tops.set_split_precision(prev)
