@@ -894,7 +894,7 @@ def test_residual_and_layernorm_in_the_register_a_epilogue(M, K):
         tops.set_split_precision(prev)
 
 
-@pytest.mark.parametrize("B,H,W,NC,keep", [(24, 56, 56, 4, True), (12, 56, 56, 3, False), (9, 60, 52, 2, True)])
+@pytest.mark.parametrize("B,H,W,NC,keep", [(24, 56, 56, 4, True), (12, 56, 56, 3, False), (11, 60, 52, 2, True)])
 def test_final_expand_layernorm_and_head_on_the_register_a_kernel(B, H, W, NC, keep):
     """mis_gemm_expand_ln_head_split: the persistent resident-panel register-A kernel with LayerNorm + output head on the
     accumulators (a lane holds 24 of a shuffled token's 96 values; cross-group sums) against mis_gemm_expand + mis_ln_head_fwd:
