@@ -562,7 +562,7 @@ def _physical_cores():
     return os.cpu_count() or 1
 
 
-def cpu_baseline(kind, wl, timed=5, warm=2, budget_s=150.0, cands=(16, 32, 64)):
+def cpu_baseline(kind, wl, timed=5, warm=2, budget_s=150.0, cands=(16, 32, 64), full_batch=True, also_threads=None):
     """The oracle step (reference arithmetic on stock torch CPU ops, dropout + noise active) on this host's cores.
     ``torch.set_num_threads`` is swept over ``cands`` on the reduced batch ``wl["cpu_sample"]`` of the same geometry
     (1 warm-up + 1 timed step each; 8 and the physical core count lost every sweep of rounds 2-4 and are no longer
@@ -621,21 +621,45 @@ def cpu_baseline(kind, wl, timed=5, warm=2, budget_s=150.0, cands=(16, 32, 64)):
     best = min(sweep, key=sweep.get)
     torch.set_num_threads(best)
     ts = sweep[best]
+    sp = "x".join(map(str, wl["shape"][2:]))
+    if not full_batch:
+        # token workloads (north_star names ACDC / BraTS for the CPU figure; this completes the table): the reduced batch only
+        # -- images/s of these per-sample networks barely depends on the batch -- 1 warm-up + 3 timed steps, median
+        small()
+        times = sorted(small() for _ in range(3))
+        t = times[1]
+        torch.set_num_threads(default_threads)
+        return dict(value=Bs / t, unit=UNIT.get(kind, "images/s"), cores=best, kind="port", warmup_steps=1, timed_steps=3,
+                    s_per_step_all=[round(x, 3) for x in times], host=dict(logical_cpus=logical, physical_cores=physical),
+                    thread_sweep_s_per_step={str(k): round(v, 3) for k, v in sweep.items()},
+                    extrapolation=f"measured on the reduced batch {Ls}+{Bs - Ls}; quoted as images/s for the GPU line's {Lf}+{Bf - Lf} "
+                                  "(the full batch on the CPU is not run: ~12 x the time for the same rate)",
+                    sample=f"oracle.step.mean_teacher_step on the REDUCED batch {Ls}+{Bs - Ls} of {sp}: 1 warm-up + 3 timed steps, "
+                           f"median {t:.3f} s/step, at {best} threads (best of {sorted(sweep)} on this batch), torch "
+                           f"{torch.__version__} CPU")
     for _ in range(warm):
         full()
     times = sorted(full() for _ in range(timed))
     t = times[len(times) // 2]
+    other = None
+    if also_threads and also_threads != best and also_threads <= logical:
+        # the thread count was chosen on the reduced batch: one full-batch step at another count settles whether it holds there
+        torch.set_num_threads(also_threads)
+        full()
+        to = full()
+        other = dict(threads=also_threads, s_per_step=round(to, 3), value=Bf / to, warmup_steps=1, timed_steps=1)
     torch.set_num_threads(default_threads)
-    sp = "x".join(map(str, wl["shape"][2:]))
     return dict(value=Bf / t, unit=UNIT.get(kind, "images/s"), cores=best, kind="port", warmup_steps=warm, timed_steps=timed,
                 s_per_step_all=[round(x, 3) for x in times],
                 host=dict(logical_cpus=logical, physical_cores=physical),
                 thread_sweep_s_per_step={str(k): round(v, 3) for k, v in sweep.items()},
                 reduced_batch=dict(batch=f"{Ls}+{Bs - Ls}", value=Bs / ts, s_per_step=round(ts, 3)),
+                full_batch_at_other_thread_count=other,
                 sample=f"oracle.step.mean_teacher_step on the GPU line's batch {Lf}+{Bf - Lf} of {sp}: {warm} warm-up + "
-                       f"{timed} timed steps, median {t:.3f} s/step, at {best} threads (torch.set_num_threads swept over "
-                       f"{sorted(sweep)} on the reduced batch {Ls}+{Bs - Ls}: {ts:.3f} s/step there), torch "
-                       f"{torch.__version__} CPU")
+                       f"{timed} timed steps, median {t:.3f} s/step, at {best} threads -- the BEST OF THE SWEEP "
+                       f"{sorted(sweep)} ON THE REDUCED BATCH {Ls}+{Bs - Ls} ({ts:.3f} s/step there), applied to the full batch"
+                       + (f"; one full-batch step at {other['threads']} threads: {other['s_per_step']:.3f} s" if other else "")
+                       + f"; torch {torch.__version__} CPU")
 
 
 # ------------------------------------------------------------------------------------------------ in-run HBM traffic
@@ -833,6 +857,13 @@ def main():
                              "no larger than the fp32 MFMA kernels' (tests/test_token_kernels_gpu.py, both forms)",
                              ms_per_step_fp32_mfma=r32["ms_per_step"], value_fp32_mfma=r32["value"],
                              losses_fp32_mfma=r32["losses"], losses=r["losses"])
+            if name in ("swin", "cross") and rf and not args.no_traffic and not args.no_kernel_events:
+                # HBM bytes of THIS workload's dominant kernel over its algorithmic bytes, from two PMC passes of this run
+                torch.cuda.synchronize()
+                torch.cuda.empty_cache()
+                tr, why = inrun_traffic(name, rf["kernel"], rf["algorithmic_bytes_per_launch_avg"], budget_s=60.0)
+                extra["dominant_kernel_hbm_over_algorithmic"] = None if tr is None else tr["over_algorithmic"]
+                extra["dominant_kernel_traffic"] = tr if tr is not None else dict(unavailable=why)
             others[name] = dict(workload=WORKLOADS[name]["config"], value=r["value"], unit=r["unit"], **extra,
                                 ms_per_step=r["ms_per_step"], steps=oargs.steps,
                                 host_enqueue_ms_per_step=r["host_enqueue_ms_per_step"],
@@ -870,8 +901,12 @@ def main():
             if tr is None:
                 rf["traffic_unavailable"] = why
         if single and not args.no_cpu_baseline and wl["cpu_sample"] is not None:
-            out["cpu_baseline"] = cpu_baseline(args.workload, wl)
+            out["cpu_baseline"] = cpu_baseline(args.workload, wl, also_threads=64 if args.workload == "unet3d" else None)
             out["gpu_over_cpu"] = round(out["value"] / out["cpu_baseline"]["value"], 2)
+            if "others" in out and "swin" in out["others"] and args.workload == "unet3d":
+                o4 = out["others"]["swin"]
+                o4["cpu_baseline"] = cpu_baseline("swin", WORKLOADS["swin"], budget_s=40.0, cands=(16, 32), full_batch=False)
+                o4["gpu_over_cpu"] = round(o4["value"] / o4["cpu_baseline"]["value"], 2)
             if "others" in out and "unet2d" in out["others"] and args.workload == "unet3d":
                 # the ACDC figure the north star asks for beside the BraTS one: the same oracle step on config 2's batch
                 o2 = out["others"]["unet2d"]

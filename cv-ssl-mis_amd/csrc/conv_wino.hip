@@ -592,6 +592,14 @@ int wino_splits(int N, int Cin, int Cout, int D, int H, int W, int variant) {
     const int nst = (Cin + 3) / 4;
     int ks = 1;
     while (entries * ks < 192 && ks < 8 && nst % (2 * ks) == 0 && nst / (2 * ks) >= 8 && (nst / (2 * ks)) % 2 == 0) ks *= 2;
+    // Round-6 prototype (MIS_WINO_SPLIT_QUANT=1, off by default: measured, profiles/r06_wino_quant.txt): a launch whose entries
+    // fill the 256 persistent workgroups badly -- the 24^3 level of config 3: 864 entries = 3.375 -> 4 rounds, 18.5 % idle --
+    // cut into two contraction slices: 1728 half entries = 6.75 -> 7 half rounds = 3.5 rounds, for a reduction launch
+    static const bool quant = [] { const char* e = getenv("MIS_WINO_SPLIT_QUANT"); return e && e[0] == '1'; }();
+    if (quant && ks == 1 && entries > 256 && nst % 2 == 0 && nst / 2 >= 8 && (nst / 2) % 2 == 0) {
+        const long long r1 = mis_cdiv(entries, 256) * 2, r2 = mis_cdiv(entries * 2, 256);      // in half rounds
+        if (r2 * 100 <= r1 * 90) ks = 2;
+    }
     return ks;
 }
 

@@ -395,7 +395,7 @@ def linear_rampup(current, rampup_length):
     return 1.0 if current >= rampup_length else current / rampup_length
 
 
-class CnnMeetVitTrainer:
+class CnnMeetVitTrainer(_TapedStep):
     """CNN student + Transformer student + EMA Transformer teacher (reference code/train_cnn_meet_vit_2D.py:293-352).
 
     ``model1`` (CNN) and ``model2`` (SwinUnet) see the whole batch and cross-teach through Dice on each other's
@@ -408,9 +408,13 @@ class CnnMeetVitTrainer:
 
     def __init__(self, model1, model2, ema_model, *, labeled_bs, num_classes, base_lr=0.01, max_iterations=30000,
                  ema_decay=0.99, consistency=0.1, consistency_rampup=200.0, seed=1337, iter_num=0, momentum=0.9,
-                 weight_decay=1e-4, process_group=None):
+                 weight_decay=1e-4, process_group=None, use_tape=None):
         if model2.flat_param.numel() != ema_model.flat_param.numel():
             raise RuntimeError("the teacher is the EMA of model2: same architecture required")
+        # the two ramp weights are HOST floats of iter_num and arguments of the loss tails: the tape is recorded again whenever
+        # they change (every ramp_div = 150 iterations, and at iteration 1000)
+        self.use_tape = STEP_TAPE if use_tape is None else bool(use_tape)
+        self._tape_weights = None
         self.model1, self.model2, self.ema_model = model1, model2, ema_model
         self.labeled_bs, self.num_classes = labeled_bs, num_classes
         self.hyper = dict(base_lr=float(base_lr), max_iterations=float(max_iterations), ema_decay=float(ema_decay),
@@ -444,6 +448,19 @@ class CnnMeetVitTrainer:
     def step(self, volume_batch, label_batch, noise=None):
         if not (self.model1.training and self.model2.training and self.ema_model.training):
             raise RuntimeError("train_cnn_meet_vit runs all three networks in train mode")
+        if self.use_tape and noise is None:
+            w = self.weights()
+            if self._tape is not None and w != self._tape_weights:
+                self._tape, self._tape_warm = None, self.TAPE_WARMUP       # plans and buffers are warm: record at once
+            if self._tape is None and self._tape_warm >= self.TAPE_WARMUP:
+                self._tape_weights = w
+            self._tape_step(lambda v, l: self._run(v, l, None), (volume_batch, label_batch))
+        else:
+            self._run(volume_batch, label_batch, noise)
+        self.iter_num += 1
+        return self.out1, self.out2
+
+    def _run(self, volume_batch, label_batch, noise):
         L = self.labeled_bs
         unl = volume_batch[L:].contiguous()
         if self._ema_in is None or self._ema_in.shape != unl.shape:
@@ -481,16 +498,16 @@ class CnnMeetVitTrainer:
             # finish() (defer_tail), as for the side-stream student of cross teaching
             _lib.wait_stream(self._side, main)
             if b1 is not None:
-                b1.begin()
-                b2.begin()
+                _lib.tape_call(b1.begin)
+                _lib.tape_call(b2.begin)
             with torch.cuda.stream(self._side):
                 self.model1.backward_raw(on_progress=None if b1 is None else b1.advance)
             self.model2.backward_raw(on_progress=None if b2 is None else b2.advance)
             _lib.wait_stream(main, self._side)
             if b1 is not None:
-                scales = [b1.finish(), b2.finish()]
+                scales = [_lib.tape_call(b1.finish), _lib.tape_call(b2.finish)]
             else:
-                scales = [dist.sync_gradients(m.flat_grad, self.pg) for m in (self.model1, self.model2)]
+                scales = [_lib.tape_call(dist.sync_gradients, m.flat_grad, self.pg) for m in (self.model1, self.model2)]
         else:
             scales = [backward_and_sync(self.model1, self.pg, b1), backward_and_sync(self.model2, self.pg, b2)]
         for m, mom, ema, scale in ((self.model1, self.mom1, None, scales[0]),
@@ -500,8 +517,6 @@ class CnnMeetVitTrainer:
         h = self.hyper
         ops.step_advance(self.state, h["base_lr"], h["max_iterations"], h["ema_decay"], h["consistency"], h["rampup"],
                          h["ramp_div"], h["cons_start_iter"])
-        self.iter_num += 1
-        return self.out1, self.out2
 
     def losses(self):
         a, b = self.out1.cpu(), self.out2.cpu()

@@ -114,3 +114,37 @@ def test_tape_refuses_another_input_geometry_and_survives_an_eager_forward_betwe
     assert torch.equal(m.flat_param, ref_m.flat_param) and torch.equal(e.flat_param, ref_e.flat_param)
     with pytest.raises(RuntimeError):
         tr.step(batches[0][0][:6], batches[0][1][:6])
+
+
+def test_taped_cnn_meet_vit_step_rerecords_when_the_ramp_weights_change():
+    """CnnMeetVitTrainer passes two HOST floats of iter_num (the ramp weights: they change every 150 iterations and at 1000) to
+    its loss tails: the tape is recorded again when they change.  Eight steps across iteration 1050 (a ramp step) -- bit-identical
+    to the eager trainer."""
+    from config import lite_config
+    from mis_hip.step import CnnMeetVitTrainer
+    from networks.net_factory import net_factory
+    from networks.vision_transformer import SwinUnet
+    from oracle import filler
+    from oracle.nets import OracleUNet2D
+    from oracle.swin import OracleSwinUnet
+    sds = [filler.fill_state_dict(OracleUNet2D(1, 4).new_state()), filler.fill_state_dict(OracleSwinUnet(4).new_state())]
+    batches = _batches((4, 1, 224, 224), 4, torch.uint8, 8)
+    res = []
+    for tape in (False, True):
+        models = [net_factory("unet", 1, 4), SwinUnet(lite_config(), num_classes=4), SwinUnet(lite_config(), num_classes=4)]
+        for m, sd in zip(models, (sds[0], sds[1], sds[1])):
+            m.load_state_dict(sd)
+            m.train()
+        tr = CnnMeetVitTrainer(models[0], models[1], models[2], labeled_bs=2, num_classes=4, seed=9, iter_num=1045, use_tape=tape)
+        outs, tapes = [], []
+        for v, l in batches:
+            o1, o2 = tr.step(v, l)
+            outs.append(torch.cat([o1, o2]).clone())
+            if tr._tape is not None and all(tr._tape is not t for t in tapes):
+                tapes.append(tr._tape)
+        torch.cuda.synchronize()
+        if tape:
+            assert len(tapes) == 2                 # recorded at step 3 and again at iteration 1050
+        res.append((torch.stack(outs), models[0].flat_param.clone(), models[1].flat_param.clone(), models[2].flat_param.clone()))
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
