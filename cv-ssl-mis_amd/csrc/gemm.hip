@@ -979,33 +979,47 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     constexpr int RB3 = BN / 16, PB3 = 3 * RB3, NB3 = (PB3 + 3) / 4;
     constexpr int B_FLOATS = BN * BK * 3 / 2;                   // one stage: three planes [BN][32] bf16
     float* const lds = mis_gemm_lds;
-    const unsigned L = mis_xcd_remap(blockIdx.x, a.n_blocks_padded);
-    if (L >= a.n_blocks) return;
-    const int tn = L % a.tiles_n, tm = L / a.tiles_n;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4, lj = lane & 15;
-    const int m0 = tm * BMT, n0 = tn * BN, wm = wave * 32;
+    const int wm = wave * 32;
     const unsigned lds0 = lds_addr(lds);
     const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.A), 0,
                                                                         (int)(((long long)(a.M - 1) * a.lda + a.K) * 4), 0x00020000);
     const i32x4 rB3 = make_rsrc(a.B3, 3u * a.b3_plane);
-    // A: lane (lj, g) of tile i reads row m0 + wm + 16 i + lj, floats k0 + 8 g .. + 7 (two 16-byte loads)
+    // Tiles: the grid is at most three workgroups per CU; a workgroup walks the (XCD-remapped) tile list with stride gridDim.x
+    // (a multiple of the XCD count, so a workgroup's tiles stay in its XCD's contiguous range) and requests the first stage of
+    // its NEXT tile during the last k-step of the current one: the epilogue runs with that stage already in LDS / registers.
+    auto tile_after = [&](unsigned v) -> unsigned {            // next v (>= the argument) with a real tile, or ~0u
+        for (; v < a.n_blocks_padded; v += gridDim.x)
+            if (mis_xcd_remap(v, a.n_blocks_padded) < a.n_blocks) return v;
+        return ~0u;
+    };
+    unsigned v = tile_after(blockIdx.x);
+    if (v == ~0u) return;
+    int m0, n0;
     int voA[MI];
-#pragma unroll
-    for (int i = 0; i < MI; ++i) {
-        const int row = m0 + wm + 16 * i + lj;
-        voA[i] = row < a.M ? (int)(((long long)row * a.lda + 8 * g) * 4) : (int)OOB;
-    }
-    // B planes: piece q = (plane q / RB3, rows (q % RB3) * 16 ..+16) x the 64 bytes of the k-step (as gemm_nt_kernel, PREC = 2)
     unsigned voB3[NB3];
+    auto place = [&](unsigned vv) {
+        const unsigned L = mis_xcd_remap(vv, a.n_blocks_padded);
+        const int tn = L % a.tiles_n, tm = L / a.tiles_n;
+        m0 = tm * BMT;
+        n0 = tn * BN;
+        // A: lane (lj, g) of tile i reads row m0 + wm + 16 i + lj, floats k0 + 8 g .. + 7 (two 16-byte loads)
 #pragma unroll
-    for (int i = 0; i < NB3; ++i) {
-        const int q = wave + 4 * i, plane = q / RB3, row = (q % RB3) * 16 + (lane >> 2);
-        voB3[i] = (q < PB3 && n0 + row < a.N)
-                      ? (unsigned)plane * a.b3_plane + (unsigned)(((long long)(n0 + row) * a.K3 + (lane & 3) * 8) * 2)
-                      : OOB;
-    }
+        for (int i = 0; i < MI; ++i) {
+            const int row = m0 + wm + 16 * i + lj;
+            voA[i] = row < a.M ? (int)(((long long)row * a.lda + 8 * g) * 4) : (int)OOB;
+        }
+        // B planes: piece q = (plane q / RB3, rows (q % RB3) * 16 ..+16) x the 64 bytes of the k-step (as gemm_nt_kernel, PREC = 2)
+#pragma unroll
+        for (int i = 0; i < NB3; ++i) {
+            const int q = wave + 4 * i, plane = q / RB3, row = (q % RB3) * 16 + (lane >> 2);
+            voB3[i] = (q < PB3 && n0 + row < a.N)
+                          ? (unsigned)plane * a.b3_plane + (unsigned)(((long long)(n0 + row) * a.K3 + (lane & 3) * 8) * 2)
+                          : OOB;
+        }
+    };
     auto stage_b = [&](int buf, int k0) {
         const unsigned st = lds0 + (unsigned)buf * (B_FLOATS * 4);
 #pragma unroll
@@ -1024,56 +1038,71 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     };
 
     f32x4 acc[MI][NJ];
-#pragma unroll
-    for (int i = 0; i < MI; ++i)
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     f32x4 cur[MI][2], nxt[MI][2];
 
     float* const gb = lds + 2 * B_FLOATS;          // EP_RESIDUAL_LN: [gamma 96][beta 96] behind the two stages
     if constexpr (EP == EP_RESIDUAL_LN) {
         if (tid < 96) { gb[tid] = a.ln_g[tid]; gb[96 + tid] = a.ln_b[tid]; }
     }
+    place(v);
     stage_b(0, 0);
     load_a(cur, 0);
     dma_wait();
     __syncthreads();
     int s = 0;
-    for (int k0 = 0; k0 < a.K; k0 += BK, ++s) {
-        const bool more = k0 + BK < a.K;
-        if (more) { stage_b((s + 1) & 1, k0 + BK); load_a(nxt, k0 + BK); }
-        MisBf3 a3[MI];
+    while (true) {
+        const int tm0 = m0, tn0 = n0;               // this tile's origin (place() moves m0 / n0 on during the last k-step)
+        const unsigned vn = tile_after(v + gridDim.x);
 #pragma unroll
         for (int i = 0; i < MI; ++i)
-            a3[i] = mis_bf3_from8(cur[i][0][0], cur[i][0][1], cur[i][0][2], cur[i][0][3], cur[i][1][0], cur[i][1][1], cur[i][1][2], cur[i][1][3]);
-        const u32x4* __restrict__ sB3 = reinterpret_cast<const u32x4*>(lds + (s & 1) * B_FLOATS);
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-            const int r = (j * 16 + lj) * 4 + g;
-            const u32x4 bh = sB3[r], bm = sB3[BN * 4 + r], bl = sB3[2 * BN * 4 + r];
-#pragma unroll
-            for (int i = 0; i < MI; ++i) {
-                // the WEIGHT tile is the MFMA's row operand: D[row = column n of C, 4 g + r][col = token lj] -- a lane ends up
-                // with four consecutive n of one token, i.e. a float4 of a C row (see the epilogue)
-                f32x4 c = acc[i][j];
-                c = bf3_mfma(bh, a3[i].l, c);
-                c = bf3_mfma(bl, a3[i].h, c);
-                c = bf3_mfma(bm, a3[i].m, c);
-                c = bf3_mfma(bh, a3[i].m, c);
-                c = bf3_mfma(bm, a3[i].h, c);
-                c = bf3_mfma(bh, a3[i].h, c);
-                acc[i][j] = c;
+            for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int k0 = 0; k0 < a.K; k0 += BK, ++s) {
+            const bool more = k0 + BK < a.K;
+            bool loaded = more;
+            if (more) {
+                stage_b((s + 1) & 1, k0 + BK);
+                load_a(nxt, k0 + BK);
+            } else if (vn != ~0u) {
+                place(vn);
+                stage_b((s + 1) & 1, 0);
+                load_a(nxt, 0);
+                loaded = true;
             }
-        }
-        if (more) {
+            MisBf3 a3[MI];
 #pragma unroll
-            for (int i = 0; i < MI; ++i) { cur[i][0] = nxt[i][0]; cur[i][1] = nxt[i][1]; }
+            for (int i = 0; i < MI; ++i)
+                a3[i] = mis_bf3_from8(cur[i][0][0], cur[i][0][1], cur[i][0][2], cur[i][0][3], cur[i][1][0], cur[i][1][1], cur[i][1][2], cur[i][1][3]);
+            const u32x4* __restrict__ sB3 = reinterpret_cast<const u32x4*>(lds + (s & 1) * B_FLOATS);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int r = (j * 16 + lj) * 4 + g;
+                const u32x4 bh = sB3[r], bm = sB3[BN * 4 + r], bl = sB3[2 * BN * 4 + r];
+#pragma unroll
+                for (int i = 0; i < MI; ++i) {
+                    // the WEIGHT tile is the MFMA's row operand: D[row = column n of C, 4 g + r][col = token lj] -- a lane ends up
+                    // with four consecutive n of one token, i.e. a float4 of a C row (see the epilogue)
+                    f32x4 c = acc[i][j];
+                    c = bf3_mfma(bh, a3[i].l, c);
+                    c = bf3_mfma(bl, a3[i].h, c);
+                    c = bf3_mfma(bm, a3[i].m, c);
+                    c = bf3_mfma(bh, a3[i].m, c);
+                    c = bf3_mfma(bm, a3[i].h, c);
+                    c = bf3_mfma(bh, a3[i].h, c);
+                    acc[i][j] = c;
+                }
+            }
+            if (loaded) {
+#pragma unroll
+                for (int i = 0; i < MI; ++i) { cur[i][0] = nxt[i][0]; cur[i][1] = nxt[i][1]; }
+            }
+            dma_wait();
+            __syncthreads();
         }
-        dma_wait();
-        __syncthreads();
+        rega_store<NJ, EP>(a, acc, tm0 + wm, tn0, lj, g, nullptr, nullptr, gb);
+        if (vn == ~0u) break;
+        v = vn;
     }
-
-    rega_store<NJ, EP>(a, acc, m0 + wm, n0, lj, g, nullptr, nullptr, gb);
 }
 
 template <int BN>
@@ -1943,7 +1972,7 @@ int launch_nt_rega_ep(const GemmArgs& a, hipStream_t stream) {
     static std::atomic<unsigned long long> attr_done{0};
     constexpr int LDSB = rega_lds_bytes<BN>();
     if (mis_set_lds_attr(reinterpret_cast<const void*>(&gemm_nt_rega_kernel<BN, EP>), LDSB, attr_done) != MIS_OK) return MIS_ERR_LAUNCH;
-    hipLaunchKernelGGL((gemm_nt_rega_kernel<BN, EP>), dim3(a.n_blocks_padded), dim3(256), LDSB, stream, a);
+    hipLaunchKernelGGL((gemm_nt_rega_kernel<BN, EP>), dim3((unsigned)a.KS), dim3(256), LDSB, stream, a);
     return mis_launch_status();
 }
 
@@ -1985,6 +2014,9 @@ int launch_nt_rega(GemmArgs& a, hipStream_t stream) {
     a.n_blocks = (unsigned)nb;
     a.n_blocks_padded = (unsigned)(mis_cdiv(nb, MIS_NUM_XCD) * MIS_NUM_XCD);
     a.KS = 1;
+    // persistent above three workgroups per CU (KS carries the grid size; MIS_GEMM_REGA_WALK=0: one workgroup per tile)
+    static const int walk = getenv("MIS_GEMM_REGA_WALK") ? atoi(getenv("MIS_GEMM_REGA_WALK")) : 768;
+    a.KS = (walk > 0 && a.n_blocks_padded > (unsigned)walk) ? walk / MIS_NUM_XCD * MIS_NUM_XCD : (int)a.n_blocks_padded;
     if (a.ep == EP_NONE) return launch_nt_rega_ep<96, EP_NONE>(a, stream);
     if (a.ep == EP_GELU_FWD) return launch_nt_rega_ep<96, EP_GELU_FWD>(a, stream);
     if (a.ep == EP_GELU_BWD) return launch_nt_rega_ep<96, EP_GELU_BWD>(a, stream);

@@ -166,8 +166,22 @@ def pin_rank_to_numa(local_rank, local_world, pci_bus_ids=None, sysfs="/sys", ap
         info["cpus"] = (f"{mine[0]}-{mine[-1]}" if mine == list(range(mine[0], mine[-1] + 1)) else
                         ",".join(map(str, mine)))
         if apply and os.environ.get("MIS_PIN_NUMA", "1") != "0":
+            # every thread of the process, not only the caller (threads created before this call keep their own mask)
+            try:
+                tids = [int(t) for t in os.listdir("/proc/self/task")]
+            except OSError:
+                tids = []
+            for tid in tids or [0]:
+                try:
+                    os.sched_setaffinity(tid, mine)
+                except OSError:
+                    pass                                     # a thread that exited meanwhile
             os.sched_setaffinity(0, mine)
-            info["applied"] = True
+            # ... and torch's intra-op pool sized to the share (augmentation / validation metrics on the host would
+            # otherwise run the machine-wide default thread count on these few cores)
+            torch.set_num_threads(max(1, len(mine)))
+            os.environ["OMP_NUM_THREADS"] = str(max(1, len(mine)))
+            info["applied"], info["threads"] = True, len(mine)
     except Exception as e:       # affinity is an optimisation: never fail a run over it
         info["error"] = f"{type(e).__name__}: {e}"[:200]
     return info

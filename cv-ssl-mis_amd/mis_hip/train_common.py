@@ -110,9 +110,14 @@ def setup_distributed():
     if world > 1:
         # this rank's threads next to its GPU's PCIe root: its share of the cores of the device's NUMA node
         from . import dist as _dist
-        local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
-        pin = _dist.pin_rank_to_numa(local_rank, local_world, _dist.device_bus_ids(min(local_world,
-                                                                                         torch.cuda.device_count())))
+        local_world = int(os.environ.get("LOCAL_WORLD_SIZE", "0"))
+        if local_world <= 0 and world <= torch.cuda.device_count():
+            local_world = world                               # one node, launched without torchrun's LOCAL_WORLD_SIZE
+        if local_world > 0:
+            pin = _dist.pin_rank_to_numa(local_rank, local_world, _dist.device_bus_ids(min(local_world,
+                                                                                             torch.cuda.device_count())))
+        else:                                                 # several nodes and no LOCAL_WORLD_SIZE: the share is unknown
+            pin = dict(applied=False, reason="LOCAL_WORLD_SIZE unset and WORLD_SIZE > local device count")
         logging.info("rank %d: CPU affinity %s", rank, pin)
     if world > 1 and not torch.distributed.is_initialized():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")

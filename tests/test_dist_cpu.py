@@ -362,9 +362,21 @@ def test_rank_pinning_follows_the_gpus_numa_node(tmp_path):
     assert all(not (sets[a] & sets[b]) for a in range(4) for b in range(a + 1, 4))
     unknown = [mdist.pin_rank_to_numa(r, 2, None, sysfs=str(tmp_path), apply=False) for r in range(2)]
     assert all(i["numa_node"] == -1 for i in unknown) and not (cpus_of(unknown[0]) & cpus_of(unknown[1]))
-    before = os.sched_getaffinity(0)
+    before, threads, omp = os.sched_getaffinity(0), torch.get_num_threads(), os.environ.get("OMP_NUM_THREADS")
     try:
         i = mdist.pin_rank_to_numa(1, 4, ids, sysfs=str(tmp_path), apply=True)
         assert i["applied"] and os.sched_getaffinity(0) == cpus_of(i)
+        # every thread of the process carries the mask, and torch's intra-op pool is sized to the share
+        assert all(os.sched_getaffinity(int(t)) == cpus_of(i) for t in os.listdir("/proc/self/task"))
+        assert torch.get_num_threads() == i["n_cpus"] == i["threads"] and os.environ["OMP_NUM_THREADS"] == str(i["n_cpus"])
     finally:
-        os.sched_setaffinity(0, before)
+        for t in os.listdir("/proc/self/task"):
+            try:
+                os.sched_setaffinity(int(t), before)
+            except OSError:
+                pass
+        torch.set_num_threads(threads)
+        if omp is None:
+            os.environ.pop("OMP_NUM_THREADS", None)
+        else:
+            os.environ["OMP_NUM_THREADS"] = omp

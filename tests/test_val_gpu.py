@@ -107,12 +107,15 @@ def test_single_case_3d_matches_the_reference_function():
     sd = filler.fill_state_dict(net.state_dict())
     sd["final.weight"] = sd["final.weight"] * float(g["weight_scale"])
     net.load_state_dict(sd)
-    net.eval()
     for n in range(2):
+        # the training loop calls validation with the network in whatever mode it is in (train_mean_teacher_3D.py:201-204 sets
+        # eval() first; the drop-in switches itself and must hand the mode back): case 0 enters in train mode, case 1 in eval
+        net.train(n == 0)
         shape = tuple(int(v) for v in g[f"shape{n}"])
         image = filler.image((1, 1) + shape, "valvol")[0, 0].numpy()
         assert abs(float(image.astype(np.float64).sum()) - float(g[f"image_sum{n}"])) < 1e-6
         got = val_3D.test_single_case(net, image, stride, stride, patch, num_classes=2)
+        assert net.training == (n == 0), "test_single_case must restore the mode it was called in"
         want, ties = g[f"label_map{n}"], g[f"ties{n}"]
         assert got.shape == want.shape == shape
         diff = got != want
