@@ -83,7 +83,7 @@ extern __shared__ __attribute__((aligned(16))) float mis_gemm_lds[];
 #define MIS_GEMM_DBG_CT 0
 #endif
 // ablation builds of the NT kernel (timing only, results wrong): 1 no global stores in the float4 epilogue, 2 no DMA in
-// the k-loop, 4 no MFMAs, 8 no epilogue at all
+// the k-loop, 4 no MFMAs (fp32 form), 8 no epilogue at all, 16 / 32 no B / A split, 64 no MFMAs in the pre-split bf16x3 form
 constexpr int GDBG = MIS_GEMM_DBG_CT;
 
 // ------------------------------------------------------------------------------------------------ split-precision products
@@ -358,6 +358,11 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs a) {
 #pragma unroll
             for (int i = 0; i < G::MI; ++i) {
                 f32x4 c = acc[i][j];
+                if constexpr (GDBG & 64) {      // timing only: no MFMA (one integer op keeps every operand read alive)
+                    c[0] += __uint_as_float((al[i][0] ^ am[i][1] ^ ah[i][2] ^ bh[0] ^ bm[1] ^ bl[2]) & 0x007fffffu);
+                    acc[i][j] = c;
+                    continue;
+                }
                 c = bf3_mfma(al[i], bh, c);
                 c = bf3_mfma(ah[i], bl, c);
                 c = bf3_mfma(am[i], bm, c);
@@ -1963,7 +1968,10 @@ bool nt_rega_shape(int M, int N, int K) {
     // per-shape sweep at 48 images (scripts/gemm_nt_bench.py --rega, profiles/r06_gemm_nt_rega.txt): ahead of the staged kernels
     // for the 10^5-row stage and, at 4 x 10^4 rows, where the output is wider than the contraction; behind them below that
     static const int msq = getenv("MIS_GEMM_REGA_MSQ") ? atoi(getenv("MIS_GEMM_REGA_MSQ")) : 100000;
-    if (M < mmin || (M < msq && N <= K)) return false;
+    // N == 96 (proj / fc2 of a 96-channel block): the register-A kernels carry the residual add AND the next LayerNorm in their
+    // epilogue (mis_gemm_nt_residual_ln) -- a LayerNorm pass less outweighs the few us the staged kernel is ahead by at 7 x 10^4 rows
+    static const int n96 = getenv("MIS_GEMM_REGA_N96") ? atoi(getenv("MIS_GEMM_REGA_N96")) : 1;
+    if (M < mmin || (M < msq && N <= K && !(n96 && N == 96))) return false;
     return mis_cdiv(M, 128) * (N / 96) >= tmin;
 }
 
