@@ -820,6 +820,13 @@ __global__ __launch_bounds__(256) void gemm_nt_short_kernel(const GemmArgs a) {
 // ...sys.py:276-281, :244-250).  The row's 96 values sit in the four lanes (lj, g = 0 .. 3): two in-lane sums of 24 and two
 // cross-group steps each for mean and variance -- no LDS pass, and the LayerNorm launch with its read of x is gone.  gamma / beta
 // come from LDS (`gb`: [gamma 96][beta 96], staged by the kernel): a global load here would wait behind the A prefetch.
+#ifndef MIS_GEMM_REGA_PAIR
+#define MIS_GEMM_REGA_PAIR 1
+#endif
+// the value of the lane 8 positions away in this lane's 16-lane row (v_mov_b32_dpp row_ror:8)
+__device__ __forceinline__ float rega_ror8(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xF, 0xF, false));
+}
 template <int NJ, int EP, bool PRE = false>
 __device__ __forceinline__ void rega_store(const GemmArgs& a, const f32x4 (&acc)[2][NJ], int mrow, int n0, int lj, int g,
                                            const float4* bv = nullptr, const float4 (*ev)[NJ] = nullptr, const float* gb = nullptr) {
@@ -937,6 +944,72 @@ __device__ __forceinline__ void rega_store(const GemmArgs& a, const f32x4 (&acc)
         }
         return;
     }
+    // Stores in 128-byte runs: a lane group (lj, g = 0 .. 3) holds 64 contiguous bytes of its row per tile j, and HBM gives 64-byte
+    // pieces 3.1 TB/s where 128-byte pieces get 4.4 (scripts/ubench/hbm_pieces.hip).  So the lanes lj and lj ^ 8 of a 16-lane row
+    // trade halves of a PAIR of tiles (j, j + 1) -- one v_mov_dpp row_ror:8 per value -- and each store instruction writes rows
+    // (lj & 7) [+ 8] with eight lanes = 128 contiguous bytes per row: lanes lj < 8 the columns of tile j, lanes lj >= 8 those of
+    // tile j + 1 (MIS_GEMM_REGA_PAIR=0 at build time keeps the 64-byte form).
+#if MIS_GEMM_REGA_PAIR
+    static_assert(NJ % 2 == 0, "tile pairs");
+    const bool hi = lj >= 8;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int m = mrow + 16 * i + lj;
+        const bool live = m < a.M;
+        const float rs = (EP == EP_RESIDUAL && a.rowscale && live) ? a.rowscale[m / a.rps] : 1.f;
+        float4 out[NJ], out2[NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int n = n0 + 16 * j + 4 * g;
+            float4 v = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+            if constexpr (PRE) {
+                v.x += bv[j].x; v.y += bv[j].y; v.z += bv[j].z; v.w += bv[j].w;
+            } else if (a.bias) {
+                const float4 b = *reinterpret_cast<const float4*>(a.bias + n);
+                v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+            }
+            if constexpr (EP == EP_GELU_FWD) {
+                out2[j] = make_float4(gelu_f(v.x), gelu_f(v.y), gelu_f(v.z), gelu_f(v.w));
+            } else if constexpr (EP == EP_GELU_BWD) {
+                float4 h = make_float4(0.f, 0.f, 0.f, 0.f);
+                if constexpr (PRE) h = ev[i][j]; else if (live) h = *reinterpret_cast<const float4*>(a.E1 + (long long)m * a.lde1 + n);
+                v.x *= gelu_grad_f(h.x); v.y *= gelu_grad_f(h.y); v.z *= gelu_grad_f(h.z); v.w *= gelu_grad_f(h.w);
+            } else if constexpr (EP == EP_RESIDUAL) {
+                float4 sc = make_float4(0.f, 0.f, 0.f, 0.f);
+                if constexpr (PRE) sc = ev[i][j]; else if (live) sc = *reinterpret_cast<const float4*>(a.E1 + (long long)m * a.lde1 + n);
+                v.x = sc.x + rs * v.x; v.y = sc.y + rs * v.y; v.z = sc.z + rs * v.z; v.w = sc.w + rs * v.w;
+            } else {
+                if (a.accumulate) {
+                    float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if constexpr (PRE) o = ev[i][j]; else if (live) o = *reinterpret_cast<const float4*>(a.C + (long long)m * a.ldc + n);
+                    v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+                }
+            }
+            out[j] = v;
+        }
+        // rows of the two store instructions of a pair, and this lane's column in both
+        const int r1 = mrow + 16 * i + (lj & 7), r2 = r1 + 8;
+        const bool live1 = r1 < a.M, live2 = r2 < a.M;
+        auto paired = [&](const float4 (&o)[NJ], float* base, long long ld) {
+#pragma unroll
+            for (int j = 0; j < NJ; j += 2) {
+                const float4 A = o[j], B = o[j + 1];
+                const float4 send = hi ? A : B;
+                const float4 recv = make_float4(rega_ror8(send.x), rega_ror8(send.y), rega_ror8(send.z), rega_ror8(send.w));
+                const float4 d1 = hi ? recv : A, d2 = hi ? B : recv;
+                const int n = n0 + 16 * (j + (hi ? 1 : 0)) + 4 * g;
+                if (live1) *reinterpret_cast<float4*>(base + (long long)r1 * ld + n) = d1;
+                if (live2) *reinterpret_cast<float4*>(base + (long long)r2 * ld + n) = d2;
+            }
+        };
+        if constexpr (EP == EP_GELU_FWD) {
+            paired(out2, a.C2, a.ldc2);
+            if (a.C) paired(out, a.C, a.ldc);
+        } else {
+            paired(out, a.C, a.ldc);
+        }
+    }
+#else
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int m = mrow + 16 * i + lj;
@@ -976,6 +1049,7 @@ __device__ __forceinline__ void rega_store(const GemmArgs& a, const f32x4 (&acc)
             *reinterpret_cast<float4*>(cp) = v;
         }
     }
+#endif
 }
 
 template <int BN, int EP>
@@ -1116,6 +1190,27 @@ constexpr int rega_lds_bytes() { return 2 * (BN * BK * 3 / 2) * 4 + 768; }      
 template <int NJ>
 __device__ __forceinline__ void rega_store_plain(const GemmArgs& a, const f32x4 (&acc)[2][NJ], int mrow, int n0, int lj, int g,
                                                  const float4* bv) {
+#if MIS_GEMM_REGA_PAIR
+    // 128-byte runs per row and store instruction (see rega_store)
+    const bool hi = lj >= 8;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int r1 = mrow + 16 * i + (lj & 7), r2 = r1 + 8;
+        const bool live1 = r1 < a.M, live2 = r2 < a.M;
+#pragma unroll
+        for (int j = 0; j < NJ; j += 2) {
+            const float4 A = make_float4(acc[i][j][0] + bv[j].x, acc[i][j][1] + bv[j].y, acc[i][j][2] + bv[j].z, acc[i][j][3] + bv[j].w);
+            const float4 B = make_float4(acc[i][j + 1][0] + bv[j + 1].x, acc[i][j + 1][1] + bv[j + 1].y, acc[i][j + 1][2] + bv[j + 1].z,
+                                         acc[i][j + 1][3] + bv[j + 1].w);
+            const float4 send = hi ? A : B;
+            const float4 recv = make_float4(rega_ror8(send.x), rega_ror8(send.y), rega_ror8(send.z), rega_ror8(send.w));
+            const float4 d1 = hi ? recv : A, d2 = hi ? B : recv;
+            const int n = n0 + 16 * (j + (hi ? 1 : 0)) + 4 * g;
+            if (live1) *reinterpret_cast<float4*>(a.C + (long long)r1 * a.ldc + n) = d1;
+            if (live2) *reinterpret_cast<float4*>(a.C + (long long)r2 * a.ldc + n) = d2;
+        }
+    }
+#else
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int m = mrow + 16 * i + lj;
@@ -1128,6 +1223,7 @@ __device__ __forceinline__ void rega_store_plain(const GemmArgs& a, const f32x4 
                 make_float4(acc[i][j][0] + bv[j].x, acc[i][j][1] + bv[j].y, acc[i][j][2] + bv[j].z, acc[i][j][3] + bv[j].w);
         }
     }
+#endif
 }
 
 // The same kernel for K <= 96 (the 96-channel stage: qkv / proj / fc1 forward, proj / fc2 data gradient -- ~2 ms of a SwinUnet step

@@ -23,7 +23,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, out_dir, overlap, kind):
+def _worker(rank, world, port, out_dir, overlap, kind, steps=3, taped=False):
     os.environ["MIS_GRAD_OVERLAP"] = "1" if overlap else "0"
     for p in (os.path.join(ROOT, "cv-ssl-mis_amd"), ROOT, os.path.join(ROOT, "tests")):
         sys.path.insert(0, p)
@@ -62,12 +62,17 @@ def _worker(rank, world, port, out_dir, overlap, kind):
     lab = torch.randint(0, C, (shape[0],) + shape[2:], generator=g, device="cuda").to(torch.int64 if kind == "unet3d" else torch.uint8)
     noise = torch.zeros((1,) + shape[1:], device="cuda")                 # injected: no device RNG in the comparison
     model.dropout_enabled = ema.dropout_enabled = False
-    for _ in range(3):
+    for _ in range(steps):
         if kind == "cross":
             out1, _ = tr.step(vol, lab)
         else:
-            tr.step(vol, lab, noise=noise)
+            # taped: the teacher noise comes from the device RNG (an injected tensor keeps the step eager); the same seed on both
+            # ranks, so only the shards differ
+            tr.step(vol, lab, noise=None if taped else noise)
     torch.cuda.synchronize()
+    if taped:
+        # steps 4.. were replays of the recorded launch sequence, the bucketer's collectives among its entries
+        assert mstep.STEP_TAPE and tr._tape is not None and len(tr._tape) > 50
     loss = float(out1[0]) if kind == "cross" else tr.losses()["loss"]
     torch.save(dict(student=model.flat_param.cpu(), teacher=ema.flat_param.cpu(), loss=loss),
                os.path.join(out_dir, f"{kind}_{int(overlap)}_{rank}.pt"))
@@ -87,6 +92,24 @@ def test_two_ranks_on_one_gpu_exchange_gradients(tmp_path, kind):
         assert torch.equal(r[(o, 0)]["teacher"], r[(o, 1)]["teacher"])
         assert r[(o, 0)]["loss"] != r[(o, 1)]["loss"]                    # the shards really differ
     # overlapped, bucketed exchange == one blocking all-reduce
+    assert torch.equal(r[(0, 0)]["student"], r[(1, 0)]["student"])
+    assert torch.equal(r[(0, 0)]["teacher"], r[(1, 0)]["teacher"])
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("kind", ["unet2d", "cross"])
+def test_two_ranks_replay_the_launch_tape_with_the_exchange_inside(tmp_path, kind):
+    """Six steps on two ranks (gloo): the third is recorded, steps 4 - 6 are REPLAYS of the launch tape whose entries include the
+    bucketer's advance / finish calls -- the collectives are issued from the tape in the recorded order on both ranks.  Ranks end
+    with identical weights, and the overlapped bucketed exchange equals the blocking all-reduce bit for bit, as in the eager test."""
+    world = 2
+    for overlap in (0, 1):
+        mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), overlap, kind, 6, True), nprocs=world, join=True)
+    r = {(o, k): torch.load(os.path.join(tmp_path, f"{kind}_{o}_{k}.pt")) for o in (0, 1) for k in (0, 1)}
+    for o in (0, 1):
+        assert torch.equal(r[(o, 0)]["student"], r[(o, 1)]["student"]), "ranks diverged"
+        assert torch.equal(r[(o, 0)]["teacher"], r[(o, 1)]["teacher"])
+        assert r[(o, 0)]["loss"] != r[(o, 1)]["loss"]
     assert torch.equal(r[(0, 0)]["student"], r[(1, 0)]["student"])
     assert torch.equal(r[(0, 0)]["teacher"], r[(1, 0)]["teacher"])
 
