@@ -298,6 +298,9 @@ def run_workload(name, args, rank, world, kernel_events=True):
         tr.step(vol, lab)
     # the product step is a launch tape (mis_hip/step.py::_TapedStep: two eager steps, one recorded, then replays): the timed
     # region must be replays whatever --warmup says (more untimed steps than asked for, never fewer)
+    pmc_child = bool(getattr(args, "pmc_child", False))     # the re-execution under rocprofv3 --pmc (inrun_traffic): as few launches as
+    if pmc_child and hasattr(tr, "use_tape"):               # possible -- every launch is serialised around its counter reads there
+        tr.use_tape = False
     for _ in range(4):
         if not getattr(tr, "use_tape", False) or getattr(tr, "_tape", None) is not None:
             break
@@ -308,7 +311,7 @@ def run_workload(name, args, rank, world, kernel_events=True):
     # not that once the host is faster than the device: the runtime's queues fill up and the loop waits for the device in them
     # (20 steps of ~600 launches), i.e. it converges to the device time
     host_enqueue_ms = host_loop_ms
-    if not stub:
+    if not stub and not pmc_child:
         one = []
         for _ in range(5):
             sync()
@@ -566,7 +569,8 @@ def _physical_cores():
     return os.cpu_count() or 1
 
 
-def cpu_baseline(kind, wl, timed=5, warm=2, budget_s=150.0, cands=(16, 32, 64), full_batch=True, also_threads=None):
+def cpu_baseline(kind, wl, timed=5, warm=2, budget_s=150.0, cands=(16, 32, 64), full_batch=True, also_threads=None, deadline=None,
+                 min_timed=3):
     """The oracle step (reference arithmetic on stock torch CPU ops, dropout + noise active) on this host's cores.
     ``torch.set_num_threads`` is swept over ``cands`` on the reduced batch ``wl["cpu_sample"]`` of the same geometry
     (1 warm-up + 1 timed step each; 8 and the physical core count lost every sweep of rounds 2-4 and are no longer
@@ -641,12 +645,27 @@ def cpu_baseline(kind, wl, timed=5, warm=2, budget_s=150.0, cands=(16, 32, 64), 
                     sample=f"oracle.step.mean_teacher_step on the REDUCED batch {Ls}+{Bs - Ls} of {sp}: 1 warm-up + 3 timed steps, "
                            f"median {t:.3f} s/step, at {best} threads (best of {sorted(sweep)} on this batch), torch "
                            f"{torch.__version__} CPU")
-    for _ in range(warm):
+    # ``deadline`` (time.perf_counter() value, the caller's budget for the whole CPU leg): host speed differs by 2x between boxes
+    # of the pool, so a slow host gives up the second warm-up step and the timed steps beyond ``min_timed`` rather than the run's
+    # "minutes" contract; what was actually run is what `sample` / warmup_steps / timed_steps report
+    late = (lambda: deadline is not None and time.perf_counter() > deadline)
+    first = full()
+    warm_done = 1
+    while warm_done < warm and not (deadline is not None and time.perf_counter() + (timed + 1) * first > deadline):
         full()
-    times = sorted(full() for _ in range(timed))
+        warm_done += 1
+    warm = warm_done
+    times = []
+    for k in range(timed):
+        if k >= min_timed and late():
+            break
+        times.append(full())
+    timed = len(times)
+    times = sorted(times)
     t = times[len(times) // 2]
     other = None
-    if also_threads and also_threads != best and also_threads <= logical:
+    if also_threads and also_threads != best and also_threads <= logical and \
+            not (deadline is not None and time.perf_counter() + 2.2 * t > deadline):
         # the thread count was chosen on the reduced batch: one full-batch step at another count settles whether it holds there
         torch.set_num_threads(also_threads)
         full()
@@ -703,7 +722,7 @@ def inrun_traffic(workload, dom, alg_bytes, budget_s=90.0):
             out = os.path.join(tmp, counter)
             cmd = [exe, "--pmc", counter, "--kernel-trace", "-d", out, "-o", "pmc", "--output-format", "csv", "--",
                    sys.executable, os.path.abspath(__file__), "--workload", workload, "--serial", "--steps", "2",
-                   "--warmup", "1", "--no-cpu-baseline", "--no-others", "--no-kernel-events", "--no-traffic"]
+                   "--warmup", "1", "--no-cpu-baseline", "--no-others", "--no-kernel-events", "--no-traffic", "--pmc-child"]
             try:
                 p = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True,
                                    errors="replace", timeout=left)
@@ -737,6 +756,10 @@ def inrun_traffic(workload, dom, alg_bytes, budget_s=90.0):
 
 # ------------------------------------------------------------------------------------------------ main
 def main():
+    marks = [("start", time.perf_counter())]          # wall-clock phases of this process, reported as `timing_s` (rank 0, N = 1)
+
+    def mark(name):
+        marks.append((name, time.perf_counter()))
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -751,6 +774,7 @@ def main():
                     help="side streams off in the timed region too (MIS_TWO_STREAM=0 MIS_WGRAD_STREAM=0): every kernel has "
                          "the chip to itself -- what the rocprofv3 kernel statistics under profiles/ are collected with")
     ap.add_argument("--stub", action="store_true", help=argparse.SUPPRESS)   # CPU/gloo launcher test only
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)   # set by inrun_traffic for its re-execution
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -838,6 +862,7 @@ def main():
                 "mis_gemm_set_split_precision(0) / MIS_GEMM_BF3=0 selects the fp32 MFMA)")
         if args.stub:
             out["data"] = "stub (CPU/gloo launcher test, not a measurement)"
+    mark("setup_and_headline")
     if not _dist_on(world) and not args.stub and not args.no_others and args.workload == "unet3d":
         # the other single-GPU configurations of BASELINE.json, shorter runs of the same protocol
         import copy
@@ -878,6 +903,7 @@ def main():
                                 dominant_kernel=rf.get("kernel"), dominant_kernel_frac=rf.get("frac"),
                                 dominant_kernel_algorithmic_tflops=rf.get("algorithmic_tflops"))
         out["others"] = others
+        mark("others")
     if _dist_on(world) and not args.no_others and args.workload == "unet3d":
         # config 5 (cross teaching, the BASELINE configuration that is DEFINED on 8 GPUs: 16+16 images per GPU) behind the
         # default workload: two students, two gradient bucketers, the second student's backward on a side stream
@@ -904,18 +930,27 @@ def main():
             rf["traffic"] = tr
             if tr is None:
                 rf["traffic_unavailable"] = why
+            mark("traffic")
         if single and not args.no_cpu_baseline and wl["cpu_sample"] is not None:
-            out["cpu_baseline"] = cpu_baseline(args.workload, wl, also_threads=64 if args.workload == "unet3d" else None)
+            # one budget for the CPU legs of the line (MIS_BENCH_CPU_BUDGET_S, default 170 s; 120 of them for the headline workload)
+            cpu_t0 = time.perf_counter()
+            cpu_budget = float(os.environ.get("MIS_BENCH_CPU_BUDGET_S", "170"))
+            out["cpu_baseline"] = cpu_baseline(args.workload, wl, also_threads=64 if args.workload == "unet3d" else None,
+                                               deadline=cpu_t0 + cpu_budget * 0.7)
             out["gpu_over_cpu"] = round(out["value"] / out["cpu_baseline"]["value"], 2)
             if "others" in out and "swin" in out["others"] and args.workload == "unet3d":
                 o4 = out["others"]["swin"]
-                o4["cpu_baseline"] = cpu_baseline("swin", WORKLOADS["swin"], budget_s=40.0, cands=(16, 32), full_batch=False)
+                o4["cpu_baseline"] = cpu_baseline("swin", WORKLOADS["swin"], budget_s=40.0, cands=(16, 32), full_batch=False)      # ~5 s
                 o4["gpu_over_cpu"] = round(o4["value"] / o4["cpu_baseline"]["value"], 2)
             if "others" in out and "unet2d" in out["others"] and args.workload == "unet3d":
                 # the ACDC figure the north star asks for beside the BraTS one: the same oracle step on config 2's batch
                 o2 = out["others"]["unet2d"]
-                o2["cpu_baseline"] = cpu_baseline("unet2d", WORKLOADS["unet2d"], budget_s=60.0)
+                o2["cpu_baseline"] = cpu_baseline("unet2d", WORKLOADS["unet2d"], budget_s=60.0, deadline=cpu_t0 + cpu_budget)
                 o2["gpu_over_cpu"] = round(o2["value"] / o2["cpu_baseline"]["value"], 2)
+        if single:
+            mark("cpu_baseline")
+            out["timing_s"] = {b[0]: round(b[1] - a[1], 1) for a, b in zip(marks, marks[1:])}
+            out["timing_s"]["total"] = round(marks[-1][1] - marks[0][1], 1)
         print(json.dumps(out), flush=True)
     if _dist_on(world):
         torch.distributed.destroy_process_group()
