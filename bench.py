@@ -374,9 +374,12 @@ def run_workload(name, args, rank, world, kernel_events=True):
             """The Linear GEMMs in their bf16x3 form (gemm.hip: last template argument 1, or 2 = B pre-split by
             mis_gemm_split_batch): every algorithmic multiply-add is six bf16 piece products (v_mfma_f32_16x16x32_bf16;
             16x16x16 in the short-contraction kernel), priced against the dense bf16 matrix peak."""
-            t = k.rstrip(" >")
-            return (k.startswith(("gemm_nt_kernel<", "gemm_nt_short_kernel<")) and t.endswith((", 1", ", 2"))) or \
-                k.startswith("gemm_tn_reg_kernel<1")
+            targs = k[k.index("<") + 1:].rstrip(" >").split(", ") if "<" in k else []
+            if k.startswith("gemm_nt_kernel<"):          # <BM, BN, EP, PREC, waves per workgroup>
+                return len(targs) >= 4 and targs[3] in ("1", "2")
+            if k.startswith("gemm_nt_short_kernel<"):    # <BN, EP, PREC>
+                return bool(targs) and targs[-1] in ("1", "2")
+            return k.startswith("gemm_tn_reg_kernel<1")
 
         def pipe_seconds(k, flops):
             """Time the matrix pipe needs for this launch's EXECUTED flops at its peak."""

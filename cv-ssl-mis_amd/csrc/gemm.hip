@@ -165,9 +165,13 @@ bool gemm_bf3() { return gemm_bf3_state().load(std::memory_order_relaxed) & 1; }
 bool gemm_bf3_tn() { return gemm_bf3_state().load(std::memory_order_relaxed) & 2; }
 
 // ------------------------------------------------------------------------------------------------ NT
-template <int BMT, int BN, int PREC = 0>
+// NW waves per workgroup: 4 (2 x 2 wave tiles of BMT/2 x BN/2) or 8 (4 x 2 wave tiles of BMT/4 x BN/2: the same tile, stages and
+// LDS, twice the waves per SIMD -- the operand stage is what limits residency (52 KB: three workgroups per CU), the kernel needs
+// ~75 registers, and what the k-loop lacks is waves to hide its per-k-step DMA wait and barrier behind: profiles/r06_gemm_nt_pmc.txt)
+template <int BMT, int BN, int PREC = 0, int NW = 4>
 struct NtCfg {
-    static constexpr int MI = BMT / 32;                   // 16-row MFMA tiles per wave (wave = BMT/2 x BN/2)
+    static constexpr int WROWS = BMT / (NW / 2);          // rows of a wave tile
+    static constexpr int MI = WROWS / 16;                 // 16-row MFMA tiles per wave
     static constexpr int NJ = BN / 32;                    // 16-column MFMA tiles per wave
     // PREC = 2: the B stage holds three bf16 planes [BN][32] (64-byte rows) instead of fp32 [BN][32]
     static constexpr int A_FLOATS = BMT * BK, B_FLOATS = PREC == 2 ? BN * BK * 3 / 2 : BN * BK;
@@ -177,18 +181,23 @@ struct NtCfg {
     // apart) so that C -- and the operands of the fused epilogues -- move as float4 rows instead of 64-byte dword pieces
     static constexpr int LDC_T = BN + 4;
     static constexpr int CT_FLOATS = BMT * LDC_T;
+    // (a ring of THREE stages -- two in flight per workgroup, two workgroups per CU -- was measured in round 6 and is slower: 1335
+    // -> 1514 us over the 20 shapes of a step, profiles/r06_gemm_nt_stages.txt; residency hides more than prefetch depth)
     static constexpr int LDS_FLOATS = 2 * STAGE > CT_FLOATS ? 2 * STAGE : CT_FLOATS;
     static constexpr int LDS_BYTES = LDS_FLOATS * 4;      // double-buffered operand stage, re-used by the epilogue
     static constexpr int PA = BMT / 8, PB = BN / 8;       // 8-row DMA pieces of the A / B tile
-    static_assert(BMT % 32 == 0 && BN % 32 == 0 && PA % 4 == 0 && PB % 4 == 0, "pieces split evenly over 4 waves");
+    static_assert(NW == 4 || NW == 8, "2 x 2 or 4 x 2 waves");
+    static_assert(BMT % 32 == 0 && BN % 32 == 0 && PA % NW == 0 && (PREC == 2 || PB % NW == 0), "pieces split evenly over the waves");
+    static_assert(WROWS % 16 == 0 && (BMT * (BN / 4)) % (NW * 64) == 0, "wave tiles / epilogue rows");
 };
 
 // EP: compile-time epilogue (EP_NONE / EP_GELU_FWD / EP_GELU_BWD / EP_RESIDUAL).  The fused epilogues are separate
 // instantiations: compiled into the plain kernel they cost it 41 registers and one resident workgroup per CU
 // (measured: every Linear of the step slowed down, 38.5 -> 41.7 ms).
-template <int BMT, int BN, int EP, int PREC = 0>
-__global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs a) {
-    using G = NtCfg<BMT, BN, PREC>;
+template <int BMT, int BN, int EP, int PREC = 0, int NW = 4>
+__global__ __launch_bounds__(NW * 64) void gemm_nt_kernel(const GemmArgs a) {
+    using G = NtCfg<BMT, BN, PREC, NW>;
+    static_assert(NW == 4 || EP != EP_LNHEAD, "the fused tail's row passes assume 256 threads");
     float* const lds = mis_gemm_lds;
 
     const unsigned L = mis_xcd_remap(blockIdx.x, a.n_blocks_padded);
@@ -201,7 +210,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs a) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lk = lane >> 4, lj = lane & 15;
-    const int wm = (wave >> 1) * (BMT / 2), wn = (wave & 1) * (BN / 2);
+    const int wm = (wave >> 1) * G::WROWS, wn = (wave & 1) * (BN / 2);
     const int m0 = tm * BMT, n0 = tn * BN;
     const int kbeg = kz * a.kchunk;
     const int kend = kbeg + a.kchunk < a.K ? kbeg + a.kchunk : a.K;
@@ -212,30 +221,30 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs a) {
     // per-lane DMA source offsets (bytes, without the k-step term): piece p = 8 rows x 32 k (64 lanes x 16 B);
     // lane -> row p*8 + (lane>>3), LDS k-slot (lane&7)*4 holds source k = slot ^ swz(row).  (row>>1)&7 only depends
     // on lane>>4 and the piece parity, and a wave's pieces w, w+4, ... share their parity: one ksrc per lane.
-    unsigned voA[G::PA / 4], voB[G::PB / 4];
+    unsigned voA[G::PA / NW], voB[(G::PB + NW - 1) / NW];
     const int ksrc = ((lane & 7) * 4) ^ ((((wave * 8 + (lane >> 3)) >> 1) & 7) * 4);
 #pragma unroll
-    for (int i = 0; i < G::PA / 4; ++i) {
-        const int row = (wave + 4 * i) * 8 + (lane >> 3);
+    for (int i = 0; i < G::PA / NW; ++i) {
+        const int row = (wave + NW * i) * 8 + (lane >> 3);
         voA[i] = m0 + row < a.M ? (unsigned)((long long)(m0 + row) * a.lda + ksrc) * 4u : OOB;
     }
     if constexpr (PREC != 2) {
 #pragma unroll
-        for (int i = 0; i < G::PB / 4; ++i) {
-            const int row = (wave + 4 * i) * 8 + (lane >> 3);
+        for (int i = 0; i < G::PB / NW; ++i) {
+            const int row = (wave + NW * i) * 8 + (lane >> 3);
             voB[i] = n0 + row < a.N ? (unsigned)((long long)(n0 + row) * a.ldb + ksrc) * 4u : OOB;
         }
     }
     // PREC = 2: piece q = (plane q / RB3, rows (q % RB3) * 16 ..+16) x 64 bytes of the k-step: lane -> row lane >> 2, 16-byte
     // group lane & 3 (= the 8 contraction elements of lane group lk, in the order mis_gemm_split_b stored them); the 1 KiB a
     // DMA instruction writes is 16 whole rows of the plane, and a wave's operand read is one contiguous KiB again: no swizzle
-    constexpr int NB3 = (G::PB3 + 3) / 4;
+    constexpr int NB3 = (G::PB3 + NW - 1) / NW;
     unsigned voB3[NB3];
     const i32x4 rB3 = PREC == 2 ? make_rsrc(a.B3, 3u * a.b3_plane) : rB;
     if constexpr (PREC == 2) {
 #pragma unroll
         for (int i = 0; i < NB3; ++i) {
-            const int q = wave + 4 * i, plane = q / G::RB3, row = (q % G::RB3) * 16 + (lane >> 2);
+            const int q = wave + NW * i, plane = q / G::RB3, row = (q % G::RB3) * 16 + (lane >> 2);
             voB3[i] = (q < G::PB3 && n0 + row < a.N)
                           ? (unsigned)plane * a.b3_plane + (unsigned)(((long long)(n0 + row) * a.K3 + (lane & 3) * 8) * 2)
                           : OOB;
@@ -247,16 +256,16 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs a) {
         const bool kout = k0 + BK > kend && k0 + ksrc >= kend;   // only the last k-step can be partial
         const unsigned kb = (unsigned)k0 * 4u;
 #pragma unroll
-        for (int i = 0; i < G::PA / 4; ++i) dma_dwordx4(st + (unsigned)((wave + 4 * i) * 256) * 4u, kout ? OOB : voA[i] + kb, rA);
+        for (int i = 0; i < G::PA / NW; ++i) dma_dwordx4(st + (unsigned)((wave + NW * i) * 256) * 4u, kout ? OOB : voA[i] + kb, rA);
         if constexpr (PREC == 2) {
 #pragma unroll
             for (int i = 0; i < NB3; ++i)
-                if (wave + 4 * i < G::PB3)      // uniform; the planes are zero beyond K: no k test
-                    dma_dwordx4(st + (unsigned)(G::A_FLOATS * 4 + (wave + 4 * i) * 1024), voB3[i] + (unsigned)k0 * 2u, rB3);
+                if (wave + NW * i < G::PB3)      // uniform; the planes are zero beyond K: no k test
+                    dma_dwordx4(st + (unsigned)(G::A_FLOATS * 4 + (wave + NW * i) * 1024), voB3[i] + (unsigned)k0 * 2u, rB3);
         } else {
 #pragma unroll
-            for (int i = 0; i < G::PB / 4; ++i)
-                dma_dwordx4(st + (unsigned)(G::A_FLOATS + (wave + 4 * i) * 256) * 4u, kout ? OOB : voB[i] + kb, rB);
+            for (int i = 0; i < G::PB / NW; ++i)
+                dma_dwordx4(st + (unsigned)(G::A_FLOATS + (wave + NW * i) * 256) * 4u, kout ? OOB : voB[i] + kb, rB);
         }
     };
 
@@ -519,8 +528,8 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs a) {
         __syncthreads();
         constexpr int Q = BN / 4;
 #pragma unroll 4
-        for (int it = 0; it < BMT * Q / 256; ++it) {
-            const int e = tid + it * 256;
+        for (int it = 0; it < BMT * Q / (NW * 64); ++it) {
+            const int e = tid + it * (NW * 64);
             const int row = e / Q, q = e - row * Q;
             const int m = m0 + row, n = n0 + q * 4;
             if (m >= a.M || n >= a.N) continue;
@@ -1938,14 +1947,31 @@ bool a16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 // works because ITS operands are contraction-major and a lane group reads 128 contiguous bytes.  The NT GEMMs need the transpose
 // that the LDS stage provides.  Removed; scripts/gemm_nt_bench.py is the measurement.)
 
+template <int BMT, int BN, int EP, int PREC, int NW = 4>
+int launch_nt_waves(const GemmArgs& a, hipStream_t stream) {
+    static std::atomic<unsigned long long> attr_done{0};   // per instantiation, one bit per device
+    using G = NtCfg<BMT, BN, PREC, NW>;
+    if (mis_set_lds_attr(reinterpret_cast<const void*>(&gemm_nt_kernel<BMT, BN, EP, PREC, NW>), G::LDS_BYTES, attr_done) != MIS_OK)
+        return MIS_ERR_LAUNCH;
+    hipLaunchKernelGGL((gemm_nt_kernel<BMT, BN, EP, PREC, NW>), dim3(a.n_blocks_padded), dim3(NW * 64), G::LDS_BYTES, stream, a);
+    return mis_launch_status();
+}
+
+// MIS_GEMM_NT_WAVES=8: eight waves per workgroup for the 64 x 96 tiles of the pre-split form.  Measured (profiles/r06_gemm_nt_waves.txt):
+// alone, most shapes gain 3 .. 10 % (six waves per SIMD hide the k-step's DMA wait and barrier), the split-K shapes lose 4 .. 11 %,
+// 1305 -> 1293 us over the 20 shapes of a step; INSIDE the step, where the weight-gradient and teacher streams already fill the idle
+// issue slots, it is 0.1 .. 0.15 ms SLOWER (SwinUnet 18.69 -> 18.80 ms, cross teaching 18.95 -> 19.12).  Default: four.
+inline bool nt_eight_waves() {
+    static const int w = getenv("MIS_GEMM_NT_WAVES") ? atoi(getenv("MIS_GEMM_NT_WAVES")) : 4;
+    return w == 8;
+}
+
 template <int BMT, int BN, int EP, int PREC>
 int launch_nt_prec(const GemmArgs& a, hipStream_t stream) {
-    static std::atomic<unsigned long long> attr_done{0};   // per instantiation, one bit per device
-    using G = NtCfg<BMT, BN, PREC>;
-    if (mis_set_lds_attr(reinterpret_cast<const void*>(&gemm_nt_kernel<BMT, BN, EP, PREC>), G::LDS_BYTES, attr_done) != MIS_OK)
-        return MIS_ERR_LAUNCH;
-    hipLaunchKernelGGL((gemm_nt_kernel<BMT, BN, EP, PREC>), dim3(a.n_blocks_padded), dim3(256), G::LDS_BYTES, stream, a);
-    return mis_launch_status();
+    if constexpr (BMT == 64 && BN == 96 && PREC == 2 && EP != EP_LNHEAD) {
+        if (nt_eight_waves()) return launch_nt_waves<BMT, BN, EP, PREC, 8>(a, stream);
+    }
+    return launch_nt_waves<BMT, BN, EP, PREC, 4>(a, stream);
 }
 
 template <int BMT, int BN, int EP>
@@ -2150,7 +2176,7 @@ extern "C" int mis_gemm_nt_kernel_name(int M, int N, int K, int epilogue, char* 
     a.M = M; a.N = N; a.K = K; a.vec4 = N % 4 == 0; a.KS = pick_ks(M, N, K, 0);
     const int bn = nt_tile_n(N);
     if (nt_short(a)) snprintf(name, name_len, "gemm_nt_short_kernel<%d, %d, %d>", bn, epilogue, gemm_bf3() ? 1 : 0);
-    else snprintf(name, name_len, "gemm_nt_kernel<%d, %d, %d, %d>", nt_tile_m(M, N, K), bn, a.KS > 1 ? 0 : epilogue, gemm_bf3() ? 1 : 0);
+    else snprintf(name, name_len, "gemm_nt_kernel<%d, %d, %d, %d, 4>", nt_tile_m(M, N, K), bn, a.KS > 1 ? 0 : epilogue, gemm_bf3() ? 1 : 0);
     return MIS_OK;
 }
 
@@ -2159,7 +2185,8 @@ extern "C" int mis_gemm_nt_split_kernel_name(int M, int N, int K, int epilogue, 
     if (M <= 0 || N <= 0 || K <= 0 || !name || name_len <= 0) return MIS_ERR_ARG;
     int bm, bn, ks;
     if (!b3_choice(M, N, K, bm, bn, ks)) return MIS_ERR_UNSUPPORTED;
-    snprintf(name, name_len, "gemm_nt_kernel<%d, %d, %d, 2>", bm, bn, ks > 1 ? 0 : epilogue);
+    const int ep = ks > 1 ? 0 : epilogue;
+    snprintf(name, name_len, "gemm_nt_kernel<%d, %d, %d, 2, %d>", bm, bn, ep, (bm == 64 && bn == 96 && ep != EP_LNHEAD && nt_eight_waves()) ? 8 : 4);
     return MIS_OK;
 }
 static int split_k3(int K);

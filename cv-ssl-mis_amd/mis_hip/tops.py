@@ -412,7 +412,7 @@ def gemm_expand_ln_head(x, w, out, B, H, W, P, c, gamma, beta, head_w, mean, rst
     if prof is not None:
         e1.record()
         prec = 1 if (set_split_precision(-1) & 1) else 0
-        prof.append((f"gemm_nt_kernel<64, 96, 4, {prec}>", 2.0 * M * N * K, e0, e1, 4.0 * (M * K + N * K + (M * N if out is not None else 0))))
+        prof.append((f"gemm_nt_kernel<64, 96, 4, {prec}, 4>", 2.0 * M * N * K, e0, e1, 4.0 * (M * K + N * K + (M * N if out is not None else 0))))
     return True
 
 

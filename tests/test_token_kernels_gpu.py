@@ -53,7 +53,7 @@ def test_gemm_nt_and_tn(M, N, K, prec):
     # products of the general kernel win from K = 192 on (last template argument: 1 = bf16x3)
     assert name.value.decode().startswith("gemm_nt_short_kernel<") == (M >= 33000 and (not prec & 1 or K <= 96))
     if not name.value.decode().startswith("gemm_nt_short_kernel<"):
-        assert name.value.decode().endswith(", %d>" % (prec & 1))
+        assert name.value.decode().endswith(", %d, 4>" % (prec & 1))      # <BM, BN, EP, arithmetic, waves per workgroup>
     C = torch.empty(M, N, device="cuda")
     tops.gemm(Ad, Bd, C, bias=bias.cuda())
     _close(C, ref)
