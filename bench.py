@@ -822,7 +822,13 @@ def main():
 
     wl = WORKLOADS[args.workload]
     try:
-        res = run_workload(args.workload, args, rank, world, kernel_events=not args.no_kernel_events)
+        if os.environ.get("MIS_MAIN_PRIORITY") and not args.stub:
+            # experiment: the whole workload on a stream of this HIP priority (the side streams keep the default one)
+            import torch as _t
+            with _t.cuda.stream(_t.cuda.Stream(priority=int(os.environ["MIS_MAIN_PRIORITY"]))):
+                res = run_workload(args.workload, args, rank, world, kernel_events=not args.no_kernel_events)
+        else:
+            res = run_workload(args.workload, args, rank, world, kernel_events=not args.no_kernel_events)
     except BaseException as e:
         if _dist_on(world) and rank == 0 and "MIS_BENCH_LAUNCHED" not in os.environ:
             print(json.dumps({"metric": "training images-or-volumes/sec/node (Mean-Teacher step)", "value": None,

@@ -429,3 +429,13 @@ def require_gpu(*tensors):
         if t is not None and not t.is_cuda:
             raise RuntimeError("mis_hip kernels need device tensors (HIP/gfx950); got a CPU tensor. "
                                "There is no CPU fallback in the product path.")
+
+
+def side_stream(kind):
+    """A side stream of the step (``kind``: "wgrad" = the weight-gradient stream of a plan, "side" = the teacher / second network of a
+    trainer).  MIS_WGRAD_PRIORITY / MIS_SIDE_PRIORITY give it a HIP stream priority (torch's convention: lower = more urgent, the
+    range is ``torch.cuda.Stream.priority_range()``); unset: the default priority, like the main stream."""
+    p = os.environ.get({"wgrad": "MIS_WGRAD_PRIORITY", "side": "MIS_SIDE_PRIORITY"}[kind])
+    if p is None or p == "":
+        return torch.cuda.Stream()
+    return torch.cuda.Stream(priority=int(p))

@@ -805,7 +805,7 @@ class Plan:
         side = None
         if WGRAD_STREAM:
             if self._wgrad_stream is None:
-                self._wgrad_stream = torch.cuda.Stream()
+                self._wgrad_stream = _lib.side_stream("wgrad")
             side = self._wgrad_stream
         ctx.wgrad_stream = side
         ctx.deferred = [] if side is not None else None      # see defer(): finishing launches queued for the side stream

@@ -130,7 +130,7 @@ class MeanTeacherTrainer(_TapedStep):
             # and fills the CUs the student's small deep layers leave idle
             main = torch.cuda.current_stream()
             if self._side is None:
-                self._side = torch.cuda.Stream()
+                self._side = _lib.side_stream("side")
             _lib.wait_stream(self._side, main)
             with torch.cuda.stream(self._side):
                 t_logits = self.ema_model.forward_raw(self._ema_in, no_backward=True)
@@ -241,7 +241,7 @@ class UAMTTrainer(MeanTeacherTrainer):
             # the student in the loss tail: they run on a side stream beside the student's forward (bit-identical)
             main = torch.cuda.current_stream()
             if self._side is None:
-                self._side = torch.cuda.Stream()
+                self._side = _lib.side_stream("side")
             _lib.wait_stream(self._side, main)
             with torch.cuda.stream(self._side):
                 t_logits = teacher_passes()
@@ -331,7 +331,7 @@ class CrossTeachingTrainer(_TapedStep):
             # the two students only meet in the loss tails: model2's forward and backward run on a side stream
             main = torch.cuda.current_stream()
             if self._side is None:
-                self._side = torch.cuda.Stream()
+                self._side = _lib.side_stream("side")
             _lib.wait_stream(self._side, main)
             with torch.cuda.stream(self._side):
                 o2 = self.model2.forward_raw(volume_batch)
@@ -475,7 +475,7 @@ class CnnMeetVitTrainer(_TapedStep):
             # Transformer student -- roughly equal work; later the CNN's backward beside the Transformer's.  Bit-identical
             main = torch.cuda.current_stream()
             if self._side is None:
-                self._side = torch.cuda.Stream()
+                self._side = _lib.side_stream("side")
             _lib.wait_stream(self._side, main)
             with torch.cuda.stream(self._side):
                 o1 = self.model1.forward_raw(volume_batch)

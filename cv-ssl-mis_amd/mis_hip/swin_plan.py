@@ -760,7 +760,7 @@ class SwinPlan:
         main, side = torch.cuda.current_stream(), None
         if _plan.WGRAD_STREAM:
             if self._wgrad_stream is None:
-                self._wgrad_stream = torch.cuda.Stream()
+                self._wgrad_stream = _lib.side_stream("wgrad")
             side = self._wgrad_stream
         ctx.wgrad_stream = side
         ctx.deferred = [] if side is not None else None
