@@ -65,3 +65,25 @@ def test_single_process_default_and_world_mismatch():
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--stub", "--gpus", "4"], capture_output=True,
                        text=True, timeout=300, env=env)
     assert p.returncode != 0 and "must equal --gpus" in p.stderr
+
+
+def test_cpu_baseline_gives_up_steps_before_its_deadline_not_the_protocol_silently():
+    """bench.cpu_baseline on a tiny geometry of the 2-D workload: without a deadline the BASELINE protocol (2 warm-up + 5 timed
+    steps); with a deadline that has already passed, one warm-up and the minimum of timed steps -- and the dict says which."""
+    import importlib.util
+    import time
+    import torch
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    wl = dict(bench.WORKLOADS["unet2d"], shape=(4, 1, 32, 32), labeled=2, cpu_sample=(2, 1))
+    threads = torch.get_num_threads()
+    try:
+        full = bench.cpu_baseline("unet2d", wl, cands=(2,), also_threads=None)
+        assert (full["warmup_steps"], full["timed_steps"]) == (2, 5) and len(full["s_per_step_all"]) == 5
+        assert full["cores"] == 2 and full["value"] > 0 and "2 warm-up + 5 timed" in full["sample"]
+        late = bench.cpu_baseline("unet2d", wl, cands=(2,), also_threads=4, deadline=time.perf_counter() - 1.0)
+        assert (late["warmup_steps"], late["timed_steps"]) == (1, 3) and len(late["s_per_step_all"]) == 3
+        assert late["full_batch_at_other_thread_count"] is None and "1 warm-up + 3 timed" in late["sample"]
+    finally:
+        torch.set_num_threads(threads)
